@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: spots/sec of the multimodal f∘g training step (BASELINE.json configs[3], "C4").
+
+One step = one pass of the hot path over one synthetic 78x64 Visium array per GPU, exactly what one
+iteration of `train_gridwise` does in the reference's multimodal tutorial (Tutorial_multimodal.ipynb
+cells 23-28): DenseNet-121 image f (frozen, eval) over all 4992 spots of 128-px patches, count-MLP f over
+the 2000-gene count grid, concat, 5-layer hex corrector g, foreground-masked CE, backward through g (and
+the count MLP, whose parameters still require grad - the reference's GridNetHexMM quirk), gradient
+all-reduce over ranks, Adam step on the corrector.  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task description) with `roofline` for the dominant kernel
+(conv3x3 of the dense layers; FLOP-weighted over its 58 launches per step, timed with HIP events on the
+launch stream inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H, W, GENES, CLASSES = 78, 64, 2000, 8
+DENSENET121 = dict(growth_rate=32, block_config=(6, 12, 24, 16), num_init_features=64, bn_size=4, drop_rate=0,
+                   small_inputs=False)
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def conv3x3_flops_per_spot(patch):
+    """Algorithmic FLOPs of all dense-layer 3x3 convs per spot (2*K*N MAC-flops per output position)."""
+    s = ((patch + 6 - 7) // 2 + 1 + 2 - 3) // 2 + 1
+    total = 0
+    for n_layers in DENSENET121['block_config']:
+        total += n_layers * s * s * 2 * (9 * 128) * 32
+        s //= 2
+    return total
+
+
+def build_model(device):
+    import gridnext_amd as ga
+    from gridnext_amd.synthetic import count_mlp
+    torch.manual_seed(0)
+    f_img = ga.DenseNet(num_classes=CLASSES, **DENSENET121)
+    f_cnt = count_mlp(GENES, CLASSES)
+    return ga.GridNetHexMM(f_img, f_cnt, (3, 128, 128), (GENES,), (H, W), CLASSES).to(device)
+
+
+def cpu_baseline(patch, seed=0):
+    """The CPU oracle (oracle/, kind 'port') on a bounded sample of the same step: a 26x16 = 416-spot
+    sub-grid, same model family, same loss/backward/optimizer work, host cores of this box."""
+    from oracle import densenet as odn, gridnet as ogn, masked_ce as oce
+    from gridnext_amd.synthetic import count_mlp
+    hs, ws = 26, 16
+    torch.manual_seed(seed)
+    f_img = odn.DenseNet(num_classes=CLASSES, **{k: v for k, v in DENSENET121.items()})
+    g = ogn.GridNetHexMM(f_img, count_mlp(GENES, CLASSES), (3, patch, patch), (GENES,), (hs, ws), CLASSES)
+    for p in g.patch_classifier.parameters():
+        p.requires_grad = False
+    opt = torch.optim.Adam(g.corrector.parameters(), lr=1e-3)
+    gen = torch.Generator().manual_seed(seed)
+    x_img = torch.rand((1, hs, ws, 3, patch, patch), generator=gen)
+    x_cnt = torch.randint(0, 10, (1, GENES, hs, ws), generator=gen).float()
+    y = torch.randint(0, CLASSES + 1, (1, hs, ws), generator=gen)
+    g.train()
+    g.patch_classifier.eval()
+    t0 = time.time()
+    out = g([x_img, x_cnt])
+    loss, _, _ = oce.masked_ce(out, y, 1)
+    loss.backward()
+    opt.step()
+    opt.zero_grad()
+    dt = time.time() - t0
+    n = hs * ws
+    return {"value": n / dt, "unit": "spots/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 step on a %dx%d sub-grid (%d spots of %d px, 2000 genes), %.1f s" % (hs, ws, n, patch, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--patch', type=int, default=128)
+    ap.add_argument('--arrays', type=int, default=2, help='distinct synthetic arrays resident per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    from gridnext_amd import distributed as gdist
+    from gridnext_amd import training as gtrain
+    from gridnext_amd.synthetic import visium_array
+    rank, world, device = gdist.init_from_env()
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; no HIP device visible"
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    model = build_model(device)
+    gdist.broadcast_module(model)
+    for p in model.patch_classifier.parameters():               # Tutorial_multimodal.ipynb cell 27
+        p.requires_grad = False
+    model.image_classifier.features[0].weight.requires_grad = False
+    optimizer = torch.optim.Adam(model.corrector.parameters(), lr=1e-3)
+    criterion = nn.CrossEntropyLoss()
+    stepped = gdist.optimizer_params(optimizer)
+
+    # synthetic arrays, resident in HBM (different per rank: weak scaling, 1 array per GPU per step)
+    arrays = []
+    for a in range(args.arrays):
+        x_img, x_cnt, y = visium_array(1000 * rank + a, GENES, CLASSES, args.patch, device=device)
+        arrays.append(([x_img.unsqueeze(0), x_cnt.unsqueeze(0)], y.unsqueeze(0)))
+
+    f_img = model.image_classifier
+    model.train()
+    model.patch_classifier.eval()
+
+    def step(i):
+        inputs, labels = arrays[i % len(arrays)]
+        loss, correct, n_fg = gtrain._grid_loss(model, inputs, labels, criterion, 1, True)
+        loss.backward()
+        gdist.allreduce_gradients(stepped)
+        optimizer.step()
+        optimizer.zero_grad()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    if not args.no_kernel_timing:
+        f_img._probe = []                                       # (kind, start_event, end_event) per timed launch
+    if gdist.is_active():
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if gdist.is_active():
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if gdist.is_active():
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    spots = H * W * world * args.steps
+    result = {
+        "metric": "spots/sec training throughput (multimodal f+g)",
+        "value": spots / elapsed, "unit": "spots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C4: multimodal f(DenseNet-121 @%dpx + count-MLP 2000 genes) + hex g on 78x64 Visium "
+                               "grids, 1 array (4992 spots) per GPU per step, f frozen/eval (tutorial mode), "
+                               "g trained with Adam, masked CE" % args.patch,
+                   "arrays_per_gpu_per_step": 1, "spots_per_array": H * W, "parallelism": "dp%d" % world,
+                   "final_loss": float(last.item())},
+    }
+    probe = getattr(f_img, '_probe', None)
+    if probe:
+        ms = sum(s.elapsed_time(e) for kind, s, e in probe if kind == 'conv3x3')
+        n_launch = sum(1 for kind, _, _ in probe if kind == 'conv3x3')
+        flops = conv3x3_flops_per_spot(args.patch) * H * W * args.steps
+        achieved = flops / (ms * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "kernel": "conv3x3_kernel", "achieved": achieved,
+                              "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS,
+                              "traffic": None, "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
+                              "flops_per_launch_avg": flops / max(n_launch, 1)}
+        ms1 = sum(s.elapsed_time(e) for kind, s, e in probe if kind == 'conv1x1')
+        result["roofline"]["conv1x1_ms_per_step"] = ms1 / args.steps
+        result["roofline"]["conv3x3_ms_per_step"] = ms / args.steps
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.patch)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if gdist.is_active():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,272 @@
+// Batch normalisation (+ReLU) over the rows of a channels-last matrix x[M][C] (row stride ld).
+//
+// Serves BatchNorm2d(32) inside the corrector g (gridnet_models.py:134-146; a channels-last
+// [B][H][W][C] grid is an [M=B*H*W][C] matrix) and BatchNorm1d(100|50) of the count MLP
+// (Tutorial_visium_count.ipynb cell 12).  torch defaults: eps 1e-5, momentum 0.1, biased variance for
+// normalisation, unbiased for running_var.
+//
+// Statistics are two-pass (mean, then centred second moment) with fixed-order partial slabs, so results
+// are deterministic and free of E[x^2]-E[x]^2 cancellation.  Reductions: per-thread strided rows ->
+// LDS across the 4 row-lanes of a 256-thread workgroup -> slab per workgroup -> fixed-order final sum.
+// HBM-bound: 4 B read per element per pass.
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 256;
+
+// partial[blockIdx.x][c] = sum over the block's rows of f(x[r][c]); MODE 0: x ; 1: (x-mean[c])^2
+template <int MODE>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, long M, int C,
+                                                     const float* __restrict__ sum_partial, int nprev,
+                                                     float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    float mean = 0.f;
+    if (MODE == 1 && c < C) {
+        float s = 0.f;
+        for (int b = 0; b < nprev; ++b) s += sum_partial[(size_t)b * C + c];
+        mean = s / (float)M;
+    }
+    const long r0 = (long)blockIdx.x * ROWS_PER_BLOCK;
+    const long r1 = min(r0 + ROWS_PER_BLOCK, M);
+    float acc = 0.f;
+    if (c < C) {
+        for (long r = r0 + rl; r < r1; r += 4) {
+            const float v = x[r * ld + c];
+            if (MODE == 0) acc += v;
+            else { const float d = v - mean; acc = fmaf(d, d, acc); }
+        }
+    }
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C)
+        partial[(size_t)blockIdx.x * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+// mean/var from the slabs; running-stat update; folded scale/shift; saved mean & invstd for backward
+__global__ void bn_finalize_train_kernel(const float* __restrict__ sum_partial, const float* __restrict__ m2_partial,
+                                         int nblk, long M, int C, const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, float* running_mean, float* running_var,
+                                         long long* num_batches_tracked, float momentum, float eps,
+                                         float* __restrict__ scale, float* __restrict__ shift,
+                                         float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (c >= C) return;
+    float s = 0.f, m2 = 0.f;
+    for (int b = 0; b < nblk; ++b) s += sum_partial[(size_t)b * C + c];
+    for (int b = 0; b < nblk; ++b) m2 += m2_partial[(size_t)b * C + c];
+    const float mean = s / (float)M;
+    const float var = m2 / (float)M;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    scale[c] = g * invstd;
+    shift[c] = bt - mean * g * invstd;
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    if (running_var) {
+        const float unbiased = M > 1 ? m2 / (float)(M - 1) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+__global__ void bn_fold_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                    float eps, float* __restrict__ scale, float* __restrict__ shift,
+                                    float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    scale[c] = g * invstd;
+    shift[c] = bt - running_mean[c] * g * invstd;
+    if (save_mean) save_mean[c] = running_mean[c];
+    if (save_invstd) save_invstd[c] = invstd;
+}
+
+// y = [relu](x*scale + shift)
+__global__ __launch_bounds__(256) void scale_shift_relu_kernel(const float* __restrict__ x, long ldx,
+                                                               float* __restrict__ y, long ldy, long M, int C,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, int relu) {
+    const long total = M * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / C;
+        const int c = (int)(idx - r * C);
+        float v = fmaf(x[r * ldx + c], scale[c], shift[c]);
+        if (relu) v = fmaxf(v, 0.f);
+        y[r * ldy + c] = v;
+    }
+}
+
+// backward pass 1: partial[blk][0][c] = sum dz ; partial[blk][1][c] = sum dz * xhat
+// dz = dy * (relu ? 1[x*scale+shift > 0] : 1), xhat = (x-mean)*invstd
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, long lddy,
+                                                             const float* __restrict__ x, long ldx, long M, int C,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, int relu,
+                                                             float* __restrict__ partial) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const long r0 = (long)blockIdx.x * ROWS_PER_BLOCK;
+    const long r1 = min(r0 + ROWS_PER_BLOCK, M);
+    float a1 = 0.f, a2 = 0.f;
+    if (c < C) {
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+        for (long r = r0 + rl; r < r1; r += 4) {
+            const float xv = x[r * ldx + c];
+            float dz = dy[r * lddy + c];
+            if (relu && fmaf(xv, sc, sh) <= 0.f) dz = 0.f;
+            a1 += dz;
+            a2 = fmaf(dz, (xv - mu) * is, a2);
+        }
+    }
+    red[0][rl][cl] = a1;
+    red[1][rl][cl] = a2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    }
+}
+
+// backward pass 2: sums -> dgamma/dbeta (optionally accumulated), sums[2][C] kept for the dx pass
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums,
+                                     float* dgamma, float* dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += partial[((size_t)b * 2 + 0) * C + c];
+        s2 += partial[((size_t)b * 2 + 1) * C + c];
+    }
+    sums[c] = s1;
+    sums[C + c] = s2;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + s2 : s2;
+}
+
+// backward pass 3: dx.  training: scale*(dz - s1/M - xhat*s2/M) ; eval: scale*dz   (scale = gamma*invstd)
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict__ dy, long lddy,
+                                                        const float* __restrict__ x, long ldx,
+                                                        float* __restrict__ dx, long lddx, long M, int C,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd,
+                                                        const float* __restrict__ sums, int relu, int training) {
+    const long total = M * C;
+    const float invM = 1.0f / (float)M;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / C;
+        const int c = (int)(idx - r * C);
+        const float xv = x[r * ldx + c];
+        float dz = dy[r * lddy + c];
+        if (relu && fmaf(xv, scale[c], shift[c]) <= 0.f) dz = 0.f;
+        float g = dz;
+        if (training) {
+            const float xhat = (xv - mean[c]) * invstd[c];
+            g = dz - sums[c] * invM - xhat * sums[C + c] * invM;
+        }
+        dx[r * lddx + c] = scale[c] * g;
+    }
+}
+
+// out[c] = fixed-order sum of the slabs (used for bias gradients)
+__global__ void slab_reduce_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out,
+                                   int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+inline int elementwise_grid(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+// floats of workspace needed by gnx_bn_train_stats / gnx_bn_relu_bwd for an [M][C] matrix
+GNX_EXPORT long gnx_bn_workspace(long M, int C) {
+    return 2L * gnx_cdiv(M, ROWS_PER_BLOCK) * C + 2L * C;
+}
+
+// Training-mode statistics of x[M][C]: fills scale/shift (folded affine), save_mean/save_invstd and
+// applies torch's running-stat update (momentum; unbiased running_var; num_batches_tracked += 1).
+GNX_EXPORT int gnx_bn_train_stats(const float* x, long ld, long M, int C, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, long long* num_batches_tracked,
+                                  float momentum, float eps, float* scale, float* shift, float* save_mean,
+                                  float* save_invstd, float* workspace, hipStream_t stream) {
+    if (!x || !scale || !shift || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0 || ld < C)
+        return GNX_ERR_BAD_ARG;
+    const int nblk = gnx_cdiv(M, ROWS_PER_BLOCK);
+    float* p_sum = workspace;
+    float* p_m2 = workspace + (size_t)nblk * C;
+    dim3 grid(nblk, gnx_cdiv(C, 64));
+    colsum_kernel<0><<<grid, 256, 0, stream>>>(x, ld, M, C, nullptr, 0, p_sum);
+    colsum_kernel<1><<<grid, 256, 0, stream>>>(x, ld, M, C, p_sum, nblk, p_m2);
+    bn_finalize_train_kernel<<<gnx_cdiv(C, 64), 64, 0, stream>>>(p_sum, p_m2, nblk, M, C, gamma, beta,
+                                                                 running_mean, running_var, num_batches_tracked,
+                                                                 momentum, eps, scale, shift, save_mean,
+                                                                 save_invstd);
+    return gnx_launch_status();
+}
+
+// Eval-mode fold: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale
+GNX_EXPORT int gnx_bn_fold_eval(int C, const float* gamma, const float* beta, const float* running_mean,
+                                const float* running_var, float eps, float* scale, float* shift,
+                                float* save_mean, float* save_invstd, hipStream_t stream) {
+    if (C <= 0 || !running_mean || !running_var || !scale || !shift) return GNX_ERR_BAD_ARG;
+    bn_fold_eval_kernel<<<gnx_cdiv(C, 256), 256, 0, stream>>>(C, gamma, beta, running_mean, running_var, eps,
+                                                              scale, shift, save_mean, save_invstd);
+    return gnx_launch_status();
+}
+
+GNX_EXPORT int gnx_scale_shift_relu(const float* x, long ldx, float* y, long ldy, long M, int C,
+                                    const float* scale, const float* shift, int relu, hipStream_t stream) {
+    if (!x || !y || !scale || !shift || M < 0 || C <= 0 || ldx < C || ldy < C) return GNX_ERR_BAD_ARG;
+    if (M == 0) return GNX_OK;
+    scale_shift_relu_kernel<<<elementwise_grid(M * C), 256, 0, stream>>>(x, ldx, y, ldy, M, C, scale, shift, relu);
+    return gnx_launch_status();
+}
+
+// Backward of y = [relu](bn(x)).  dgamma/dbeta may be null; `training` selects batch-stat or running-stat form.
+GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long ldx, float* dx, long lddx, long M,
+                               int C, const float* scale, const float* shift, const float* save_mean,
+                               const float* save_invstd, float* dgamma, float* dbeta, int relu, int training,
+                               int accumulate, float* workspace, hipStream_t stream) {
+    if (!dy || !x || !scale || !shift || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0)
+        return GNX_ERR_BAD_ARG;
+    const int nblk = gnx_cdiv(M, ROWS_PER_BLOCK);
+    float* partial = workspace;
+    float* sums = workspace + (size_t)2 * nblk * C;
+    dim3 grid(nblk, gnx_cdiv(C, 64));
+    bn_bwd_partial_kernel<<<grid, 256, 0, stream>>>(dy, lddy, x, ldx, M, C, scale, shift, save_mean, save_invstd,
+                                                    relu, partial);
+    bn_bwd_reduce_kernel<<<gnx_cdiv(C, 64), 64, 0, stream>>>(partial, nblk, C, sums, dgamma, dbeta, accumulate);
+    if (dx)
+        bn_bwd_dx_kernel<<<elementwise_grid(M * C), 256, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale,
+                                                                      shift, save_mean, save_invstd, sums, relu,
+                                                                      training);
+    return gnx_launch_status();
+}
+
+// out[c] = sum_r x[r][c]  (bias gradient of a Linear layer); workspace: gnx_bn_workspace(M, C) floats
+GNX_EXPORT int gnx_colsum(const float* x, long ld, long M, int C, float* out, int accumulate, float* workspace,
+                          hipStream_t stream) {
+    if (!x || !out || !workspace || M <= 0 || C <= 0 || ld < C) return GNX_ERR_BAD_ARG;
+    const int nblk = gnx_cdiv(M, ROWS_PER_BLOCK);
+    dim3 grid(nblk, gnx_cdiv(C, 64));
+    colsum_kernel<0><<<grid, 256, 0, stream>>>(x, ld, M, C, nullptr, 0, workspace);
+    slab_reduce_kernel<<<gnx_cdiv(C, 64), 64, 0, stream>>>(workspace, nblk, C, out, accumulate);
+    return gnx_launch_status();
+}

@@ -1,0 +1,511 @@
+// DenseNet-BC forward kernels for the image spot classifier f (gfx950, exact fp32 on the matrix cores).
+//
+// Replaces, for /root/reference/gridnext/densenet.py:
+//   _DenseLayer.forward :35-44   cat -> BN -> ReLU -> conv1x1   => gnx_conv1x1_bnrelu   (BN+ReLU fused into the A-operand load)
+//                                BN -> ReLU -> conv3x3 p1       => gnx_conv3x3_bnrelu   (same prologue, zero padding applied AFTER the activation)
+//   _DenseBlock.forward :70-75   torch.cat of features           => none: every layer writes its `growth` channels into
+//                                                                   a column range of one channels-last block buffer
+//   _Transition :47-54           BN -> ReLU -> conv1x1 -> avgpool2 => gnx_conv1x1_bnrelu(pool=1): the 2x2 average is taken on the
+//                                                                   activated input first (both maps are linear: 4x fewer MACs)
+//   stem :105-112                conv7x7 s2 p3 | conv3x3 s1 p1   => gnx_conv_stem ; BN -> ReLU -> maxpool3 s2 p1 => gnx_bnrelu_maxpool
+//   tail  :152-156               BN -> ReLU -> adaptive_avg_pool(1,1) -> flatten => gnx_bnrelu_avgpool (classifier: gnx_gemm_f32)
+//
+// HBM layout: activations are channels-last matrices X[M = spots*S*S][C] with a leading dimension (a dense block is ONE
+// buffer of leading dimension C_total; a layer reads columns [0, C_in) and writes [C_in, C_in+growth)).
+// Weights: conv1x1 as torch stores them [N][K]; conv3x3 repacked once to [tap][N][K] (gnx_repack_conv3x3).
+//
+// MFMA: v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate = an exact fmaf chain; 157.3 TFLOP/s dense peak).
+// LDS images are [row][K-chunk of 32 + 4 pad] (144-B rows): 16-B aligned for ds_read_b128 and conflict-free
+// (row stride = 9 sixteen-byte slots, odd).  One ds_read_b128 per operand feeds four MFMAs: lane half h supplies
+// k = 8*s + 4*h + j for the j-th of them, identically for A and B, so the k-order inside the sum is a fixed permutation.
+#include "common.h"
+
+namespace {
+
+constexpr int LDK = 36;     // floats per LDS row: 32 + 4 pad
+
+__device__ __forceinline__ float act1(float v, float sc, float sh) { return fmaxf(fmaf(v, sc, sh), 0.f); }
+__device__ __forceinline__ float4 act4(float4 v, float4 sc, float4 sh) {
+    return make_float4(act1(v.x, sc.x, sh.x), act1(v.y, sc.y, sh.y), act1(v.z, sc.z, sh.z), act1(v.w, sc.w, sh.w));
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// bounds-checked / unaligned-safe 4-float load of src[0..3], zero beyond `valid` elements
+__device__ __forceinline__ float4 ld4_safe(const float* p, int valid, bool vec) {
+    if (vec && valid >= 4) return ld4(p);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid > 0) r.x = p[0];
+    if (valid > 1) r.y = p[1];
+    if (valid > 2) r.z = p[2];
+    if (valid > 3) r.w = p[3];
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ conv1x1
+// out[m][n] = sum_k act(A[m][k]) * W[n][k];  act(a) = relu(a*scale[k]+shift[k]) (identity when scale == nullptr)
+// POOL: row m is a position of the (S_in/2)^2 grid; its A-row is the mean of the 4 activated source rows.
+constexpr int C1_BM = 128, C1_BN = 128, C1_BK = 32;
+
+template <bool POOL>
+__global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ A, long lda,
+                                                      const float* __restrict__ W, float* __restrict__ out, long ldc,
+                                                      long M, int N, int K, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int S_in, int vecA, int vecW) {
+    __shared__ __attribute__((aligned(16))) float As[C1_BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[C1_BN * LDK];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, i = lane & 31;
+    const int kq = t & 7, r0 = t >> 3;
+    const long m0 = (long)blockIdx.x * C1_BM;
+    const int n0 = blockIdx.y * C1_BN;
+
+    long src[4];
+    bool rok[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const long row = m0 + r0 + 32 * p;
+        rok[p] = row < M;
+        if (POOL) {
+            const int So = S_in >> 1;
+            const long img = row / (So * So);
+            const int rem = (int)(row - img * So * So);
+            const int oy = rem / So, ox = rem - oy * So;
+            src[p] = ((img * S_in + 2 * oy) * S_in + 2 * ox) * lda;
+        } else {
+            src[p] = row * lda;
+        }
+    }
+    const bool has_act = scale != nullptr;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 ra[4], rb[4], sc4, sh4;
+    auto fetch = [&](int k0) {
+        const int k = k0 + 4 * kq;
+        const int valid = K - k;
+        sc4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_act && valid > 0) {
+            sc4 = ld4_safe(scale + k, valid, vecA);
+            sh4 = ld4_safe(shift + k, valid, vecA);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (!rok[p] || valid <= 0) { ra[p] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
+            if (POOL) {
+                const float* b0 = A + src[p] + k;
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = ld4_safe(b0 + ((q >> 1) * (long)S_in + (q & 1)) * lda, valid, vecA);
+                    if (has_act) v = act4(v, sc4, sh4);
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+                ra[p] = make_float4(0.25f * s.x, 0.25f * s.y, 0.25f * s.z, 0.25f * s.w);
+            } else {
+                ra[p] = ld4_safe(A + src[p] + k, valid, vecA);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int n = n0 + r0 + 32 * p;
+            rb[p] = (n < N && valid > 0) ? ld4_safe(W + (long)n * K + k, valid, vecW) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int k0) {
+        const int valid = K - (k0 + 4 * kq);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float4 v = ra[p];
+            if (!POOL && has_act && rok[p]) v = act4(v, sc4, sh4);
+            // lanes of the K tail must hold exact zeros (they meet zero weights; 0*garbage must stay 0)
+            if (valid < 4) {
+                if (valid < 1) v.x = 0.f;
+                if (valid < 2) v.y = 0.f;
+                if (valid < 3) v.z = 0.f;
+                v.w = 0.f;
+            }
+            if (!rok[p]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&As[(r0 + 32 * p) * LDK + 4 * kq]) = v;
+            *reinterpret_cast<float4*>(&Bs[(r0 + 32 * p) * LDK + 4 * kq]) = rb[p];
+        }
+    };
+
+    const int nkt = (K + C1_BK - 1) / C1_BK;
+    fetch(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        stash(kt * C1_BK);
+        __syncthreads();
+        if (kt + 1 < nkt) fetch((kt + 1) * C1_BK);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) a[mt] = ld4(&As[(64 * wm + 32 * mt + i) * LDK + 8 * s + 4 * h]);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) b[nt] = ld4(&Bs[(64 * wn + 32 * nt + i) * LDK + 8 * s + 4 * h]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = n0 + 64 * wn + 32 * nt + i;
+            if (col >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = m0 + 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) out[row * ldc + col] = acc[mt][nt][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ conv3x3 (pad 1)
+// out[P][n] = sum_tap sum_k pad0(act(A))[nbr(P,tap)][k] * Wr[tap][n][k]
+// A tile of 128 consecutive flattened positions (image, y, x) needs the flattened range [P0-S-1, P0+127+S+1]:
+// it is staged ONCE per K-chunk as a contiguous strip, tap (dy,dx) of row i is strip row i + (S+1) + dy*S + dx,
+// and the per-lane 9-bit validity mask (image border / row wrap) zeroes a fragment after the read.
+constexpr int C3_BM = 128, C3_BN = 32;
+
+__global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ A, long lda,
+                                                      const float* __restrict__ Wr, float* __restrict__ out, long ldc,
+                                                      long M, int N, int K, int S, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int vecA, int vecW) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int strip = C3_BM + 2 * S + 2;
+    float* As = lds;                    // [strip][LDK]
+    float* Bs = lds + strip * LDK;      // [9][32][LDK]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    const long P0 = (long)blockIdx.x * C3_BM;
+    const long base = P0 - S - 1;
+    const int n0 = blockIdx.y * C3_BN;
+    const bool has_act = scale != nullptr;
+
+    // validity of the 9 taps for this lane's output position
+    const long P = P0 + 32 * wave + i;
+    unsigned mask = 0;
+    if (P < M) {
+        const int rem = (int)(P % ((long)S * S));
+        const int y = rem / S, x = rem - y * S;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy >= 0 && yy < S && xx >= 0 && xx < S) mask |= 1u << tap;
+        }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const int kq = t & 7;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const int k = k0 + 4 * kq;
+        const int valid = K - k;
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_act && valid > 0) {
+            sc4 = ld4_safe(scale + k, valid, vecA);
+            sh4 = ld4_safe(shift + k, valid, vecA);
+        }
+        __syncthreads();
+        for (int row = t >> 3; row < strip; row += 32) {
+            const long Pr = base + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (Pr >= 0 && Pr < M && valid > 0) {
+                v = ld4_safe(A + Pr * lda + k, valid, vecA);
+                if (has_act) v = act4(v, sc4, sh4);
+                if (valid < 4) {
+                    if (valid < 2) v.y = 0.f;
+                    if (valid < 3) v.z = 0.f;
+                    v.w = 0.f;
+                }
+            }
+            *reinterpret_cast<float4*>(&As[row * LDK + 4 * kq]) = v;
+        }
+        for (int idx = t >> 3; idx < 9 * 32; idx += 32) {
+            const int tap = idx >> 5, n = n0 + (idx & 31);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < N && valid > 0) v = ld4_safe(Wr + ((long)tap * N + n) * K + k, valid, vecW);
+            *reinterpret_cast<float4*>(&Bs[idx * LDK + 4 * kq]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int off = (S + 1) + (tap / 3 - 1) * S + (tap % 3 - 1);
+            const bool ok = (mask >> tap) & 1u;
+            const float* ap = &As[(32 * wave + i + off) * LDK + 4 * h];
+            const float* bp = &Bs[(tap * 32 + i) * LDK + 4 * h];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float4 a = ld4(ap + 8 * s);
+                const float4 b = ld4(bp + 8 * s);
+                if (!ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            }
+        }
+    }
+    const int col = n0 + i;
+    if (col < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = P0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < M) out[row * ldc + col] = acc[r];
+        }
+    }
+}
+
+// [N][K][3][3] (torch) -> [tap][N][K]
+__global__ void repack3x3_kernel(const float* __restrict__ w, float* __restrict__ wr, int N, int K) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)9 * N * K;
+    if (idx >= total) return;
+    const int k = (int)(idx % K), n = (int)((idx / K) % N), tap = (int)(idx / ((long)K * N));
+    wr[idx] = w[((long)n * K + k) * 9 + tap];
+}
+
+// ------------------------------------------------------------------------------------------------ stem conv (NCHW in, NHWC out)
+// out[(img,oy,ox)][o] = sum_{c,ky,kx} x[img][c][oy*st+ky-pad][ox*st+kx-pad] * w[o][c][ky][kx]
+// im2col is built in LDS one input channel at a time: K-chunk = KH x 8 (kx padded to 8 with zero weights).
+constexpr int ST_BM = 128, ST_BN = 64;
+
+__global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ out, long ldc, long M, int Cin, int H,
+                                                        int Wd, int Ho, int Wo, int O, int KH, int KW, int stride,
+                                                        int pad) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int KC = KH * 8, LD = KC + 4;
+    float* As = lds;                 // [128][LD]
+    float* Bs = lds + ST_BM * LD;    // [64][LD]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long m0 = (long)blockIdx.x * ST_BM;
+    const int n0 = blockIdx.y * ST_BN;
+    const int kx = t & 7, rr = t >> 3;
+
+    long ibase[4];
+    int iy0[4], ix0[4];
+    bool rok[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const long row = m0 + rr + 32 * p;
+        rok[p] = row < M;
+        const long img = row / ((long)Ho * Wo);
+        const int rem = (int)(row - img * Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        ibase[p] = img * Cin * (long)H * Wd;
+        iy0[p] = oy * stride - pad;
+        ix0[p] = ox * stride - pad + kx;
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    for (int c = 0; c < Cin; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool xok = rok[p] && kx < KW && ix0[p] >= 0 && ix0[p] < Wd;
+            const float* xc = x + ibase[p] + (long)c * H * Wd;
+            for (int ky = 0; ky < KH; ++ky) {
+                const int iy = iy0[p] + ky;
+                float v = 0.f;
+                if (xok && iy >= 0 && iy < H) v = xc[(long)iy * Wd + ix0[p]];
+                As[(rr + 32 * p) * LD + ky * 8 + kx] = v;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int o = n0 + rr + 32 * p;
+            for (int ky = 0; ky < KH; ++ky) {
+                float v = 0.f;
+                if (o < O && kx < KW) v = w[(((long)o * Cin + c) * KH + ky) * KW + kx];
+                Bs[(rr + 32 * p) * LD + ky * 8 + kx] = v;
+            }
+        }
+        __syncthreads();
+        for (int s = 0; s < KH; ++s) {
+            const float4 a0 = ld4(&As[(64 * wm + i) * LD + 8 * s + 4 * h]);
+            const float4 a1 = ld4(&As[(64 * wm + 32 + i) * LD + 8 * s + 4 * h]);
+            const float4 b = ld4(&Bs[(32 * wn + i) * LD + 8 * s + 4 * h]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc[1], 0, 0, 0);
+        }
+    }
+    const int col = n0 + 32 * wn + i;
+    if (col < O) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = m0 + 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) out[row * ldc + col] = acc[mt][r];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BN+ReLU+maxpool 3x3 s2 p1
+__global__ __launch_bounds__(256) void bnrelu_maxpool_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out,
+                                                             long ldo, long Mout, int C, int Hi, int Wi, int Ho, int Wo,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift) {
+    const long total = Mout * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long row = idx / C;
+        const int c = (int)(idx - row * C);
+        const long img = row / ((long)Ho * Wo);
+        const int rem = (int)(row - img * Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        const float sc = scale[c], sh = shift[c];
+        float m = 0.f;     // relu output is >= 0 and the window always holds a valid tap
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int iy = 2 * oy + dy;
+            if (iy < 0 || iy >= Hi) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int ix = 2 * ox + dx;
+                if (ix < 0 || ix >= Wi) continue;
+                m = fmaxf(m, fmaf(in[((img * Hi + iy) * Wi + ix) * ldi + c], sc, sh));
+            }
+        }
+        out[row * ldo + c] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BN+ReLU+global average pool
+// out[img][c] = mean over the S2 positions of relu(x*scale+shift)
+__global__ __launch_bounds__(256) void bnrelu_avgpool_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out,
+                                                             long ldo, int C, int S2, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const long img = blockIdx.x;
+    float acc = 0.f;
+    if (c < C) {
+        const float sc = scale[c], sh = shift[c];
+        for (int r = rl; r < S2; r += 4) acc += fmaxf(fmaf(in[(img * S2 + r) * ldi + c], sc, sh), 0.f);
+    }
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C)
+        out[img * ldo + c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)S2;
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// out[M][N] (ldc) = act(A[M][K] (lda)) . W[N][K]^T ; pool != 0: A is on an S_in x S_in grid per image and M counts the
+// (S_in/2)^2 pooled positions.  scale/shift may both be NULL (no activation).
+GNX_EXPORT int gnx_conv1x1_bnrelu(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
+                                  const float* scale, const float* shift, int pool, int S_in, hipStream_t stream) {
+    if (!A || !W || !out || M < 0 || N <= 0 || K <= 0 || lda < K || ldc < N || (!scale) != (!shift))
+        return GNX_ERR_BAD_ARG;
+    if (pool && (S_in < 2)) return GNX_ERR_BAD_ARG;
+    if (M == 0) return GNX_OK;
+    const int vecA = al16(A) && lda % 4 == 0 && (!scale || (al16(scale) && al16(shift)));
+    const int vecW = al16(W) && K % 4 == 0;
+    dim3 grid(gnx_cdiv(M, C1_BM), gnx_cdiv(N, C1_BN));
+    if (pool)
+        conv1x1_kernel<true><<<grid, 256, 0, stream>>>(A, lda, W, out, ldc, M, N, K, scale, shift, S_in, vecA, vecW);
+    else
+        conv1x1_kernel<false><<<grid, 256, 0, stream>>>(A, lda, W, out, ldc, M, N, K, scale, shift, S_in, vecA, vecW);
+    return gnx_launch_status();
+}
+
+GNX_EXPORT int gnx_repack_conv3x3(const float* w, float* wr, int N, int K, hipStream_t stream) {
+    if (!w || !wr || N <= 0 || K <= 0) return GNX_ERR_BAD_ARG;
+    repack3x3_kernel<<<gnx_cdiv(9L * N * K, 256), 256, 0, stream>>>(w, wr, N, K);
+    return gnx_launch_status();
+}
+
+// out[M][N] (ldc) = conv3x3_pad1(act(A[M = imgs*S*S][K] (lda))) with weights repacked to [tap][N][K]
+GNX_EXPORT int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, float* out, long ldc, long M, int N, int K,
+                                  int S, const float* scale, const float* shift, hipStream_t stream) {
+    if (!A || !Wr || !out || M < 0 || N <= 0 || K <= 0 || S <= 0 || lda < K || ldc < N || (!scale) != (!shift) ||
+        (M % ((long)S * S)) != 0)
+        return GNX_ERR_BAD_ARG;
+    if (M == 0) return GNX_OK;
+    const size_t lds_bytes = ((size_t)(C3_BM + 2 * S + 2) * LDK + 9 * 32 * LDK) * sizeof(float);
+    if (lds_bytes > 160 * 1024) return GNX_ERR_UNSUPPORTED;
+    static size_t configured = 0;
+    if (lds_bytes > configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess)
+            return GNX_ERR_LAUNCH;
+        configured = lds_bytes;
+    }
+    const int vecA = al16(A) && lda % 4 == 0 && (!scale || (al16(scale) && al16(shift)));
+    const int vecW = al16(Wr) && K % 4 == 0;
+    dim3 grid(gnx_cdiv(M, C3_BM), gnx_cdiv(N, C3_BN));
+    conv3x3_kernel<<<grid, 256, lds_bytes, stream>>>(A, lda, Wr, out, ldc, M, N, K, S, scale, shift, vecA, vecW);
+    return gnx_launch_status();
+}
+
+// x [imgs][Cin][H][W] (NCHW, as the datasets deliver patches) -> out [imgs*Ho*Wo][O] channels-last (ldc)
+GNX_EXPORT int gnx_conv_stem(const float* x, const float* w, float* out, long ldc, long imgs, int Cin, int H, int W,
+                             int O, int KH, int KW, int stride, int pad, hipStream_t stream) {
+    if (!x || !w || !out || imgs < 0 || Cin <= 0 || O <= 0 || KH <= 0 || KH > 7 || KW <= 0 || KW > 8 || stride <= 0 ||
+        ldc < O)
+        return GNX_ERR_BAD_ARG;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return GNX_ERR_BAD_ARG;
+    const long M = imgs * Ho * Wo;
+    if (M == 0) return GNX_OK;
+    const size_t lds_bytes = (size_t)(ST_BM + ST_BN) * (KH * 8 + 4) * sizeof(float);
+    dim3 grid(gnx_cdiv(M, ST_BM), gnx_cdiv(O, ST_BN));
+    conv_stem_kernel<<<grid, 256, lds_bytes, stream>>>(x, w, out, ldc, M, Cin, H, W, Ho, Wo, O, KH, KW, stride, pad);
+    return gnx_launch_status();
+}
+
+// in [imgs*Hi*Wi][C] (ldi) -> out [imgs*Ho*Wo][C] (ldo): max over 3x3 s2 p1 windows of relu(in*scale+shift)
+GNX_EXPORT int gnx_bnrelu_maxpool(const float* in, long ldi, float* out, long ldo, long imgs, int C, int Hi, int Wi,
+                                  const float* scale, const float* shift, hipStream_t stream) {
+    if (!in || !out || !scale || !shift || imgs < 0 || C <= 0 || Hi <= 0 || Wi <= 0 || ldi < C || ldo < C)
+        return GNX_ERR_BAD_ARG;
+    const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+    const long Mout = imgs * Ho * Wo;
+    if (Mout == 0) return GNX_OK;
+    long blocks = (Mout * C + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    bnrelu_maxpool_kernel<<<(int)blocks, 256, 0, stream>>>(in, ldi, out, ldo, Mout, C, Hi, Wi, Ho, Wo, scale, shift);
+    return gnx_launch_status();
+}
+
+// in [imgs*S2][C] (ldi) -> out [imgs][C] (ldo): mean over positions of relu(in*scale+shift)
+GNX_EXPORT int gnx_bnrelu_avgpool(const float* in, long ldi, float* out, long ldo, long imgs, int C, int S2,
+                                  const float* scale, const float* shift, hipStream_t stream) {
+    if (!in || !out || !scale || !shift || imgs < 0 || C <= 0 || S2 <= 0 || ldi < C || ldo < C) return GNX_ERR_BAD_ARG;
+    if (imgs == 0) return GNX_OK;
+    if (imgs > 2147483647L) return GNX_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)imgs, gnx_cdiv(C, 64));
+    bnrelu_avgpool_kernel<<<grid, 256, 0, stream>>>(in, ldi, out, ldo, C, S2, scale, shift);
+    return gnx_launch_status();
+}

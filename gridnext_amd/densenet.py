@@ -1,0 +1,276 @@
+"""DenseNet-BC image spot classifier, MI355X-native.
+
+Drop-in for `gridnext.densenet.DenseNet` (/root/reference/gridnext/densenet.py:78-159): same constructor
+(:93-95), same parameter/buffer names (state_dict keys `features.conv0.weight`,
+`features.denseblock{b}.denselayer{l}.{norm1,conv1,norm2,conv2}.*`, `features.transition{t}.{norm,conv}.*`,
+`features.norm_final.*`, `classifier.*`), same initialisation (:141-150), same output.
+
+The module tree below holds PARAMETERS ONLY (stock torch containers, so `.to()`, `.train()`, `state_dict()`
+and optimizers behave as for the reference).  `forward` does not call them: it drives the hand-written gfx950
+kernels of csrc/densenet_fwd.hip through the C ABI:
+  * activations are channels-last matrices [spots*S*S, C]; a dense block is ONE buffer, each layer writes its
+    `growth_rate` columns in place, so the reference's `torch.cat` (:14, :75) never happens;
+  * BN+ReLU are folded into the operand load of the following conv; the transition averages 2x2 first;
+  * a whole array's spots go through each kernel together (chunks only when activations would exceed ~40 GB,
+    or when the caller sets `atonce` / GridNet.atonce_patch_limit).
+`efficient=True` (checkpointing, :36-40) is accepted and ignored: 288 GB of HBM make recompute unnecessary.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import functional as GF
+
+F32 = torch.float32
+
+
+class _DenseLayer(nn.Module):
+    def __init__(self, c_in, growth_rate, bn_size, drop_rate):
+        super().__init__()
+        self.norm1 = nn.BatchNorm2d(c_in)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(c_in, bn_size * growth_rate, kernel_size=1, stride=1, bias=False)
+        self.norm2 = nn.BatchNorm2d(bn_size * growth_rate)
+        self.relu2 = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(bn_size * growth_rate, growth_rate, kernel_size=3, stride=1, padding=1, bias=False)
+        self.drop_rate = drop_rate
+
+
+class _Transition(nn.Module):
+    def __init__(self, c_in, c_out):
+        super().__init__()
+        self.norm = nn.BatchNorm2d(c_in)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv = nn.Conv2d(c_in, c_out, kernel_size=1, stride=1, bias=False)
+        self.pool = nn.AvgPool2d(kernel_size=2, stride=2)
+
+
+class DenseNet(nn.Module):
+    def __init__(self, growth_rate=12, block_config=(16, 16, 16), compression=0.5,
+                 num_init_features=24, bn_size=4, drop_rate=0,
+                 num_classes=10, small_inputs=True, efficient=False, classify=True):
+        super().__init__()
+        assert 0 < compression <= 1, 'compression of densenet should be between 0 and 1'
+        if drop_rate and drop_rate > 0:
+            raise NotImplementedError("dropout inside dense layers (drop_rate>0) is not used on the GridNext path")
+        self.growth_rate, self.block_config = growth_rate, tuple(block_config)
+        self.bn_size, self.small_inputs, self.classify = bn_size, small_inputs, classify
+        self.atonce = None          # spots per chunk in eval mode (None = auto)
+
+        feats = OrderedDict()
+        if small_inputs:
+            feats['conv0'] = nn.Conv2d(3, num_init_features, kernel_size=3, stride=1, padding=1, bias=False)
+        else:
+            feats['conv0'] = nn.Conv2d(3, num_init_features, kernel_size=7, stride=2, padding=3, bias=False)
+            feats['norm0'] = nn.BatchNorm2d(num_init_features)
+            feats['relu0'] = nn.ReLU(inplace=True)
+            feats['pool0'] = nn.MaxPool2d(kernel_size=3, stride=2, padding=1, ceil_mode=False)
+        c = num_init_features
+        self._blocks = []           # [(c_in, [layers], transition|None, c_total)]
+        for bi, n_layers in enumerate(self.block_config):
+            block = nn.Module()
+            layers = []
+            for li in range(n_layers):
+                layer = _DenseLayer(c + li * growth_rate, growth_rate, bn_size, drop_rate)
+                block.add_module('denselayer%d' % (li + 1), layer)
+                layers.append(layer)
+            feats['denseblock%d' % (bi + 1)] = block
+            c_total = c + n_layers * growth_rate
+            trans = None
+            if bi != len(self.block_config) - 1:
+                trans = _Transition(c_total, int(c_total * compression))
+                feats['transition%d' % (bi + 1)] = trans
+            self._blocks.append((c, layers, trans, c_total))
+            c = int(c_total * compression) if trans is not None else c_total
+        feats['norm_final'] = nn.BatchNorm2d(c)
+        self.features = nn.Sequential(feats)
+        self.num_features = c
+        self.classifier = nn.Linear(c, num_classes)
+
+        for name, param in self.named_parameters():          # densenet.py:141-150
+            if 'conv' in name and 'weight' in name:
+                n = param.size(0) * param.size(2) * param.size(3)
+                param.data.normal_().mul_(math.sqrt(2. / n))
+            elif 'norm' in name and 'weight' in name:
+                param.data.fill_(1)
+            elif 'norm' in name and 'bias' in name:
+                param.data.fill_(0)
+            elif 'classifier' in name and 'bias' in name:
+                param.data.fill_(0)
+        self._cache = {}
+
+    # ------------------------------------------------------------------ cached, derived device tensors
+    def _bn_modules(self):
+        mods = []
+        if not self.small_inputs:
+            mods.append(self.features.norm0)
+        for _, layers, trans, _ in self._blocks:
+            for l in layers:
+                mods += [l.norm1, l.norm2]
+            if trans is not None:
+                mods.append(trans.norm)
+        mods.append(self.features.norm_final)
+        return mods
+
+    def _folded_eval(self):
+        """{bn module: (scale, shift)} for running-stat BN; refreshed when any BN tensor changed."""
+        mods = self._bn_modules()
+        key = tuple(t._version for m in mods for t in (m.weight, m.bias, m.running_mean, m.running_var)) + \
+            (str(mods[0].weight.device),)
+        hit = self._cache.get('fold')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        total = sum((m.num_features + 3) // 4 * 4 for m in mods)   # every slice starts 16-B aligned (float4 loads)
+        dev = mods[0].weight.device
+        buf = torch.empty((2, total), device=dev, dtype=F32)
+        table, off = {}, 0
+        st = L.stream()
+        for m in mods:
+            c = m.num_features
+            sc, sh = buf[0, off:off + c], buf[1, off:off + c]
+            L.call('gnx_bn_fold_eval', c, L.ptr(m.weight), L.ptr(m.bias), L.ptr(m.running_mean),
+                   L.ptr(m.running_var), float(m.eps), L.ptr(sc), L.ptr(sh), None, None, st)
+            table[m] = (sc, sh)
+            off += (c + 3) // 4 * 4
+        self._cache['fold'] = (key, table, buf)
+        return table
+
+    def _repacked_conv2(self):
+        """{layer: conv2 weight as [tap][growth][mid]} refreshed when a conv2 weight changed."""
+        layers = [l for _, ls, _, _ in self._blocks for l in ls]
+        key = tuple(l.conv2.weight._version for l in layers) + (str(layers[0].conv2.weight.device),)
+        hit = self._cache.get('w2')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        table = {}
+        st = L.stream()
+        for l in layers:
+            w = l.conv2.weight
+            n, k = w.shape[0], w.shape[1]
+            wr = torch.empty((9, n, k), device=w.device, dtype=F32)
+            L.call('gnx_repack_conv3x3', L.ptr(w.detach().contiguous()), L.ptr(wr), n, k, st)
+            table[l] = wr
+        self._cache['w2'] = (key, table)
+        return table
+
+    def _geometry(self, P):
+        if self.small_inputs:
+            hs, s = None, P
+        else:
+            hs = (P + 6 - 7) // 2 + 1
+            s = (hs + 2 - 3) // 2 + 1
+        sizes = []
+        for _ in self._blocks:
+            sizes.append(s)
+            s = s // 2
+        return hs, sizes
+
+    def _auto_chunk(self, P, n):
+        if self.atonce is not None:
+            return max(1, min(int(self.atonce), n))
+        hs, sizes = self._geometry(P)
+        per_spot = 0
+        if hs is not None:
+            per_spot += hs * hs * self.features.conv0.out_channels
+        for (c_in, layers, trans, c_total), s in zip(self._blocks, sizes):
+            per_spot += s * s * c_total
+        per_spot += sizes[0] * sizes[0] * self.bn_size * self.growth_rate
+        # Later blocks have few positions per spot (S=4: 16), so a launch only fills 256 CUs when thousands of
+        # spots go through together: size chunks by HBM (288 GB), not by cache - a whole 128-px array is 17 GB.
+        budget = 40 * 1024 ** 3 // 4               # floats
+        return max(1, min(n, max(32, budget // max(per_spot, 1))))
+
+    # ------------------------------------------------------------------ optional per-kernel timing (bench.py)
+    _probe = None      # when a list: (kind, start_event, end_event) per dense-layer launch, on the launch stream
+
+    def _probe_begin(self):
+        if self._probe is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def _probe_mark(self, kind, start):
+        if self._probe is None:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self._probe.append((kind, start, ev))
+        return ev
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("gridnext_amd.DenseNet runs on a HIP device only (input is on %s); "
+                               "there is no CPU fallback" % x.device)
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3]:
+            raise ValueError("expected square RGB patches (N, 3, P, P), got %s" % (tuple(x.shape),))
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if self.training or needs_grad:
+            from .densenet_train import densenet_autograd       # training / gradient path
+            return densenet_autograd(self, x)
+        return self._forward_eval(x.detach())
+
+    @torch.no_grad()
+    def _forward_eval(self, x):
+        x = x.contiguous().float()
+        N, _, P, _ = x.shape
+        dev = x.device
+        st = L.stream()
+        fold = self._folded_eval()
+        w2 = self._repacked_conv2()
+        hs, sizes = self._geometry(P)
+        chunk = self._auto_chunk(P, N)
+        mid = self.bn_size * self.growth_rate
+        conv0 = self.features.conv0
+        c0 = conv0.out_channels
+        # workspace for one chunk
+        bufs = [torch.empty((chunk * s * s, c_total), device=dev, dtype=F32)
+                for (_, _, _, c_total), s in zip(self._blocks, sizes)]
+        bott = torch.empty((chunk * sizes[0] * sizes[0], mid), device=dev, dtype=F32)
+        stem_out = torch.empty((chunk * hs * hs, c0), device=dev, dtype=F32) if hs is not None else None
+        feats = torch.empty((N, self.num_features), device=dev, dtype=F32)
+        w0 = conv0.weight.detach().contiguous()
+
+        for s0 in range(0, N, chunk):
+            n = min(chunk, N - s0)
+            xs = x[s0:s0 + n]
+            ld1 = bufs[0].shape[1]
+            if self.small_inputs:
+                L.call('gnx_conv_stem', L.ptr(xs), L.ptr(w0), L.ptr(bufs[0]), ld1, n, 3, P, P, c0, 3, 3, 1, 1, st)
+            else:
+                sc, sh = fold[self.features.norm0]
+                L.call('gnx_conv_stem', L.ptr(xs), L.ptr(w0), L.ptr(stem_out), c0, n, 3, P, P, c0, 7, 7, 2, 3, st)
+                L.call('gnx_bnrelu_maxpool', L.ptr(stem_out), c0, L.ptr(bufs[0]), ld1, n, c0, hs, hs,
+                       L.ptr(sc), L.ptr(sh), st)
+            for bi, ((c_in, layers, trans, c_total), s) in enumerate(zip(self._blocks, sizes)):
+                buf = bufs[bi]
+                M = n * s * s
+                for li, layer in enumerate(layers):
+                    cin = c_in + li * self.growth_rate
+                    sc1, sh1 = fold[layer.norm1]
+                    sc2, sh2 = fold[layer.norm2]
+                    t0 = self._probe_begin()
+                    L.call('gnx_conv1x1_bnrelu', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid,
+                           M, mid, cin, L.ptr(sc1), L.ptr(sh1), 0, 0, st)
+                    t1 = self._probe_mark('conv1x1', t0)
+                    L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2[layer]), buf.data_ptr() + 4 * cin,
+                           c_total, M, self.growth_rate, mid, s, L.ptr(sc2), L.ptr(sh2), st)
+                    self._probe_mark('conv3x3', t1)
+                if trans is not None:
+                    nxt = bufs[bi + 1]
+                    so = s // 2
+                    sct, sht = fold[trans.norm]
+                    L.call('gnx_conv1x1_bnrelu', L.ptr(buf), c_total, L.ptr(trans.conv.weight), L.ptr(nxt),
+                           nxt.shape[1], n * so * so, trans.conv.out_channels, c_total, L.ptr(sct), L.ptr(sht),
+                           1, s, st)
+            scf, shf = fold[self.features.norm_final]
+            s_last = sizes[-1]
+            L.call('gnx_bnrelu_avgpool', L.ptr(bufs[-1]), bufs[-1].shape[1], L.ptr(feats[s0:]), self.num_features,
+                   n, self.num_features, s_last * s_last, L.ptr(scf), L.ptr(shf), st)
+        if not self.classify:
+            return feats
+        return GF.linear(feats, self.classifier.weight.detach(), self.classifier.bias.detach())

@@ -1,0 +1,132 @@
+"""Data-parallel layer for the f∘g training loops (new: the reference is single-process).
+
+One process per GPU (torchrun / torch.distributed.run); Visium arrays (grid loop) or spots (spot loop) are
+sharded round-robin over ranks; each rank runs f, g and the masked CE on its own arrays and the parameter
+gradients are summed with ONE flat all-reduce (RCCL over xGMI when the backend is "nccl") just before
+`optimizer.step()`, then divided by the world size.  With the corrector-only recipe of the tutorials the
+message is 27 144 floats (108.6 KB): a single latency-bound call; with f trainable it is 32 MB, still
+<1 ms against >=100 ms of compute per array, so no bucketing/overlap machinery is needed at this size.
+
+Semantics: per-rank batch = the reference's batch (1 array); averaging gradients over ranks equals the
+reference's gradient accumulation over `world` arrays with each array's foreground-mean weighted equally.
+BatchNorm statistics stay per-rank (as they are per-batch in the reference).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+from torch.utils.data import Sampler
+
+
+def is_active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def init_from_env(backend=None):
+    """Join the job described by RANK/WORLD_SIZE/MASTER_ADDR/MASTER_PORT (no-op for a single process).
+    Returns (rank, world_size, device)."""
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device('cuda:%d' % local) if use_gpu else torch.device('cpu')
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend or ('nccl' if use_gpu else 'gloo'))
+    return rank(), world_size(), device
+
+
+def default_device():
+    if torch.cuda.is_available():
+        return torch.device('cuda:%d' % int(os.environ.get('LOCAL_RANK', '0'))) if is_active() \
+            else torch.device('cuda:0')
+    return torch.device('cpu')
+
+
+def optimizer_params(*optimizers):
+    seen, out = set(), []
+    for opt in optimizers:
+        if opt is None:
+            continue
+        for group in opt.param_groups:
+            for p in group['params']:
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    out.append(p)
+    return out
+
+
+def allreduce_gradients(params):
+    """Average .grad over ranks with one flat all-reduce. Parameters without a gradient contribute zeros
+    (every rank must issue the same collective)."""
+    if not is_active():
+        return
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return
+    grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(world_size())
+    off = 0
+    for p, g in zip(params, grads):
+        n = g.numel()
+        if p.grad is None:
+            p.grad = flat[off:off + n].view_as(p).clone()
+        else:
+            p.grad.copy_(flat[off:off + n].view_as(p))
+        off += n
+
+
+def allreduce_sums(values, device):
+    """Sum a list of python numbers over ranks (epoch statistics)."""
+    if not is_active():
+        return list(values)
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.tolist()
+
+
+def broadcast_module(module, src=0):
+    """Make every rank start from rank `src`'s parameters and buffers."""
+    if not is_active():
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
+
+
+class ShardedSampler(Sampler):
+    """Round-robin shard of a dataset: rank r takes items r, r+world, ... (optionally reshuffled per epoch
+    with a seed shared by all ranks).  Every rank gets the same number of items (the tail wraps around)."""
+
+    def __init__(self, dataset, shuffle=False, seed=0, rank_=None, world=None):
+        self.n = len(dataset)
+        self.rank = rank() if rank_ is None else rank_
+        self.world = world_size() if world is None else world
+        self.shuffle, self.seed, self.epoch = shuffle, seed, 0
+        self.per_rank = (self.n + self.world - 1) // self.world
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.per_rank
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        while len(order) < self.per_rank * self.world:
+            order += order[:self.per_rank * self.world - len(order)]
+        return iter(order[self.rank::self.world])

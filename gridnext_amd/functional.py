@@ -1,0 +1,289 @@
+"""torch.autograd bridges from tensors to the C-ABI kernels (gridnext_amd/csrc, include/gridnext_hip.h).
+
+torch is plumbing here: it owns device memory (caching allocator), streams and the autograd tape;
+every arithmetic step below is a hand-written gfx950 kernel.  All matrices are channels-last:
+a spot (grid position) is a row, its features are contiguous.
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _lib as L
+
+F32 = torch.float32
+
+
+def _rows(t):
+    """(pointer-compatible 2-D view, leading dimension) of a [M, C] tensor whose rows are contiguous."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        t = t.contiguous()
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    return t, ld
+
+
+# ----------------------------------------------------------------------------- hexagonal convolution
+class _HexConv(Function):
+    @staticmethod
+    def forward(ctx, x, kernel0, kernel1, bias, mode):
+        x = x.contiguous()
+        B, H, W, I = x.shape
+        O = kernel0.shape[0]
+        k0, k1 = kernel0.contiguous(), kernel1.contiguous()
+        y = torch.empty((B, H, W, O), device=x.device, dtype=F32)
+        L.call('gnx_hexconv_fwd', L.ptr(x), L.ptr(k0), L.ptr(k1), L.ptr(bias), L.ptr(y), B, H, W, I, O, mode,
+               L.stream())
+        ctx.save_for_backward(x, k0, k1)
+        ctx.mode, ctx.has_bias = mode, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, k0, k1 = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, H, W, I = x.shape
+        O = k0.shape[0]
+        dx = dk0 = dk1 = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.call('gnx_hexconv_bwd_data', L.ptr(dy), L.ptr(k0), L.ptr(k1), L.ptr(dx), B, H, W, I, O, ctx.mode,
+                   L.stream())
+        if any(ctx.needs_input_grad[1:4]):
+            dk0, dk1 = torch.empty_like(k0), torch.empty_like(k1)
+            db = torch.empty(O, device=x.device, dtype=F32) if ctx.has_bias else None
+            ws = torch.empty(L.query('gnx_hexconv_bwd_weight_workspace', B, H, W, I, O), device=x.device, dtype=F32)
+            L.call('gnx_hexconv_bwd_weight', L.ptr(x), L.ptr(dy), L.ptr(dk0), L.ptr(dk1), L.ptr(db), L.ptr(ws),
+                   B, H, W, I, O, ctx.mode, 0, L.stream())
+        return dx, dk0, dk1, db, None
+
+
+def hexconv(x_nhwc, kernel0, kernel1, bias, oddr):
+    """7-neighbour hex conv on a channels-last grid [B, H, W, C]; oddr=True applies it on the Visium
+    odd-right grid directly (what gridnet_models.py:178-185 does with rot90/flip copies)."""
+    return _HexConv.apply(x_nhwc, kernel0, kernel1, bias, 1 if oddr else 0)
+
+
+# ----------------------------------------------------------------------------- batch norm (+ReLU)
+class _BNReLU(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps,
+                relu):
+        x, ld = _rows(x)
+        M, C = x.shape
+        dev = x.device
+        stats = torch.empty((4, C), device=dev, dtype=F32)          # scale, shift, mean, invstd
+        if training:
+            if momentum is None:
+                raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not on the GridNext path")
+            ws = torch.empty(L.query('gnx_bn_workspace', M, C), device=dev, dtype=F32)
+            L.call('gnx_bn_train_stats', L.ptr(x), ld, M, C, L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
+                   L.ptr(running_var), L.ptr(num_batches_tracked, torch.int64), float(momentum), float(eps),
+                   L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(ws), L.stream())
+        else:
+            L.call('gnx_bn_fold_eval', C, L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var),
+                   float(eps), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.stream())
+        y = torch.empty((M, C), device=dev, dtype=F32)
+        L.call('gnx_scale_shift_relu', L.ptr(x), ld, L.ptr(y), C, M, C, L.ptr(stats[0]), L.ptr(stats[1]),
+               1 if relu else 0, L.stream())
+        ctx.save_for_backward(x, stats)
+        ctx.cfg = (ld, bool(training), bool(relu), gamma is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats = ctx.saved_tensors
+        ld, training, relu, affine = ctx.cfg
+        M, C = x.shape
+        dy, lddy = _rows(dy)
+        dev = x.device
+        dx = torch.empty((M, C), device=dev, dtype=F32) if ctx.needs_input_grad[0] else None
+        want_affine = affine and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        dgamma = torch.empty(C, device=dev, dtype=F32) if want_affine else None
+        dbeta = torch.empty(C, device=dev, dtype=F32) if want_affine else None
+        ws = torch.empty(L.query('gnx_bn_workspace', M, C), device=dev, dtype=F32)
+        L.call('gnx_bn_relu_bwd', L.ptr(dy), lddy, L.ptr(x), ld, L.ptr(dx), C, M, C, L.ptr(stats[0]),
+               L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(dgamma), L.ptr(dbeta), 1 if relu else 0,
+               1 if training else 0, 0, L.ptr(ws), L.stream())
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def batch_norm_relu(x2d, bn, relu):
+    """BatchNorm1d/2d semantics of torch over the rows of x2d [M, C], optionally fused with ReLU.
+    Uses (and, in training mode, updates) the module's own parameters and buffers."""
+    training = bn.training or not bn.track_running_stats
+    return _BNReLU.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                         training, bn.momentum, bn.eps, relu)
+
+
+class _ReLURows(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x, ld = _rows(x)
+        M, C = x.shape
+        one = torch.ones(C, device=x.device, dtype=F32)
+        zero = torch.zeros(C, device=x.device, dtype=F32)
+        y = torch.empty((M, C), device=x.device, dtype=F32)
+        L.call('gnx_scale_shift_relu', L.ptr(x), ld, L.ptr(y), C, M, C, L.ptr(one), L.ptr(zero), 1, L.stream())
+        ctx.save_for_backward(x, one, zero)
+        ctx.ld = ld
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, one, zero = ctx.saved_tensors
+        M, C = x.shape
+        dy, lddy = _rows(dy)
+        dx = torch.empty((M, C), device=x.device, dtype=F32)
+        ws = torch.empty(L.query('gnx_bn_workspace', M, C), device=x.device, dtype=F32)
+        L.call('gnx_bn_relu_bwd', L.ptr(dy), lddy, L.ptr(x), ctx.ld, L.ptr(dx), C, M, C, L.ptr(one), L.ptr(zero),
+               L.ptr(zero), L.ptr(one), None, None, 1, 0, 0, L.ptr(ws), L.stream())
+        return dx
+
+
+def relu_rows(x2d):
+    return _ReLURows.apply(x2d)
+
+
+# ----------------------------------------------------------------------------- Linear (fp32 MFMA GEMM)
+class _Linear(Function):
+    """y[M,N] = A x W^T + b.  `x` is either [M, K] with contiguous rows, or - kmajor - a tensor
+    [B, K, S] (spot index contiguous: a (B, genes, H*W) count grid read in place), M = B*S."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, kmajor):
+        w = weight.contiguous()
+        N, K = w.shape
+        dev = x.device
+        if kmajor:
+            x = x.contiguous()
+            Bn, Kx, S = x.shape
+            assert Kx == K
+            M = Bn * S
+            y = torch.empty((M, N), device=dev, dtype=F32)
+            for b in range(Bn):
+                L.call('gnx_gemm_f32', L.ptr(x[b]), S, 1, L.ptr(w), K, 0, L.ptr(bias), L.ptr(y[b * S:]), N,
+                       S, N, K, 0, L.stream())
+            ctx.ld = S
+        else:
+            x, ld = _rows(x)
+            M = x.shape[0]
+            assert x.shape[1] == K
+            y = torch.empty((M, N), device=dev, dtype=F32)
+            L.call('gnx_gemm_f32', L.ptr(x), ld, 0, L.ptr(w), K, 0, L.ptr(bias), L.ptr(y), N, M, N, K, 0,
+                   L.stream())
+            ctx.ld = ld
+        ctx.save_for_backward(x, w)
+        ctx.kmajor, ctx.has_bias = bool(kmajor), bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, K = w.shape
+        dy, lddy = _rows(dy)
+        M = dy.shape[0]
+        dev = dy.device
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dX[M,K] = dY[M,N] . W[N,K]   (B operand stored [k'=n][n'=k] -> b_kmajor)
+            dxr = torch.empty((M, K), device=dev, dtype=F32)
+            L.call('gnx_gemm_f32', L.ptr(dy), lddy, 0, L.ptr(w), K, 1, None, L.ptr(dxr), K, M, K, N, 0, L.stream())
+            if ctx.kmajor:
+                Bn, _, S = x.shape
+                dx = dxr.view(Bn, S, K).transpose(1, 2)
+            else:
+                dx = dxr
+        if ctx.needs_input_grad[1]:
+            # dW[N,K] = dY^T[N,M] . X[M,K]   (A = dY read K-major)
+            dw = torch.empty((N, K), device=dev, dtype=F32)
+            if ctx.kmajor:
+                Bn, _, S = x.shape
+                for b in range(Bn):
+                    L.call('gnx_gemm_f32', L.ptr(dy[b * S:]), lddy, 1, L.ptr(x[b]), S, 0, None, L.ptr(dw), K,
+                           N, K, S, 1 if b else 0, L.stream())
+            else:
+                L.call('gnx_gemm_f32', L.ptr(dy), lddy, 1, L.ptr(x), ctx.ld, 1, None, L.ptr(dw), K, N, K, M, 0,
+                       L.stream())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(N, device=dev, dtype=F32)
+            ws = torch.empty(L.query('gnx_bn_workspace', M, N), device=dev, dtype=F32)
+            L.call('gnx_colsum', L.ptr(dy), lddy, M, N, L.ptr(db), 0, L.ptr(ws), L.stream())
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias, kmajor=False):
+    return _Linear.apply(x, weight, bias, kmajor)
+
+
+# ----------------------------------------------------------------------------- count-MLP as a fused pipeline
+_MLP_LAYERS = (nn.Linear, nn.BatchNorm1d, nn.ReLU)
+
+
+def is_hip_sequential(module):
+    """True for an nn.Sequential built only from Linear / BatchNorm1d / ReLU that starts with a Linear -
+    the spot head of the tutorials (Tutorial_visium_count.ipynb cell 12)."""
+    return (isinstance(module, nn.Sequential) and len(module) > 0 and isinstance(module[0], nn.Linear)
+            and all(type(m) in _MLP_LAYERS for m in module))
+
+
+def sequential_forward(seq, x, kmajor=False):
+    """Run the user's own nn.Sequential (its parameters, its BN buffers) through the HIP kernels.
+    x: [M, K] rows, or with kmajor a [B, K, S] count grid (see _Linear)."""
+    layers = list(seq)
+    i = 0
+    first = True
+    while i < len(layers):
+        m = layers[i]
+        if isinstance(m, nn.Linear):
+            x = linear(x, m.weight, m.bias, kmajor if first else False)
+            first = False
+            i += 1
+        elif isinstance(m, nn.BatchNorm1d):
+            fuse = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)
+            x = batch_norm_relu(x, m, relu=fuse)
+            i += 2 if fuse else 1
+        elif isinstance(m, nn.ReLU):
+            x = relu_rows(x)
+            i += 1
+        else:
+            raise TypeError("unsupported layer %r" % type(m))
+    return x
+
+
+# ----------------------------------------------------------------------------- masked cross-entropy
+class _MaskedCE(Function):
+    @staticmethod
+    def forward(ctx, logits, labels, label_base, accum_iters):
+        z, ld = _rows(logits)
+        M, C = z.shape
+        lab = labels.reshape(-1).contiguous()
+        if lab.dtype != torch.int64:
+            lab = lab.long()
+        dev = z.device
+        loss = torch.empty((), device=dev, dtype=F32)
+        stats = torch.empty(2, device=dev, dtype=torch.int64)
+        preds = torch.empty(M, device=dev, dtype=torch.int64)
+        ws = torch.empty(L.query('gnx_masked_ce_workspace', M), device=dev, dtype=torch.float64)
+        L.call('gnx_masked_ce_fwd', L.ptr(z), ld, L.ptr(lab, torch.int64), M, C, label_base, float(accum_iters),
+               L.ptr(loss), L.ptr(stats, torch.int64), L.ptr(preds, torch.int64), L.ptr(ws, torch.float64),
+               L.stream())
+        ctx.save_for_backward(z, lab, stats)
+        ctx.cfg = (ld, label_base, float(accum_iters))
+        ctx.mark_non_differentiable(stats, preds)
+        return loss, stats, preds
+
+    @staticmethod
+    def backward(ctx, dloss, _ds, _dp):
+        z, lab, stats = ctx.saved_tensors
+        ld, label_base, accum = ctx.cfg
+        M, C = z.shape
+        dz = torch.empty((M, C), device=z.device, dtype=F32)
+        dloss = dloss.contiguous()
+        L.call('gnx_masked_ce_bwd', L.ptr(z), ld, L.ptr(lab, torch.int64), M, C, label_base,
+               L.ptr(stats, torch.int64), L.ptr(dloss), accum, L.ptr(dz), C, L.stream())
+        return dz, None, None, None
+
+
+def masked_cross_entropy(logits_rows, labels, accum_iters=1, label_base=1):
+    """(loss, stats=[n_foreground, n_correct], preds) of training.py:152-160 on channels-last rows [M, C].
+    label_base=1: 0 is background (grid loop); label_base=0: plain mean CE (train_spotwise)."""
+    return _MaskedCE.apply(logits_rows, labels, label_base, accum_iters)

@@ -1,0 +1,228 @@
+"""Training loops of the f∘g path: `train_spotwise` (f alone) and `train_gridwise` (f frozen or not, then g).
+
+Drop-in for /root/reference/gridnext/training.py (:11-98, :101-209): same signatures, same printed lines
+('{phase} Loss: {:.4f} Acc: {:.4f}'), same return value (model, val_history, train_history), same side-effect
+files (`outfile`, and `<outfile stem>.opt` in the grid loop), and the reference's number-changing quirks:
+  * spot loop: zero_grad before every batch; epoch loss = sum(loss*batch)/len(dataset);
+  * grid loop: `model.patch_classifier.eval()` in BOTH phases (:126); no zero_grad before the first backward;
+    loss divided by `accum_iters` (also in the reported loss, :174); step iff batch_ind % accum_iters == 0
+    (batch 0 steps alone); optional second optimiser `f_opt`; accuracy over foreground spots only.
+
+What differs underneath (MI355X-first):
+  * on a HIP device with a plain `nn.CrossEntropyLoss()` the permute -> mask-gather -> CE -> argmax chain is ONE
+    fused kernel pair on channels-last logits (no dynamic shapes, no host sync per batch); epoch statistics are
+    accumulated on the device and read back once per phase;
+  * when torch.distributed is initialised with world_size > 1 the loop is data-parallel: gradients of the
+    optimised parameters are all-reduced (RCCL over xGMI) before every optimizer step, epoch statistics are
+    summed over ranks, rank 0 writes checkpoints.  Shard the arrays with `distributed.ShardedSampler`.
+Any other criterion, or CPU tensors, takes the generic path that spells the reference's tensor ops out.
+"""
+import copy
+import os
+import time
+
+import torch
+import torch.nn as nn
+
+from . import distributed as gdist
+from . import functional as GF
+
+
+def _plain_ce(criterion):
+    return (type(criterion) is nn.CrossEntropyLoss and criterion.weight is None and criterion.reduction == 'mean'
+            and criterion.ignore_index == -100 and getattr(criterion, 'label_smoothing', 0.0) == 0.0)
+
+
+def _to_device(inputs, device):
+    if isinstance(inputs, list):
+        return [t.to(device) for t in inputs]      # multi-modal input to GridNetHexMM
+    return inputs.to(device)
+
+
+class _PhaseMeter:
+    """Running loss / correct / counted-spot sums for one phase, kept where the numbers are produced."""
+
+    def __init__(self, device):
+        self.device = device
+        self.loss = 0.0            # python float (host path) or 0-dim float64 tensor (device path)
+        self.correct = 0
+        self.counted = 0
+
+    def add(self, loss, batch_size, correct, counted):
+        if torch.is_tensor(loss):
+            loss = loss.detach().double() * batch_size
+        self.loss = self.loss + loss
+        self.correct = self.correct + correct
+        self.counted = self.counted + counted
+
+    def totals(self):
+        vals = [float(v) for v in (self.loss, self.correct, self.counted)]      # the only host sync of a phase
+        return gdist.allreduce_sums(vals, self.device)
+
+
+class _BestKeeper:
+    def __init__(self, model):
+        self.model = model
+        self.best_loss = float('inf')
+        self.best_wts = copy.deepcopy(model.state_dict())
+
+    def offer(self, epoch_loss):
+        if epoch_loss < self.best_loss:
+            self.best_loss = epoch_loss
+            self.best_wts = copy.deepcopy(self.model.state_dict())
+            return True
+        return False
+
+
+def _banner(epoch, num_epochs):
+    if gdist.rank() == 0:
+        print('Epoch {}/{}'.format(epoch, num_epochs - 1), flush=True)
+        print('-' * 10, flush=True)
+
+
+def _report(phase, loss, acc):
+    if gdist.rank() == 0:
+        print('{} Loss: {:.4f} Acc: {:.4f}'.format(phase, loss, acc), flush=True)
+
+
+def _finish(since, best_loss):
+    if gdist.rank() == 0:
+        elapsed = time.time() - since
+        print('Training complete in {:.0f}m {:.0f}s'.format(elapsed // 60, elapsed % 60), flush=True)
+        print('Best val loss: {:4f}'.format(best_loss), flush=True)
+
+
+# --------------------------------------------------------------------------------------------------- spot loop
+def train_spotwise(model, dataloaders, criterion, optimizer, num_epochs=10, outfile=None, display=False):
+    since = time.time()
+    val_history, train_history = [], []
+    keeper = _BestKeeper(model)
+    device = gdist.default_device()
+    model.to(device)
+    fused_ok = _plain_ce(criterion)
+    hip_mlp = GF.is_hip_sequential(model)
+
+    for epoch in range(num_epochs):
+        _banner(epoch, num_epochs)
+        for phase in ('train', 'val'):
+            model.train(phase == 'train')
+            meter = _PhaseMeter(device)
+            loader = dataloaders[phase]
+            if hasattr(getattr(loader, 'sampler', None), 'set_epoch'):
+                loader.sampler.set_epoch(epoch)
+            if display:
+                from tqdm import tqdm
+                loader = tqdm(loader)
+            for inputs, labels in loader:
+                batch_size = labels.size(0)
+                inputs, labels = _to_device(inputs, device), labels.to(device)
+                optimizer.zero_grad()
+                with torch.set_grad_enabled(phase == 'train'):
+                    if hip_mlp and torch.is_tensor(inputs) and inputs.is_cuda:
+                        outputs = GF.sequential_forward(model, inputs.reshape(batch_size, -1))
+                    else:
+                        outputs = model(inputs)
+                    if fused_ok and outputs.is_cuda and outputs.dim() == 2:
+                        loss, stats, _ = GF.masked_cross_entropy(outputs, labels, 1, label_base=0)
+                        correct = stats[1]
+                    else:
+                        loss = criterion(outputs, labels)
+                        correct = torch.sum(torch.max(outputs, 1)[1] == labels.data)
+                    if phase == 'train':
+                        loss.backward()
+                        gdist.allreduce_gradients(gdist.optimizer_params(optimizer))
+                        optimizer.step()
+                meter.add(loss if outputs.is_cuda else loss.item(), batch_size, correct, batch_size)
+            loss_sum, n_right, _ = meter.totals()
+            n_items = len(dataloaders[phase].dataset)
+            epoch_loss, epoch_acc = loss_sum / n_items, n_right / n_items
+            _report(phase, epoch_loss, epoch_acc)
+            if phase == 'val':
+                if keeper.offer(epoch_loss) and outfile is not None and gdist.rank() == 0:
+                    torch.save(model.state_dict(), outfile)
+                val_history.append(epoch_loss)
+            else:
+                train_history.append(epoch_loss)
+        if gdist.rank() == 0:
+            print()
+    _finish(since, keeper.best_loss)
+    model.load_state_dict(keeper.best_wts)
+    return model, val_history, train_history
+
+
+# --------------------------------------------------------------------------------------------------- grid loop
+def _grid_loss(model, inputs, labels, criterion, accum_iters, fused_ok):
+    """(loss, n_correct, n_foreground) for one batch of arrays."""
+    if fused_ok and hasattr(model, 'forward_nhwc') and labels.is_cuda:
+        logits = model.forward_nhwc(inputs)                         # [B, H, W, C] channels-last
+        assert logits.shape[1] == labels.shape[1] and logits.shape[2] == labels.shape[2], \
+            "Output tensor does not match label dimensions!"
+        loss, stats, _ = GF.masked_cross_entropy(logits.reshape(-1, logits.shape[-1]), labels, accum_iters,
+                                                 label_base=1)
+        return loss, stats[1], stats[0]
+    outputs = model(inputs)
+    assert outputs.shape[2] == labels.shape[1] and outputs.shape[3] == labels.shape[2], \
+        "Output tensor does not match label dimensions!"
+    rows = outputs.permute(0, 2, 3, 1).reshape(-1, outputs.shape[1])
+    flat = labels.reshape(-1)
+    keep = flat > 0
+    rows, flat = rows[keep], flat[keep] - 1                         # foreground classes are 1..N_CLASS
+    loss = criterion(rows, flat) / accum_iters
+    correct = torch.sum(torch.max(rows, 1)[1] == flat)
+    return loss, correct, flat.numel()
+
+
+def train_gridwise(model, dataloaders, criterion, optimizer, num_epochs=10, outfile=None,
+                   f_opt=None, accum_iters=1):
+    since = time.time()
+    train_history, val_history = [], []
+    keeper = _BestKeeper(model)
+    device = gdist.default_device()
+    model.to(device)
+    fused_ok = _plain_ce(criterion)
+    stepped = gdist.optimizer_params(optimizer, f_opt)
+
+    for epoch in range(num_epochs):
+        _banner(epoch, num_epochs)
+        for phase in ('train', 'val'):
+            model.train(phase == 'train')
+            model.patch_classifier.eval()           # f's BN/dropout stay frozen in both phases
+            meter = _PhaseMeter(device)
+            loader = dataloaders[phase]
+            if hasattr(getattr(loader, 'sampler', None), 'set_epoch'):
+                loader.sampler.set_epoch(epoch)
+            for batch_ind, (inputs, labels) in enumerate(loader):
+                batch_size = labels.size(0)
+                inputs, labels = _to_device(inputs, device), labels.to(device)
+                with torch.set_grad_enabled(phase == 'train'):
+                    loss, correct, n_fg = _grid_loss(model, inputs, labels, criterion, accum_iters, fused_ok)
+                    if phase == 'train':
+                        loss.backward()
+                        if batch_ind % accum_iters == 0:
+                            gdist.allreduce_gradients(stepped)
+                            optimizer.step()
+                            optimizer.zero_grad()
+                            if f_opt is not None:
+                                f_opt.step()
+                                f_opt.zero_grad()
+                meter.add(loss if labels.is_cuda else loss.item(), batch_size, correct, n_fg)
+            loss_sum, n_right, n_fg_total = meter.totals()
+            epoch_loss = loss_sum / len(dataloaders[phase].dataset)
+            epoch_acc = n_right / n_fg_total if n_fg_total else float('nan')
+            _report(phase, epoch_loss, epoch_acc)
+            if phase == 'val':
+                if keeper.offer(epoch_loss) and outfile is not None and gdist.rank() == 0:
+                    torch.save(model.state_dict(), outfile)
+                    opt_file = os.path.splitext(outfile)[0] + ".opt"
+                    if f_opt is not None:
+                        torch.save({'g_opt': optimizer.state_dict(), 'f_opt': f_opt.state_dict()}, opt_file)
+                    else:
+                        torch.save(optimizer.state_dict(), opt_file)
+                val_history.append(epoch_loss)
+            else:
+                train_history.append(epoch_loss)
+        if gdist.rank() == 0:
+            print()
+    _finish(since, keeper.best_loss)
+    model.load_state_dict(keeper.best_wts)
+    return model, val_history, train_history

@@ -1,0 +1,101 @@
+/* gridnext_hip.h - C ABI of libgridnext_hip.so: the MI355X (gfx950) kernels of GridNext's f∘g training path.
+ *
+ * The reference (adaly/gridnext) is pure Python on stock PyTorch and has NO FFI of its own; each entry point
+ * below replaces the torch operator sequence at the cited reference location (paths relative to the reference
+ * root).  Conventions:
+ *   - plain C: device pointers + sizes + a stream handle (hipStream_t passed as void*); no torch types;
+ *   - the caller owns every buffer (outputs and workspaces included); nothing is allocated, freed or cached
+ *     across calls inside the library, kernels are enqueued on `stream` and the call returns immediately;
+ *   - return value 0 = enqueued, <0 = error (GNX_ERR_*), never throws; re-entrant per stream;
+ *   - activations are channels-last fp32 matrices X[rows][channels] with a leading dimension `ld*` in
+ *     elements (rows = spots, or spots x H x W); labels are int64.
+ */
+#ifndef GRIDNEXT_HIP_H
+#define GRIDNEXT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNX_OK 0
+#define GNX_ERR_BAD_ARG (-1)
+#define GNX_ERR_LAUNCH (-2)
+#define GNX_ERR_UNSUPPORTED (-3)
+
+typedef void* gnx_stream_t; /* hipStream_t */
+
+/* ---- corrector g: hexagonal convolution --------------------------------------------------------------------
+ * Replaces hexagdly.Conv2d(kernel_size=1, stride=1, bias=True) as instantiated in
+ * gridnext/gridnet_models.py:130-147.  x/y/dx/dy: [B][H][W][C] channels-last.  kernel0 [O][I][3][1],
+ * kernel1 [O][I][2][2], bias [O] (hexagdly's parameter shapes).  mode 0: hexagdly addressing (odd columns
+ * shifted down, gridnext/hexagdly_tools.py:68); mode 1: Visium odd-right grid, i.e. the
+ * rot90/flip -> conv -> flip/rot90 sandwich of gridnet_models.py:178-185 without moving data. */
+int gnx_hexconv_fwd(const float* x, const float* kernel0, const float* kernel1, const float* bias, float* y,
+                    int B, int H, int W, int I, int O, int mode, gnx_stream_t stream);
+int gnx_hexconv_bwd_data(const float* dy, const float* kernel0, const float* kernel1, float* dx,
+                         int B, int H, int W, int I, int O, int mode, gnx_stream_t stream);
+long gnx_hexconv_bwd_weight_workspace(int B, int H, int W, int I, int O); /* floats */
+int gnx_hexconv_bwd_weight(const float* x, const float* dy, float* dkernel0, float* dkernel1, float* dbias,
+                           float* workspace, int B, int H, int W, int I, int O, int mode, int accumulate,
+                           gnx_stream_t stream);
+
+/* ---- batch normalisation (+ReLU) over matrix rows -----------------------------------------------------------
+ * nn.BatchNorm2d(32) of the corrector (gridnet_models.py:134-146) and nn.BatchNorm1d of the count MLP
+ * (notebooks/Tutorial_visium_count.ipynb cell 12), torch semantics (biased var to normalise, unbiased for
+ * running_var, momentum, num_batches_tracked). */
+long gnx_bn_workspace(long M, int C); /* floats, for train_stats / relu_bwd / colsum */
+int gnx_bn_train_stats(const float* x, long ld, long M, int C, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                       float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
+                       float* workspace, gnx_stream_t stream);
+int gnx_bn_fold_eval(int C, const float* gamma, const float* beta, const float* running_mean,
+                     const float* running_var, float eps, float* scale, float* shift, float* save_mean,
+                     float* save_invstd, gnx_stream_t stream);
+int gnx_scale_shift_relu(const float* x, long ldx, float* y, long ldy, long M, int C, const float* scale,
+                         const float* shift, int relu, gnx_stream_t stream);
+int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long ldx, float* dx, long lddx, long M, int C,
+                    const float* scale, const float* shift, const float* save_mean, const float* save_invstd,
+                    float* dgamma, float* dbeta, int relu, int training, int accumulate, float* workspace,
+                    gnx_stream_t stream);
+int gnx_colsum(const float* x, long ld, long M, int C, float* out, int accumulate, float* workspace,
+               gnx_stream_t stream);
+
+/* ---- foreground-masked softmax cross-entropy + argmax/accuracy ------------------------------------------------
+ * The permute/reshape/boolean-gather/labels-1/CrossEntropyLoss/torch.max chain of gridnext/training.py:152-160,
+ * :176-177 (label_base 1) and the plain CE + argmax of :61-62 (label_base 0).  stats = {n_counted, n_correct}. */
+long gnx_masked_ce_workspace(long M); /* doubles */
+int gnx_masked_ce_fwd(const float* logits, long ld, const long long* labels, long M, int C, int label_base,
+                      float accum_iters, float* loss, long long* stats, long long* preds, double* workspace,
+                      gnx_stream_t stream);
+int gnx_masked_ce_bwd(const float* logits, long ld, const long long* labels, long M, int C, int label_base,
+                      const long long* stats, const float* dloss, float accum_iters, float* dlogits, long lddz,
+                      gnx_stream_t stream);
+
+/* ---- count-MLP spot head: fp32 MFMA GEMM -------------------------------------------------------------------------
+ * F.linear forward / input-gradient / weight-gradient of the nn.Sequential in Tutorial_visium_count.ipynb cell 12.
+ * C[M][N] = opA(A) opB(B) (+bias) (+C).  a_kmajor: A[k*lda+m] (a (genes, H*W) count grid read in place, replacing
+ * the permute+copy of gridnet_models.py:167-169); b_kmajor: B[k*ldb+n]. */
+int gnx_gemm_f32(const float* A, long lda, int a_kmajor, const float* B, long ldb, int b_kmajor, const float* bias,
+                 float* C, long ldc, long M, long N, long K, int accumulate, gnx_stream_t stream);
+
+/* ---- DenseNet-BC image spot classifier, forward (gridnext/densenet.py) ------------------------------------------------
+ * conv1x1_bnrelu : _DenseLayer norm1->relu1->conv1 (:35-40) and _Transition norm->relu->conv->pool (:47-54, pool=1)
+ * conv3x3_bnrelu : _DenseLayer norm2->relu2->conv2 (:41); weights repacked by gnx_repack_conv3x3 to [tap][N][K]
+ * conv_stem      : features.conv0 (:98-105), NCHW patches in, channels-last out
+ * bnrelu_maxpool : norm0->relu0->pool0 (:106-110);  bnrelu_avgpool : norm_final->relu->adaptive_avg_pool (:153-156) */
+int gnx_conv1x1_bnrelu(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
+                       const float* scale, const float* shift, int pool, int S_in, gnx_stream_t stream);
+int gnx_repack_conv3x3(const float* w, float* wr, int N, int K, gnx_stream_t stream);
+int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, float* out, long ldc, long M, int N, int K, int S,
+                       const float* scale, const float* shift, gnx_stream_t stream);
+int gnx_conv_stem(const float* x, const float* w, float* out, long ldc, long imgs, int Cin, int H, int W, int O,
+                  int KH, int KW, int stride, int pad, gnx_stream_t stream);
+int gnx_bnrelu_maxpool(const float* in, long ldi, float* out, long ldo, long imgs, int C, int Hi, int Wi,
+                       const float* scale, const float* shift, gnx_stream_t stream);
+int gnx_bnrelu_avgpool(const float* in, long ldi, float* out, long ldo, long imgs, int C, int S2,
+                       const float* scale, const float* shift, gnx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRIDNEXT_HIP_H */

@@ -1,0 +1,307 @@
+"""GPU parity: every C-ABI kernel family against the CPU oracle / a plain fp32 torch reference on the same
+seeded inputs.  Tolerances are fp32 round-off (different summation order), stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from conftest import load_golden, sub
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, what=''):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.numel() == 0:
+        return
+    err = (a - b).abs().max().item()
+    tol = atol + rtol * b.abs().max().item()
+    assert err <= tol, "%s max abs err %.3e > tol %.3e" % (what, err, tol)
+
+
+@pytest.fixture(scope='module')
+def GF():
+    from gridnext_amd import functional
+    return functional
+
+
+@pytest.fixture(scope='module')
+def L():
+    from gridnext_amd import _lib
+    return _lib
+
+
+# ----------------------------------------------------------------------------------------------- hex conv
+@pytest.mark.parametrize("B,H,W,I,O,oddr", [(2, 7, 6, 5, 9, True), (1, 78, 64, 16, 32, True),
+                                             (2, 9, 8, 32, 7, False), (1, 5, 4, 14, 32, True),
+                                             (3, 1, 1, 3, 4, True), (1, 2, 3, 32, 32, False)])
+def test_hexconv_fwd_bwd(GF, B, H, W, I, O, oddr):
+    from oracle import hexconv as ohex
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + I)
+    x = torch.randn(B, I, H, W, generator=g)
+    k0 = torch.randn(O, I, 3, 1, generator=g) * 0.3
+    k1 = torch.randn(O, I, 2, 2, generator=g) * 0.3
+    b = torch.randn(O, generator=g)
+    dy = torch.randn(B, O, H, W, generator=g)
+    xr, k0r, k1r, br = [t.clone().requires_grad_(True) for t in (x, k0, k1, b)]
+    ref = ohex.hexconv_oddr(xr, k0r, k1r, br) if oddr else ohex.hexconv_gather(xr, k0r, k1r, br)
+    ref.backward(dy)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    k0d, k1d, bd = [t.to(DEV).requires_grad_(True) for t in (k0, k1, b)]
+    out = GF.hexconv(xd, k0d, k1d, bd, oddr)
+    out.backward(dy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    close(out.permute(0, 3, 1, 2), ref, what='y')
+    close(xd.grad.permute(0, 3, 1, 2), xr.grad, what='dx')
+    close(k0d.grad, k0r.grad, rtol=2e-4, what='dk0')
+    close(k1d.grad, k1r.grad, rtol=2e-4, what='dk1')
+    close(bd.grad, br.grad, rtol=2e-4, what='db')
+
+
+def test_hexagdly_compatible_module(GF):
+    import gridnext_amd.hexconv as hexagdly
+    from oracle import hexconv as ohex
+    torch.manual_seed(3)
+    m = hexagdly.Conv2d(6, 10, kernel_size=1, stride=1, bias=True)
+    assert set(dict(m.named_parameters())) == {'kernel0', 'kernel1', 'bias_tensor'}
+    assert float(m.bias_tensor.detach()[0]) == pytest.approx(0.01)
+    x = torch.randn(2, 6, 9, 7)
+    ref = ohex.hexconv_subconv(x, m.kernel0.detach(), m.kernel1.detach(), m.bias_tensor.detach())
+    close(m.to(DEV)(x.to(DEV)), ref)
+
+
+# ----------------------------------------------------------------------------------------------- batch norm
+@pytest.mark.parametrize("M,C,relu,training", [(300, 32, True, True), (4992, 100, True, True), (77, 50, False, True),
+                                               (512, 32, True, False), (5, 3, True, True)])
+def test_bn_relu_fwd_bwd(GF, M, C, relu, training):
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g) * 3 + 5            # mean >> 0: exercises the two-pass variance
+    dy = torch.randn(M, C, generator=g)
+    bn_ref = nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn_ref.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn_ref.bias.copy_(torch.randn(C, generator=g))
+        bn_ref.running_mean.copy_(torch.randn(C, generator=g))
+        bn_ref.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    import copy
+    bn_hip = copy.deepcopy(bn_ref).to(DEV)
+    bn_ref.train(training)
+    bn_hip.train(training)
+    xr = x.clone().requires_grad_(True)
+    yr = bn_ref(xr)
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy)
+    xd = x.to(DEV).requires_grad_(True)
+    yd = GF.batch_norm_relu(xd, bn_hip, relu)
+    yd.backward(dy.to(DEV))
+    close(yd, yr, what='y')
+    close(xd.grad, xr.grad, rtol=3e-4, what='dx')
+    close(bn_hip.weight.grad, bn_ref.weight.grad, rtol=3e-4, atol=1e-4, what='dgamma')
+    close(bn_hip.bias.grad, bn_ref.bias.grad, rtol=3e-4, atol=1e-4, what='dbeta')
+    close(bn_hip.running_mean, bn_ref.running_mean, what='running_mean')
+    close(bn_hip.running_var, bn_ref.running_var, what='running_var')
+    assert int(bn_hip.num_batches_tracked) == int(bn_ref.num_batches_tracked)
+
+
+# ----------------------------------------------------------------------------------------------- masked CE
+def test_masked_ce_reference_maps(GF):
+    g = load_golden('masked_ce_maynard')
+    z = torch.from_numpy(g['logits'])                      # (7, 78, 64)
+    lab = torch.from_numpy(g['labels'])
+    rows = z.permute(1, 2, 0).reshape(-1, 7).contiguous().to(DEV)
+    for accum in (1, 4):
+        r = rows.clone().requires_grad_(True)
+        loss, stats, preds = GF.masked_cross_entropy(r, lab.to(DEV), accum)
+        loss.backward()
+        assert abs(loss.item() - float(g['loss_accum%d' % accum])) < 1e-5          # north-star CE tolerance 1e-4
+        grad = r.grad.reshape(78, 64, 7).permute(2, 0, 1)
+        close(grad, g['grad_accum%d' % accum], rtol=1e-4, atol=1e-9)
+        assert int(stats[0]) == int((lab > 0).sum())
+    from oracle import masked_ce as oce
+    _, p_ref, t_ref = oce.masked_ce(z.unsqueeze(0), lab.unsqueeze(0))
+    fg = (lab.reshape(-1) > 0)
+    assert torch.equal(preds.cpu()[fg], p_ref)
+    assert int(stats[1]) == int((p_ref == t_ref).sum())
+
+
+@pytest.mark.parametrize("M,C,base", [(1, 2, 1), (1000, 8, 1), (257, 5, 0), (4992, 8, 1)])
+def test_masked_ce_random(GF, M, C, base):
+    g = torch.Generator().manual_seed(M)
+    z = torch.randn(M, C, generator=g) * 4
+    lab = torch.randint(0, C + base, (M,), generator=g)
+    if base == 1:
+        lab[0] = 1
+    zr = z.clone().requires_grad_(True)
+    keep = lab >= base
+    ref = F.cross_entropy(zr[keep], lab[keep] - base) / 3
+    ref.backward()
+    zd = z.to(DEV).requires_grad_(True)
+    loss, stats, preds = GF.masked_cross_entropy(zd, lab.to(DEV), 3, label_base=base)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5
+    close(zd.grad, zr.grad, rtol=1e-4, atol=1e-9)
+    assert int(stats[0]) == int(keep.sum())
+    assert torch.equal(preds.cpu(), z.argmax(1))
+
+
+def test_masked_ce_no_foreground_is_nan_like_torch(GF):
+    z = torch.randn(10, 4).to(DEV)
+    loss, stats, _ = GF.masked_cross_entropy(z, torch.zeros(10, dtype=torch.long, device=DEV), 1)
+    assert torch.isnan(loss).item() and int(stats[0]) == 0
+
+
+# ----------------------------------------------------------------------------------------------- Linear / MLP
+@pytest.mark.parametrize("M,K,N", [(128, 2000, 500), (4992, 100, 50), (77, 53, 9), (1, 7, 3), (300, 64, 130)])
+def test_linear_rows(GF, M, K, N):
+    g = torch.Generator().manual_seed(M + K + N)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    F.linear(xr, wr, br).backward(dy)
+    xd, wd, bd = [t.to(DEV).requires_grad_(True) for t in (x, w, b)]
+    y = GF.linear(xd, wd, bd)
+    y.backward(dy.to(DEV))
+    close(y, F.linear(x, w, b), rtol=2e-5 * max(1, K ** 0.5), what='y')
+    close(xd.grad, xr.grad, rtol=1e-4, what='dx')
+    close(wd.grad, wr.grad, rtol=1e-4 * max(1, M ** 0.5 / 8), what='dw')
+    close(bd.grad, br.grad, rtol=1e-4 * max(1, M ** 0.5 / 8), what='db')
+
+
+def test_linear_count_grid_in_place(GF):
+    # (B, genes, H*W) count grid consumed K-major == permute(0,2,1).reshape(-1, genes) rows
+    g = torch.Generator().manual_seed(5)
+    B, G, S, N = 2, 203, 78 * 64, 37
+    x = torch.randint(0, 10, (B, G, S), generator=g).float()
+    w, b = torch.randn(N, G, generator=g) * 0.05, torch.randn(N, generator=g)
+    dy = torch.randn(B * S, N, generator=g)
+    wr = w.clone().requires_grad_(True)
+    ref = F.linear(x.permute(0, 2, 1).reshape(-1, G), wr, b)
+    ref.backward(dy)
+    wd = w.to(DEV).requires_grad_(True)
+    y = GF.linear(x.to(DEV), wd, b.to(DEV), kmajor=True)
+    y.backward(dy.to(DEV))
+    close(y, ref, rtol=1e-4)
+    close(wd.grad, wr.grad, rtol=2e-3)
+
+
+def test_count_mlp_pipeline_vs_reference_fixture(GF):
+    from gridnext_amd.synthetic import count_mlp
+    g = load_golden('mlp_count')
+    f = count_mlp(200, 8)
+    f.load_state_dict(sub(g, 'sd'))
+    f.to(DEV)
+    x = torch.from_numpy(g['x']).to(DEV)
+    f.eval()
+    close(GF.sequential_forward(f, x), g['eval_out'], rtol=1e-4, what='eval')
+    f.train()
+    xg = x.clone().requires_grad_(True)
+    y = GF.sequential_forward(f, xg)
+    close(y, g['train_out'], rtol=2e-4, what='train')
+    loss, stats, _ = GF.masked_cross_entropy(y, torch.from_numpy(g['labels']).to(DEV), 1, label_base=0)
+    loss.backward()
+    assert abs(loss.item() - float(g['train_loss'])) < 1e-4
+    close(xg.grad, g['traingrad/x'], rtol=1e-3, atol=1e-7)
+    for k, p in f.named_parameters():
+        close(p.grad, g['traingrad/' + k], rtol=2e-3, atol=1e-6, what=k)
+    for k, ref in sub(g, 'post').items():
+        close(f.state_dict()[k], ref, rtol=1e-4, what=k)
+
+
+# ----------------------------------------------------------------------------------------------- DenseNet pieces
+def _call_conv1x1(L, A, W, scale, shift, pool=0, S=0, ldc=None, col0=0):
+    M_in, K = A.shape
+    N = W.shape[0]
+    M = M_in // 4 if pool else M_in
+    ldc = ldc or N
+    out = torch.zeros((M, ldc), device=DEV)
+    L.call('gnx_conv1x1_bnrelu', L.ptr(A), A.stride(0), L.ptr(W), out.data_ptr() + 4 * col0, ldc, M, N, K,
+           L.ptr(scale), L.ptr(shift), pool, S, L.stream())
+    return out
+
+
+@pytest.mark.parametrize("M,K,N,act", [(1024, 64, 128, True), (300, 22, 12, True), (129, 96, 128, False),
+                                       (4096, 224, 128, True), (64, 1024, 512, True), (5, 3, 2, True)])
+def test_conv1x1_bnrelu(L, M, K, N, act):
+    g = torch.Generator().manual_seed(M + K)
+    Afull = torch.randn(M, K + 8, generator=g)                   # leading dimension != K
+    A = Afull[:, :K]
+    W = torch.randn(N, K, generator=g) * 0.1
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+    a = torch.relu(A * sc + sh) if act else A
+    ref = a @ W.t()
+    Ad = Afull.to(DEV)[:, :K]
+    assert Ad.stride(0) == K + 8
+    out = _call_conv1x1(L, Ad, W.to(DEV), sc.to(DEV) if act else None, sh.to(DEV) if act else None)
+    close(out, ref, rtol=1e-4 * max(1, K ** 0.5 / 4))
+
+
+@pytest.mark.parametrize("n,S,K,N", [(3, 8, 64, 32), (2, 7, 10, 5), (1, 32, 256, 128)])
+def test_transition_pool_first(L, n, S, K, N):
+    g = torch.Generator().manual_seed(S + K)
+    x = torch.randn(n, K, S, S, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.1
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+    ref = F.avg_pool2d(F.conv2d(torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), W.view(N, K, 1, 1)), 2, 2)
+    A = x.permute(0, 2, 3, 1).reshape(-1, K).contiguous().to(DEV)
+    So = S // 2
+    out = torch.zeros((n * So * So, N), device=DEV)
+    Wd, scd, shd = W.to(DEV), sc.to(DEV), sh.to(DEV)          # keep device buffers alive across the async launch
+    L.call('gnx_conv1x1_bnrelu', L.ptr(A), K, L.ptr(Wd), L.ptr(out), N, n * So * So, N, K,
+           L.ptr(scd), L.ptr(shd), 1, S, L.stream())
+    close(out.reshape(n, So, So, N).permute(0, 3, 1, 2), ref, rtol=2e-4)
+
+
+@pytest.mark.parametrize("n,S,K,N,act", [(2, 8, 128, 32, True), (3, 4, 12, 6, True), (1, 32, 128, 32, True),
+                                         (5, 7, 16, 4, False), (2, 14, 128, 32, True), (1, 56, 8, 4, True),
+                                         (33, 4, 128, 32, True), (1, 1, 8, 4, True), (2, 2, 128, 32, True)])
+def test_conv3x3_bnrelu(L, n, S, K, N, act):
+    g = torch.Generator().manual_seed(S * 100 + K)
+    x = torch.randn(n, K, S, S, generator=g)
+    W = torch.randn(N, K, 3, 3, generator=g) * 0.1
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+    a = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if act else x
+    ref = F.conv2d(a, W, padding=1)
+    A = x.permute(0, 2, 3, 1).reshape(-1, K).contiguous().to(DEV)
+    Wd = W.to(DEV)
+    Wr = torch.empty((9, N, K), device=DEV)
+    L.call('gnx_repack_conv3x3', L.ptr(Wd), L.ptr(Wr), N, K, L.stream())
+    ldc = N + 5
+    out = torch.full((n * S * S, ldc), 7.0, device=DEV)
+    scd, shd = sc.to(DEV), sh.to(DEV)
+    L.call('gnx_conv3x3_bnrelu', L.ptr(A), K, L.ptr(Wr), out.data_ptr() + 4 * 3, ldc, n * S * S, N, K, S,
+           L.ptr(scd) if act else None, L.ptr(shd) if act else None, L.stream())
+    close(out[:, 3:3 + N].reshape(n, S, S, N).permute(0, 3, 1, 2), ref, rtol=2e-4)
+    assert float(out[:, :3].min()) == 7.0 and float(out[:, 3 + N:].min()) == 7.0     # neighbours untouched
+
+
+@pytest.mark.parametrize("n,P,O,KH,stride,pad", [(3, 32, 8, 7, 2, 3), (2, 128, 64, 7, 2, 3), (2, 16, 10, 3, 1, 1),
+                                                 (1, 30, 24, 7, 2, 3)])
+def test_stem_conv_and_pools(L, n, P, O, KH, stride, pad):
+    g = torch.Generator().manual_seed(P + O)
+    x = torch.rand(n, 3, P, P, generator=g)
+    W = torch.randn(O, 3, KH, KH, generator=g) * 0.1
+    ref = F.conv2d(x, W, stride=stride, padding=pad)
+    Ho = ref.shape[2]
+    out = torch.zeros((n * Ho * Ho, O), device=DEV)
+    xd, Wd = x.to(DEV), W.to(DEV)
+    L.call('gnx_conv_stem', L.ptr(xd), L.ptr(Wd), L.ptr(out), O, n, 3, P, P, O, KH, KH, stride, pad,
+           L.stream())
+    close(out.reshape(n, Ho, Ho, O).permute(0, 3, 1, 2), ref, rtol=1e-4)
+    sc, sh = torch.rand(O, generator=g) + 0.5, torch.randn(O, generator=g) * 0.2
+    act = torch.relu(ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    mp = F.max_pool2d(act, 3, 2, 1)
+    Hp = mp.shape[2]
+    pooled = torch.zeros((n * Hp * Hp, O + 4), device=DEV)
+    scd, shd = sc.to(DEV), sh.to(DEV)
+    L.call('gnx_bnrelu_maxpool', L.ptr(out), O, L.ptr(pooled), O + 4, n, O, Ho, Ho, L.ptr(scd),
+           L.ptr(shd), L.stream())
+    close(pooled[:, :O].reshape(n, Hp, Hp, O).permute(0, 3, 1, 2), mp, rtol=1e-4)
+    gap = torch.zeros((n, O), device=DEV)
+    L.call('gnx_bnrelu_avgpool', L.ptr(out), O, L.ptr(gap), O, n, O, Ho * Ho, L.ptr(scd), L.ptr(shd),
+           L.stream())
+    close(gap, act.mean((2, 3)), rtol=1e-4)
