@@ -46,7 +46,7 @@ __device__ __forceinline__ float4 ld4_safe(const float* p, int valid, bool vec) 
 // POOL: row m is a position of the (S_in/2)^2 grid; its A-row is the mean of the 4 activated source rows.
 constexpr int C1_BM = 128, C1_BN = 128, C1_BK = 32;
 
-template <bool POOL>
+template <bool POOL, bool FAST>
 __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ A, long lda,
                                                       const float* __restrict__ W, float* __restrict__ out, long ldc,
                                                       long M, int N, int K, const float* __restrict__ scale,
@@ -86,28 +86,50 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     float4 ra[4], rb[4], sc4, sh4;
+    // FAST (aligned pointers, K % 4 == 0): branch-free loads from clamped addresses, zeroed at the LDS write, so the
+    // compiler keeps the prefetch in flight across the MFMA loop.  Otherwise the bounds-checked scalar-safe loads.
     auto fetch = [&](int k0) {
         const int k = k0 + 4 * kq;
         const int valid = K - k;
+        const int kc = valid > 0 ? k : 0;
         sc4 = make_float4(1.f, 1.f, 1.f, 1.f);
         sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (has_act && valid > 0) {
+        if (FAST) {
+            if (has_act) { sc4 = ld4(scale + kc); sh4 = ld4(shift + kc); }
+        } else if (has_act && valid > 0) {
             sc4 = ld4_safe(scale + k, valid, vecA);
             sh4 = ld4_safe(shift + k, valid, vecA);
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
+            if (FAST) {
+                const long sp = rok[p] ? src[p] : 0;
+                if (POOL) {
+                    const float* b0 = A + sp + kc;
+                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 v = ld4(b0 + ((q >> 1) * (long)S_in + (q & 1)) * lda);
+                        if (has_act) v = act4(v, sc4, sh4);
+                        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                    }
+                    ra[p] = make_float4(0.25f * sum.x, 0.25f * sum.y, 0.25f * sum.z, 0.25f * sum.w);
+                } else {
+                    ra[p] = ld4(A + sp + kc);
+                }
+                continue;
+            }
             if (!rok[p] || valid <= 0) { ra[p] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
             if (POOL) {
                 const float* b0 = A + src[p] + k;
-                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float4 v = ld4_safe(b0 + ((q >> 1) * (long)S_in + (q & 1)) * lda, valid, vecA);
                     if (has_act) v = act4(v, sc4, sh4);
-                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
                 }
-                ra[p] = make_float4(0.25f * s.x, 0.25f * s.y, 0.25f * s.z, 0.25f * s.w);
+                ra[p] = make_float4(0.25f * sum.x, 0.25f * sum.y, 0.25f * sum.z, 0.25f * sum.w);
             } else {
                 ra[p] = ld4_safe(A + src[p] + k, valid, vecA);
             }
@@ -115,7 +137,12 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int n = n0 + r0 + 32 * p;
-            rb[p] = (n < N && valid > 0) ? ld4_safe(W + (long)n * K + k, valid, vecW) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FAST) {
+                rb[p] = ld4(W + (long)(n < N ? n : N - 1) * K + kc);
+            } else {
+                rb[p] = (n < N && valid > 0) ? ld4_safe(W + (long)n * K + k, valid, vecW)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     auto stash = [&](int k0) {
@@ -123,7 +150,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             float4 v = ra[p];
-            if (!POOL && has_act && rok[p]) v = act4(v, sc4, sh4);
+            if (!POOL && has_act && (FAST || rok[p])) v = act4(v, sc4, sh4);
             // lanes of the K tail must hold exact zeros (they meet zero weights; 0*garbage must stay 0)
             if (valid < 4) {
                 if (valid < 1) v.x = 0.f;
@@ -132,8 +159,10 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
                 v.w = 0.f;
             }
             if (!rok[p]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 wv = rb[p];
+            if (FAST && (valid < 4 || n0 + r0 + 32 * p >= N)) wv = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(&As[(r0 + 32 * p) * LDK + 4 * kq]) = v;
-            *reinterpret_cast<float4*>(&Bs[(r0 + 32 * p) * LDK + 4 * kq]) = rb[p];
+            *reinterpret_cast<float4*>(&Bs[(r0 + 32 * p) * LDK + 4 * kq]) = wv;
         }
     };
 
@@ -143,22 +172,30 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
         stash(kt * C1_BK);
         __syncthreads();
         if (kt + 1 < nkt) fetch((kt + 1) * C1_BK);
+        // fragments of step s+1 are read while step s multiplies; the four accumulators are visited round-robin so
+        // consecutive MFMAs never depend on each other
+        const float* apA = &As[(64 * wm + i) * LDK + 4 * h];
+        const float* bpB = &Bs[(64 * wn + i) * LDK + 4 * h];
+        float4 a0 = ld4(apA), a1 = ld4(apA + 32 * LDK), b0 = ld4(bpB), b1 = ld4(bpB + 32 * LDK);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            float4 a[2], b[2];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) a[mt] = ld4(&As[(64 * wm + 32 * mt + i) * LDK + 8 * s + 4 * h]);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) b[nt] = ld4(&Bs[(64 * wn + 32 * nt + i) * LDK + 8 * s + 4 * h]);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
-                }
+            float4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+            if (s < 3) {
+                na0 = ld4(apA + 8 * (s + 1));
+                na1 = ld4(apA + 32 * LDK + 8 * (s + 1));
+                nb0 = ld4(bpB + 8 * (s + 1));
+                nb1 = ld4(bpB + 32 * LDK + 8 * (s + 1));
+            }
+#define GNX_MM(c) \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b0.c, acc[0][0], 0, 0, 0); \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b1.c, acc[0][1], 0, 0, 0); \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b0.c, acc[1][0], 0, 0, 0); \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b1.c, acc[1][1], 0, 0, 0);
+            GNX_MM(x) GNX_MM(y) GNX_MM(z) GNX_MM(w)
+#undef GNX_MM
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
         }
         __syncthreads();
     }
@@ -268,6 +305,132 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const float* __restrict__ 
         for (int r = 0; r < 16; ++r) {
             const long row = P0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (row < M) out[row * ldc + col] = acc[r];
+        }
+    }
+}
+
+// Software-pipelined form: the next K-chunk's strip rows and weight rows are fetched into registers while the
+// current chunk is multiplied (issue-early / write-late), so HBM/L2 latency hides under the 144 MFMAs of a chunk.
+// NJ = ceil(strip/32) strip rows per thread (compile-time so the prefetch array stays in registers).
+template <int NJ>
+__global__ __launch_bounds__(256) void conv3x3_pipe_kernel(const float* __restrict__ A, long lda,
+                                                           const float* __restrict__ Wr, float* __restrict__ out,
+                                                           long ldc, long M, int N, int K, int S,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int vecA, int vecW) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int strip = C3_BM + 2 * S + 2;
+    float* As = lds;
+    float* Bs = lds + strip * LDK;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    const long P0 = (long)blockIdx.x * C3_BM;
+    const long base = P0 - S - 1;
+    const int n0 = blockIdx.y * C3_BN;
+    const bool has_act = scale != nullptr;
+    const int kq = t & 7, r0 = t >> 3;
+
+    const long P = P0 + 32 * wave + i;
+    unsigned mask = 0;
+    if (P < M) {
+        const int rem = (int)(P % ((long)S * S));
+        const int y = rem / S, x = rem - y * S;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy >= 0 && yy < S && xx >= 0 && xx < S) mask |= 1u << tap;
+        }
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    // a tap that falls outside the image reads a row of zeros kept behind the weight tile (no select on the data path)
+    float* Zs = Bs + 9 * 32 * LDK;
+    if (t < LDK) Zs[t] = 0.f;
+    int aoff[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int off = (S + 1) + (tap / 3 - 1) * S + (tap % 3 - 1);
+        aoff[tap] = ((mask >> tap) & 1u) ? (32 * wave + i + off) * LDK + 4 * h : (strip + 9 * 32) * LDK;
+    }
+
+    // Branch-free prefetch (this kernel is only launched when every pointer is 16-B aligned and K % 4 == 0, so a
+    // k-quad is entirely valid or entirely past K): out-of-range rows/quads load from a clamped, always-valid address
+    // and are zeroed when written to LDS.  No branch, no wait between the loads and the MFMA loop that hides them.
+    float4 ra[NJ], rb[9], sc4, sh4;
+    const int nload = n0 + r0 < N ? n0 + r0 : N - 1;
+    auto fetch = [&](int k0) {
+        const int k = k0 + 4 * kq;
+        const int kc = k < K ? k : 0;
+        sc4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_act) {
+            sc4 = ld4(scale + kc);
+            sh4 = ld4(shift + kc);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            long Pr = base + r0 + 32 * j;
+            Pr = Pr < 0 ? 0 : (Pr >= M ? M - 1 : Pr);
+            ra[j] = ld4(A + Pr * lda + kc);
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) rb[j] = ld4(Wr + ((long)j * N + nload) * K + kc);
+    };
+    auto stash = [&](int k0) {
+        const bool kok = k0 + 4 * kq < K;
+        const bool nok = n0 + r0 < N;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int row = r0 + 32 * j;
+            if (row >= strip) continue;
+            const long Pr = base + row;
+            float4 v = ra[j];
+            if (has_act) v = act4(v, sc4, sh4);
+            if (!(kok && Pr >= 0 && Pr < M)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&As[row * LDK + 4 * kq]) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            float4 v = rb[j];
+            if (!(kok && nok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&Bs[(r0 + 32 * j) * LDK + 4 * kq]) = v;
+        }
+    };
+
+    const float* bbase = &Bs[i * LDK + 4 * h];
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        __syncthreads();
+        stash(k0);
+        __syncthreads();
+        if (k0 + 32 < K) fetch(k0 + 32);
+        float4 a = ld4(lds + aoff[0]), b = ld4(bbase);
+#pragma unroll
+        for (int step = 0; step < 36; ++step) {
+            const int tap = step >> 2, sidx = step & 3;
+            float4 na = a, nb = b;
+            if (step < 35) {
+                const int ntap = (step + 1) >> 2, ns = (step + 1) & 3;
+                na = ld4(lds + aoff[ntap] + 8 * ns);
+                nb = ld4(bbase + ntap * 32 * LDK + 8 * ns);
+            }
+            (void)tap; (void)sidx;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc1, 0, 0, 0);
+            a = na; b = nb;
+            // pin the order: the two LDS reads of step+1 go out ahead of the four MFMAs of this step
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+    }
+    const int col = n0 + i;
+    if (col < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = P0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < M) out[row * ldc + col] = acc0[r] + acc1[r];
         }
     }
 }
@@ -430,13 +593,14 @@ GNX_EXPORT int gnx_conv1x1_bnrelu(const float* A, long lda, const float* W, floa
         return GNX_ERR_BAD_ARG;
     if (pool && (S_in < 2)) return GNX_ERR_BAD_ARG;
     if (M == 0) return GNX_OK;
-    const int vecA = al16(A) && lda % 4 == 0 && (!scale || (al16(scale) && al16(shift)));
+    const int vecA = al16(A) && lda % 4 == 0 && K % 4 == 0 && (!scale || (al16(scale) && al16(shift)));
     const int vecW = al16(W) && K % 4 == 0;
     dim3 grid(gnx_cdiv(M, C1_BM), gnx_cdiv(N, C1_BN));
-    if (pool)
-        conv1x1_kernel<true><<<grid, 256, 0, stream>>>(A, lda, W, out, ldc, M, N, K, scale, shift, S_in, vecA, vecW);
-    else
-        conv1x1_kernel<false><<<grid, 256, 0, stream>>>(A, lda, W, out, ldc, M, N, K, scale, shift, S_in, vecA, vecW);
+    const bool fast = vecA && vecW;
+#define GNX_C1(P, F) conv1x1_kernel<P, F><<<grid, 256, 0, stream>>>(A, lda, W, out, ldc, M, N, K, scale, shift, S_in, vecA, vecW)
+    if (pool) { if (fast) GNX_C1(true, true); else GNX_C1(true, false); }
+    else { if (fast) GNX_C1(false, true); else GNX_C1(false, false); }
+#undef GNX_C1
     return gnx_launch_status();
 }
 
@@ -453,7 +617,7 @@ GNX_EXPORT int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, flo
         (M % ((long)S * S)) != 0)
         return GNX_ERR_BAD_ARG;
     if (M == 0) return GNX_OK;
-    const size_t lds_bytes = ((size_t)(C3_BM + 2 * S + 2) * LDK + 9 * 32 * LDK) * sizeof(float);
+    const size_t lds_bytes = ((size_t)(C3_BM + 2 * S + 2) * LDK + 9 * 32 * LDK + LDK) * sizeof(float);
     if (lds_bytes > 160 * 1024) return GNX_ERR_UNSUPPORTED;
     static size_t configured = 0;
     if (lds_bytes > configured) {
@@ -462,10 +626,29 @@ GNX_EXPORT int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, flo
             return GNX_ERR_LAUNCH;
         configured = lds_bytes;
     }
-    const int vecA = al16(A) && lda % 4 == 0 && (!scale || (al16(scale) && al16(shift)));
+    const int vecA = al16(A) && lda % 4 == 0 && K % 4 == 0 && (!scale || (al16(scale) && al16(shift)));
     const int vecW = al16(Wr) && K % 4 == 0;
     dim3 grid(gnx_cdiv(M, C3_BM), gnx_cdiv(N, C3_BN));
-    conv3x3_kernel<<<grid, 256, lds_bytes, stream>>>(A, lda, Wr, out, ldc, M, N, K, S, scale, shift, vecA, vecW);
+    const int nj = gnx_cdiv(C3_BM + 2 * S + 2, 32);
+#define GNX_PIPE(NJ)                                                                                              \
+    do {                                                                                                          \
+        static size_t conf = 0;                                                                                   \
+        if (lds_bytes > conf) {                                                                                   \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_pipe_kernel<NJ>),                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)    \
+                return GNX_ERR_LAUNCH;                                                                            \
+            conf = lds_bytes;                                                                                     \
+        }                                                                                                         \
+        conv3x3_pipe_kernel<NJ><<<grid, 256, lds_bytes, stream>>>(A, lda, Wr, out, ldc, M, N, K, S, scale, shift, \
+                                                                  vecA, vecW);                                    \
+    } while (0)
+    const bool fast = vecA && vecW;      // aligned pointers/leading dimensions and K % 4 == 0
+    if (fast && nj <= 5) GNX_PIPE(5);
+    else if (fast && nj == 6) GNX_PIPE(6);
+    else if (fast && nj == 7) GNX_PIPE(7);
+    else if (fast && nj <= 9) GNX_PIPE(9);
+    else conv3x3_kernel<<<grid, 256, lds_bytes, stream>>>(A, lda, Wr, out, ldc, M, N, K, S, scale, shift, vecA, vecW);
+#undef GNX_PIPE
     return gnx_launch_status();
 }
 

@@ -59,6 +59,9 @@ class DenseNet(nn.Module):
         self.growth_rate, self.block_config = growth_rate, tuple(block_config)
         self.bn_size, self.small_inputs, self.classify = bn_size, small_inputs, classify
         self.atonce = None          # spots per chunk in eval mode (None = auto)
+        self.l3_blocking = False    # option: run each dense block over Infinity-Cache-sized sub-ranges of spots
+                                    # (measured r01: slower - 15x more, smaller launches; kept for experiments)
+        self.l3_budget = 160 * 1024 * 1024
 
         feats = OrderedDict()
         if small_inputs:
@@ -238,35 +241,48 @@ class DenseNet(nn.Module):
         for s0 in range(0, N, chunk):
             n = min(chunk, N - s0)
             xs = x[s0:s0 + n]
-            ld1 = bufs[0].shape[1]
-            if self.small_inputs:
-                L.call('gnx_conv_stem', L.ptr(xs), L.ptr(w0), L.ptr(bufs[0]), ld1, n, 3, P, P, c0, 3, 3, 1, 1, st)
-            else:
-                sc, sh = fold[self.features.norm0]
-                L.call('gnx_conv_stem', L.ptr(xs), L.ptr(w0), L.ptr(stem_out), c0, n, 3, P, P, c0, 7, 7, 2, 3, st)
-                L.call('gnx_bnrelu_maxpool', L.ptr(stem_out), c0, L.ptr(bufs[0]), ld1, n, c0, hs, hs,
-                       L.ptr(sc), L.ptr(sh), st)
             for bi, ((c_in, layers, trans, c_total), s) in enumerate(zip(self._blocks, sizes)):
                 buf = bufs[bi]
-                M = n * s * s
-                for li, layer in enumerate(layers):
-                    cin = c_in + li * self.growth_rate
-                    sc1, sh1 = fold[layer.norm1]
-                    sc2, sh2 = fold[layer.norm2]
-                    t0 = self._probe_begin()
-                    L.call('gnx_conv1x1_bnrelu', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid,
-                           M, mid, cin, L.ptr(sc1), L.ptr(sh1), 0, 0, st)
-                    t1 = self._probe_mark('conv1x1', t0)
-                    L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2[layer]), buf.data_ptr() + 4 * cin,
-                           c_total, M, self.growth_rate, mid, s, L.ptr(sc2), L.ptr(sh2), st)
-                    self._probe_mark('conv3x3', t1)
-                if trans is not None:
-                    nxt = bufs[bi + 1]
-                    so = s // 2
-                    sct, sht = fold[trans.norm]
-                    L.call('gnx_conv1x1_bnrelu', L.ptr(buf), c_total, L.ptr(trans.conv.weight), L.ptr(nxt),
-                           nxt.shape[1], n * so * so, trans.conv.out_channels, c_total, L.ptr(sct), L.ptr(sht),
-                           1, s, st)
+                # L3 blocking: run a block's whole layer chain over a sub-range of spots whose buffers fit the
+                # 256 MiB Infinity Cache (so the 2*L re-reads of the block buffer are served on-die), but never so
+                # few spots that a launch has fewer than ~512 workgroups.
+                per_spot = s * s * (c_total + mid) + (hs * hs * c0 if (bi == 0 and hs is not None) else 0)
+                fit = max(1, self.l3_budget // (4 * per_spot))
+                fill = -(-512 * 128 // (s * s))
+                sub = n if not self.l3_blocking else max(1, min(n, max(fit, fill)))
+                for u0 in range(0, n, sub):
+                    nu = min(sub, n - u0)
+                    rows = buf[u0 * s * s:(u0 + nu) * s * s]
+                    M = nu * s * s
+                    if bi == 0:
+                        xu = xs[u0:u0 + nu]
+                        if self.small_inputs:
+                            L.call('gnx_conv_stem', L.ptr(xu), L.ptr(w0), L.ptr(rows), c_total, nu, 3, P, P, c0,
+                                   3, 3, 1, 1, st)
+                        else:
+                            sc, sh = fold[self.features.norm0]
+                            L.call('gnx_conv_stem', L.ptr(xu), L.ptr(w0), L.ptr(stem_out), c0, nu, 3, P, P, c0,
+                                   7, 7, 2, 3, st)
+                            L.call('gnx_bnrelu_maxpool', L.ptr(stem_out), c0, L.ptr(rows), c_total, nu, c0, hs, hs,
+                                   L.ptr(sc), L.ptr(sh), st)
+                    for li, layer in enumerate(layers):
+                        cin = c_in + li * self.growth_rate
+                        sc1, sh1 = fold[layer.norm1]
+                        sc2, sh2 = fold[layer.norm2]
+                        t0 = self._probe_begin()
+                        L.call('gnx_conv1x1_bnrelu', L.ptr(rows), c_total, L.ptr(layer.conv1.weight), L.ptr(bott),
+                               mid, M, mid, cin, L.ptr(sc1), L.ptr(sh1), 0, 0, st)
+                        t1 = self._probe_mark('conv1x1', t0)
+                        L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2[layer]), rows.data_ptr() + 4 * cin,
+                               c_total, M, self.growth_rate, mid, s, L.ptr(sc2), L.ptr(sh2), st)
+                        self._probe_mark('conv3x3', t1)
+                    if trans is not None:
+                        nxt = bufs[bi + 1]
+                        so = s // 2
+                        sct, sht = fold[trans.norm]
+                        L.call('gnx_conv1x1_bnrelu', L.ptr(rows), c_total, L.ptr(trans.conv.weight),
+                               L.ptr(nxt[u0 * so * so:]), nxt.shape[1], nu * so * so, trans.conv.out_channels,
+                               c_total, L.ptr(sct), L.ptr(sht), 1, s, st)
             scf, shf = fold[self.features.norm_final]
             s_last = sizes[-1]
             L.call('gnx_bnrelu_avgpool', L.ptr(bufs[-1]), bufs[-1].shape[1], L.ptr(feats[s0:]), self.num_features,

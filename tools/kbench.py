@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark harness for the DenseNet conv kernels (tuning aid; runs on the GPU box).
+
+    python tools/kbench.py [--spots 4992] [--reps 5] [--only conv3x3|conv1x1|stem|pool]
+Prints per-shape time and achieved TFLOP/s (algorithmic FLOPs) using HIP events on the launch stream.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gridnext_amd import _lib as L   # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--spots', type=int, default=4992)
+    ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--only', default='')
+    args = ap.parse_args()
+    n = args.spots
+    st = L.stream()
+    torch.manual_seed(0)
+    shapes = [(32, 64, 256), (32, 224, 256), (16, 128, 512), (16, 480, 512), (8, 256, 1024), (8, 992, 1024),
+              (4, 512, 1024), (4, 992, 1024)]
+    if args.only in ('', 'conv1x1'):
+        for S, K, ct in shapes:
+            M = n * S * S
+            A = torch.randn(M, ct, device=DEV)
+            W = torch.randn(128, K, device=DEV) * 0.05
+            out = torch.empty(M, 128, device=DEV)
+            sc, sh = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
+            ms = timeit(lambda: L.call('gnx_conv1x1_bnrelu', L.ptr(A), ct, L.ptr(W), L.ptr(out), 128, M, 128, K,
+                                       L.ptr(sc), L.ptr(sh), 0, 0, st), args.reps)
+            fl = 2.0 * M * K * 128
+            byts = 4.0 * M * (K + 128)
+            print("conv1x1 S=%2d K=%4d M=%8d  %8.3f ms  %6.1f TFLOP/s  %5.2f TB/s" % (S, K, M, ms, fl / ms / 1e9, byts / ms / 1e9))
+            del A, out
+    if args.only in ('', 'conv3x3'):
+        for S in (32, 16, 8, 4):
+            M = n * S * S
+            A = torch.randn(M, 128, device=DEV)
+            Wr = torch.randn(9, 32, 128, device=DEV) * 0.05
+            ct = 256
+            out = torch.empty(M, ct, device=DEV)
+            sc, sh = torch.rand(128, device=DEV) + 0.5, torch.randn(128, device=DEV) * 0.1
+            ms = timeit(lambda: L.call('gnx_conv3x3_bnrelu', L.ptr(A), 128, L.ptr(Wr), out.data_ptr() + 4 * 64, ct, M,
+                                       32, 128, S, L.ptr(sc), L.ptr(sh), st), args.reps)
+            fl = 2.0 * M * 1152 * 32
+            print("conv3x3 S=%2d M=%8d  %8.3f ms  %6.1f TFLOP/s" % (S, M, ms, fl / ms / 1e9))
+            del A, out
+    if args.only in ('', 'stem'):
+        x = torch.rand(n, 3, 128, 128, device=DEV)
+        w = torch.randn(64, 3, 7, 7, device=DEV) * 0.05
+        out = torch.empty(n * 64 * 64, 64, device=DEV)
+        ms = timeit(lambda: L.call('gnx_conv_stem', L.ptr(x), L.ptr(w), L.ptr(out), 64, n, 3, 128, 128, 64, 7, 7, 2, 3,
+                                   st), args.reps)
+        fl = 2.0 * n * 64 * 64 * 147 * 64
+        print("stem7x7 n=%d  %8.3f ms  %6.1f TFLOP/s  (in %.2f GB, out %.2f GB -> %.2f TB/s)" %
+              (n, ms, fl / ms / 1e9, x.numel() * 4 / 1e9, out.numel() * 4 / 1e9, (x.numel() + out.numel()) * 4 / ms / 1e9))
+        if args.only in ('', 'stem', 'pool'):
+            sc, sh = torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.1
+            pooled = torch.empty(n * 32 * 32, 256, device=DEV)
+            ms = timeit(lambda: L.call('gnx_bnrelu_maxpool', L.ptr(out), 64, L.ptr(pooled), 256, n, 64, 64, 64,
+                                       L.ptr(sc), L.ptr(sh), st), args.reps)
+            print("maxpool n=%d  %8.3f ms  %.2f TB/s" % (n, ms, (out.numel() + n * 32 * 32 * 64) * 4 / ms / 1e9))
+
+
+if __name__ == '__main__':
+    main()
