@@ -50,8 +50,8 @@ class _PhaseMeter:
 
     def add(self, loss, batch_size, correct, counted):
         if torch.is_tensor(loss):
-            loss = loss.detach().double() * batch_size
-        self.loss = self.loss + loss
+            loss = loss.detach().double()
+        self.loss = self.loss + loss * batch_size
         self.correct = self.correct + correct
         self.counted = self.counted + counted
 

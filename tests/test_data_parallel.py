@@ -1,0 +1,116 @@
+"""CPU, world_size 2 over gloo: the data-parallel layer (gridnext_amd/distributed.py) that the training
+loops use.  Checks, against a single-process run over the same arrays:
+  * ShardedSampler covers the dataset exactly once across ranks, same count per rank;
+  * allreduce_gradients averages .grad over ranks (and tolerates a parameter without a gradient);
+  * a 2-rank train_gridwise run (1 array per rank per step) gives both ranks the same weights and the
+    same reported epoch losses, equal to a single-process run that accumulates the two arrays' gradients
+    (the semantics documented in distributed.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+import torch.nn as nn
+from torch.utils.data import DataLoader, TensorDataset
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_problem():
+    from oracle import gridnet as ogn
+    from oracle.mlp import count_mlp
+    torch.manual_seed(5)
+    G, H, W, C = 12, 6, 5, 4
+    f = count_mlp(G, C)
+    m = ogn.GridNetHexOddr(f, (G,), (H, W), C, use_bn=True)
+    for p in m.patch_classifier.parameters():
+        p.requires_grad = False
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randint(0, 10, (4, G, H, W), generator=gen).float()
+    y = torch.randint(0, C + 1, (4, H, W), generator=gen)
+    return m, x, y
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import contextlib
+    import io
+    from gridnext_amd import distributed as gdist
+    from gridnext_amd.training import train_gridwise
+    r, w, dev = gdist.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    # gradient averaging primitive
+    lin = nn.Linear(3, 2)
+    with torch.no_grad():
+        lin.weight.fill_(1.0)
+        lin.bias.fill_(0.0)
+    lin.weight.grad = torch.full((2, 3), float(rank + 1))
+    gdist.allreduce_gradients([lin.weight, lin.bias])
+    assert torch.allclose(lin.weight.grad, torch.full((2, 3), 1.5))
+    assert lin.bias.grad is not None and float(lin.bias.grad.abs().max()) == 0.0
+    # sampler
+    ds = TensorDataset(torch.arange(7))
+    mine = list(gdist.ShardedSampler(ds))
+    assert len(mine) == 4 and mine == list(range(7))[rank::2] + ([0] if rank == 1 else [])
+    # the loop
+    m, x, y = _make_problem()
+    gdist.broadcast_module(m)
+    data = TensorDataset(x, y)
+    dl = {'train': DataLoader(data, batch_size=1, sampler=gdist.ShardedSampler(data)),
+          'val': DataLoader(data, batch_size=1, sampler=gdist.ShardedSampler(data))}
+    opt = torch.optim.SGD(m.corrector.parameters(), lr=0.05)
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        m, vh, th = train_gridwise(m, dl, nn.CrossEntropyLoss(), opt, num_epochs=2)
+    torch.save({'state': m.state_dict(), 'vh': vh, 'th': th, 'printed': buf.getvalue()},
+               os.path.join(out_dir, 'rank%d.pt' % rank))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_training_matches_gradient_accumulation(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(str(tmp_path / 'rank0.pt'))
+    r1 = torch.load(str(tmp_path / 'rank1.pt'))
+    for k in r0['state']:
+        assert torch.equal(r0['state'][k], r1['state'][k]) or 'running' in k or 'num_batches' in k, k
+    assert r0['th'] == r1['th'] and r0['vh'] == r1['vh']
+    assert 'Loss:' in r0['printed'] and r1['printed'].strip() == ''            # rank 0 reports
+    # single-process equivalent: step every 2 arrays with the MEAN of the two per-array gradients
+    torch.set_num_threads(1)
+    from oracle import masked_ce as oce
+    m, x, y = _make_problem()
+    opt = torch.optim.SGD(m.corrector.parameters(), lr=0.05)
+    hist = []
+    for epoch in range(2):
+        m.train()
+        m.patch_classifier.eval()
+        total = 0.0
+        for pair in ((0, 1), (2, 3)):
+            opt.zero_grad()
+            for i in pair:
+                loss, _, _ = oce.masked_ce(m(x[i:i + 1]), y[i:i + 1], 1)
+                (loss / 2).backward()
+                total += loss.item()
+            opt.step()
+        hist.append(total / 4)
+    np.testing.assert_allclose(r0['th'], hist, rtol=1e-5)
+    for k, v in m.corrector.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            continue                      # BN statistics stay per-rank (documented)
+        assert torch.allclose(r0['state']['corrector.' + k], v, rtol=1e-4, atol=1e-6), k

@@ -1,0 +1,181 @@
+"""CPU: host-side logic of the product package (no kernels run here).
+
+ * the C-ABI library loads and exports every symbol include/gridnext_hip.h declares, with ctypes signatures
+   for each one;
+ * the product path fails loudly without a HIP device (no CPU fallback);
+ * gridnext_amd.training's loops - generic path, driven with the CPU oracle models - reproduce the histories
+   the reference's own loops produced (tests/golden);
+ * module surfaces: state_dict key order of the drop-in classes equals the reference's.
+"""
+import contextlib
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+from torch.utils.data import DataLoader, TensorDataset
+
+from conftest import ROOT, load_golden, sub
+
+torch.set_num_threads(1)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        r = fn(*a, **k)
+    return r, buf.getvalue()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'gridnext_hip.h')).read()
+    return sorted(set(re.findall(r'\b(gnx_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gridnext_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    handle = _lib.lib()
+    declared = header_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(handle, name), "libgridnext_hip.so does not export %s" % name
+        assert name in _lib.SIGNATURES, "no ctypes signature for %s" % name
+    assert sorted(_lib.SIGNATURES) == declared, "header and ctypes table disagree"
+
+
+def test_product_path_fails_loudly_without_hip():
+    if torch.cuda.is_available():
+        pytest.skip("needs a CPU-only box")
+    import gridnext_amd as ga
+    from gridnext_amd import functional as GF
+    m = ga.DenseNet(growth_rate=4, block_config=(2,), num_init_features=8, bn_size=2, num_classes=3, small_inputs=True)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(torch.rand(1, 3, 8, 8))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        GF.masked_cross_entropy(torch.rand(4, 3), torch.ones(4, dtype=torch.long), 1)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        GF.hexconv(torch.rand(1, 4, 4, 2), torch.rand(3, 2, 3, 1), torch.rand(3, 2, 2, 2), None, True)
+
+
+def test_no_product_module_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'gridnext_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, re.M), f
+
+
+def test_state_dict_keys_match_reference_order():
+    import gridnext_amd as ga
+    from gridnext_amd.synthetic import count_mlp
+    g = load_golden('densenet_tiny_large')
+    m = ga.DenseNet(growth_rate=4, block_config=(2, 2), num_init_features=8, bn_size=2, num_classes=5,
+                    small_inputs=False)
+    assert list(m.state_dict()) == [k[3:] for k in g if k.startswith('sd/')]
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(g['sd/' + k].shape), k
+    g = load_golden('gridwise_hexmm_tutorial')
+    mm = ga.GridNetHexMM(m, count_mlp(20, 5), (3, 32, 32), (20,), (6, 4), 5)
+    assert list(mm.state_dict()) == [k[5:] for k in g if k.startswith('init/')]
+    g = load_golden('gridwise_cartesian')
+    gn = ga.GridNet(count_mlp(24, 5), (24,), (7, 6), 5)
+    assert list(gn.state_dict()) == [k[5:] for k in g if k.startswith('init/')]
+    # reference quirk: the MM model leaves patch_classifier on the image network (gridnet_models.py:229-233)
+    assert mm.patch_classifier is mm.image_classifier
+
+
+def test_densenet_init_statistics_follow_reference():
+    import gridnext_amd as ga
+    torch.manual_seed(0)
+    m = ga.DenseNet(growth_rate=32, block_config=(6, 12, 24, 16), num_init_features=64, bn_size=4, num_classes=8,
+                    small_inputs=False)
+    assert sum(p.numel() for p in m.parameters()) == 6962056
+    w = m.features.denseblock1.denselayer1.conv2.weight               # N(0, sqrt(2/(out*kh*kw))), densenet.py:142-144
+    assert abs(w.std().item() - (2.0 / (32 * 9)) ** 0.5) < 0.01
+    assert float(m.features.norm0.weight.detach().min()) == 1.0
+    assert float(m.classifier.bias.detach().abs().max()) == 0.0
+
+
+def _loaders(x, y, n_train, batch):
+    return {'train': DataLoader(TensorDataset(x[:n_train], y[:n_train]), batch_size=batch, shuffle=False),
+            'val': DataLoader(TensorDataset(x[n_train:], y[n_train:]), batch_size=batch, shuffle=False)}
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU walk of the generic loop path")
+def test_product_spot_loop_generic_path_reproduces_reference_history(tmp_path):
+    from gridnext_amd.training import train_spotwise
+    from oracle import densenet as odn
+    g = load_golden('spotwise_densenet_tiny')
+    f = odn.DenseNet(growth_rate=4, block_config=(2, 2), num_init_features=8, bn_size=2, num_classes=5,
+                     small_inputs=False)
+    f.load_named_state(sub(g, 'init'))
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    dl = _loaders(x, y, int(g['n_train']), int(g['batch']))
+    opt = torch.optim.Adam(f.parameters(), lr=float(g['lr']))
+    out = str(tmp_path / 'f.pth')
+    (f, vh, th), text = quiet(train_spotwise, f, dl, nn.CrossEntropyLoss(), opt, num_epochs=int(g['epochs']),
+                              outfile=out)
+    np.testing.assert_allclose(th, g['train_history'], rtol=1e-4)
+    np.testing.assert_allclose(vh, g['val_history'], rtol=1e-4)
+    assert os.path.exists(out)
+    # printed lines have the reference's format (training.py:76)
+    ref_lines = [l for l in str(g['stdout']).splitlines() if 'Loss:' in l]
+    got_lines = [l for l in text.splitlines() if 'Loss:' in l]
+    assert [l.split()[0] for l in ref_lines] == [l.split()[0] for l in got_lines]
+    assert all(re.fullmatch(r'(train|val) Loss: \d+\.\d{4} Acc: \d+\.\d{4}', l) for l in got_lines)
+    assert text.splitlines()[0] == 'Epoch 0/%d' % (int(g['epochs']) - 1)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU walk of the generic loop path")
+@pytest.mark.parametrize("name,accum,limit,fopt,ntrain", [("gridwise_hexoddr", 3, None, False, 5),
+                                                          ("gridwise_hexoddr_fopt", 1, 7, True, 3)])
+def test_product_grid_loop_generic_path_reproduces_reference_history(tmp_path, name, accum, limit, fopt, ntrain):
+    from gridnext_amd.training import train_gridwise
+    from oracle import gridnet as ogn
+    from oracle.mlp import count_mlp
+    g = load_golden(name)
+    G, H, W, C = 24, 8, 6, 5
+    m = ogn.GridNetHexOddr(count_mlp(G, C), (G,), (H, W), C, use_bn=True, atonce_patch_limit=limit)
+    m.load_state_dict(sub(g, 'init'))
+    if not fopt:
+        for p in m.patch_classifier.parameters():
+            p.requires_grad = False
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    dl = _loaders(x, y, ntrain, 1)
+    opt = torch.optim.Adam(m.corrector.parameters(), lr=1e-3)
+    f_opt = torch.optim.Adam(m.patch_classifier.parameters(), lr=1e-4) if fopt else None
+    out = str(tmp_path / 'g.pth')
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        (m, vh, th), text = quiet(train_gridwise, m, dl, nn.CrossEntropyLoss(), opt, num_epochs=2, outfile=out,
+                                  f_opt=f_opt, accum_iters=accum)
+    np.testing.assert_allclose(th, g['train_history'], rtol=1e-4)
+    np.testing.assert_allclose(vh, g['val_history'], rtol=1e-4)
+    assert os.path.exists(out) and os.path.exists(str(tmp_path / 'g.opt'))       # training.py:187-195
+    saved = torch.load(str(tmp_path / 'g.opt'))
+    assert (set(saved) == {'g_opt', 'f_opt'}) if fopt else ('state' in saved and 'param_groups' in saved)
+    assert str(g['stdout']).count('Loss:') == text.count('Loss:')
+
+
+def test_mmstack_dataset_contract():
+    from gridnext_amd import MMStackDataset
+    xi = torch.rand(3, 4, 4, 3, 8, 8)
+    xc = torch.rand(3, 10, 4, 4)
+    y1 = torch.randint(0, 4, (3, 4, 4))
+    y2 = y1.clone()
+    y2[0, 0, 0] = (y2[0, 0, 0] + 1) % 4
+    ds = MMStackDataset(TensorDataset(xi, y1), TensorDataset(xc, y2))
+    (a, b), y = ds[0]
+    assert a.shape == (4, 4, 3, 8, 8) and b.shape == (10, 4, 4)
+    assert y[0, 0] == 0 and torch.equal(y.flatten()[1:], y1[0].flatten()[1:])       # disagreeing labels are zeroed
+    inputs, labels = next(iter(DataLoader(ds, batch_size=2)))
+    assert isinstance(inputs, list) and len(inputs) == 2                              # what the loops test for
+    with pytest.raises(AssertionError):
+        MMStackDataset(TensorDataset(xi, y1), TensorDataset(xc[:2], y2[:2]))
