@@ -23,7 +23,7 @@ SIGNATURES = {
     'gnx_bn_train_stats': (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
     'gnx_bn_fold_eval': (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
     'gnx_scale_shift_relu': (_I, [_P, _L, _P, _L, _L, _I, _P, _P, _I, _P]),
-    'gnx_bn_relu_bwd': (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    'gnx_bn_relu_bwd': (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     'gnx_colsum': (_I, [_P, _L, _L, _I, _P, _I, _P, _P]),
     'gnx_masked_ce_workspace': (_L, [_L]),
     'gnx_masked_ce_fwd': (_I, [_P, _L, _P, _L, _I, _I, _F, _P, _P, _P, _P, _P]),
@@ -34,6 +34,15 @@ SIGNATURES = {
     'gnx_conv_stem': (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'gnx_bnrelu_maxpool': (_I, [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
     'gnx_bnrelu_avgpool': (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _P]),
+    'gnx_wgrad_workspace': (_L, [_L, _I, _I, _I]),
+    'gnx_wgrad_bnrelu': (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
+    'gnx_transpose_weight': (_I, [_P, _P, _I, _I, _P]),
+    'gnx_repack_conv3x3_bwd': (_I, [_P, _P, _I, _I, _P]),
+    'gnx_rows_broadcast': (_I, [_P, _L, _P, _L, _L, _I, _I, _F, _P]),
+    'gnx_avgpool2_bwd': (_I, [_P, _L, _P, _L, _L, _I, _I, _P]),
+    'gnx_maxpool_bwd': (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
+    'gnx_conv0_wgrad_workspace': (_L, [_L, _I, _I, _I, _I, _I, _I, _I]),
+    'gnx_conv0_wgrad': (_I, [_P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'gnx_gemm_f32': (_I, [_P, _L, _I, _P, _L, _I, _P, _P, _L, _L, _L, _L, _I, _P]),
 }
 

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
                                                         const float* __restrict__ shift,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ invstd,
-                                                        const float* __restrict__ sums, int relu, int training) {
+                                                        const float* __restrict__ sums, int relu, int training,
+                                                        int dx_accumulate) {
     const long total = M * C;
     const float invM = 1.0f / (float)M;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -174,7 +175,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
             const float xhat = (xv - mean[c]) * invstd[c];
             g = dz - sums[c] * invM - xhat * sums[C + c] * invM;
         }
-        dx[r * lddx + c] = scale[c] * g;
+        const float o = scale[c] * g;
+        dx[r * lddx + c] = dx_accumulate ? dx[r * lddx + c] + o : o;
     }
 }
 
@@ -239,11 +241,13 @@ GNX_EXPORT int gnx_scale_shift_relu(const float* x, long ldx, float* y, long ldy
     return gnx_launch_status();
 }
 
-// Backward of y = [relu](bn(x)).  dgamma/dbeta may be null; `training` selects batch-stat or running-stat form.
+// Backward of y = [relu](bn(x)).  dgamma/dbeta may be null; `training` selects batch-stat or running-stat form;
+// `accumulate` adds into dgamma/dbeta, `dx_accumulate` adds into dx (DenseNet: gradients of a block buffer's columns
+// arrive from every later layer of the block).
 GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long ldx, float* dx, long lddx, long M,
                                int C, const float* scale, const float* shift, const float* save_mean,
                                const float* save_invstd, float* dgamma, float* dbeta, int relu, int training,
-                               int accumulate, float* workspace, hipStream_t stream) {
+                               int accumulate, int dx_accumulate, float* workspace, hipStream_t stream) {
     if (!dy || !x || !scale || !shift || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0)
         return GNX_ERR_BAD_ARG;
     const int nblk = gnx_cdiv(M, ROWS_PER_BLOCK);
@@ -256,7 +260,7 @@ GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long 
     if (dx)
         bn_bwd_dx_kernel<<<elementwise_grid(M * C), 256, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale,
                                                                       shift, save_mean, save_invstd, sums, relu,
-                                                                      training);
+                                                                      training, dx_accumulate);
     return gnx_launch_status();
 }
 

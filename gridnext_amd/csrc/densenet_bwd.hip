@@ -1,0 +1,465 @@
+// DenseNet-BC backward kernels (gfx950, exact fp32 on the matrix cores).
+//
+// Autograd of /root/reference/gridnext/densenet.py is torch's; these kernels compute the same gradients:
+//   data gradients of conv1x1 / conv3x3 reuse the FORWARD kernels of densenet_fwd.hip with transformed weights
+//     (gnx_transpose_weight: W[N][K] -> [K][N];  gnx_repack_conv3x3_bwd: W[N][K][3][3] -> [flipped tap][K][N]);
+//   gnx_wgrad_bnrelu   : weight gradient of conv1x1 (taps=1, optionally through the transition's 2x2 average) and
+//                        conv3x3 (taps=9): dW[tap][n][k] = sum_m dY[m][n] * act(X)[nbr(m,tap)][k], the BN+ReLU of the
+//                        forward prologue recomputed while staging (the activated tensor is never stored);
+//   gnx_conv0_wgrad    : weight gradient of the stem conv from NCHW patches (patch-resident, like the forward);
+//   gnx_maxpool_bwd, gnx_avgpool2_bwd, gnx_rows_broadcast : the pooling adjoints.
+// The reduction over positions (millions of rows) is split over workgroups; each writes a partial slab and
+// gnx_wgrad_reduce sums the slabs in a fixed order (deterministic, no float atomics).
+// MFMA operand maps for a weight gradient (reduction index = position m): A[i=n][kk=m] = dY[m][n],
+// B[kk=m][j=k] = act(X)[m'][k]; both are read from [position][channel] LDS images with conflict-free ds_read_b32.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float act1(float v, float sc, float sh) { return fmaxf(fmaf(v, sc, sh), 0.f); }
+
+constexpr int WG_BM = 64;        // positions per staged tile
+constexpr int WG_KR = 128;       // k-range per workgroup (4 waves x 32)
+constexpr int LDX = WG_KR + 4;   // LDS row stride of the X strip (floats)
+constexpr int LDY = 32;          // LDS row stride of the dY tile
+
+// slab[(split*T + tap)*N*K + n*K + k]
+template <int T, bool POOL>
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY, long lddy,
+                                                    const float* __restrict__ X, long ldx,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    float* __restrict__ slabs, long M, int N, int K, int S,
+                                                    long tiles_per_split, int vec) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int halo = (T == 9) ? S + 1 : 0;
+    const int strip = WG_BM + 2 * halo;
+    float* Ys = lds;                               // [WG_BM][LDY]
+    float* Xs = lds + WG_BM * LDY;                 // [strip][LDX]
+    unsigned* Vm = reinterpret_cast<unsigned*>(Xs + strip * LDX);   // [WG_BM] tap-validity bits (T == 9)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    const int n0 = blockIdx.y * 32;
+    const int kbase = blockIdx.z * WG_KR;
+    const int kc = kbase + 32 * wave;              // this wave's 32 k columns
+    const bool has_act = scale != nullptr;
+    const long ntiles = (M + WG_BM - 1) / WG_BM;
+    const long tile0 = (long)blockIdx.x * tiles_per_split;
+    const long tile1 = min(tile0 + tiles_per_split, ntiles);
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int a = 0; a < T; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    for (long tile = tile0; tile < tile1; ++tile) {
+        const long m0 = tile * WG_BM;
+        __syncthreads();
+        // dY tile: [64][32]
+        for (int idx = t; idx < WG_BM * 32; idx += 256) {
+            const int r = idx >> 5, c = idx & 31;
+            const long m = m0 + r;
+            Ys[r * LDY + c] = (m < M && n0 + c < N) ? dY[m * lddy + n0 + c] : 0.f;
+        }
+        // X strip (activated), [strip][128]
+        for (int idx = t; idx < strip * (WG_KR / 4); idx += 256) {
+            const int r = idx / (WG_KR / 4), q = idx - r * (WG_KR / 4);
+            const int k = kbase + 4 * q;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            const long p = m0 - halo + r;
+            if (p >= 0 && p < M && k < K) {
+                if (POOL) {
+                    const int So = S >> 1;
+                    const long img = p / (So * So);
+                    const int rem = (int)(p - img * So * So);
+                    const int oy = rem / So, ox = rem - oy * So;
+                    const long src = ((img * S + 2 * oy) * S + 2 * ox) * ldx;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (k + e < K) {
+                            const float sc = has_act ? scale[k + e] : 1.f, sh = has_act ? shift[k + e] : 0.f;
+                            float s4 = 0.f;
+#pragma unroll
+                            for (int qd = 0; qd < 4; ++qd) {
+                                const float xv = X[src + ((qd >> 1) * (long)S + (qd & 1)) * ldx + k + e];
+                                s4 += has_act ? act1(xv, sc, sh) : xv;
+                            }
+                            v[e] = 0.25f * s4;
+                        }
+                    }
+                } else if (vec && k + 3 < K) {
+                    const float4 xv = *reinterpret_cast<const float4*>(X + p * ldx + k);
+                    v[0] = xv.x; v[1] = xv.y; v[2] = xv.z; v[3] = xv.w;
+                    if (has_act) {
+                        const float4 sc = *reinterpret_cast<const float4*>(scale + k);
+                        const float4 sh = *reinterpret_cast<const float4*>(shift + k);
+                        v[0] = act1(v[0], sc.x, sh.x); v[1] = act1(v[1], sc.y, sh.y);
+                        v[2] = act1(v[2], sc.z, sh.z); v[3] = act1(v[3], sc.w, sh.w);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k + e < K) {
+                            const float xv = X[p * ldx + k + e];
+                            v[e] = has_act ? act1(xv, scale[k + e], shift[k + e]) : xv;
+                        }
+                }
+            }
+            *reinterpret_cast<float4*>(&Xs[r * LDX + 4 * q]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (T == 9) {
+            for (int r = t; r < WG_BM; r += 256) {
+                const long m = m0 + r;
+                unsigned mask = 0;
+                if (m < M) {
+                    const int rem = (int)(m % ((long)S * S));
+                    const int y = rem / S, x = rem - y * S;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                        if (yy >= 0 && yy < S && xx >= 0 && xx < S) mask |= 1u << tap;
+                    }
+                }
+                Vm[r] = mask;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int mm = 0; mm < WG_BM; mm += 2) {
+            const float a = Ys[(mm + h) * LDY + i];
+            if (T == 9) {
+                const unsigned vm = Vm[mm + h];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int off = (S + 1) + (tap / 3 - 1) * S + (tap % 3 - 1);
+                    const float b = Xs[(mm + h + off) * LDX + 32 * wave + i];
+                    const float am = ((vm >> tap) & 1u) ? a : 0.f;
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(am, b, acc[tap], 0, 0, 0);
+                }
+            } else {
+                const float b = Xs[(mm + h) * LDX + 32 * wave + i];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0], 0, 0, 0);
+            }
+        }
+    }
+    const int k = kc + i;
+    if (k < K) {
+#pragma unroll
+        for (int tap = 0; tap < T; ++tap) {
+            float* dst = slabs + ((long)blockIdx.x * T + tap) * N * K;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (n < N) dst[(long)n * K + k] = acc[tap][r];
+            }
+        }
+    }
+}
+
+// dW (torch layout [N][K][T]) = fixed-order sum over splits of slab[split][tap][n][k]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, int T, int N, int K,
+                                    float* __restrict__ dW, int accumulate) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)T * N * K;
+    if (idx >= total) return;
+    const int k = (int)(idx % K), n = (int)((idx / K) % N), tap = (int)(idx / ((long)K * N));
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += slabs[(long)sp * total + idx];
+    float* dst = dW + ((long)n * K + k) * T + tap;
+    *dst = accumulate ? *dst + s : s;
+}
+
+__global__ void transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int K) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)N * K) return;
+    const int k = (int)(idx % K), n = (int)(idx / K);
+    wt[(long)k * N + n] = w[idx];
+}
+
+// W[N][K][3][3] -> Wb[tap'][K][N] with tap' = 8 - tap (the adjoint of a pad-1 cross-correlation)
+__global__ void repack3x3_bwd_kernel(const float* __restrict__ w, float* __restrict__ wb, int N, int K) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)9 * N * K;
+    if (idx >= total) return;
+    const int tap = (int)(idx % 9), k = (int)((idx / 9) % K), n = (int)(idx / (9L * K));
+    wb[((long)(8 - tap) * K + k) * N + n] = w[idx];
+}
+
+// out[img*S2 + p][c] = in[img][c] * alpha
+__global__ void rows_broadcast_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out, long ldo,
+                                      long rows, int C, int S2, float alpha) {
+    const long total = rows * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / C;
+        const int c = (int)(idx - r * C);
+        out[r * ldo + c] = in[(r / S2) * ldi + c] * alpha;
+    }
+}
+
+// dA[(img, 2oy+dy, 2ox+dx)][c] = 0.25 * dP[(img, oy, ox)][c]; positions not covered by a window (odd S) get 0
+__global__ void avgpool2_bwd_kernel(const float* __restrict__ dP, long ldp, float* __restrict__ dA, long lda,
+                                    long Min, int C, int S) {
+    const long total = Min * C;
+    const int So = S >> 1;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / C;
+        const int c = (int)(idx - r * C);
+        const long img = r / ((long)S * S);
+        const int rem = (int)(r - img * S * S);
+        const int y = rem / S, x = rem - y * S;
+        float v = 0.f;
+        if ((y >> 1) < So && (x >> 1) < So) v = 0.25f * dP[((img * So + (y >> 1)) * So + (x >> 1)) * ldp + c];
+        dA[r * lda + c] = v;
+    }
+}
+
+// adjoint of out = maxpool3x3s2p1(relu(in*scale+shift)) with respect to the ACTIVATED input:
+// dAct[pos][c] = sum over the (<=4) windows containing pos of dOut[window] * [act(pos) is that window's maximum and > 0]
+__global__ void maxpool_bwd_kernel(const float* __restrict__ in, long ldi, const float* __restrict__ pooled, long ldp,
+                                   const float* __restrict__ dOut, long lddo, float* __restrict__ dAct, long lda,
+                                   long Min, int C, int Hi, int Wi, int Ho, int Wo, const float* __restrict__ scale,
+                                   const float* __restrict__ shift) {
+    const long total = Min * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / C;
+        const int c = (int)(idx - r * C);
+        const long img = r / ((long)Hi * Wi);
+        const int rem = (int)(r - img * Hi * Wi);
+        const int y = rem / Wi, x = rem - y * Wi;
+        const float a = fmaxf(fmaf(in[r * ldi + c], scale[c], shift[c]), 0.f);
+        float g = 0.f;
+        if (a > 0.f) {
+            // windows: oy with 2oy-1 <= y <= 2oy+1
+            for (int oy = (y) / 2; oy <= (y + 1) / 2; ++oy) {
+                if (oy < 0 || oy >= Ho) continue;
+                for (int ox = (x) / 2; ox <= (x + 1) / 2; ++ox) {
+                    if (ox < 0 || ox >= Wo) continue;
+                    const long o = (img * Ho + oy) * Wo + ox;
+                    if (pooled[o * ldp + c] == a) g += dOut[o * lddo + c];
+                }
+            }
+        }
+        dAct[r * lda + c] = g;
+    }
+}
+
+// ---- stem conv weight gradient: dW[o][c][ky][kx] = sum_{img,oy,ox} dS[(img,oy,ox)][o] * x[img][c][oy*st+ky-pad][ox*st+kx-pad]
+// Workgroup = 8x16 output tile; the input patch is staged like the forward; wave w reduces positions 32w..32w+31 of the
+// tile into 2 (o-tiles) x CIN x 2 (k-tiles of 32 over ky*8+kx) accumulators and the four waves write separate slabs.
+template <int STRIDE, int KH, int CIN>
+__global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dS,
+                                                          long ldd, float* __restrict__ slabs, int H, int Wd, int Ho,
+                                                          int Wo, int O, int KW, int pad, int tiles_x, int tiles_y,
+                                                          long ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PH = 7 * STRIDE + KH, PW = (15 * STRIDE + 8 + 1) & ~1;
+    constexpr int KT = KH * 8;                      // k index inside a channel: ky*8 + kx
+    constexpr int NKT = (KT + 31) / 32;
+    float* Ps = lds;                                // [CIN][PH][PW] (+ slack row for the padded k lanes)
+    float* Ds = lds + CIN * PH * PW + 64;           // [128][64]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    f32x16 acc[2][CIN][NKT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+            for (int q = 0; q < NKT; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][c][q][r] = 0.f;
+    // this lane's k = 32*q + i -> (ky, kx); lanes past KT read a harmless in-range address and are dropped at the store
+    int koff[NKT];
+#pragma unroll
+    for (int q = 0; q < NKT; ++q) {
+        const int k = 32 * q + i;
+        const int ky = k < KT ? k >> 3 : 0, kx = k < KT ? k & 7 : 0;
+        koff[q] = ky * PW + kx;
+    }
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long img = tile / ((long)tiles_x * tiles_y);
+        const int trem = (int)(tile - img * tiles_x * tiles_y);
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int oy0 = ty * 8, ox0 = tx * 16;
+        const int iy0 = oy0 * STRIDE - pad, ix0 = ox0 * STRIDE - pad;
+        __syncthreads();
+        for (int idx = t; idx < CIN * PH * PW; idx += 256) {
+            const int px = idx % PW, py = (idx / PW) % PH, c = idx / (PW * PH);
+            const int iy = iy0 + py, ix = ix0 + px;
+            float v = 0.f;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < Wd) v = x[((img * CIN + c) * H + iy) * (long)Wd + ix];
+            Ps[idx] = v;
+        }
+        for (int idx = t; idx < 128 * 64; idx += 256) {
+            const int r = idx >> 6, o = idx & 63;
+            const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
+            float v = 0.f;
+            if (oy < Ho && ox < Wo && o < O) v = dS[((img * Ho + oy) * (long)Wo + ox) * ldd + o];
+            Ds[idx] = v;
+        }
+        __syncthreads();
+        for (int mm = 0; mm < 32; mm += 2) {
+            const int r = 32 * wave + mm + h;            // tile position handled by this lane half
+            const int poff = (STRIDE * (r >> 4)) * PW + STRIDE * (r & 15);
+            const float a0 = Ds[r * 64 + i], a1 = Ds[r * 64 + 32 + i];
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int q = 0; q < NKT; ++q) {
+                    const float b = Ps[c * PH * PW + poff + koff[q]];
+                    acc[0][c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][c][q], 0, 0, 0);
+                    acc[1][c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][c][q], 0, 0, 0);
+                }
+        }
+    }
+    // slab[(block*4 + wave)][o][c][ky][kx]  (torch weight layout, KW columns)
+    float* dst = slabs + ((long)blockIdx.x * 4 + wave) * O * CIN * KH * KW;
+#pragma unroll
+    for (int q = 0; q < NKT; ++q) {
+        const int k = 32 * q + i;
+        const int ky = k >> 3, kx = k & 7;
+        if (k >= KT || kx >= KW) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (o < O) dst[(((long)o * CIN + c) * KH + ky) * KW + kx] = acc[a][c][q][r];
+                }
+    }
+}
+
+__global__ void slab_sum_kernel(const float* __restrict__ slabs, int nslab, long n, float* __restrict__ out,
+                                int accumulate) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nslab; ++b) s += slabs[(long)b * n + idx];
+    out[idx] = accumulate ? out[idx] + s : s;
+}
+
+bool al16b(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+int ew_grid(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+int wgrad_splits(long M, int N, int K) {
+    const long ntiles = (M + WG_BM - 1) / WG_BM;
+    const long per = (long)gnx_cdiv(N, 32) * gnx_cdiv(K, WG_KR);
+    long s = 1024 / (per > 0 ? per : 1);
+    if (s < 1) s = 1;
+    if (s > ntiles) s = ntiles;
+    if (s > 512) s = 512;
+    return (int)s;
+}
+
+}  // namespace
+
+// floats of slab workspace for gnx_wgrad_bnrelu
+GNX_EXPORT long gnx_wgrad_workspace(long M, int N, int K, int taps) {
+    return (long)wgrad_splits(M, N, K) * taps * N * K;
+}
+
+// dW[n][k][tap] (= torch [N][K][kh][kw], taps = 1 or 9) of out = conv(act(X)) given dY = d out.
+//   taps=9: X is [M = imgs*S*S][K]; taps=1, pool=0: plain 1x1; taps=1, pool=1: X is on the S x S grid and M counts the
+//   (S/2)^2 pooled positions (the transition).  scale/shift NULL = no activation.
+GNX_EXPORT int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long ldx, const float* scale,
+                                const float* shift, float* dW, float* workspace, long M, int N, int K, int S, int taps,
+                                int pool, int accumulate, hipStream_t stream) {
+    if (!dY || !X || !dW || !workspace || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldx < K || (taps != 1 && taps != 9) ||
+        (!scale) != (!shift) || (taps == 9 && (S <= 0 || M % ((long)S * S) != 0 || pool)) || (pool && S < 2))
+        return GNX_ERR_BAD_ARG;
+    const int nsplit = wgrad_splits(M, N, K);
+    const long ntiles = (M + WG_BM - 1) / WG_BM;
+    const long tps = (ntiles + nsplit - 1) / nsplit;
+    const int halo = taps == 9 ? S + 1 : 0;
+    const size_t lds_bytes = ((size_t)WG_BM * LDY + (size_t)(WG_BM + 2 * halo) * LDX + WG_BM) * sizeof(float);
+    if (lds_bytes > 160 * 1024) return GNX_ERR_UNSUPPORTED;
+    const int vec = al16b(X) && ldx % 4 == 0 && (!scale || (al16b(scale) && al16b(shift)));
+    dim3 grid(nsplit, gnx_cdiv(N, 32), gnx_cdiv(K, WG_KR));
+#define GNX_WG(T, P)                                                                                               \
+    do {                                                                                                           \
+        static size_t conf = 0;                                                                                    \
+        if (lds_bytes > conf) {                                                                                    \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, P>),                             \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)     \
+                return GNX_ERR_LAUNCH;                                                                             \
+            conf = lds_bytes;                                                                                      \
+        }                                                                                                          \
+        wgrad_kernel<T, P><<<grid, 256, lds_bytes, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, N, K, S, \
+                                                             tps, vec);                                            \
+    } while (0)
+    if (taps == 9) GNX_WG(9, false);
+    else if (pool) GNX_WG(1, true);
+    else GNX_WG(1, false);
+#undef GNX_WG
+    const long total = (long)taps * N * K;
+    wgrad_reduce_kernel<<<gnx_cdiv(total, 256), 256, 0, stream>>>(workspace, nsplit, taps, N, K, dW, accumulate);
+    return gnx_launch_status();
+}
+
+GNX_EXPORT int gnx_transpose_weight(const float* w, float* wt, int N, int K, hipStream_t stream) {
+    if (!w || !wt || N <= 0 || K <= 0) return GNX_ERR_BAD_ARG;
+    transpose_kernel<<<gnx_cdiv((long)N * K, 256), 256, 0, stream>>>(w, wt, N, K);
+    return gnx_launch_status();
+}
+
+GNX_EXPORT int gnx_repack_conv3x3_bwd(const float* w, float* wb, int N, int K, hipStream_t stream) {
+    if (!w || !wb || N <= 0 || K <= 0) return GNX_ERR_BAD_ARG;
+    repack3x3_bwd_kernel<<<gnx_cdiv(9L * N * K, 256), 256, 0, stream>>>(w, wb, N, K);
+    return gnx_launch_status();
+}
+
+GNX_EXPORT int gnx_rows_broadcast(const float* in, long ldi, float* out, long ldo, long imgs, int C, int S2, float alpha,
+                                  hipStream_t stream) {
+    if (!in || !out || imgs <= 0 || C <= 0 || S2 <= 0 || ldi < C || ldo < C) return GNX_ERR_BAD_ARG;
+    rows_broadcast_kernel<<<ew_grid(imgs * S2 * C), 256, 0, stream>>>(in, ldi, out, ldo, imgs * S2, C, S2, alpha);
+    return gnx_launch_status();
+}
+
+GNX_EXPORT int gnx_avgpool2_bwd(const float* dP, long ldp, float* dA, long lda, long imgs, int C, int S,
+                                hipStream_t stream) {
+    if (!dP || !dA || imgs <= 0 || C <= 0 || S < 2 || ldp < C || lda < C) return GNX_ERR_BAD_ARG;
+    avgpool2_bwd_kernel<<<ew_grid(imgs * S * S * C), 256, 0, stream>>>(dP, ldp, dA, lda, imgs * S * S, C, S);
+    return gnx_launch_status();
+}
+
+GNX_EXPORT int gnx_maxpool_bwd(const float* in, long ldi, const float* pooled, long ldp, const float* dOut, long lddo,
+                               float* dAct, long lda, long imgs, int C, int Hi, int Wi, const float* scale,
+                               const float* shift, hipStream_t stream) {
+    if (!in || !pooled || !dOut || !dAct || !scale || !shift || imgs <= 0 || C <= 0 || Hi <= 0 || Wi <= 0)
+        return GNX_ERR_BAD_ARG;
+    const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+    maxpool_bwd_kernel<<<ew_grid(imgs * Hi * Wi * C), 256, 0, stream>>>(in, ldi, pooled, ldp, dOut, lddo, dAct, lda,
+                                                                       imgs * Hi * Wi, C, Hi, Wi, Ho, Wo, scale, shift);
+    return gnx_launch_status();
+}
+
+GNX_EXPORT long gnx_conv0_wgrad_workspace(long imgs, int H, int W, int O, int KH, int KW, int stride, int pad) {
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    const long ntiles = imgs * gnx_cdiv(Wo, 16) * gnx_cdiv(Ho, 8);
+    const long blocks = ntiles < 512 ? ntiles : 512;
+    return blocks * 4 * (long)O * 3 * KH * KW;
+}
+
+// dW0 [O][3][KH][KW] from x [imgs][3][H][W] and dS [imgs*Ho*Wo][O] (ldd)
+GNX_EXPORT int gnx_conv0_wgrad(const float* x, const float* dS, long ldd, float* dW, float* workspace, long imgs, int H,
+                               int W, int O, int KH, int KW, int stride, int pad, int accumulate, hipStream_t stream) {
+    if (!x || !dS || !dW || !workspace || imgs <= 0 || O <= 0 || O > 64 || ldd < O) return GNX_ERR_BAD_ARG;
+    if (!((stride == 2 && KH == 7 && KW == 7) || (stride == 1 && KH == 3 && KW == 3))) return GNX_ERR_UNSUPPORTED;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    const int tiles_x = gnx_cdiv(Wo, 16), tiles_y = gnx_cdiv(Ho, 8);
+    const long ntiles = imgs * tiles_x * tiles_y;
+    const int blocks = (int)(ntiles < 512 ? ntiles : 512);
+    const int PH = 7 * stride + KH, PW = (15 * stride + 8 + 1) & ~1;
+    const size_t lds_bytes = ((size_t)3 * PH * PW + 64 + 128 * 64) * sizeof(float);
+    if (stride == 2)
+        conv0_wgrad_kernel<2, 7, 3><<<blocks, 256, lds_bytes, stream>>>(x, dS, ldd, workspace, H, W, Ho, Wo, O, KW, pad,
+                                                                        tiles_x, tiles_y, ntiles);
+    else
+        conv0_wgrad_kernel<1, 3, 3><<<blocks, 256, lds_bytes, stream>>>(x, dS, ldd, workspace, H, W, Ho, Wo, O, KW, pad,
+                                                                        tiles_x, tiles_y, ntiles);
+    const long n = (long)O * 3 * KH * KW;
+    slab_sum_kernel<<<gnx_cdiv(n, 256), 256, 0, stream>>>(workspace, blocks * 4, n, dW, accumulate);
+    return gnx_launch_status();
+}

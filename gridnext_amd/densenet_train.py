@@ -1,0 +1,283 @@
+"""DenseNet-BC forward-with-tape and backward on the HIP kernels (training / gradient path).
+
+Used by `DenseNet.forward` whenever the module is in training mode or a gradient is required - i.e.
+`train_spotwise` on an image classifier (BatchNorm batch statistics, /root/reference/gridnext/training.py:60-67)
+and `train_gridwise` with `f_opt` (f kept in eval mode by training.py:126, but its parameters trained).
+
+MI355X-first: nothing is recomputed and nothing is checkpointed (the reference's `efficient=True` and
+`atonce_patch_limit` recompute paths exist to save memory; a 128-px array's full tape is ~42 GB of the 288 GB
+HBM).  The tape holds the raw (pre-BN) tensors only: stem output, the dense-block buffers and each layer's
+1x1-conv output; every BN+ReLU is re-evaluated inside the consuming kernel's operand load, forward and backward.
+One autograd node covers the whole network; gradients are returned for every parameter that requires one.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+F32 = torch.float32
+
+
+def _cols(t, c0):
+    """Device address of column c0 of a row-major [M, ld] matrix."""
+    return t.data_ptr() + 4 * c0
+
+
+class _Tape:
+    pass
+
+
+def _bn(model_bn, X_ptr, ld, M, training, dev, st):
+    """Fold one BatchNorm over rows of X[M][C]: returns stats[4][Cpad] = scale, shift, mean, invstd."""
+    C = model_bn.num_features
+    cp = (C + 3) // 4 * 4
+    stats = torch.empty((4, cp), device=dev, dtype=F32)
+    if training:
+        ws = torch.empty(L.query('gnx_bn_workspace', M, C), device=dev, dtype=F32)
+        L.call('gnx_bn_train_stats', X_ptr, ld, M, C, L.ptr(model_bn.weight), L.ptr(model_bn.bias),
+               L.ptr(model_bn.running_mean), L.ptr(model_bn.running_var),
+               L.ptr(model_bn.num_batches_tracked, torch.int64), float(model_bn.momentum), float(model_bn.eps),
+               L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(ws), st)
+    else:
+        L.call('gnx_bn_fold_eval', C, L.ptr(model_bn.weight), L.ptr(model_bn.bias), L.ptr(model_bn.running_mean),
+               L.ptr(model_bn.running_var), float(model_bn.eps), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]),
+               L.ptr(stats[3]), st)
+    return stats
+
+
+class _DenseNetFn(Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        x = x.contiguous().float()
+        N, _, P, _ = x.shape
+        dev = x.device
+        st = L.stream()
+        training = model.training
+        hs, sizes = model._geometry(P)
+        mid = model.bn_size * model.growth_rate
+        g = model.growth_rate
+        conv0 = model.features.conv0
+        c0 = conv0.out_channels
+        tape = _Tape()
+        tape.x, tape.N, tape.P, tape.hs, tape.sizes, tape.training = x, N, P, hs, sizes, training
+        bufs = [torch.empty((N * s * s, c_total), device=dev, dtype=F32)
+                for (_, _, _, c_total), s in zip(model._blocks, sizes)]
+        tape.bufs = bufs
+        w0 = conv0.weight.detach().contiguous()
+        ld1 = bufs[0].shape[1]
+        if model.small_inputs:
+            L.call('gnx_conv_stem', L.ptr(x), L.ptr(w0), L.ptr(bufs[0]), ld1, N, 3, P, P, c0, 3, 3, 1, 1, st)
+            tape.stem_out = tape.stats0 = None
+        else:
+            stem_out = torch.empty((N * hs * hs, c0), device=dev, dtype=F32)
+            L.call('gnx_conv_stem', L.ptr(x), L.ptr(w0), L.ptr(stem_out), c0, N, 3, P, P, c0, 7, 7, 2, 3, st)
+            s0 = _bn(model.features.norm0, L.ptr(stem_out), c0, N * hs * hs, training, dev, st)
+            L.call('gnx_bnrelu_maxpool', L.ptr(stem_out), c0, L.ptr(bufs[0]), ld1, N, c0, hs, hs, L.ptr(s0[0]),
+                   L.ptr(s0[1]), st)
+            tape.stem_out, tape.stats0 = stem_out, s0
+        tape.layers = []          # per block: list of (bott, stats1, stats2, w2 repacked)
+        tape.trans = []           # per block: stats of the transition BN (or None)
+        for bi, ((c_in, layers, trans, c_total), s) in enumerate(zip(model._blocks, sizes)):
+            buf = bufs[bi]
+            M = N * s * s
+            recs = []
+            for li, layer in enumerate(layers):
+                cin = c_in + li * g
+                s1 = _bn(layer.norm1, L.ptr(buf), c_total, M, training, dev, st)
+                bott = torch.empty((M, mid), device=dev, dtype=F32)
+                L.call('gnx_conv1x1_bnrelu', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid, M, mid,
+                       cin, L.ptr(s1[0]), L.ptr(s1[1]), 0, 0, st)
+                s2 = _bn(layer.norm2, L.ptr(bott), mid, M, training, dev, st)
+                w2 = torch.empty((9, g, mid), device=dev, dtype=F32)
+                L.call('gnx_repack_conv3x3', L.ptr(layer.conv2.weight.detach().contiguous()), L.ptr(w2), g, mid, st)
+                L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2), _cols(buf, cin), c_total, M, g, mid, s,
+                       L.ptr(s2[0]), L.ptr(s2[1]), st)
+                recs.append((bott, s1, s2))
+            tape.layers.append(recs)
+            if trans is not None:
+                nxt = bufs[bi + 1]
+                so = s // 2
+                stt = _bn(trans.norm, L.ptr(buf), c_total, M, training, dev, st)
+                L.call('gnx_conv1x1_bnrelu', L.ptr(buf), c_total, L.ptr(trans.conv.weight), L.ptr(nxt), nxt.shape[1],
+                       N * so * so, trans.conv.out_channels, c_total, L.ptr(stt[0]), L.ptr(stt[1]), 1, s, st)
+                tape.trans.append(stt)
+            else:
+                tape.trans.append(None)
+        s_last = sizes[-1]
+        c_last = model.num_features
+        sf = _bn(model.features.norm_final, L.ptr(bufs[-1]), bufs[-1].shape[1], N * s_last * s_last, training, dev, st)
+        tape.statsf = sf
+        feats = torch.empty((N, c_last), device=dev, dtype=F32)
+        L.call('gnx_bnrelu_avgpool', L.ptr(bufs[-1]), bufs[-1].shape[1], L.ptr(feats), c_last, N, c_last,
+               s_last * s_last, L.ptr(sf[0]), L.ptr(sf[1]), st)
+        tape.feats = feats
+        ctx.tape, ctx.model = tape, model
+        ctx.x_needs_grad = x.requires_grad
+        if not model.classify:
+            return feats.clone()
+        nc = model.classifier.out_features
+        out = torch.empty((N, nc), device=dev, dtype=F32)
+        L.call('gnx_gemm_f32', L.ptr(feats), c_last, 0, L.ptr(model.classifier.weight), c_last, 0,
+               L.ptr(model.classifier.bias), L.ptr(out), nc, N, nc, c_last, 0, st)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, tape = ctx.model, ctx.tape
+        if ctx.x_needs_grad:
+            raise NotImplementedError("gradient with respect to the input patches is not part of the GridNext path")
+        dout = dout.contiguous()
+        dev = dout.device
+        st = L.stream()
+        N, P, hs, sizes, training = tape.N, tape.P, tape.hs, tape.sizes, tape.training
+        g = model.growth_rate
+        mid = model.bn_size * g
+        grads = {}
+
+        def want(p):
+            return p is not None and p.requires_grad
+
+        def new_like(p):
+            t = torch.empty_like(p, memory_format=torch.contiguous_format)
+            grads[p] = t
+            return t
+
+        def bn_bwd(bn, stats, dy_ptr, lddy, x_ptr, ldx, dx_ptr, lddx, M, C, dx_acc):
+            dg = new_like(bn.weight) if want(bn.weight) else None
+            db = new_like(bn.bias) if want(bn.bias) else None
+            ws = torch.empty(L.query('gnx_bn_workspace', M, C), device=dev, dtype=F32)
+            L.call('gnx_bn_relu_bwd', dy_ptr, lddy, x_ptr, ldx, dx_ptr, lddx, M, C, L.ptr(stats[0]), L.ptr(stats[1]),
+                   L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(dg), L.ptr(db), 1, 1 if training else 0, 0, dx_acc,
+                   L.ptr(ws), st)
+
+        def wgrad(w, dy_ptr, lddy, x_ptr, ldx, stats, M, Nn, K, S, taps, pool):
+            if not want(w):
+                return
+            dw = new_like(w)
+            ws = torch.empty(L.query('gnx_wgrad_workspace', M, Nn, K, taps), device=dev, dtype=F32)
+            L.call('gnx_wgrad_bnrelu', dy_ptr, lddy, x_ptr, ldx, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(dw), L.ptr(ws),
+                   M, Nn, K, S, taps, pool, 0, st)
+
+        # ---- classifier
+        c_last = model.num_features
+        if model.classify:
+            cls = model.classifier
+            nc = cls.out_features
+            dfeats = torch.empty((N, c_last), device=dev, dtype=F32)
+            L.call('gnx_gemm_f32', L.ptr(dout), nc, 0, L.ptr(cls.weight), c_last, 1, None, L.ptr(dfeats), c_last,
+                   N, c_last, nc, 0, st)
+            if want(cls.weight):
+                dw = new_like(cls.weight)
+                L.call('gnx_gemm_f32', L.ptr(dout), nc, 1, L.ptr(tape.feats), c_last, 1, None, L.ptr(dw), c_last,
+                       nc, c_last, N, 0, st)
+            if want(cls.bias):
+                db = new_like(cls.bias)
+                ws = torch.empty(L.query('gnx_bn_workspace', N, nc), device=dev, dtype=F32)
+                L.call('gnx_colsum', L.ptr(dout), nc, N, nc, L.ptr(db), 0, L.ptr(ws), st)
+        else:
+            dfeats = dout
+
+        # ---- tail: norm_final -> relu -> global average
+        bufs = tape.bufs
+        dbufs = [None] * len(bufs)
+        s_last = sizes[-1]
+        M_last = N * s_last * s_last
+        dY = torch.empty((M_last, c_last), device=dev, dtype=F32)
+        L.call('gnx_rows_broadcast', L.ptr(dfeats), c_last, L.ptr(dY), c_last, N, c_last, s_last * s_last,
+               1.0 / (s_last * s_last), st)
+        dbufs[-1] = torch.empty_like(bufs[-1])
+        bn_bwd(model.features.norm_final, tape.statsf, L.ptr(dY), c_last, L.ptr(bufs[-1]), bufs[-1].shape[1],
+               L.ptr(dbufs[-1]), bufs[-1].shape[1], M_last, c_last, 0)
+        del dY
+
+        # ---- dense blocks, last to first
+        for bi in range(len(model._blocks) - 1, -1, -1):
+            c_in, layers, trans, c_total = model._blocks[bi]
+            s = sizes[bi]
+            M = N * s * s
+            buf, dbuf = bufs[bi], dbufs[bi]
+            tA = torch.empty((M, mid), device=dev, dtype=F32)
+            tB = torch.empty((M, mid), device=dev, dtype=F32)
+            tC = torch.empty((M, c_total), device=dev, dtype=F32)
+            for li in range(len(layers) - 1, -1, -1):
+                layer = layers[li]
+                bott, s1, s2 = tape.layers[bi][li]
+                cin = c_in + li * g
+                dy2 = _cols(dbuf, cin)
+                # conv2: weight gradient, then data gradient (adjoint conv with flipped taps)
+                wgrad(layer.conv2.weight, dy2, c_total, L.ptr(bott), mid, s2, M, g, mid, s, 9, 0)
+                wb = torch.empty((9, mid, g), device=dev, dtype=F32)
+                L.call('gnx_repack_conv3x3_bwd', L.ptr(layer.conv2.weight.detach().contiguous()), L.ptr(wb), g, mid, st)
+                L.call('gnx_conv3x3_bnrelu', dy2, c_total, L.ptr(wb), L.ptr(tA), mid, M, mid, g, s, None, None, st)
+                # norm2 + relu2
+                bn_bwd(layer.norm2, s2, L.ptr(tA), mid, L.ptr(bott), mid, L.ptr(tB), mid, M, mid, 0)
+                # conv1
+                wgrad(layer.conv1.weight, L.ptr(tB), mid, L.ptr(buf), c_total, s1, M, mid, cin, s, 1, 0)
+                w1t = torch.empty((cin, mid), device=dev, dtype=F32)
+                L.call('gnx_transpose_weight', L.ptr(layer.conv1.weight.detach().contiguous()), L.ptr(w1t), mid, cin, st)
+                L.call('gnx_conv1x1_bnrelu', L.ptr(tB), mid, L.ptr(w1t), L.ptr(tC), c_total, M, cin, mid, None, None,
+                       0, 0, st)
+                # norm1 + relu1, accumulated into the block-buffer gradient
+                bn_bwd(layer.norm1, s1, L.ptr(tC), c_total, L.ptr(buf), c_total, L.ptr(dbuf), c_total, M, cin, 1)
+                tape.layers[bi][li] = None
+            del tA, tB, tC
+            if bi > 0:
+                # transition bi-1 -> bi : dT is columns [0, c_in) of this block's gradient
+                p_c_in, p_layers, p_trans, p_total = model._blocks[bi - 1]
+                ps = sizes[bi - 1]
+                Mp = N * ps * ps
+                stt = tape.trans[bi - 1]
+                c_out = p_trans.conv.out_channels
+                wgrad(p_trans.conv.weight, L.ptr(dbuf), c_total, L.ptr(bufs[bi - 1]), p_total, stt, M, c_out, p_total,
+                      ps, 1, 1)
+                wt = torch.empty((p_total, c_out), device=dev, dtype=F32)
+                L.call('gnx_transpose_weight', L.ptr(p_trans.conv.weight.detach().contiguous()), L.ptr(wt), c_out,
+                       p_total, st)
+                dPool = torch.empty((M, p_total), device=dev, dtype=F32)
+                L.call('gnx_conv1x1_bnrelu', L.ptr(dbuf), c_total, L.ptr(wt), L.ptr(dPool), p_total, M, p_total, c_out,
+                       None, None, 0, 0, st)
+                dAct = torch.empty((Mp, p_total), device=dev, dtype=F32)
+                L.call('gnx_avgpool2_bwd', L.ptr(dPool), p_total, L.ptr(dAct), p_total, N, p_total, ps, st)
+                del dPool
+                dbufs[bi - 1] = torch.empty_like(bufs[bi - 1])
+                bn_bwd(p_trans.norm, stt, L.ptr(dAct), p_total, L.ptr(bufs[bi - 1]), p_total, L.ptr(dbufs[bi - 1]),
+                       p_total, Mp, p_total, 0)
+                del dAct
+                dbufs[bi] = None
+                bufs[bi] = None
+
+        # ---- stem
+        conv0 = model.features.conv0
+        c0 = conv0.out_channels
+        c_total1 = bufs[0].shape[1]
+        if want(conv0.weight):
+            dw0 = new_like(conv0.weight)
+            if model.small_inputs:
+                ws = torch.empty(L.query('gnx_conv0_wgrad_workspace', N, P, P, c0, 3, 3, 1, 1), device=dev, dtype=F32)
+                L.call('gnx_conv0_wgrad', L.ptr(tape.x), L.ptr(dbufs[0]), c_total1, L.ptr(dw0), L.ptr(ws), N, P, P, c0,
+                       3, 3, 1, 1, 0, st)
+        if not model.small_inputs:
+            M0 = N * hs * hs
+            need = want(conv0.weight) or want(model.features.norm0.weight) or want(model.features.norm0.bias)
+            if need:
+                s0 = tape.stats0
+                dAct = torch.empty((M0, c0), device=dev, dtype=F32)
+                L.call('gnx_maxpool_bwd', L.ptr(tape.stem_out), c0, L.ptr(bufs[0]), c_total1, L.ptr(dbufs[0]), c_total1,
+                       L.ptr(dAct), c0, N, c0, hs, hs, L.ptr(s0[0]), L.ptr(s0[1]), st)
+                dS = torch.empty((M0, c0), device=dev, dtype=F32)
+                bn_bwd(model.features.norm0, s0, L.ptr(dAct), c0, L.ptr(tape.stem_out), c0, L.ptr(dS), c0, M0, c0, 0)
+                if want(conv0.weight):
+                    ws = torch.empty(L.query('gnx_conv0_wgrad_workspace', N, P, P, c0, 7, 7, 2, 3), device=dev, dtype=F32)
+                    L.call('gnx_conv0_wgrad', L.ptr(tape.x), L.ptr(dS), c0, L.ptr(grads[conv0.weight]), L.ptr(ws), N, P,
+                           P, c0, 7, 7, 2, 3, 0, st)
+        ctx.tape = None
+        out = [None, None]
+        for p in model.parameters():
+            out.append(grads.get(p))
+        return tuple(out)
+
+
+def densenet_autograd(model, x):
+    """Differentiable DenseNet forward (training-mode BN when model.training, running-stat BN otherwise)."""
+    params = list(model.parameters())
+    return _DenseNetFn.apply(model, x, *params)

@@ -102,7 +102,7 @@ class _BNReLU(Function):
         ws = torch.empty(L.query('gnx_bn_workspace', M, C), device=dev, dtype=F32)
         L.call('gnx_bn_relu_bwd', L.ptr(dy), lddy, L.ptr(x), ld, L.ptr(dx), C, M, C, L.ptr(stats[0]),
                L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(dgamma), L.ptr(dbeta), 1 if relu else 0,
-               1 if training else 0, 0, L.ptr(ws), L.stream())
+               1 if training else 0, 0, 0, L.ptr(ws), L.stream())
         return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
@@ -135,7 +135,7 @@ class _ReLURows(Function):
         dx = torch.empty((M, C), device=x.device, dtype=F32)
         ws = torch.empty(L.query('gnx_bn_workspace', M, C), device=x.device, dtype=F32)
         L.call('gnx_bn_relu_bwd', L.ptr(dy), lddy, L.ptr(x), ctx.ld, L.ptr(dx), C, M, C, L.ptr(one), L.ptr(zero),
-               L.ptr(zero), L.ptr(one), None, None, 1, 0, 0, L.ptr(ws), L.stream())
+               L.ptr(zero), L.ptr(one), None, None, 1, 0, 0, 0, L.ptr(ws), L.stream())
         return dx
 
 

@@ -55,8 +55,8 @@ int gnx_scale_shift_relu(const float* x, long ldx, float* y, long ldy, long M, i
                          const float* shift, int relu, gnx_stream_t stream);
 int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long ldx, float* dx, long lddx, long M, int C,
                     const float* scale, const float* shift, const float* save_mean, const float* save_invstd,
-                    float* dgamma, float* dbeta, int relu, int training, int accumulate, float* workspace,
-                    gnx_stream_t stream);
+                    float* dgamma, float* dbeta, int relu, int training, int accumulate, int dx_accumulate,
+                    float* workspace, gnx_stream_t stream);
 int gnx_colsum(const float* x, long ld, long M, int C, float* out, int accumulate, float* workspace,
                gnx_stream_t stream);
 
@@ -94,6 +94,29 @@ int gnx_bnrelu_maxpool(const float* in, long ldi, float* out, long ldo, long img
                        const float* scale, const float* shift, gnx_stream_t stream);
 int gnx_bnrelu_avgpool(const float* in, long ldi, float* out, long ldo, long imgs, int C, int S2,
                        const float* scale, const float* shift, gnx_stream_t stream);
+
+
+/* ---- DenseNet-BC backward (the gradients torch.autograd derives for gridnext/densenet.py) -----------------------------
+ * Data gradients reuse gnx_conv1x1_bnrelu / gnx_conv3x3_bnrelu with weights transformed by gnx_transpose_weight
+ * ([N][K] -> [K][N]) and gnx_repack_conv3x3_bwd ([N][K][3][3] -> [8-tap][K][N]).
+ * gnx_wgrad_bnrelu: dW of conv1 / conv2 / transition conv (taps 1|9, pool), BN+ReLU prologue recomputed while staging.
+ * gnx_conv0_wgrad : dW of features.conv0 from NCHW patches.  Pool adjoints: maxpool (pool0), avgpool2 (transition),
+ * rows_broadcast (adaptive_avg_pool). */
+long gnx_wgrad_workspace(long M, int N, int K, int taps); /* floats */
+int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long ldx, const float* scale, const float* shift,
+                     float* dW, float* workspace, long M, int N, int K, int S, int taps, int pool, int accumulate,
+                     gnx_stream_t stream);
+int gnx_transpose_weight(const float* w, float* wt, int N, int K, gnx_stream_t stream);
+int gnx_repack_conv3x3_bwd(const float* w, float* wb, int N, int K, gnx_stream_t stream);
+int gnx_rows_broadcast(const float* in, long ldi, float* out, long ldo, long imgs, int C, int S2, float alpha,
+                       gnx_stream_t stream);
+int gnx_avgpool2_bwd(const float* dP, long ldp, float* dA, long lda, long imgs, int C, int S, gnx_stream_t stream);
+int gnx_maxpool_bwd(const float* in, long ldi, const float* pooled, long ldp, const float* dOut, long lddo, float* dAct,
+                    long lda, long imgs, int C, int Hi, int Wi, const float* scale, const float* shift,
+                    gnx_stream_t stream);
+long gnx_conv0_wgrad_workspace(long imgs, int H, int W, int O, int KH, int KW, int stride, int pad); /* floats */
+int gnx_conv0_wgrad(const float* x, const float* dS, long ldd, float* dW, float* workspace, long imgs, int H, int W,
+                    int O, int KH, int KW, int stride, int pad, int accumulate, gnx_stream_t stream);
 
 #ifdef __cplusplus
 }

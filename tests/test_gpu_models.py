@@ -229,3 +229,120 @@ def test_full_size_visium_grid_properties():
     assert float(grad[~fg].abs().max()) == 0.0
     assert float(grad[fg].sum(1).abs().max()) < 1e-7
     assert m.corrector[0].kernel0.grad is not None and torch.isfinite(m.corrector[0].kernel0.grad).all()
+
+
+# ----------------------------------------------------------------------------------------------- DenseNet gradients
+@pytest.mark.parametrize("name,kw", [("densenet_tiny_large", TINY_LARGE), ("densenet_tiny_small", TINY_SMALL)])
+def test_densenet_gradients_match_reference_fixture(name, kw):
+    """eval-mode BN gradients (train_gridwise + f_opt) and train-mode BN forward/gradients/running stats
+    (train_spotwise) against what the reference's DenseNet + torch.autograd produced."""
+    import gridnext_amd as ga
+    from gridnext_amd import functional as GF
+    g = load_golden(name)
+    x = torch.from_numpy(g['x']).to(DEV)
+    labels = torch.from_numpy(g['labels']).to(DEV)
+    for mode in ('eval', 'train'):
+        m = ga.DenseNet(**kw)
+        m.load_state_dict(sub(g, 'sd'))
+        m.to(DEV).train(mode == 'train')
+        out = m(x)
+        assert out.requires_grad
+        close(out, g['%s_out' % mode], rtol=3e-4, what=mode + ' out')
+        loss, _, _ = GF.masked_cross_entropy(out, labels, 1, label_base=0)
+        assert abs(loss.item() - float(g['%s_loss' % mode])) < 1e-4
+        loss.backward()
+        ref = sub(g, '%sgrad' % mode)
+        for k, p in m.named_parameters():
+            if k in ref:
+                assert p.grad is not None, k
+                close(p.grad, ref[k], rtol=2e-3, atol=2e-6, what='%s grad %s' % (mode, k))
+        if mode == 'train':
+            for k, r in sub(g, 'post').items():
+                close(m.state_dict()[k], r, rtol=2e-4, atol=1e-6, what='post ' + k)
+
+
+def test_spotwise_tiny_densenet_history_matches_reference():
+    import gridnext_amd as ga
+    g = load_golden('spotwise_densenet_tiny')
+    f = ga.DenseNet(**TINY_LARGE)
+    f.load_state_dict(sub(g, 'init'))
+    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    dl = _loaders(x, y, int(g['n_train']), int(g['batch']))
+    opt = torch.optim.Adam(f.parameters(), lr=float(g['lr']))
+    (f, vh, th), _ = quiet(ga.train_spotwise, f, dl, nn.CrossEntropyLoss(), opt, num_epochs=int(g['epochs']))
+    np.testing.assert_allclose(th, g['train_history'], rtol=1e-3)
+    np.testing.assert_allclose(vh, g['val_history'], rtol=1e-3)
+
+
+def test_gridwise_multimodal_with_f_opt_matches_reference():
+    """Both classifiers trained through f_opt, accum_iters=2: exercises the DenseNet backward with eval-mode BN
+    (training.py:126) and the count MLP left in train mode (GridNetHexMM quirk)."""
+    import gridnext_amd as ga
+    from gridnext_amd.synthetic import count_mlp
+    g = load_golden('gridwise_hexmm_fopt')
+    G, H, W, P, C = 20, 6, 4, 32, 5
+    m = ga.GridNetHexMM(ga.DenseNet(**TINY_LARGE), count_mlp(G, C), (3, P, P), (G,), (H, W), C)
+    m.load_state_dict(sub(g, 'init'))
+    xi, xc, y = torch.from_numpy(g['x_img']), torch.from_numpy(g['x_cnt']), torch.from_numpy(g['y'])
+    data = [((xi[i], xc[i]), y[i]) for i in range(4)]
+    dl = {'train': DataLoader(data[:3], batch_size=1, shuffle=False),
+          'val': DataLoader(data[3:], batch_size=1, shuffle=False)}
+    opt = torch.optim.Adam(m.corrector.parameters(), lr=1e-3)
+    f_opt = torch.optim.Adam(list(m.image_classifier.parameters()) + list(m.count_classifier.parameters()), lr=1e-4)
+    (m, vh, th), _ = quiet(ga.train_gridwise, m, dl, nn.CrossEntropyLoss(), opt, num_epochs=2, f_opt=f_opt,
+                           accum_iters=2)
+    np.testing.assert_allclose(th, g['train_history'], rtol=1e-3)
+    np.testing.assert_allclose(vh, g['val_history'], rtol=1e-3)
+
+
+def _oracle_grads(cfg, labels, training, dtype):
+    from oracle import densenet as odn
+    sd = odn.closed_form_state(cfg, dtype=dtype)
+    x = odn.closed_form_images(6, 64, dtype=dtype)
+    ref_sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
+              for k, v in sd.items()}
+    out = odn.forward(ref_sd, x, cfg, training=training)
+    loss = nn.functional.cross_entropy(out, labels)
+    loss.backward()
+    return out.detach(), loss.item(), {k: v.grad.double() for k, v in ref_sd.items()
+                                       if v.is_floating_point() and v.grad is not None}, ref_sd
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_densenet121_gradients_as_accurate_as_fp32_reference(training):
+    """Full-width layers (vectorised kernel paths): DenseNet-121, 6 spots of 64 px, all 364 parameter gradients.
+    Ground truth = the oracle in fp64.  A 121-layer net with 6-spot batch statistics is ill-conditioned, so the bar
+    is relative: per parameter, the HIP gradient must be as close to fp64 as the fp32 CPU run of the same network
+    is (x4 slack, floor 1e-3 of the gradient's max)."""
+    import gridnext_amd as ga
+    from oracle import densenet as odn
+    cfg = odn.DenseNetCfg(num_classes=8, **odn.DENSENET121)
+    labels = torch.tensor([0, 3, 5, 7, 1, 2])
+    out64, loss64, g64, _ = _oracle_grads(cfg, labels, training, torch.float64)
+    out32, loss32, g32, sd32 = _oracle_grads(cfg, labels, training, torch.float32)
+    m = ga.DenseNet(num_classes=8, **odn.DENSENET121)
+    m.load_state_dict(odn.closed_form_state(cfg))
+    m.to(DEV).train(training)
+    out = m(odn.closed_form_images(6, 64).to(DEV))
+    loss = nn.functional.cross_entropy(out, labels.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - loss64) < max(4 * abs(loss32 - loss64), 1e-4)
+    errs_hip, errs_cpu = [], []
+    for k, p in m.named_parameters():
+        ref = g64[k]
+        scale = ref.abs().max().item() + 1e-30
+        err_hip = (p.grad.double().cpu() - ref).abs().max().item() / scale
+        err_cpu = (g32[k] - ref).abs().max().item() / scale
+        if not training:
+            assert err_hip <= max(4 * err_cpu, 1e-3), (k, err_hip, err_cpu)
+        errs_hip.append(err_hip)
+        errs_cpu.append(err_cpu)
+    assert len(errs_hip) == 364
+    # with 6-spot batch statistics the fp32 round-off itself is amplified to 5-50 % on single parameters (the CPU
+    # fp32 run shows the same), so in that mode the comparison is distributional
+    assert np.median(errs_hip) <= 3 * np.median(errs_cpu) + 1e-3, (np.median(errs_hip), np.median(errs_cpu))
+    assert max(errs_hip) <= 2 * max(errs_cpu) + 1e-3, (max(errs_hip), max(errs_cpu))
+    if training:
+        for k in ('features.norm0.running_mean', 'features.denseblock4.denselayer16.norm2.running_var',
+                  'features.norm_final.running_mean'):
+            close(m.state_dict()[k], sd32[k], rtol=1e-3, atol=1e-6, what=k)
