@@ -91,6 +91,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--patch', type=int, default=128)
     ap.add_argument('--arrays', type=int, default=2, help='distinct synthetic arrays resident per GPU')
+    ap.add_argument('--train-f', action='store_true',
+                    help='second series (SURVEY 8d): both classifiers trained through f_opt, DenseNet backward included')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -104,12 +106,16 @@ def main():
 
     model = build_model(device)
     gdist.broadcast_module(model)
-    for p in model.patch_classifier.parameters():               # Tutorial_multimodal.ipynb cell 27
-        p.requires_grad = False
-    model.image_classifier.features[0].weight.requires_grad = False
     optimizer = torch.optim.Adam(model.corrector.parameters(), lr=1e-3)
+    f_opt = None
+    if args.train_f:
+        f_opt = torch.optim.Adam(list(model.image_classifier.parameters()) +
+                                 list(model.count_classifier.parameters()), lr=1e-4)
+    else:
+        for p in model.patch_classifier.parameters():           # Tutorial_multimodal.ipynb cell 27
+            p.requires_grad = False
     criterion = nn.CrossEntropyLoss()
-    stepped = gdist.optimizer_params(optimizer)
+    stepped = gdist.optimizer_params(optimizer, f_opt)
 
     # synthetic arrays, resident in HBM (different per rank: weak scaling, 1 array per GPU per step)
     arrays = []
@@ -128,6 +134,9 @@ def main():
         gdist.allreduce_gradients(stepped)
         optimizer.step()
         optimizer.zero_grad()
+        if f_opt is not None:
+            f_opt.step()
+            f_opt.zero_grad()
         return loss
 
     for i in range(args.warmup):
@@ -156,8 +165,10 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C4: multimodal f(DenseNet-121 @%dpx + count-MLP 2000 genes) + hex g on 78x64 Visium "
-                               "grids, 1 array (4992 spots) per GPU per step, f frozen/eval (tutorial mode), "
-                               "g trained with Adam, masked CE" % args.patch,
+                               "grids, 1 array (4992 spots) per GPU per step, %s, "
+                               "g trained with Adam, masked CE" % (args.patch, "f AND g trained (f_opt; DenseNet "
+                               "forward+backward, eval-mode BN as training.py:126)" if args.train_f else
+                               "f frozen/eval (tutorial mode)"),
                    "arrays_per_gpu_per_step": 1, "spots_per_array": H * W, "parallelism": "dp%d" % world,
                    "final_loss": float(last.item())},
     }

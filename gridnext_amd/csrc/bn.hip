@@ -14,6 +14,12 @@
 namespace {
 
 constexpr int ROWS_PER_BLOCK = 256;
+constexpr int MAX_SLABS = 512;      // slabs per reduction: more rows per workgroup instead of more slabs
+
+inline int slab_count(long M) {
+    const long nb = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    return (int)(nb < MAX_SLABS ? nb : MAX_SLABS);
+}
 
 // partial[blockIdx.x][c] = sum over the block's rows of f(x[r][c]); MODE 0: x ; 1: (x-mean[c])^2
 template <int MODE>
@@ -29,14 +35,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
         for (int b = 0; b < nprev; ++b) s += sum_partial[(size_t)b * C + c];
         mean = s / (float)M;
     }
-    const long r0 = (long)blockIdx.x * ROWS_PER_BLOCK;
-    const long r1 = min(r0 + ROWS_PER_BLOCK, M);
     float acc = 0.f;
     if (c < C) {
-        for (long r = r0 + rl; r < r1; r += 4) {
-            const float v = x[r * ld + c];
-            if (MODE == 0) acc += v;
-            else { const float d = v - mean; acc = fmaf(d, d, acc); }
+        for (long r0 = (long)blockIdx.x * ROWS_PER_BLOCK; r0 < M; r0 += (long)gridDim.x * ROWS_PER_BLOCK) {
+            const long r1 = min(r0 + ROWS_PER_BLOCK, M);
+            for (long r = r0 + rl; r < r1; r += 4) {
+                const float v = x[r * ld + c];
+                if (MODE == 0) acc += v;
+                else { const float d = v - mean; acc = fmaf(d, d, acc); }
+            }
         }
     }
     red[rl][cl] = acc;
@@ -114,17 +121,18 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     __shared__ float red[2][4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
-    const long r0 = (long)blockIdx.x * ROWS_PER_BLOCK;
-    const long r1 = min(r0 + ROWS_PER_BLOCK, M);
     float a1 = 0.f, a2 = 0.f;
     if (c < C) {
         const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
-        for (long r = r0 + rl; r < r1; r += 4) {
-            const float xv = x[r * ldx + c];
-            float dz = dy[r * lddy + c];
-            if (relu && fmaf(xv, sc, sh) <= 0.f) dz = 0.f;
-            a1 += dz;
-            a2 = fmaf(dz, (xv - mu) * is, a2);
+        for (long r0 = (long)blockIdx.x * ROWS_PER_BLOCK; r0 < M; r0 += (long)gridDim.x * ROWS_PER_BLOCK) {
+            const long r1 = min(r0 + ROWS_PER_BLOCK, M);
+            for (long r = r0 + rl; r < r1; r += 4) {
+                const float xv = x[r * ldx + c];
+                float dz = dy[r * lddy + c];
+                if (relu && fmaf(xv, sc, sh) <= 0.f) dz = 0.f;
+                a1 += dz;
+                a2 = fmaf(dz, (xv - mu) * is, a2);
+            }
         }
     }
     red[0][rl][cl] = a1;
@@ -180,6 +188,50 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
     }
 }
 
+
+// 4 channels per thread, 16-B accesses (C % 4 == 0, aligned pointers and leading dimensions)
+__global__ __launch_bounds__(256) void bn_bwd_dx_vec4_kernel(const float* __restrict__ dy, long lddy,
+                                                             const float* __restrict__ x, long ldx,
+                                                             float* __restrict__ dx, long lddx, long M, int C4,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ sums, int relu, int training,
+                                                             int dx_accumulate) {
+    const long total = M * C4;
+    const float invM = 1.0f / (float)M;
+    const int C = 4 * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / C4;
+        const int c = 4 * (int)(idx - r * C4);
+        const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        const float4 dv = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+        float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+        const float scs[4] = {sc.x, sc.y, sc.z, sc.w}, shs[4] = {sh.x, sh.y, sh.z, sh.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float dz = ds[e];
+            if (relu && fmaf(xs[e], scs[e], shs[e]) <= 0.f) dz = 0.f;
+            float g = dz;
+            if (training) {
+                const float xhat = (xs[e] - mean[c + e]) * invstd[c + e];
+                g = dz - sums[c + e] * invM - xhat * sums[C + c + e] * invM;
+            }
+            o[e] = scs[e] * g;
+        }
+        float4* dst = reinterpret_cast<float4*>(dx + r * lddx + c);
+        if (dx_accumulate) {
+            const float4 old = *dst;
+            o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+        }
+        *dst = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // out[c] = fixed-order sum of the slabs (used for bias gradients)
 __global__ void slab_reduce_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out,
                                    int accumulate) {
@@ -199,7 +251,7 @@ inline int elementwise_grid(long total) {
 
 // floats of workspace needed by gnx_bn_train_stats / gnx_bn_relu_bwd for an [M][C] matrix
 GNX_EXPORT long gnx_bn_workspace(long M, int C) {
-    return 2L * gnx_cdiv(M, ROWS_PER_BLOCK) * C + 2L * C;
+    return 2L * slab_count(M) * C + 2L * C;
 }
 
 // Training-mode statistics of x[M][C]: fills scale/shift (folded affine), save_mean/save_invstd and
@@ -210,7 +262,7 @@ GNX_EXPORT int gnx_bn_train_stats(const float* x, long ld, long M, int C, const 
                                   float* save_invstd, float* workspace, hipStream_t stream) {
     if (!x || !scale || !shift || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0 || ld < C)
         return GNX_ERR_BAD_ARG;
-    const int nblk = gnx_cdiv(M, ROWS_PER_BLOCK);
+    const int nblk = slab_count(M);
     float* p_sum = workspace;
     float* p_m2 = workspace + (size_t)nblk * C;
     dim3 grid(nblk, gnx_cdiv(C, 64));
@@ -250,17 +302,28 @@ GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long 
                                int accumulate, int dx_accumulate, float* workspace, hipStream_t stream) {
     if (!dy || !x || !scale || !shift || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0)
         return GNX_ERR_BAD_ARG;
-    const int nblk = gnx_cdiv(M, ROWS_PER_BLOCK);
+    const int nblk = slab_count(M);
     float* partial = workspace;
     float* sums = workspace + (size_t)2 * nblk * C;
     dim3 grid(nblk, gnx_cdiv(C, 64));
     bn_bwd_partial_kernel<<<grid, 256, 0, stream>>>(dy, lddy, x, ldx, M, C, scale, shift, save_mean, save_invstd,
                                                     relu, partial);
     bn_bwd_reduce_kernel<<<gnx_cdiv(C, 64), 64, 0, stream>>>(partial, nblk, C, sums, dgamma, dbeta, accumulate);
-    if (dx)
-        bn_bwd_dx_kernel<<<elementwise_grid(M * C), 256, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale,
-                                                                      shift, save_mean, save_invstd, sums, relu,
-                                                                      training, dx_accumulate);
+    if (dx) {
+        const bool v4 = C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 &&
+                        ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) |
+                          reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(scale) |
+                          reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(save_mean) |
+                          reinterpret_cast<uintptr_t>(save_invstd) | reinterpret_cast<uintptr_t>(sums)) & 15) == 0;
+        if (v4)
+            bn_bwd_dx_vec4_kernel<<<elementwise_grid(M * (C / 4)), 256, 0, stream>>>(
+                dy, lddy, x, ldx, dx, lddx, M, C / 4, scale, shift, save_mean, save_invstd, sums, relu, training,
+                dx_accumulate);
+        else
+            bn_bwd_dx_kernel<<<elementwise_grid(M * C), 256, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale,
+                                                                          shift, save_mean, save_invstd, sums, relu,
+                                                                          training, dx_accumulate);
+    }
     return gnx_launch_status();
 }
 
@@ -268,7 +331,7 @@ GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long 
 GNX_EXPORT int gnx_colsum(const float* x, long ld, long M, int C, float* out, int accumulate, float* workspace,
                           hipStream_t stream) {
     if (!x || !out || !workspace || M <= 0 || C <= 0 || ld < C) return GNX_ERR_BAD_ARG;
-    const int nblk = gnx_cdiv(M, ROWS_PER_BLOCK);
+    const int nblk = slab_count(M);
     dim3 grid(nblk, gnx_cdiv(C, 64));
     colsum_kernel<0><<<grid, 256, 0, stream>>>(x, ld, M, C, nullptr, 0, workspace);
     slab_reduce_kernel<<<gnx_cdiv(C, 64), 64, 0, stream>>>(workspace, nblk, C, out, accumulate);

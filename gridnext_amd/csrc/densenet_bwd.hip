@@ -21,10 +21,10 @@ __device__ __forceinline__ float act1(float v, float sc, float sh) { return fmax
 constexpr int WG_BM = 64;        // positions per staged tile
 constexpr int WG_KR = 128;       // k-range per workgroup (4 waves x 32)
 constexpr int LDX = WG_KR + 4;   // LDS row stride of the X strip (floats)
-constexpr int LDY = 32;          // LDS row stride of the dY tile
 
 // slab[(split*T + tap)*N*K + n*K + k]
-template <int T, bool POOL>
+// NT = 32-wide n-tiles per workgroup (1x1: NT=4 so a staged X row meets 128 output channels; 3x3: NT=1, 9 taps)
+template <int T, int NT, bool POOL>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY, long lddy,
                                                     const float* __restrict__ X, long ldx,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
@@ -33,11 +33,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int halo = (T == 9) ? S + 1 : 0;
     const int strip = WG_BM + 2 * halo;
+    constexpr int LDY = 32 * NT;
     float* Ys = lds;                               // [WG_BM][LDY]
     float* Xs = lds + WG_BM * LDY;                 // [strip][LDX]
     unsigned* Vm = reinterpret_cast<unsigned*>(Xs + strip * LDX);   // [WG_BM] tap-validity bits (T == 9)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
-    const int n0 = blockIdx.y * 32;
+    const int n0 = blockIdx.y * 32 * NT;
     const int kbase = blockIdx.z * WG_KR;
     const int kc = kbase + 32 * wave;              // this wave's 32 k columns
     const bool has_act = scale != nullptr;
@@ -45,20 +46,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY
     const long tile0 = (long)blockIdx.x * tiles_per_split;
     const long tile1 = min(tile0 + tiles_per_split, ntiles);
 
-    f32x16 acc[T];
+    f32x16 acc[T * NT];
 #pragma unroll
-    for (int a = 0; a < T; ++a)
+    for (int a = 0; a < T * NT; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
     for (long tile = tile0; tile < tile1; ++tile) {
         const long m0 = tile * WG_BM;
         __syncthreads();
-        // dY tile: [64][32]
-        for (int idx = t; idx < WG_BM * 32; idx += 256) {
-            const int r = idx >> 5, c = idx & 31;
+        // dY tile: [64][32*NT]
+        for (int idx = t; idx < WG_BM * LDY; idx += 256) {
+            const int r = idx / LDY, c = idx - r * LDY;
             const long m = m0 + r;
-            Ys[r * LDY + c] = (m < M && n0 + c < N) ? dY[m * lddy + n0 + c] : 0.f;
+            Ys[idx] = (m < M && n0 + c < N) ? dY[m * lddy + n0 + c] : 0.f;
         }
         // X strip (activated), [strip][128]
         for (int idx = t; idx < strip * (WG_KR / 4); idx += 256) {
@@ -138,18 +139,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY
             } else {
                 const float b = Xs[(mm + h) * LDX + 32 * wave + i];
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0], 0, 0, 0);
+#pragma unroll
+                for (int nt = 1; nt < NT; ++nt) {
+                    const float an = Ys[(mm + h) * LDY + 32 * nt + i];
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(an, b, acc[nt], 0, 0, 0);
+                }
             }
         }
     }
     const int k = kc + i;
     if (k < K) {
 #pragma unroll
-        for (int tap = 0; tap < T; ++tap) {
+        for (int a = 0; a < T * NT; ++a) {
+            const int tap = (T == 1) ? 0 : a, nt = (T == 1) ? a : 0;
             float* dst = slabs + ((long)blockIdx.x * T + tap) * N * K;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (n < N) dst[(long)n * K + k] = acc[tap][r];
+                const int n = n0 + 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (n < N) dst[(long)n * K + k] = acc[a][r];
             }
         }
     }
@@ -345,7 +352,7 @@ int ew_grid(long total) {
 }
 int wgrad_splits(long M, int N, int K) {
     const long ntiles = (M + WG_BM - 1) / WG_BM;
-    const long per = (long)gnx_cdiv(N, 32) * gnx_cdiv(K, WG_KR);
+    const long per = (long)gnx_cdiv(N, 128) * gnx_cdiv(K, WG_KR);
     long s = 1024 / (per > 0 ? per : 1);
     if (s < 1) s = 1;
     if (s > ntiles) s = ntiles;
@@ -373,25 +380,26 @@ GNX_EXPORT int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long
     const long ntiles = (M + WG_BM - 1) / WG_BM;
     const long tps = (ntiles + nsplit - 1) / nsplit;
     const int halo = taps == 9 ? S + 1 : 0;
-    const size_t lds_bytes = ((size_t)WG_BM * LDY + (size_t)(WG_BM + 2 * halo) * LDX + WG_BM) * sizeof(float);
+    const int nt = taps == 9 ? 1 : 4;
+    const size_t lds_bytes = ((size_t)WG_BM * 32 * nt + (size_t)(WG_BM + 2 * halo) * LDX + WG_BM) * sizeof(float);
     if (lds_bytes > 160 * 1024) return GNX_ERR_UNSUPPORTED;
     const int vec = al16b(X) && ldx % 4 == 0 && (!scale || (al16b(scale) && al16b(shift)));
-    dim3 grid(nsplit, gnx_cdiv(N, 32), gnx_cdiv(K, WG_KR));
-#define GNX_WG(T, P)                                                                                               \
+    dim3 grid(nsplit, gnx_cdiv(N, 32 * nt), gnx_cdiv(K, WG_KR));
+#define GNX_WG(T, NTT, P)                                                                                               \
     do {                                                                                                           \
         static size_t conf = 0;                                                                                    \
         if (lds_bytes > conf) {                                                                                    \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, P>),                             \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<T, NTT, P>),                             \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)     \
                 return GNX_ERR_LAUNCH;                                                                             \
             conf = lds_bytes;                                                                                      \
         }                                                                                                          \
-        wgrad_kernel<T, P><<<grid, 256, lds_bytes, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, N, K, S, \
+        wgrad_kernel<T, NTT, P><<<grid, 256, lds_bytes, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, N, K, S, \
                                                              tps, vec);                                            \
     } while (0)
-    if (taps == 9) GNX_WG(9, false);
-    else if (pool) GNX_WG(1, true);
-    else GNX_WG(1, false);
+    if (taps == 9) GNX_WG(9, 1, false);
+    else if (pool) GNX_WG(1, 4, true);
+    else GNX_WG(1, 4, false);
 #undef GNX_WG
     const long total = (long)taps * N * K;
     wgrad_reduce_kernel<<<gnx_cdiv(total, 256), 256, 0, stream>>>(workspace, nsplit, taps, N, K, dW, accumulate);
