@@ -182,6 +182,13 @@ def main():
                               "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS,
                               "traffic": None, "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
                               "flops_per_launch_avg": flops / max(n_launch, 1)}
+        # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in separate
+        # runs, KiB units, FETCH doubled for 16-B/lane loads as MI355X_MICROARCH.md prescribes); see profiles/README.md
+        tfile = os.path.join(ROOT, 'profiles', 'r01b_pmc_traffic.json')
+        if os.path.exists(tfile) and args.patch == 128:
+            with open(tfile) as fh:
+                result["roofline"]["traffic"] = json.load(fh)["conv3x3"]["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_source"] = "profiles/r01b_pmc_traffic.json (PMC, separate passes)"
         ms1 = sum(s.elapsed_time(e) for kind, s, e in probe if kind == 'conv1x1')
         result["roofline"]["conv1x1_ms_per_step"] = ms1 / args.steps
         result["roofline"]["conv3x3_ms_per_step"] = ms / args.steps

@@ -43,6 +43,7 @@ SIGNATURES = {
     'gnx_maxpool_bwd': (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
     'gnx_conv0_wgrad_workspace': (_L, [_L, _I, _I, _I, _I, _I, _I, _I]),
     'gnx_conv0_wgrad': (_I, [_P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'gnx_softmax_rows': (_I, [_P, _L, _L, _I, _P, _L, _P, _P]),
     'gnx_gemm_f32': (_I, [_P, _L, _I, _P, _L, _I, _P, _P, _L, _L, _L, _L, _I, _P]),
 }
 

@@ -166,11 +166,15 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
         }
     };
 
+    // Loop shape: loads of tile kt+1 are issued, tile kt is multiplied out of LDS, then (same iteration) the loaded
+    // registers are activated and written to LDS.  Issue and consumption sit in ONE iteration on purpose: when the
+    // prefetch registers were carried across the back edge the compiler shuffled them right after the loads and had
+    // to wait for them before the MFMA loop, exposing the memory latency it was meant to hide.
     const int nkt = (K + C1_BK - 1) / C1_BK;
     fetch(0);
+    stash(0);
+    __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-        stash(kt * C1_BK);
-        __syncthreads();
         if (kt + 1 < nkt) fetch((kt + 1) * C1_BK);
         // fragments of step s+1 are read while step s multiplies; the four accumulators are visited round-robin so
         // consecutive MFMAs never depend on each other
@@ -198,6 +202,10 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
             __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
         }
         __syncthreads();
+        if (kt + 1 < nkt) {
+            stash((kt + 1) * C1_BK);
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -399,11 +407,11 @@ __global__ __launch_bounds__(256) void conv3x3_pipe_kernel(const float* __restri
 
     const float* bbase = &Bs[i * LDK + 4 * h];
     fetch(0);
+    __syncthreads();            // zero row written
+    stash(0);
+    __syncthreads();
     for (int k0 = 0; k0 < K; k0 += 32) {
-        __syncthreads();
-        stash(k0);
-        __syncthreads();
-        if (k0 + 32 < K) fetch(k0 + 32);
+        if (k0 + 32 < K) fetch(k0 + 32);        // issued here, consumed at the end of THIS iteration (see conv1x1)
         float4 a = ld4(lds + aoff[0]), b = ld4(bbase);
 #pragma unroll
         for (int step = 0; step < 36; ++step) {
@@ -423,6 +431,11 @@ __global__ __launch_bounds__(256) void conv3x3_pipe_kernel(const float* __restri
             // pin the order: the two LDS reads of step+1 go out ahead of the four MFMAs of this step
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        if (k0 + 32 < K) {
+            __syncthreads();
+            stash(k0 + 32);
+            __syncthreads();
         }
     }
     const int col = n0 + i;

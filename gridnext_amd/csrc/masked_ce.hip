@@ -101,6 +101,26 @@ __global__ __launch_bounds__(256) void masked_ce_bwd_kernel(const float* __restr
     }
 }
 
+// probs[r][:] = softmax(z[r][:]); preds[r] = first argmax   (evaluation: utils.py:43-47)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ z, long ld, long M, int C,
+                                                           float* __restrict__ probs, long ldp,
+                                                           long long* __restrict__ preds) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    const float* zr = z + r * ld;
+    float mx = zr[0];
+    int arg = 0;
+    for (int c = 1; c < C; ++c) {
+        const float v = zr[c];
+        if (v > mx) { mx = v; arg = c; }
+    }
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(zr[c] - mx);
+    const float inv = 1.f / s;
+    for (int c = 0; c < C; ++c) probs[r * ldp + c] = expf(zr[c] - mx) * inv;
+    if (preds) preds[r] = arg;
+}
+
 }  // namespace
 
 // doubles of workspace for M rows
@@ -124,5 +144,13 @@ GNX_EXPORT int gnx_masked_ce_bwd(const float* logits, long ld, const long long* 
         return GNX_ERR_BAD_ARG;
     masked_ce_bwd_kernel<<<gnx_cdiv(M, 256), 256, 0, stream>>>(logits, ld, labels, M, C, label_base, stats, dloss,
                                                                  accum_iters, dlogits, lddz);
+    return gnx_launch_status();
+}
+
+// Row softmax + argmax of channels-last logits (all_fgd_predictions, gridnext/utils.py:36-47)
+GNX_EXPORT int gnx_softmax_rows(const float* logits, long ld, long M, int C, float* probs, long ldp, long long* preds,
+                                hipStream_t stream) {
+    if (!logits || !probs || M <= 0 || C <= 0 || C > MAXC || ld < C || ldp < C) return GNX_ERR_BAD_ARG;
+    softmax_rows_kernel<<<gnx_cdiv(M, 256), 256, 0, stream>>>(logits, ld, M, C, probs, ldp, preds);
     return gnx_launch_status();
 }

@@ -71,6 +71,10 @@ int gnx_masked_ce_bwd(const float* logits, long ld, const long long* labels, lon
                       const long long* stats, const float* dloss, float accum_iters, float* dlogits, long lddz,
                       gnx_stream_t stream);
 
+/* Row softmax + first-argmax of channels-last logits: torch.argmax / F.softmax of gridnext/utils.py:43-47. */
+int gnx_softmax_rows(const float* logits, long ld, long M, int C, float* probs, long ldp, long long* preds,
+                     gnx_stream_t stream);
+
 /* ---- count-MLP spot head: fp32 MFMA GEMM -------------------------------------------------------------------------
  * F.linear forward / input-gradient / weight-gradient of the nn.Sequential in Tutorial_visium_count.ipynb cell 12.
  * C[M][N] = opA(A) opB(B) (+bias) (+C).  a_kmajor: A[k*lda+m] (a (genes, H*W) count grid read in place, replacing

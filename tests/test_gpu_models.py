@@ -346,3 +346,30 @@ def test_densenet121_gradients_as_accurate_as_fp32_reference(training):
         for k in ('features.norm0.running_mean', 'features.denseblock4.denselayer16.norm2.running_var',
                   'features.norm_final.running_mean'):
             close(m.state_dict()[k], sd32[k], rtol=1e-3, atol=1e-6, what=k)
+
+
+def test_all_fgd_predictions_including_multimodal_lists():
+    """utils.all_fgd_predictions (reference utils.py:20-57) on the HIP path vs the oracle's masked softmax/argmax;
+    list inputs work here (the reference helper cannot take them)."""
+    import gridnext_amd as ga
+    from gridnext_amd.synthetic import count_mlp
+    from gridnext_amd.utils import all_fgd_predictions
+    from oracle import masked_ce as oce
+    g = load_golden('gridwise_hexmm_tutorial')
+    G, H, W, P, C = 20, 6, 4, 32, 5
+    m = ga.GridNetHexMM(ga.DenseNet(**TINY_LARGE), count_mlp(G, C), (3, P, P), (G,), (H, W), C)
+    m.load_state_dict(sub(g, 'init'))
+    xi, xc, y = torch.from_numpy(g['x_img']), torch.from_numpy(g['x_cnt']), torch.from_numpy(g['y'])
+    data = [((xi[i], xc[i]), y[i]) for i in range(4)]
+    t, p, s = all_fgd_predictions(DataLoader(data, batch_size=2), m)
+    ref_logits = torch.from_numpy(g['fwd0'])                       # reference forward of arrays 0,1 (eval mode)
+    rt, rp, rs = oce.fgd_softmax_argmax(ref_logits, y[:2])
+    n = rt.numel()
+    assert t.shape[0] == int((y > 0).sum()) and s.shape[1] == C
+    assert np.array_equal(t[:n], rt.numpy())
+    close(s[:n], rs, rtol=1e-3, what='softmax')
+    margin = rs.topk(2, dim=1).values
+    decided = ((margin[:, 0] - margin[:, 1]) > 1e-3).numpy()
+    assert np.array_equal(p[:n][decided], rp.numpy()[decided])
+    tf, pf, sf = all_fgd_predictions(DataLoader(data, batch_size=2), m, f_only=True)
+    assert sf.shape == (t.shape[0], 2 * C)

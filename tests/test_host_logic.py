@@ -179,3 +179,15 @@ def test_mmstack_dataset_contract():
     assert isinstance(inputs, list) and len(inputs) == 2                              # what the loops test for
     with pytest.raises(AssertionError):
         MMStackDataset(TensorDataset(xi, y1), TensorDataset(xc[:2], y2[:2]))
+
+
+def test_visium_coordinate_maps_match_reference_formulas():
+    # reference utils.py:64-79: even rows x = col/2 ; odd rows x = (col-1)/2 ; inverse 2*col (+1 on odd rows)
+    from gridnext_amd.utils import oddr_to_pseudo_hex, pseudo_hex_to_oddr, pseudo_to_true_hex
+    for row in range(6):
+        for col in range(5):
+            pc, pr = oddr_to_pseudo_hex(col, row)
+            assert (pc, pr) == ((2 * col if row % 2 == 0 else 2 * col + 1), row)
+            assert pseudo_hex_to_oddr(pc, pr) == (col, row)
+    x, y = pseudo_to_true_hex(3, 2)
+    assert x == 1.5 and abs(y - 3 ** 0.5) < 1e-12
