@@ -191,3 +191,77 @@ def test_visium_coordinate_maps_match_reference_formulas():
             assert pseudo_hex_to_oddr(pc, pr) == (col, row)
     x, y = pseudo_to_true_hex(3, 2)
     assert x == 1.5 and abs(y - 3 ** 0.5) < 1e-12
+
+
+def test_count_datasets_match_reference_on_visium_files():
+    """File-backed CountDataset / CountGridDataset (reference count_datasets.py:77-303) on the small Visium-style
+    files under tests/golden/files/; expected tensors were produced by the reference's own classes
+    (tools/gen_golden_datasets.py)."""
+    from gridnext_amd.count_datasets import CountDataset, CountGridDataset
+    g = load_golden('count_datasets')
+    files = os.path.join(ROOT, 'tests', 'golden', 'files')
+    cf = [os.path.join(files, 'array%d.counts.tsv' % a) for a in range(2)]
+    af = [os.path.join(files, 'array%d.loupe.csv' % a) for a in range(2)]
+    pf = [os.path.join(files, 'array%d.tissue_positions.csv' % a) for a in range(2)]
+    (ds, text) = quiet(CountDataset, cf, af, pf, Visium=True)
+    assert text == str(g['spot_stdout'])                                   # "N un-annotated spots"
+    assert list(ds.classes) == list(g['spot_classes']) and len(ds) == int(g['spot_len'])
+    for i in range(len(ds)):
+        x, y = ds[i]
+        assert x.dtype == torch.float32 and y.dtype == torch.int64 and y.dim() == 0
+        assert np.array_equal(x.numpy(), g['spot_x'][i]) and int(y) == int(g['spot_y'][i])
+    sel, _ = quiet(CountDataset, cf, af, pf, Visium=True, select_genes=['G3', 'G1'])
+    assert np.array_equal(sel[0][0].numpy(), g['spot_sel_x0'])
+    gd = CountGridDataset(cf, af, pf, Visium=True, h_st=8, w_st=6)
+    assert list(gd.classes) == list(g['grid_classes']) and len(gd) == 2
+    for i in range(2):
+        x, y = gd[i]
+        assert x.shape == (5, 8, 6) and x.dtype == torch.float32 and y.dtype == torch.int64
+        assert np.array_equal(x.numpy(), g['grid_x'][i]) and np.array_equal(y.numpy(), g['grid_y'][i])
+    with pytest.raises(ValueError, match='Length of count_files and annot_files must match'):
+        CountGridDataset(cf, af[:1], pf)
+    with pytest.raises(ValueError, match='Must provide Spaceranger position files'):
+        CountDataset(cf, af, None)
+
+
+def test_patch_datasets_contract(tmp_path):
+    """PatchDataset / PatchGridDataset item contract (reference image_datasets.py:113-122, :192-232): the reference
+    classes need torchvision (absent here), so this checks the documented contract on generated PNG patches that are
+    named after the spots of the Visium fixture files."""
+    from PIL import Image
+    from gridnext_amd.image_datasets import PatchDataset, PatchGridDataset
+    g = load_golden('count_datasets')
+    files = os.path.join(ROOT, 'tests', 'golden', 'files')
+    af = [os.path.join(files, 'array%d.loupe.csv' % a) for a in range(2)]
+    pf = [os.path.join(files, 'array%d.tissue_positions.csv' % a) for a in range(2)]
+    dirs = []
+    rng = np.random.RandomState(3)
+    pixels = {}
+    for a in range(2):
+        d = tmp_path / ('array%d' % a)
+        d.mkdir()
+        dirs.append(str(d))
+        header = open(os.path.join(files, 'array%d.counts.tsv' % a)).readline().strip('\n').split('\t')[1:]
+        for cstr in header:
+            img = rng.randint(0, 256, size=(8, 8, 3), dtype=np.uint8)
+            pixels[(a, cstr)] = img
+            Image.fromarray(img).save(str(d / ('spot_%s.png' % cstr)))
+    ds = PatchDataset(dirs, af, pf, Visium=True, img_ext='png')
+    assert list(ds.classes) == list(g['spot_classes']) and len(ds) == int(g['spot_len'])
+    x, y = ds[0]
+    assert x.shape == (3, 8, 8) and x.dtype == torch.float32 and 0.0 <= float(x.min()) and float(x.max()) <= 1.0
+    assert y.dtype == torch.int64
+    gd = PatchGridDataset(dirs, af, pf, Visium=True, img_ext='png', h_st=8, w_st=6)
+    for a in range(2):
+        grid, labels = gd[a]
+        assert grid.shape == (8, 6, 3, 8, 8) and labels.shape == (8, 6)
+        assert torch.equal(labels, torch.from_numpy(g['grid_y'][a]))            # same labels as the count grid
+        has_img = (grid.abs().sum(dim=(2, 3, 4)) > 0)
+        assert int(has_img.sum()) == sum(1 for k in pixels if k[0] == a)
+        assert bool((has_img | (labels == 0)).all())                            # background = no label
+        cstr = next(k[1] for k in pixels if k[0] == a)
+        cx, cy = map(int, cstr.split('_'))
+        from gridnext_amd.utils import pseudo_hex_to_oddr
+        ox, oy = pseudo_hex_to_oddr(cx, cy)
+        want = torch.from_numpy(pixels[(a, cstr)]).permute(2, 0, 1).float() / 255
+        assert torch.equal(grid[oy, ox], want)
