@@ -15,3 +15,6 @@ from .densenet import DenseNet                                                  
 from .gridnet_models import GridNet, GridNetHex, GridNetHexOddr, GridNetHexMM      # noqa: F401
 from .training import train_spotwise, train_gridwise                               # noqa: F401
 from .multimodal_datasets import MMStackDataset                                    # noqa: F401
+from .count_datasets import CountDataset, CountGridDataset                         # noqa: F401
+from .image_datasets import PatchDataset, PatchGridDataset                         # noqa: F401
+from .utils import all_fgd_predictions                                             # noqa: F401

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgridnext_hip.so')
+LIB_PATH = os.environ.get('GNX_LIB') or os.path.join(_HERE, 'libgridnext_hip.so')   # GNX_LIB: debug builds only
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 

@@ -19,16 +19,33 @@
 // (row stride = 9 sixteen-byte slots, odd).  One ds_read_b128 per operand feeds four MFMAs: lane half h supplies
 // k = 8*s + 4*h + j for the j-th of them, identically for A and B, so the k-order inside the sum is a fixed permutation.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int LDK = 36;     // floats per LDS row: 32 + 4 pad
 
 __device__ __forceinline__ float act1(float v, float sc, float sh) { return fmaxf(fmaf(v, sc, sh), 0.f); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// packed form: (x,y) and (z,w) stay in their even-aligned register pairs (v_pk_fma_f32 / v_pk_max_f32), so the
+// compiler has no reason to shuffle freshly loaded registers (which would force a wait right behind the loads)
 __device__ __forceinline__ float4 act4(float4 v, float4 sc, float4 sh) {
-    return make_float4(act1(v.x, sc.x, sh.x), act1(v.y, sc.y, sh.y), act1(v.z, sc.z, sh.z), act1(v.w, sc.w, sh.w));
+    f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+    const f32x2 slo = {sc.x, sc.y}, shi = {sc.z, sc.w}, tlo = {sh.x, sh.y}, thi = {sh.z, sh.w}, zero = {0.f, 0.f};
+    lo = __builtin_elementwise_max(__builtin_elementwise_fma(lo, slo, tlo), zero);
+    hi = __builtin_elementwise_max(__builtin_elementwise_fma(hi, shi, thi), zero);
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release fence whose wait is vmcnt(0):
+// it would drain the global prefetch loads that are meant to stay in flight across the barrier (measured: the
+// ping-pong memory phase took 12.5k cycles instead of ~2k with __syncthreads()).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 // bounds-checked / unaligned-safe 4-float load of src[0..3], zero beyond `valid` elements
 __device__ __forceinline__ float4 ld4_safe(const float* p, int valid, bool vec) {
@@ -145,7 +162,18 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
             }
         }
     };
+    const bool interior = FAST && m0 + C1_BM <= M && (K & 31) == 0 && n0 + C1_BN <= N;
     auto stash = [&](int k0) {
+        if (interior) {          // workgroup-uniform: full tile, whole K tiles -> activation + store only
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float4 v = ra[p];
+                if (!POOL && has_act) v = act4(v, sc4, sh4);
+                *reinterpret_cast<float4*>(&As[(r0 + 32 * p) * LDK + 4 * kq]) = v;
+                *reinterpret_cast<float4*>(&Bs[(r0 + 32 * p) * LDK + 4 * kq]) = rb[p];
+            }
+            return;
+        }
         const int valid = K - (k0 + 4 * kq);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -175,7 +203,9 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
     stash(0);
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
+        __builtin_amdgcn_s_setprio(3);          // non-MFMA work at raised priority (see conv3x3_pipe_kernel)
         if (kt + 1 < nkt) fetch((kt + 1) * C1_BK);
+        __builtin_amdgcn_s_setprio(0);
         // fragments of step s+1 are read while step s multiplies; the four accumulators are visited round-robin so
         // consecutive MFMAs never depend on each other
         const float* apA = &As[(64 * wm + i) * LDK + 4 * h];
@@ -201,6 +231,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
         }
+        __builtin_amdgcn_s_setprio(3);
         __syncthreads();
         if (kt + 1 < nkt) {
             stash((kt + 1) * C1_BK);
@@ -212,6 +243,12 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int col = n0 + 64 * wn + 32 * nt + i;
+            if (interior) {
+                float* o = out + (m0 + 64 * wm + 32 * mt + 4 * h) * ldc + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2)) * ldc] = acc[mt][nt][r];
+                continue;
+            }
             if (col >= N) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -384,7 +421,24 @@ __global__ __launch_bounds__(256) void conv3x3_pipe_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 9; ++j) rb[j] = ld4(Wr + ((long)j * N + nload) * K + kc);
     };
+    // workgroup-uniform: every strip row is a real position, K is a whole number of chunks, all 32 columns exist ->
+    // nothing to zero, the LDS write is activation + store only (the stash is the non-MFMA work of the kernel:
+    // PMC showed ~2.3 VALU instructions per MFMA before this fast path)
+    const bool interior = base >= 0 && base + strip <= M && (K & 31) == 0 && n0 + C3_BN <= N;
     auto stash = [&](int k0) {
+        if (interior) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int row = r0 + 32 * j;
+                if (row >= strip) continue;
+                float4 v = ra[j];
+                if (has_act) v = act4(v, sc4, sh4);
+                *reinterpret_cast<float4*>(&As[row * LDK + 4 * kq]) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < 9; ++j) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * j) * LDK + 4 * kq]) = rb[j];
+            return;
+        }
         const bool kok = k0 + 4 * kq < K;
         const bool nok = n0 + r0 < N;
 #pragma unroll
@@ -411,7 +465,11 @@ __global__ __launch_bounds__(256) void conv3x3_pipe_kernel(const float* __restri
     stash(0);
     __syncthreads();
     for (int k0 = 0; k0 < K; k0 += 32) {
+        // loads/activation/LDS writes run at raised priority: a co-resident workgroup's back-to-back MFMAs on the same
+        // SIMD otherwise starve them of issue slots (measured ~90 cycles per instruction in the ping-pong variant)
+        __builtin_amdgcn_s_setprio(3);
         if (k0 + 32 < K) fetch(k0 + 32);        // issued here, consumed at the end of THIS iteration (see conv1x1)
+        __builtin_amdgcn_s_setprio(0);
         float4 a = ld4(lds + aoff[0]), b = ld4(bbase);
 #pragma unroll
         for (int step = 0; step < 36; ++step) {
@@ -433,11 +491,14 @@ __global__ __launch_bounds__(256) void conv3x3_pipe_kernel(const float* __restri
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
         if (k0 + 32 < K) {
+            __builtin_amdgcn_s_setprio(3);
             __syncthreads();
             stash(k0 + 32);
             __syncthreads();
+            __builtin_amdgcn_s_setprio(0);
         }
     }
+    __builtin_amdgcn_s_setprio(3);
     const int col = n0 + i;
     if (col < N) {
 #pragma unroll
@@ -445,6 +506,229 @@ __global__ __launch_bounds__(256) void conv3x3_pipe_kernel(const float* __restri
             const long row = P0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (row < M) out[row * ldc + col] = acc0[r] + acc1[r];
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ conv3x3, ping-pong form
+// EXPERIMENTAL (enabled with GNX_PINGPONG=1; r01 measurement: 110-118 TFLOP/s, no better than the pipe kernel because
+// hipcc still places a wait right behind the memory role's loads - see fetch() - so that role is as long as the
+// compute phase it hides behind).  Kept for the next round: with the loads hidden (LDS-DMA or asm) this schedule has
+// every SIMD's matrix pipe owned by exactly one wave at any time.
+// Same arithmetic and LDS images as conv3x3_pipe_kernel, different schedule.  PMC showed the two co-resident 4-wave
+// workgroups of that kernel run in lockstep (both in their MFMA phase, then both in their load/activate/LDS-write phase),
+// capping matrix-core utilisation at ~73 %.  Here ONE persistent 8-wave workgroup per CU holds two independent tile
+// pipelines (waves 0-3 and 4-7, one wave of each per SIMD) that are offset by exactly one phase: between two barriers
+// one half multiplies its K-chunk out of LDS while the other half writes its next chunk to LDS (BN+ReLU applied), stores
+// its finished tile and issues the global loads it will need two phases later.  Each SIMD therefore always has exactly
+// one wave in an MFMA phase, and all non-MFMA work is hidden behind the partner's 144 MFMAs.
+#ifdef GNX_PP_STAMPS
+__device__ unsigned long long gnx_pp_stamps[8192];
+#endif
+
+template <int NJ, bool ACT>
+__global__ __launch_bounds__(512) void conv3x3_pp_kernel(const float* __restrict__ A, long lda,
+                                                         const float* __restrict__ Wr, float* __restrict__ out,
+                                                         long ldc, long M, int N, int K, int S,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int strip = C3_BM + 2 * S + 2;
+    // wave-uniform by construction AND provably so for the compiler (readfirstlane): the role branch below becomes a
+    // scalar branch and s_setprio lands only on the waves that take it
+    const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 8;
+    const int t = threadIdx.x & 255, lane = t & 63, hw = t >> 6, h = lane >> 5, i = lane & 31;
+    const int half_floats = (strip + 1 + 9 * 32) * LDK;       // strip rows + one trash row + weight rows
+    float* As = lds + half * half_floats;
+    float* Bs = As + (strip + 1) * LDK;
+    float* Zs = lds + 2 * half_floats;
+    if (threadIdx.x < LDK) Zs[threadIdx.x] = 0.f;
+    const int zoff = (int)(Zs - As);
+    const int kq = t & 7, r0 = t >> 3;
+    const long T = (M + C3_BM - 1) / C3_BM;
+    const int nk = K >> 5;
+    const long tstep = 2L * gridDim.x;
+    const int nload = r0 < N ? r0 : N - 1;
+    const bool nok = r0 < N;
+    // LDS write offsets of this thread's strip rows; rows past the strip go to the trash row (no branch in the hot loop)
+    int woff[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int row = r0 + 32 * j;
+        woff[j] = (row < strip ? row : strip) * LDK + 4 * kq;
+    }
+
+    long m_tile = 2L * blockIdx.x + half;      // tile whose chunks the memory role is feeding
+    int mc = 0;
+    long c_tile = m_tile;                      // tile the compute role is multiplying
+    int cc = 0;
+    long e_tile = 0;                           // finished tile waiting to be stored
+    bool regs_loaded = false, regs_interior = false, lds_ready = false, epi_pending = false;
+
+    f32x16 acc0, acc1, outv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; outv[r] = 0.f; }
+    int aoff[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) aoff[tap] = zoff;
+
+    float4 ra[NJ], rb[9], sc4, sh4;
+    auto is_interior = [&](long tile) {
+        const long base = tile * C3_BM - S - 1;
+        return base >= 0 && base + (long)NJ * 32 <= M && N >= C3_BN;
+    };
+    // ONE load sequence, at ONE place in the loop: with several definition sites (prologue + loop, or fast/slow
+    // variants) the register allocator inserts copies of the freshly loaded registers right behind the loads, and
+    // every such copy needs the data, i.e. a wait that exposes the whole memory latency inside the memory phase.
+    auto fetch = [&](long tile, int chunk) {
+        const long base = tile * C3_BM - S - 1;
+        const int kc = 32 * chunk + 4 * kq;
+        if (ACT) { sc4 = ld4(scale + kc); sh4 = ld4(shift + kc); }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            long Pr = base + r0 + 32 * j;
+            Pr = Pr < 0 ? 0 : (Pr >= M ? M - 1 : Pr);
+            ra[j] = ld4(A + Pr * lda + kc);
+        }
+        const float* wp = Wr + (long)nload * K + kc;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) rb[j] = ld4(wp + (long)j * N * K);
+    };
+    auto stash = [&](long tile, bool inter) {
+        if (inter) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float4 v = ra[j];
+                if (ACT) v = act4(v, sc4, sh4);
+                *reinterpret_cast<float4*>(As + woff[j]) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < 9; ++j) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * j) * LDK + 4 * kq]) = rb[j];
+            return;
+        }
+        const long base = tile * C3_BM - S - 1;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const long Pr = base + r0 + 32 * j;
+            float4 v = ra[j];
+            if (ACT) v = act4(v, sc4, sh4);
+            if (!(Pr >= 0 && Pr < M)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(As + woff[j]) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            float4 v = rb[j];
+            if (!nok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&Bs[(r0 + 32 * j) * LDK + 4 * kq]) = v;
+        }
+    };
+
+    const long my_pairs = (T > 2L * blockIdx.x) ? (T - 2L * blockIdx.x + tstep - 1) / tstep : 0;
+    const long phases = 2L * nk * my_pairs + 5;
+    __syncthreads();                                   // zero row visible
+    const float* bbase = &Bs[i * LDK + 4 * h];
+
+    for (long ph = 0; ph < phases; ++ph) {
+        const bool mem_role = ((ph + half) & 1) == 0;
+#ifdef GNX_PP_STAMPS
+        unsigned long long st0 = clock64(), sta = st0, stb = st0;
+#endif
+        if (mem_role) {
+            // The memory role is a few hundred instructions; without priority it is starved of issue slots by the
+            // partner wave's back-to-back MFMAs on the same SIMD (measured: ~90 cycles per instruction) and becomes
+            // LONGER than the compute phase it is supposed to hide behind.
+            __builtin_amdgcn_s_setprio(3);
+            // order: LDS write (consumes the prefetch registers) -> next prefetch -> store of the finished tile
+            if (regs_loaded) {
+                stash(m_tile, regs_interior);
+                lds_ready = true;
+                regs_loaded = false;
+                if (++mc == nk) { mc = 0; m_tile += tstep; }
+            }
+#ifdef GNX_PP_STAMPS
+            sta = clock64();
+#endif
+            if (m_tile < T) {
+                if (mc == 0) regs_interior = is_interior(m_tile);
+                fetch(m_tile, mc);
+                regs_loaded = true;
+            }
+#ifdef GNX_PP_STAMPS
+            stb = clock64();
+#endif
+            if (epi_pending) {
+                float* o = out + (e_tile * C3_BM + 32 * hw + 4 * h) * ldc + i;
+                if ((e_tile + 1) * C3_BM <= M && N >= C3_BN) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2)) * ldc] = outv[r];
+                } else if (i < N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rr = (r & 3) + 8 * (r >> 2);
+                        if (e_tile * C3_BM + 32 * hw + 4 * h + rr < M) o[rr * ldc] = outv[r];
+                    }
+                }
+                epi_pending = false;
+            }
+            __builtin_amdgcn_s_setprio(0);
+        } else if (lds_ready) {
+            if (cc == 0) {
+                const long P = c_tile * C3_BM + 32 * hw + i;
+                unsigned mask = 0;
+                if (P < M) {
+                    const int rem = (int)(P % ((long)S * S));
+                    const int y = rem / S, x = rem - y * S;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                        if (yy >= 0 && yy < S && xx >= 0 && xx < S) mask |= 1u << tap;
+                    }
+                }
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int off = (S + 1) + (tap / 3 - 1) * S + (tap % 3 - 1);
+                    aoff[tap] = ((mask >> tap) & 1u) ? (32 * hw + i + off) * LDK + 4 * h : zoff;
+                }
+            }
+            float4 a = ld4(As + aoff[0]), b = ld4(bbase);
+#pragma unroll
+            for (int step = 0; step < 36; ++step) {
+                float4 na = a, nb = b;
+                if (step < 35) {
+                    const int ntap = (step + 1) >> 2, ns = (step + 1) & 3;
+                    na = ld4(As + aoff[ntap] + 8 * ns);
+                    nb = ld4(bbase + ntap * 32 * LDK + 8 * ns);
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc1, 0, 0, 0);
+                a = na; b = nb;
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            lds_ready = false;
+            if (++cc == nk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { outv[r] = acc0[r] + acc1[r]; acc0[r] = 0.f; acc1[r] = 0.f; }
+                epi_pending = true;
+                e_tile = c_tile;
+                cc = 0;
+                c_tile += tstep;
+            }
+        }
+#ifdef GNX_PP_STAMPS
+        unsigned long long st1 = clock64();
+        lds_barrier();
+        unsigned long long st2 = clock64();
+        if (blockIdx.x == 7 && lane == 0 && hw == 0 && ph < 1000) {
+            gnx_pp_stamps[(ph * 2 + half) * 4 + 0] = st0;
+            gnx_pp_stamps[(ph * 2 + half) * 4 + 1] = st1;
+            gnx_pp_stamps[(ph * 2 + half) * 4 + 2] = mem_role ? sta : st2;
+            gnx_pp_stamps[(ph * 2 + half) * 4 + 3] = mem_role ? (stb | (1ull << 63)) : 0;
+        }
+#else
+        lds_barrier();
+#endif
     }
 }
 
@@ -780,6 +1064,37 @@ GNX_EXPORT int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, flo
                                                                   vecA, vecW);                                    \
     } while (0)
     const bool fast = vecA && vecW;      // aligned pointers/leading dimensions and K % 4 == 0
+    // ping-pong persistent form: whole K chunks, one 32-wide column tile, strip pair + weights fit the 160 KB LDS
+    const size_t lds_pp = (2 * ((size_t)(C3_BM + 2 * S + 2) + 1 + 9 * 32) * LDK + LDK) * sizeof(float);
+    if (fast && (K & 31) == 0 && N <= C3_BN && nj <= 9 && lds_pp <= 160 * 1024 && getenv("GNX_PINGPONG")) {
+        const long T = (M + C3_BM - 1) / C3_BM;
+        long wgs = (T + 1) / 2;
+        if (wgs > 256) wgs = 256;
+#define GNX_PP(NJ, ACTV)                                                                                               \
+    do {                                                                                                            \
+        static size_t conf = 0;                                                                                     \
+        if (lds_pp > conf) {                                                                                        \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_pp_kernel<NJ, ACTV>),                     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp) != hipSuccess)         \
+                return GNX_ERR_LAUNCH;                                                                              \
+            conf = lds_pp;                                                                                          \
+        }                                                                                                           \
+        conv3x3_pp_kernel<NJ, ACTV><<<(int)wgs, 512, lds_pp, stream>>>(A, lda, Wr, out, ldc, M, N, K, S, scale, shift); \
+    } while (0)
+        if (scale) {
+            if (nj <= 5) GNX_PP(5, true);
+            else if (nj == 6) GNX_PP(6, true);
+            else if (nj == 7) GNX_PP(7, true);
+            else GNX_PP(9, true);
+        } else {
+            if (nj <= 5) GNX_PP(5, false);
+            else if (nj == 6) GNX_PP(6, false);
+            else if (nj == 7) GNX_PP(7, false);
+            else GNX_PP(9, false);
+        }
+#undef GNX_PP
+        return gnx_launch_status();
+    }
     if (fast && nj <= 5) GNX_PIPE(5);
     else if (fast && nj == 6) GNX_PIPE(6);
     else if (fast && nj == 7) GNX_PIPE(7);
@@ -850,3 +1165,9 @@ GNX_EXPORT int gnx_bnrelu_avgpool(const float* in, long ldi, float* out, long ld
     bnrelu_avgpool_kernel<<<grid, 256, 0, stream>>>(in, ldi, out, ldo, C, S2, scale, shift);
     return gnx_launch_status();
 }
+
+#ifdef GNX_PP_STAMPS
+GNX_EXPORT int gnx_debug_pp_stamps(unsigned long long* host_dst, int n) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(gnx_pp_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -2;
+}
+#endif

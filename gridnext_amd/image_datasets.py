@@ -25,7 +25,7 @@ Image.MAX_IMAGE_PIXELS = None
 
 def to_tensor(img):
     """PIL image -> float32 CHW in [0, 1] (what torchvision.transforms.ToTensor does for 8-bit images)."""
-    arr = np.asarray(img)
+    arr = np.array(img)                       # copy: PIL's buffer is read-only
     if arr.ndim == 2:
         arr = arr[:, :, None]
     t = torch.from_numpy(np.ascontiguousarray(arr)).permute(2, 0, 1)
