@@ -93,6 +93,9 @@ def main():
     ap.add_argument('--arrays', type=int, default=2, help='distinct synthetic arrays resident per GPU')
     ap.add_argument('--train-f', action='store_true',
                     help='second series (SURVEY 8d): both classifiers trained through f_opt, DenseNet backward included')
+    ap.add_argument('--mfma', default='f32', choices=['f32', 'f16'],
+                    help="matrix-core operand type of the DenseNet convs; 'f16' = BASELINE config 5's fp16 MFMA path "
+                         "(fp32 accumulate; NOT the headline, reported as dtype f16)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -124,6 +127,7 @@ def main():
         arrays.append(([x_img.unsqueeze(0), x_cnt.unsqueeze(0)], y.unsqueeze(0)))
 
     f_img = model.image_classifier
+    f_img.mfma = args.mfma
     model.train()
     model.patch_classifier.eval()
 
@@ -163,7 +167,7 @@ def main():
         "metric": "spots/sec training throughput (multimodal f+g)",
         "value": spots / elapsed, "unit": "spots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": args.mfma, "data": "synthetic",
         "config": {"workload": "C4: multimodal f(DenseNet-121 @%dpx + count-MLP 2000 genes) + hex g on 78x64 Visium "
                                "grids, 1 array (4992 spots) per GPU per step, %s, "
                                "g trained with Adam, masked CE" % (args.patch, "f AND g trained (f_opt; DenseNet "

@@ -1,0 +1,252 @@
+// fp16-MFMA variants of the two DenseNet conv kernels (BASELINE.json config 5: "fp16 MFMA conv path").
+//
+// Same contract as gnx_conv1x1_bnrelu / gnx_conv3x3_bnrelu (densenet_fwd.hip): fp32 activations and weights in HBM,
+// fp32 BN+ReLU prologue, fp32 accumulation, fp32 outputs.  Only the MFMA operands are narrowed: values are rounded to
+// IEEE fp16 as they are written to LDS and multiplied with v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate), so the
+// result differs from the fp32 path by operand rounding (~2^-11 relative per product); tests state the tolerance and
+// report the CE difference - no 1e-4 claim is made for this path.
+// LDS image: [row][32 halves + 8 pad] = 80-B rows (5 sixteen-byte slots, odd => ds_read_b128 conflict-free); a lane
+// reads its 8 consecutive k (k = 16*s + 8*h + j) with one ds_read_b128 per operand per MFMA.
+// This first version keeps the fp32 kernels' tiling (K chunks of 32); with the matrix phase 16x shorter it is bound
+// by staging, not by the matrix cores - restructuring (whole-K tiles, fp16 activations in HBM) is future work.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+constexpr int LDH = 40;      // halves per LDS row
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float act1(float v, float sc, float sh) { return fmaxf(fmaf(v, sc, sh), 0.f); }
+__device__ __forceinline__ half4 to_h4(float4 v) {
+    half4 r = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    return r;
+}
+__device__ __forceinline__ half8 ldh8(const _Float16* p) { return *reinterpret_cast<const half8*>(p); }
+
+// ---- conv1x1: 128x128 tile, 4 waves x (64x64), K chunks of 32; requires aligned pointers and K % 4 == 0
+template <bool POOL>
+__global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restrict__ A, long lda,
+                                                          const float* __restrict__ W, float* __restrict__ out, long ldc,
+                                                          long M, int N, int K, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int S_in) {
+    __shared__ __attribute__((aligned(16))) _Float16 As[128 * LDH];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[128 * LDH];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, i = lane & 31;
+    const int kq = t & 7, r0 = t >> 3;
+    const long m0 = (long)blockIdx.x * 128;
+    const int n0 = blockIdx.y * 128;
+    const bool has_act = scale != nullptr;
+    long src[4];
+    bool rok[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const long row = m0 + r0 + 32 * p;
+        rok[p] = row < M;
+        const long rr = rok[p] ? row : 0;
+        if (POOL) {
+            const int So = S_in >> 1;
+            const long img = rr / (So * So);
+            const int rem = (int)(rr - img * So * So);
+            const int oy = rem / So, ox = rem - oy * So;
+            src[p] = ((img * S_in + 2 * oy) * S_in + 2 * ox) * lda;
+        } else {
+            src[p] = rr * lda;
+        }
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nkt = (K + 31) / 32;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k = kt * 32 + 4 * kq;
+        const bool kok = k < K;
+        const int kc = kok ? k : 0;
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_act) { sc4 = ld4(scale + kc); sh4 = ld4(shift + kc); }
+        float4 va[4], vb[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (POOL) {
+                float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = ld4(A + src[p] + ((q >> 1) * (long)S_in + (q & 1)) * lda + kc);
+                    if (has_act) {
+                        v.x = act1(v.x, sc4.x, sh4.x); v.y = act1(v.y, sc4.y, sh4.y);
+                        v.z = act1(v.z, sc4.z, sh4.z); v.w = act1(v.w, sc4.w, sh4.w);
+                    }
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                }
+                va[p] = make_float4(0.25f * s.x, 0.25f * s.y, 0.25f * s.z, 0.25f * s.w);
+            } else {
+                float4 v = ld4(A + src[p] + kc);
+                if (has_act) {
+                    v.x = act1(v.x, sc4.x, sh4.x); v.y = act1(v.y, sc4.y, sh4.y);
+                    v.z = act1(v.z, sc4.z, sh4.z); v.w = act1(v.w, sc4.w, sh4.w);
+                }
+                va[p] = v;
+            }
+            if (!(rok[p] && kok)) va[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int n = n0 + r0 + 32 * p;
+            vb[p] = ld4(W + (long)(n < N ? n : N - 1) * K + kc);
+            if (!(n < N && kok)) vb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<half4*>(&As[(r0 + 32 * p) * LDH + 4 * kq]) = to_h4(va[p]);
+            *reinterpret_cast<half4*>(&Bs[(r0 + 32 * p) * LDH + 4 * kq]) = to_h4(vb[p]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const half8 a0 = ldh8(&As[(64 * wm + i) * LDH + 16 * s + 8 * h]);
+            const half8 a1 = ldh8(&As[(64 * wm + 32 + i) * LDH + 16 * s + 8 * h]);
+            const half8 b0 = ldh8(&Bs[(64 * wn + i) * LDH + 16 * s + 8 * h]);
+            const half8 b1 = ldh8(&Bs[(64 * wn + 32 + i) * LDH + 16 * s + 8 * h]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = n0 + 64 * wn + 32 * nt + i;
+            if (col >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = m0 + 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) out[row * ldc + col] = acc[mt][nt][r];
+            }
+        }
+}
+
+// ---- conv3x3 (pad 1): same contiguous-strip scheme as the fp32 kernel, fp16 LDS image
+__global__ __launch_bounds__(256) void conv3x3_f16_kernel(const float* __restrict__ A, long lda,
+                                                          const float* __restrict__ Wr, float* __restrict__ out, long ldc,
+                                                          long M, int N, int K, int S, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+    const int strip = 128 + 2 * S + 2;
+    _Float16* As = ldsh;                         // [strip + 1 zero row][LDH]
+    _Float16* Bs = ldsh + (strip + 1) * LDH;     // [9][32][LDH]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    const long P0 = (long)blockIdx.x * 128;
+    const long base = P0 - S - 1;
+    const int n0 = blockIdx.y * 32;
+    const bool has_act = scale != nullptr;
+    const int kq = t & 7, r0 = t >> 3;
+    if (t < LDH) As[strip * LDH + t] = (_Float16)0.f;
+    const long P = P0 + 32 * wave + i;
+    int aoff[9];
+    {
+        unsigned mask = 0;
+        if (P < M) {
+            const int rem = (int)(P % ((long)S * S));
+            const int y = rem / S, x = rem - y * S;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if (yy >= 0 && yy < S && xx >= 0 && xx < S) mask |= 1u << tap;
+            }
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int off = (S + 1) + (tap / 3 - 1) * S + (tap % 3 - 1);
+            aoff[tap] = ((mask >> tap) & 1u) ? (32 * wave + i + off) * LDH + 8 * h : strip * LDH;
+        }
+    }
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const int nload = n0 + r0 < N ? n0 + r0 : N - 1;
+
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const int k = k0 + 4 * kq;
+        const bool kok = k < K;
+        const int kc = kok ? k : 0;
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_act) { sc4 = ld4(scale + kc); sh4 = ld4(shift + kc); }
+        __syncthreads();
+        for (int row = r0; row < strip; row += 32) {
+            const long Pr = base + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (Pr >= 0 && Pr < M && kok) {
+                v = ld4(A + Pr * lda + kc);
+                if (has_act) {
+                    v.x = act1(v.x, sc4.x, sh4.x); v.y = act1(v.y, sc4.y, sh4.y);
+                    v.z = act1(v.z, sc4.z, sh4.z); v.w = act1(v.w, sc4.w, sh4.w);
+                }
+            }
+            *reinterpret_cast<half4*>(&As[row * LDH + 4 * kq]) = to_h4(v);
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            float4 v = ld4(Wr + ((long)j * N + nload) * K + kc);
+            if (!(n0 + r0 < N && kok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<half4*>(&Bs[(r0 + 32 * j) * LDH + 4 * kq]) = to_h4(v);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const half8 a0 = ldh8(As + aoff[tap]);
+            const half8 b0 = ldh8(&Bs[(tap * 32 + i) * LDH + 8 * h]);
+            const half8 a1 = ldh8(As + aoff[tap] + 16);
+            const half8 b1 = ldh8(&Bs[(tap * 32 + i) * LDH + 16 + 8 * h]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc1, 0, 0, 0);
+        }
+    }
+    const int col = n0 + i;
+    if (col < N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = P0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < M) out[row * ldc + col] = acc0[r] + acc1[r];
+        }
+    }
+}
+
+bool al16h(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+GNX_EXPORT int gnx_conv1x1_bnrelu_f16(const float* A, long lda, const float* W, float* out, long ldc, long M, int N,
+                                      int K, const float* scale, const float* shift, int pool, int S_in,
+                                      hipStream_t stream) {
+    if (!A || !W || !out || M < 0 || N <= 0 || K <= 0 || lda < K || ldc < N || (!scale) != (!shift))
+        return GNX_ERR_BAD_ARG;
+    if (!(al16h(A) && al16h(W) && lda % 4 == 0 && K % 4 == 0 && (!scale || (al16h(scale) && al16h(shift)))))
+        return GNX_ERR_UNSUPPORTED;
+    if (M == 0) return GNX_OK;
+    dim3 grid(gnx_cdiv(M, 128), gnx_cdiv(N, 128));
+    if (pool) conv1x1_f16_kernel<true><<<grid, 256, 0, stream>>>(A, lda, W, out, ldc, M, N, K, scale, shift, S_in);
+    else conv1x1_f16_kernel<false><<<grid, 256, 0, stream>>>(A, lda, W, out, ldc, M, N, K, scale, shift, S_in);
+    return gnx_launch_status();
+}
+
+GNX_EXPORT int gnx_conv3x3_bnrelu_f16(const float* A, long lda, const float* Wr, float* out, long ldc, long M, int N,
+                                      int K, int S, const float* scale, const float* shift, hipStream_t stream) {
+    if (!A || !Wr || !out || M < 0 || N <= 0 || K <= 0 || S <= 0 || lda < K || ldc < N || (!scale) != (!shift) ||
+        (M % ((long)S * S)) != 0)
+        return GNX_ERR_BAD_ARG;
+    if (!(al16h(A) && al16h(Wr) && lda % 4 == 0 && K % 4 == 0 && (!scale || (al16h(scale) && al16h(shift)))))
+        return GNX_ERR_UNSUPPORTED;
+    if (M == 0) return GNX_OK;
+    const size_t lds_bytes = ((size_t)(128 + 2 * S + 2 + 1) * LDH + 9 * 32 * LDH) * sizeof(_Float16);
+    if (lds_bytes > 64 * 1024) return GNX_ERR_UNSUPPORTED;
+    dim3 grid(gnx_cdiv(M, 128), gnx_cdiv(N, 32));
+    conv3x3_f16_kernel<<<grid, 256, lds_bytes, stream>>>(A, lda, Wr, out, ldc, M, N, K, S, scale, shift);
+    return gnx_launch_status();
+}

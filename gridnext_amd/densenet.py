@@ -59,6 +59,7 @@ class DenseNet(nn.Module):
         self.growth_rate, self.block_config = growth_rate, tuple(block_config)
         self.bn_size, self.small_inputs, self.classify = bn_size, small_inputs, classify
         self.atonce = None          # spots per chunk in eval mode (None = auto)
+        self.mfma = 'f32'           # 'f16': fp16 matrix-core operands in the eval forward (BASELINE config 5)
         self.l3_blocking = False    # option: run each dense block over Infinity-Cache-sized sub-ranges of spots
                                     # (measured r01: slower - 15x more, smaller launches; kept for experiments)
         self.l3_budget = 160 * 1024 * 1024
@@ -225,6 +226,9 @@ class DenseNet(nn.Module):
         st = L.stream()
         fold = self._folded_eval()
         w2 = self._repacked_conv2()
+        if self.mfma not in ('f32', 'f16'):
+            raise ValueError("DenseNet.mfma must be 'f32' or 'f16'")
+        sfx = '_f16' if self.mfma == 'f16' else ''
         hs, sizes = self._geometry(P)
         chunk = self._auto_chunk(P, N)
         mid = self.bn_size * self.growth_rate
@@ -270,17 +274,17 @@ class DenseNet(nn.Module):
                         sc1, sh1 = fold[layer.norm1]
                         sc2, sh2 = fold[layer.norm2]
                         t0 = self._probe_begin()
-                        L.call('gnx_conv1x1_bnrelu', L.ptr(rows), c_total, L.ptr(layer.conv1.weight), L.ptr(bott),
+                        L.call('gnx_conv1x1_bnrelu' + sfx, L.ptr(rows), c_total, L.ptr(layer.conv1.weight), L.ptr(bott),
                                mid, M, mid, cin, L.ptr(sc1), L.ptr(sh1), 0, 0, st)
                         t1 = self._probe_mark('conv1x1', t0)
-                        L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2[layer]), rows.data_ptr() + 4 * cin,
+                        L.call('gnx_conv3x3_bnrelu' + sfx, L.ptr(bott), mid, L.ptr(w2[layer]), rows.data_ptr() + 4 * cin,
                                c_total, M, self.growth_rate, mid, s, L.ptr(sc2), L.ptr(sh2), st)
                         self._probe_mark('conv3x3', t1)
                     if trans is not None:
                         nxt = bufs[bi + 1]
                         so = s // 2
                         sct, sht = fold[trans.norm]
-                        L.call('gnx_conv1x1_bnrelu', L.ptr(rows), c_total, L.ptr(trans.conv.weight),
+                        L.call('gnx_conv1x1_bnrelu' + sfx, L.ptr(rows), c_total, L.ptr(trans.conv.weight),
                                L.ptr(nxt[u0 * so * so:]), nxt.shape[1], nu * so * so, trans.conv.out_channels,
                                c_total, L.ptr(sct), L.ptr(sht), 1, s, st)
             scf, shf = fold[self.features.norm_final]

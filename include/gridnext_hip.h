@@ -99,6 +99,12 @@ int gnx_bnrelu_maxpool(const float* in, long ldi, float* out, long ldo, long img
 int gnx_bnrelu_avgpool(const float* in, long ldi, float* out, long ldo, long imgs, int C, int S2,
                        const float* scale, const float* shift, gnx_stream_t stream);
 
+/* fp16-MFMA variants (BASELINE config 5, "fp16 MFMA conv path"): same contract, operands rounded to fp16 in LDS,
+ * v_mfma_f32_32x32x16_f16, fp32 accumulate/outputs.  Return GNX_ERR_UNSUPPORTED for unaligned pointers or K % 4 != 0. */
+int gnx_conv1x1_bnrelu_f16(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
+                           const float* scale, const float* shift, int pool, int S_in, gnx_stream_t stream);
+int gnx_conv3x3_bnrelu_f16(const float* A, long lda, const float* Wr, float* out, long ldc, long M, int N, int K, int S,
+                           const float* scale, const float* shift, gnx_stream_t stream);
 
 /* ---- DenseNet-BC backward (the gradients torch.autograd derives for gridnext/densenet.py) -----------------------------
  * Data gradients reuse gnx_conv1x1_bnrelu / gnx_conv3x3_bnrelu with weights transformed by gnx_transpose_weight

@@ -373,3 +373,36 @@ def test_all_fgd_predictions_including_multimodal_lists():
     assert np.array_equal(p[:n][decided], rp.numpy()[decided])
     tf, pf, sf = all_fgd_predictions(DataLoader(data, batch_size=2), m, f_only=True)
     assert sf.shape == (t.shape[0], 2 * C)
+
+
+def test_fp16_mfma_conv_path_config5():
+    """BASELINE config 5: the fp16-MFMA conv path (operands rounded to fp16, fp32 accumulate).  Checked against the
+    fp32 CPU oracle on DenseNet-121 at 64 px: logits within 2e-2 relative (operand rounding 2^-11 per product through
+    120 conv layers), CE difference reported and bounded by 2e-2, argmax agreement on decided spots >= 95 %.
+    No 1e-4 claim is made for this path."""
+    import gridnext_amd as ga
+    from oracle import densenet as odn
+    cfg = odn.DenseNetCfg(num_classes=8, **odn.DENSENET121)
+    sd = odn.closed_form_state(cfg)
+    m = ga.DenseNet(num_classes=8, **odn.DENSENET121)
+    m.load_state_dict(sd)
+    m.to(DEV).eval()
+    x = torch.rand(96, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+    labels = torch.randint(0, 8, (96,), generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        ref = odn.forward(sd, x, cfg)
+        out32 = m(x.to(DEV)).cpu()
+        m.mfma = 'f16'
+        out16 = m(x.to(DEV)).cpu()
+    close(out32, ref, rtol=1e-3, what='f32 path')
+    err16 = (out16 - ref).abs().max().item() / ref.abs().max().item()
+    assert err16 < 2e-2, err16
+    assert err16 > 1e-6                                           # really a different arithmetic path
+    ce = lambda z: nn.functional.cross_entropy(z, labels).item()
+    d_ce = abs(ce(out16) - ce(ref))
+    print("fp16-MFMA path: max rel logit err %.2e, |dCE| %.2e" % (err16, d_ce))
+    assert d_ce < 2e-2
+    top = ref.topk(2, dim=1).values
+    decided = (top[:, 0] - top[:, 1]) > 5e-2
+    agree = (out16.argmax(1)[decided] == ref.argmax(1)[decided]).float().mean().item()
+    assert agree >= 0.95, agree

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Supplementary throughput for the other BASELINE.json configs, driven through the product's own training loops
+(bench.py is the headline, C4).  Data are synthetic and resident on the device.
+
+  C1  count-only f (5-Linear MLP, 2000 genes, 8 classes), train_spotwise, batch 128, 19 968 train + 2 560 val spots
+  C2  image-only DenseNet-121 f @128 px, train_spotwise (train-mode BN, forward+backward+Adam), batch 32
+  C3  count f (frozen) + hex g on 78x64 grids, train_gridwise, 8 train + 2 val arrays, batch 1
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+from torch.utils.data import DataLoader, TensorDataset
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gridnext_amd as ga                                   # noqa: E402
+from gridnext_amd.synthetic import count_mlp, visium_array   # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def timed(fn):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()):
+        fn()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def c1(epochs):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(0, 10, (22528, 2000), generator=g).float().to(DEV)
+    y = torch.randint(0, 8, (22528,), generator=g).to(DEV)
+    dl = {'train': DataLoader(TensorDataset(x[:19968], y[:19968]), batch_size=128, shuffle=True),
+          'val': DataLoader(TensorDataset(x[19968:], y[19968:]), batch_size=128)}
+    f = count_mlp(2000, 8)
+    opt = torch.optim.Adam(f.parameters(), lr=1e-4)
+    ga.train_spotwise(f, dl, nn.CrossEntropyLoss(), opt, num_epochs=1)          # warm-up
+    dt = timed(lambda: ga.train_spotwise(f, dl, nn.CrossEntropyLoss(), opt, num_epochs=epochs))
+    return {"config": "C1 count-MLP train_spotwise batch 128", "spots_per_s": epochs * 22528 / dt, "seconds": dt}
+
+
+def c2(n_train, epochs):
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.rand((n_train + 64, 3, 128, 128), generator=g, device=DEV)
+    y = torch.randint(0, 8, (n_train + 64,), device=DEV)
+    dl = {'train': DataLoader(TensorDataset(x[:n_train], y[:n_train]), batch_size=32, shuffle=True),
+          'val': DataLoader(TensorDataset(x[n_train:], y[n_train:]), batch_size=32)}
+    f = ga.DenseNet(num_classes=8, small_inputs=False, growth_rate=32, block_config=(6, 12, 24, 16),
+                    num_init_features=64, bn_size=4, drop_rate=0)
+    opt = torch.optim.Adam(f.parameters(), lr=1e-3)
+    ga.train_spotwise(f, {'train': DataLoader(TensorDataset(x[:64], y[:64]), batch_size=32), 'val': dl['val']},
+                      nn.CrossEntropyLoss(), opt, num_epochs=1)
+    dt = timed(lambda: ga.train_spotwise(f, dl, nn.CrossEntropyLoss(), opt, num_epochs=epochs))
+    return {"config": "C2 DenseNet-121 @128px train_spotwise batch 32 (fwd+bwd+Adam, train-mode BN)",
+            "spots_per_s": epochs * (n_train + 64) / dt, "seconds": dt}
+
+
+def c3(epochs):
+    xs, ys = [], []
+    for a in range(10):
+        _, xc, y = visium_array(a, image=False, device=DEV)
+        xs.append(xc)
+        ys.append(y)
+    x, y = torch.stack(xs), torch.stack(ys)
+    dl = {'train': DataLoader(TensorDataset(x[:8], y[:8]), batch_size=1, shuffle=True),
+          'val': DataLoader(TensorDataset(x[8:], y[8:]), batch_size=1)}
+    m = ga.GridNetHexOddr(count_mlp(2000, 8), (2000,), (78, 64), 8)
+    for p in m.patch_classifier.parameters():
+        p.requires_grad = False
+    opt = torch.optim.Adam(m.corrector.parameters(), lr=1e-3)
+    ga.train_gridwise(m, dl, nn.CrossEntropyLoss(), opt, num_epochs=1)
+    dt = timed(lambda: ga.train_gridwise(m, dl, nn.CrossEntropyLoss(), opt, num_epochs=epochs))
+    return {"config": "C3 count f (frozen) + hex g, train_gridwise, 78x64, batch 1", "spots_per_s": epochs * 10 * 4992 / dt,
+            "arrays_per_s": epochs * 10 / dt, "seconds": dt}
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default='')
+    args = ap.parse_args()
+    out = []
+    if args.only in ('', 'c1'):
+        out.append(c1(3))
+    if args.only in ('', 'c3'):
+        out.append(c3(10))
+    if args.only in ('', 'c2'):
+        out.append(c2(2048, 1))
+    for r in out:
+        print(json.dumps(r))
