@@ -96,6 +96,7 @@ def main():
     ap.add_argument('--mfma', default='f32', choices=['f32', 'f16'],
                     help="matrix-core operand type of the DenseNet convs; 'f16' = BASELINE config 5's fp16 MFMA path "
                          "(fp32 accumulate; NOT the headline, reported as dtype f16)")
+    ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     args = ap.parse_args()
@@ -103,7 +104,7 @@ def main():
     from gridnext_amd import distributed as gdist
     from gridnext_amd import training as gtrain
     from gridnext_amd.synthetic import visium_array
-    rank, world, device = gdist.init_from_env()
+    rank, world, device = gdist.init_from_env(args.backend)
     assert torch.cuda.is_available(), "bench.py measures the HIP path; no HIP device visible"
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 

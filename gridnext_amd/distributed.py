@@ -35,6 +35,8 @@ def init_from_env(backend=None):
     Returns (rank, world_size, device)."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'GNX_DEVICE_INDEX' in os.environ:            # rehearsals only: several ranks sharing one card (gloo backend)
+        local = int(os.environ['GNX_DEVICE_INDEX'])
     use_gpu = torch.cuda.is_available()
     device = torch.device('cuda:%d' % local) if use_gpu else torch.device('cpu')
     if use_gpu:
@@ -47,8 +49,9 @@ def init_from_env(backend=None):
 
 def default_device():
     if torch.cuda.is_available():
-        return torch.device('cuda:%d' % int(os.environ.get('LOCAL_RANK', '0'))) if is_active() \
-            else torch.device('cuda:0')
+        if is_active():
+            return torch.device('cuda:%d' % int(os.environ.get('GNX_DEVICE_INDEX', os.environ.get('LOCAL_RANK', '0'))))
+        return torch.device('cuda:0')
     return torch.device('cpu')
 
 
