@@ -232,6 +232,61 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_vec4_kernel(const float* __rest
     }
 }
 
+// Eval-mode (running-statistics) BN+ReLU backward in ONE pass over the data: dx (+)= scale*dz needs no batch sums, so
+// the column sums for dgamma/dbeta are accumulated by the same threads that write dx.  Thread = 4 channels x a strided
+// set of rows; slab layout as bn_bwd_partial_kernel ([blk][2][C]).
+__global__ __launch_bounds__(256) void bn_bwd_eval_fused_kernel(const float* __restrict__ dy, long lddy,
+                                                                const float* __restrict__ x, long ldx,
+                                                                float* __restrict__ dx, long lddx, long M, int C,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, int relu,
+                                                                int dx_accumulate, float* __restrict__ partial) {
+    __shared__ float red[2][16][64];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;       // 16 channel-quads x 16 row lanes
+    const int c = 4 * (blockIdx.y * 16 + cl);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+        const float scs[4] = {sc.x, sc.y, sc.z, sc.w}, shs[4] = {sh.x, sh.y, sh.z, sh.w};
+        const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, iss[4] = {is.x, is.y, is.z, is.w};
+        for (long r = (long)blockIdx.x * 16 + rl; r < M; r += (long)gridDim.x * 16) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
+            const float4 dv = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            float ds[4] = {dv.x, dv.y, dv.z, dv.w}, o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (relu && fmaf(xs[e], scs[e], shs[e]) <= 0.f) ds[e] = 0.f;
+                s1[e] += ds[e];
+                s2[e] = fmaf(ds[e], (xs[e] - mus[e]) * iss[e], s2[e]);
+                o[e] = scs[e] * ds[e];
+            }
+            if (dx) {
+                float4* dst = reinterpret_cast<float4*>(dx + r * lddx + c);
+                if (dx_accumulate) {
+                    const float4 old = *dst;
+                    o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w;
+                }
+                *dst = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][rl][4 * cl + e] = s1[e]; red[1][rl][4 * cl + e] = s2[e]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int q = threadIdx.x >> 6, cc = threadIdx.x & 63;
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a += red[q][j][cc];
+        const int cg = blockIdx.y * 64 + cc;
+        if (cg < C) partial[((size_t)blockIdx.x * 2 + q) * C + cg] = a;
+    }
+}
+
 // out[c] = fixed-order sum of the slabs (used for bias gradients)
 __global__ void slab_reduce_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out,
                                    int accumulate) {
@@ -306,6 +361,20 @@ GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long 
     float* partial = workspace;
     float* sums = workspace + (size_t)2 * nblk * C;
     dim3 grid(nblk, gnx_cdiv(C, 64));
+    {
+        const bool v4all = C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && (!dx || lddx % 4 == 0) &&
+                           ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) |
+                             reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(scale) |
+                             reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(save_mean) |
+                             reinterpret_cast<uintptr_t>(save_invstd)) & 15) == 0;
+        if (!training && v4all) {
+            // one pass: dx and the dgamma/dbeta column sums together
+            bn_bwd_eval_fused_kernel<<<grid, 256, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale, shift, save_mean,
+                                                               save_invstd, relu, dx_accumulate, partial);
+            bn_bwd_reduce_kernel<<<gnx_cdiv(C, 64), 64, 0, stream>>>(partial, nblk, C, sums, dgamma, dbeta, accumulate);
+            return gnx_launch_status();
+        }
+    }
     bn_bwd_partial_kernel<<<grid, 256, 0, stream>>>(dy, lddy, x, ldx, M, C, scale, shift, save_mean, save_invstd,
                                                     relu, partial);
     bn_bwd_reduce_kernel<<<gnx_cdiv(C, 64), 64, 0, stream>>>(partial, nblk, C, sums, dgamma, dbeta, accumulate);

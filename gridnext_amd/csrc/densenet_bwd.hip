@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY
                                                     const float* __restrict__ X, long ldx,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                     float* __restrict__ slabs, long M, int N, int K, int S,
-                                                    long tiles_per_split, int vec) {
+                                                    long tiles_per_split, int vec, int vecY) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int halo = (T == 9) ? S + 1 : 0;
     const int strip = WG_BM + 2 * halo;
@@ -56,10 +56,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY
         const long m0 = tile * WG_BM;
         __syncthreads();
         // dY tile: [64][32*NT]
-        for (int idx = t; idx < WG_BM * LDY; idx += 256) {
-            const int r = idx / LDY, c = idx - r * LDY;
-            const long m = m0 + r;
-            Ys[idx] = (m < M && n0 + c < N) ? dY[m * lddy + n0 + c] : 0.f;
+        if (vecY && n0 + LDY <= N) {
+            for (int idx = t; idx < WG_BM * (LDY / 4); idx += 256) {
+                const int r = idx / (LDY / 4), c4 = idx - r * (LDY / 4);
+                const long m = m0 + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < M) v = *reinterpret_cast<const float4*>(dY + m * lddy + n0 + 4 * c4);
+                *reinterpret_cast<float4*>(&Ys[r * LDY + 4 * c4]) = v;
+            }
+        } else {
+            for (int idx = t; idx < WG_BM * LDY; idx += 256) {
+                const int r = idx / LDY, c = idx - r * LDY;
+                const long m = m0 + r;
+                Ys[idx] = (m < M && n0 + c < N) ? dY[m * lddy + n0 + c] : 0.f;
+            }
         }
         // X strip (activated), [strip][128]
         for (int idx = t; idx < strip * (WG_KR / 4); idx += 256) {
@@ -384,6 +394,7 @@ GNX_EXPORT int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long
     const size_t lds_bytes = ((size_t)WG_BM * 32 * nt + (size_t)(WG_BM + 2 * halo) * LDX + WG_BM) * sizeof(float);
     if (lds_bytes > 160 * 1024) return GNX_ERR_UNSUPPORTED;
     const int vec = al16b(X) && ldx % 4 == 0 && (!scale || (al16b(scale) && al16b(shift)));
+    const int vecY = al16b(dY) && lddy % 4 == 0;
     dim3 grid(nsplit, gnx_cdiv(N, 32 * nt), gnx_cdiv(K, WG_KR));
 #define GNX_WG(T, NTT, P)                                                                                               \
     do {                                                                                                           \
@@ -395,7 +406,7 @@ GNX_EXPORT int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long
             conf = lds_bytes;                                                                                      \
         }                                                                                                          \
         wgrad_kernel<T, NTT, P><<<grid, 256, lds_bytes, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, N, K, S, \
-                                                             tps, vec);                                            \
+                                                             tps, vec, vecY);                                      \
     } while (0)
     if (taps == 9) GNX_WG(9, 1, false);
     else if (pool) GNX_WG(1, 4, true);
