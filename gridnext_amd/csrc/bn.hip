@@ -144,20 +144,33 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     }
 }
 
-// backward pass 2: sums -> dgamma/dbeta (optionally accumulated), sums[2][C] kept for the dx pass
-__global__ void bn_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums,
-                                     float* dgamma, float* dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// backward pass 2: sums -> dgamma/dbeta (optionally accumulated), sums[2][C] kept for the dx pass.
+// 64 channels x 4 slab-lanes per workgroup; each lane sums every 4th slab in order, the four partial sums are then
+// added in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                            float* __restrict__ sums, float* dgamma, float* dbeta,
+                                                            int accumulate) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += partial[((size_t)b * 2 + 0) * C + c];
-        s2 += partial[((size_t)b * 2 + 1) * C + c];
+    if (c < C) {
+        for (int b = sl; b < nblk; b += 4) {
+            s1 += partial[((size_t)b * 2 + 0) * C + c];
+            s2 += partial[((size_t)b * 2 + 1) * C + c];
+        }
     }
-    sums[c] = s1;
-    sums[C + c] = s2;
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + s2 : s2;
+    red[0][sl][cl] = s1;
+    red[1][sl][cl] = s2;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        s1 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        s2 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+        sums[c] = s1;
+        sums[C + c] = s2;
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + s2 : s2;
+    }
 }
 
 // backward pass 3: dx.  training: scale*(dz - s1/M - xhat*s2/M) ; eval: scale*dz   (scale = gamma*invstd)
@@ -371,13 +384,13 @@ GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long 
             // one pass: dx and the dgamma/dbeta column sums together
             bn_bwd_eval_fused_kernel<<<grid, 256, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale, shift, save_mean,
                                                                save_invstd, relu, dx_accumulate, partial);
-            bn_bwd_reduce_kernel<<<gnx_cdiv(C, 64), 64, 0, stream>>>(partial, nblk, C, sums, dgamma, dbeta, accumulate);
+            bn_bwd_reduce_kernel<<<gnx_cdiv(C, 64), 256, 0, stream>>>(partial, nblk, C, sums, dgamma, dbeta, accumulate);
             return gnx_launch_status();
         }
     }
     bn_bwd_partial_kernel<<<grid, 256, 0, stream>>>(dy, lddy, x, ldx, M, C, scale, shift, save_mean, save_invstd,
                                                     relu, partial);
-    bn_bwd_reduce_kernel<<<gnx_cdiv(C, 64), 64, 0, stream>>>(partial, nblk, C, sums, dgamma, dbeta, accumulate);
+    bn_bwd_reduce_kernel<<<gnx_cdiv(C, 64), 256, 0, stream>>>(partial, nblk, C, sums, dgamma, dbeta, accumulate);
     if (dx) {
         const bool v4 = C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 &&
                         ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) |

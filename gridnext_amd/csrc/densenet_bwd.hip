@@ -179,8 +179,17 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit,
     const long total = (long)T * N * K;
     if (idx >= total) return;
     const int k = (int)(idx % K), n = (int)((idx / K) % N), tap = (int)(idx / ((long)K * N));
-    float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += slabs[(long)sp * total + idx];
+    // four independent partial sums keep several loads in flight; combined in a fixed order
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int sp = 0;
+    for (; sp + 3 < nsplit; sp += 4) {
+        s0 += slabs[(long)sp * total + idx];
+        s1 += slabs[(long)(sp + 1) * total + idx];
+        s2 += slabs[(long)(sp + 2) * total + idx];
+        s3 += slabs[(long)(sp + 3) * total + idx];
+    }
+    for (; sp < nsplit; ++sp) s0 += slabs[(long)sp * total + idx];
+    const float s = (s0 + s1) + (s2 + s3);
     float* dst = dW + ((long)n * K + k) * T + tap;
     *dst = accumulate ? *dst + s : s;
 }
