@@ -406,3 +406,58 @@ def test_fp16_mfma_conv_path_config5():
     decided = (top[:, 0] - top[:, 1]) > 5e-2
     agree = (out16.argmax(1)[decided] == ref.argmax(1)[decided]).float().mean().item()
     assert agree >= 0.95, agree
+
+
+def test_full_size_multimodal_array_config4():
+    """BASELINE config 4 at full size: one synthetic 78x64 array of 128-px patches + 2000-gene counts through
+    GridNetHexMM (DenseNet-121 + count MLP + hex g).  Too large to rerun on the CPU in a test, so: a random sample of
+    spots is checked against the fp32 CPU oracle (logits 1e-3 relative, identical argmax where the top-2 margin
+    exceeds 1e-3), plus size-independent properties - chunked == unchunked evaluation bit for bit, f is equivariant
+    under a permutation of the spots, background rows get exactly zero CE gradient and foreground gradient rows sum
+    to zero."""
+    import gridnext_amd as ga
+    from gridnext_amd import functional as GF
+    from gridnext_amd.synthetic import count_mlp, visium_array
+    from oracle import densenet as odn
+    torch.manual_seed(0)
+    C, G, P = 8, 2000, 128
+    f_img = ga.DenseNet(num_classes=C, **odn.DENSENET121)
+    m = ga.GridNetHexMM(f_img, count_mlp(G, C), (3, P, P), (G,), (78, 64), C).to(DEV)
+    x_img, x_cnt, y = visium_array(11, G, C, P, device=DEV)
+    spots = x_img.reshape(-1, 3, P, P)
+    f_img.eval()
+    with torch.no_grad():
+        full = f_img(spots)                                   # 4992 spots in one pass
+        f_img.atonce = 1000
+        chunked = f_img(spots)
+        f_img.atonce = None
+        assert torch.equal(full, chunked)
+        perm = torch.randperm(spots.shape[0], device=DEV)[:512]
+        sub = f_img(spots[perm])
+        assert torch.allclose(sub, full[perm], rtol=0, atol=0) or (sub - full[perm]).abs().max().item() < 1e-6
+        # CPU oracle on a sample of spots (same weights)
+        idx = torch.randperm(spots.shape[0], generator=torch.Generator().manual_seed(5))[:24]
+        sd = {k: v.detach().cpu() for k, v in f_img.state_dict().items()}
+        cfg = odn.DenseNetCfg(num_classes=C, **odn.DENSENET121)
+        ref = odn.forward(sd, spots[idx.to(DEV)].cpu(), cfg)
+    got = full[idx.to(DEV)].cpu()
+    close(got, ref, rtol=1e-3, what='sampled spots vs oracle')
+    top = ref.topk(2, dim=1).values
+    decided = (top[:, 0] - top[:, 1]) > 1e-3
+    assert torch.equal(got.argmax(1)[decided], ref.argmax(1)[decided])
+    # one full training step in tutorial mode
+    for p in m.patch_classifier.parameters():
+        p.requires_grad = False
+    m.train()
+    m.patch_classifier.eval()
+    logits = m.forward_nhwc([x_img.unsqueeze(0), x_cnt.unsqueeze(0)])
+    logits.retain_grad()
+    loss, stats, preds = GF.masked_cross_entropy(logits.reshape(-1, C), y.unsqueeze(0), 1)
+    loss.backward()
+    fg = y.reshape(-1) > 0
+    assert int(stats[0]) == int(fg.sum()) and 0 <= int(stats[1]) <= int(stats[0])
+    grad = logits.grad.reshape(-1, C)
+    assert float(grad[~fg].abs().max()) == 0.0
+    assert float(grad[fg].sum(1).abs().max()) < 1e-7
+    assert torch.isfinite(loss).item() and m.corrector[8].kernel1.grad.abs().sum().item() > 0
+    assert m.count_classifier[0].weight.grad is not None          # GridNetHexMM quirk: the count f still gets gradients
