@@ -20,6 +20,7 @@
 // k = 8*s + 4*h + j for the j-th of them, identically for A and B, so the k-order inside the sum is a fixed permutation.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -67,7 +68,9 @@ template <bool POOL, bool FAST>
 __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ A, long lda,
                                                       const float* __restrict__ W, float* __restrict__ out, long ldc,
                                                       long M, int N, int K, const float* __restrict__ scale,
-                                                      const float* __restrict__ shift, int S_in, int vecA, int vecW) {
+                                                      const float* __restrict__ shift, int S_in, int vecA, int vecW,
+                                                      const float* __restrict__ oscale,
+                                                      const float* __restrict__ oshift) {
     __shared__ __attribute__((aligned(16))) float As[C1_BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[C1_BN * LDK];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -243,6 +246,11 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int col = n0 + 64 * wn + 32 * nt + i;
+            if (oscale && col < N) {          // output activation: the consumer's BN+ReLU applied at the store
+                const float osc = oscale[col], osh = oshift[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaxf(fmaf(acc[mt][nt][r], osc, osh), 0.f);
+            }
             if (interior) {
                 float* o = out + (m0 + 64 * wm + 32 * mt + 4 * h) * ldc + col;
 #pragma unroll
@@ -732,6 +740,203 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------ conv3x3, LDS-DMA form
+// For inputs that need NO prologue (scale == nullptr: the eval forward stores the bottleneck already activated, see
+// gnx_conv1x1_bnrelu's output activation).  The strip rows and the weight rows of a 32-wide K chunk go global -> LDS
+// directly (global_load_lds_dwordx4: no VGPRs, no ds_write), double-buffered, one persistent workgroup per CU: the DMA
+// of chunk g+1 is in flight while chunk g's 144 MFMAs run; one raw s_barrier per chunk orders everything
+// (vmcnt for the wave's own DMAs -> barrier -> multiply, issuing the next chunk's DMAs between the MFMAs).
+//
+// What the measurements behind this shape said (tools/ubench/mfma_loop_variants.hip, one wave per SIMD):
+//  * every VALU instruction a wave issues inside the MFMA loop costs matrix-pipe time (2 v_add per step: -7 %;
+//    4 v_cndmask on the operands per step: -25 %), so the steady-state step is 2 ds_read + 1 s_waitcnt + 4 MFMA and
+//    nothing else: fragment addresses are per-lane bases + instruction immediates, border masking is folded into the
+//    bases once per tile (a masked tap's base points at a zero region), the DMA addresses are a scalar base (SALU) +
+//    a per-lane constant offset;
+//  * hipcc puts s_waitcnt vmcnt(0) in front of every LDS read that may alias a pending LDS-DMA write, which would
+//    serialise the DMA of chunk g+1 with the multiply of chunk g: the fragment reads are inline asm with hand-counted
+//    lgkmcnt (2 reads stay in flight).
+//
+// LDS image of a chunk: rows in groups of 16 ("double pieces", 2 KB), chunk-major inside a group:
+//     byte(row r, 16-B chunk c) = (r >> 4) * 2048 + c * 256 + (r & 15) * 16
+// A quarter-wave of a ds_read_b128 (16 consecutive rows, one c) then covers all 64 banks exactly once, and the four
+// k-subchunks of a lane are base + {0, 512, 1024, 1536}.  One DMA instruction (64 lanes x 16 B, lane-linear in LDS)
+// writes half a group: 16 rows x 4 chunks; lane L fetches row (L & 15), chunk 4 * half + (L >> 4).
+constexpr int DMA_ROWB = 128;      // bytes per LDS row (32 floats of K)
+#ifndef GNX_DMA_DBG
+#define GNX_DMA_DBG 0
+#endif
+
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
+}
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read4(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Requires (checked by the dispatcher): M % (32 NW) == 0, M * max(lda, ldc) < 2^31, N == 32, K % (2 KC) == 0, 16-B
+// aligned pointers and leading dimensions.  NW waves per workgroup, each owning 32 output rows of the 32*NW-row tile;
+// KC = K elements per chunk (32: 128-B LDS rows, 1 workgroup per CU; 16: 64-B rows, half the LDS, 2 workgroups per CU
+// whose barriers, prologues and stores then hide behind each other's MFMAs).  With KC = 16 a group of 16 rows is 1 KB
+// (chunk c at c * 256, four chunks) and one DMA instruction writes a whole group.
+template <int S, int NW, int KC>
+__global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __restrict__ A, int lda,
+                                                              const float* __restrict__ Wr, float* __restrict__ out,
+                                                              int ldc, int M, int K) {
+    constexpr int BM = 32 * NW;
+    constexpr int strip = BM + 2 * S + 2;
+    constexpr int SR = (strip + 15) & ~15;                 // strip rows padded to whole groups of 16
+    constexpr int ROWB = KC * 4;                           // bytes per LDS row
+    constexpr int GB = 16 * ROWB, PPG = GB / 1024;         // group bytes; DMA pieces (1 KB) per group
+    constexpr int BUFB = (SR + 9 * 32) * ROWB;             // bytes per buffer: strip groups, then 2 groups per tap
+    constexpr int NPA = (SR >> 4) * PPG, NPW = 18 * PPG;   // DMA pieces per chunk
+    constexpr int NSA = (NPA + NW - 1) / NW, NSW = (NPW + NW - 1) / NW;     // DMA slots per wave and chunk
+    constexpr int SPT = KC / 8, STEPS = 9 * SPT;           // MFMA steps (8 k each) per tap and per chunk
+    constexpr int ZB = 2 * BUFB;                           // zero region (2 KB) behind the two buffers
+    static_assert(NSA + NSW <= STEPS, "one DMA slot per MFMA step");
+    static_assert(ZB + 2048 <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) char lds[ZB + 2048];
+    const int t = threadIdx.x, lane = t & 63, h = lane >> 5, i = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    for (int z = t; z < 512; z += 64 * NW) reinterpret_cast<float*>(lds + ZB)[z] = 0.f;
+    const int T = M / BM;
+    const int nk2 = K / (2 * KC);                          // pairs of chunks
+    int G = gridDim.x;                                     // pinned in an SGPR: no s_load may sit among the counted
+    asm volatile("" : "+s"(G));                            // lgkmcnt waits of the fragment reads
+    const unsigned lb = lds_addr(lds);
+
+    // ---- DMA side.  Per-lane constant byte offsets; everything else is scalar.
+    const unsigned voffA = ((unsigned)(lane & 15) * lda + 4 * (lane >> 4)) * 4u;
+    const unsigned voffW = ((unsigned)(lane & 15) * K + 4 * (lane >> 4)) * 4u;
+    // next chunk's DMA state.  Past this workgroup's last tile the DMA re-reads its first tile into the buffer nobody
+    // will read: cheaper than a branch around every slot.  gridDim.x <= T: every workgroup owns at least one tile.
+    int ntile = blockIdx.x, nchunk = 0;
+    auto issue_slot = [&](auto slot_c, char* dst) {
+        constexpr int slot = decltype(slot_c)::value;
+        if constexpr (slot < NSA) {
+            const int p = wave + NW * slot;                                    // piece: group p / PPG, part p % PPG
+            if ((NPA % NW) && slot == NSA - 1 && p >= NPA) return;
+            const int grp = p / PPG, part = p % PPG;
+            const int row0 = ntile * BM - S - 1 + 16 * grp;                    // first strip row of the group
+            char* d = dst + grp * GB + part * 1024;
+            if (__builtin_expect(row0 >= 0 && row0 + 15 < M, 1)) {
+                const char* sb = reinterpret_cast<const char*>(A + (long)row0 * lda + KC * nchunk + 16 * part);
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(sb + voffA), (float*)d, 16, 0, 0);
+            } else {
+                // array ends: rows outside [0, M) are only ever "read" by masked taps, any in-range row will do
+                int Pr = row0 + (lane & 15);
+                Pr = Pr < 0 ? 0 : (Pr >= M ? M - 1 : Pr);
+                __builtin_amdgcn_global_load_lds(A + (long)Pr * lda + KC * nchunk + 16 * part + 4 * (lane >> 4),
+                                                 (float*)d, 16, 0, 0);
+            }
+        } else {
+            const int p = wave + NW * (slot - NSA);                            // weight group p / PPG = 2 tap + (n >> 4)
+            if ((NPW % NW) && slot == NSA + NSW - 1 && p >= NPW) return;
+            const int grp = p / PPG, part = p % PPG;
+            const char* sb = reinterpret_cast<const char*>(Wr + (long)(grp * 16) * K + KC * nchunk + 16 * part);
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(sb + voffW),
+                                             (float*)(dst + SR * ROWB + grp * GB + part * 1024), 16, 0, 0);
+        }
+    };
+    auto advance_next = [&]() {
+        if (++nchunk == 2 * nk2) { nchunk = 0; ntile += G; }
+        if (ntile >= T) ntile = blockIdx.x;
+    };
+    static_for<0, NSA + NSW>([&](auto sc) { issue_slot(sc, lds); });
+    advance_next();
+
+    // ---- fragment side.  Per-lane constant bases relative to a buffer.
+    const int R0 = 32 * wave + i + (S + 1);                // strip row of this lane's output pixel
+    unsigned relA[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int R = R0 + (tap / 3 - 1) * S + (tap % 3 - 1);
+        relA[tap] = (R >> 4) * GB + (R & 15) * 16 + h * 256;
+    }
+    const unsigned relB = SR * ROWB + (i >> 4) * GB + (i & 15) * 16 + h * 256;
+    const unsigned bB0 = lb + relB, bB1 = lb + BUFB + relB;
+
+    bool stored = false;
+    for (int tile = blockIdx.x; tile < T; tile += G) {
+        const int P = tile * BM + 32 * wave + i;
+        const int rem = P % (S * S);
+        const int y = rem / S, x = rem - y * S;
+        unsigned bA0[9], bA1[9];                           // masked taps point at the zero region
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            const bool ok = yy >= 0 && yy < S && xx >= 0 && xx < S;
+            bA0[tap] = ok ? lb + relA[tap] : lb + ZB;
+            bA1[tap] = ok ? lb + BUFB + relA[tap] : lb + ZB;
+        }
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+        auto do_chunk = [&](auto par_c) {
+            constexpr int par = decltype(par_c)::value;
+            // this wave's DMAs into the current buffer have landed (the 16 stores of a just-finished tile may stay in
+            // flight: they are younger than those DMAs and vmcnt retires in order)
+            if (stored) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stored = false;
+#if GNX_DMA_DBG != 2
+            asm volatile("s_barrier" ::: "memory");     // everyone's data visible; everyone done with the other buffer
+#endif
+            char* nxt = lds + (par ? 0 : BUFB);
+            const unsigned bB = par ? bB1 : bB0;
+            auto rdA = [&](auto e_c) {
+                constexpr int e = decltype(e_c)::value;
+                return lds_read4<(e % SPT) * 512>(par ? bA1[e / SPT] : bA0[e / SPT]);
+            };
+            auto rdB = [&](auto e_c) {
+                constexpr int e = decltype(e_c)::value;
+                return lds_read4<(e / SPT) * 2 * GB + (e % SPT) * 512>(bB);
+            };
+            f32x4 a = rdA(std::integral_constant<int, 0>{}), bq = rdB(std::integral_constant<int, 0>{});
+            static_for<0, STEPS>([&](auto step_c) {
+                constexpr int step = decltype(step_c)::value;
+                f32x4 na, nb;
+                if constexpr (step < STEPS - 1) {
+                    na = rdA(std::integral_constant<int, step + 1>{});
+                    nb = rdB(std::integral_constant<int, step + 1>{});
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(bq));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(bq));
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bq[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], bq[1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], bq[2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], bq[3], acc1, 0, 0, 0);
+#if GNX_DMA_DBG != 1
+                if constexpr (step < NSA + NSW) issue_slot(step_c, nxt);
+#endif
+                if constexpr (step < STEPS - 1) { a = na; bq = nb; }
+            });
+            advance_next();
+        };
+        for (int c2 = 0; c2 < nk2; ++c2) {
+            do_chunk(std::integral_constant<int, 0>{});
+            do_chunk(std::integral_constant<int, 1>{});
+        }
+        float* o = out + (long)(tile * BM + 32 * wave + 4 * h) * ldc + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[(long)(((r & 3) + 8 * (r >> 2)) * ldc)] = acc0[r] + acc1[r];     // exactly 16 stores
+        stored = true;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // [N][K][3][3] (torch) -> [tap][N][K]
 __global__ void repack3x3_kernel(const float* __restrict__ w, float* __restrict__ wr, int N, int K) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1008,9 +1213,11 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // out[M][N] (ldc) = act(A[M][K] (lda)) . W[N][K]^T ; pool != 0: A is on an S_in x S_in grid per image and M counts the
 // (S_in/2)^2 pooled positions.  scale/shift may both be NULL (no activation).
-GNX_EXPORT int gnx_conv1x1_bnrelu(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
-                                  const float* scale, const float* shift, int pool, int S_in, hipStream_t stream) {
-    if (!A || !W || !out || M < 0 || N <= 0 || K <= 0 || lda < K || ldc < N || (!scale) != (!shift))
+static int conv1x1_launch(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
+                          const float* scale, const float* shift, int pool, int S_in, const float* oscale,
+                          const float* oshift, hipStream_t stream) {
+    if (!A || !W || !out || M < 0 || N <= 0 || K <= 0 || lda < K || ldc < N || (!scale) != (!shift) ||
+        (!oscale) != (!oshift))
         return GNX_ERR_BAD_ARG;
     if (pool && (S_in < 2)) return GNX_ERR_BAD_ARG;
     if (M == 0) return GNX_OK;
@@ -1018,11 +1225,28 @@ GNX_EXPORT int gnx_conv1x1_bnrelu(const float* A, long lda, const float* W, floa
     const int vecW = al16(W) && K % 4 == 0;
     dim3 grid(gnx_cdiv(M, C1_BM), gnx_cdiv(N, C1_BN));
     const bool fast = vecA && vecW;
-#define GNX_C1(P, F) conv1x1_kernel<P, F><<<grid, 256, 0, stream>>>(A, lda, W, out, ldc, M, N, K, scale, shift, S_in, vecA, vecW)
+#define GNX_C1(P, F)                                                                                               \
+    conv1x1_kernel<P, F><<<grid, 256, 0, stream>>>(A, lda, W, out, ldc, M, N, K, scale, shift, S_in, vecA, vecW, \
+                                                   oscale, oshift)
     if (pool) { if (fast) GNX_C1(true, true); else GNX_C1(true, false); }
     else { if (fast) GNX_C1(false, true); else GNX_C1(false, false); }
 #undef GNX_C1
     return gnx_launch_status();
+}
+
+GNX_EXPORT int gnx_conv1x1_bnrelu(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
+                                  const float* scale, const float* shift, int pool, int S_in, hipStream_t stream) {
+    return conv1x1_launch(A, lda, W, out, ldc, M, N, K, scale, shift, pool, S_in, nullptr, nullptr, stream);
+}
+
+// As gnx_conv1x1_bnrelu (pool = 0) with the CONSUMER's folded BN + ReLU applied at the store:
+// out[m][n] = relu(out_scale[n] * (act(A) . W^T)[m][n] + out_shift[n]).  The eval forward stores the bottleneck this way,
+// so the 3x3 convolution that follows needs no prologue and can stream its operand global -> LDS by DMA.
+GNX_EXPORT int gnx_conv1x1_bnrelu_act(const float* A, long lda, const float* W, float* out, long ldc, long M, int N,
+                                      int K, const float* scale, const float* shift, const float* out_scale,
+                                      const float* out_shift, hipStream_t stream) {
+    if (!out_scale || !out_shift) return GNX_ERR_BAD_ARG;
+    return conv1x1_launch(A, lda, W, out, ldc, M, N, K, scale, shift, 0, 0, out_scale, out_shift, stream);
 }
 
 GNX_EXPORT int gnx_repack_conv3x3(const float* w, float* wr, int N, int K, hipStream_t stream) {
@@ -1064,6 +1288,48 @@ GNX_EXPORT int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, flo
                                                                   vecA, vecW);                                    \
     } while (0)
     const bool fast = vecA && vecW;      // aligned pointers/leading dimensions and K % 4 == 0
+    // LDS-DMA persistent form for prologue-free inputs (the eval forward's pre-activated bottleneck)
+    if (!scale && fast && N == C3_BN && (K & 31) == 0 && (M % C3_BM) == 0 && M * (lda > ldc ? lda : ldc) < (1L << 31) &&
+        !getenv("GNX_NO_DMA")) {
+        // variant: 0 = 4 waves, KC 16, 2 workgroups per CU; 1 = 4 waves, KC 32; 2 = 8 waves, KC 32.  Measured sustained
+        // (tools/kbench.py --noact --reps 300): 2 wins wherever its 256-row tiles fill the chip (139 vs 133 TFLOP/s),
+        // 1 where they quantise badly (S = 4 at 4992 spots: 82 vs 107).
+        static const int forced = getenv("GNX_DMA_VARIANT") ? atoi(getenv("GNX_DMA_VARIANT")) : -1;
+        const int variant = forced >= 0 ? forced : (M / 256 >= 1024 ? 2 : 1);
+#define GNX_DMA(SS)                                                                                              \
+    do {                                                                                                         \
+        if constexpr (SS <= 32) {                                                                                \
+            if (variant == 2 && M % 256 == 0 && K % 64 == 0) {                                                   \
+                const long wgs = M / 256 > 256 ? 256 : M / 256;                                                  \
+                conv3x3_dma_kernel<SS, 8, 32><<<(int)wgs, 512, 0, stream>>>(A, (int)lda, Wr, out, (int)ldc,      \
+                                                                            (int)M, K);                          \
+                return gnx_launch_status();                                                                      \
+            }                                                                                                    \
+        }                                                                                                        \
+        if (variant == 1 && K % 64 == 0) {                                                                       \
+            const long wgs = M / 128 > 256 ? 256 : M / 128;                                                      \
+            conv3x3_dma_kernel<SS, 4, 32><<<(int)wgs, 256, 0, stream>>>(A, (int)lda, Wr, out, (int)ldc, (int)M,  \
+                                                                        K);                                      \
+            return gnx_launch_status();                                                                          \
+        }                                                                                                        \
+        const long wgs = M / 128 > 512 ? 512 : M / 128;                                                          \
+        conv3x3_dma_kernel<SS, 4, 16><<<(int)wgs, 256, 0, stream>>>(A, (int)lda, Wr, out, (int)ldc, (int)M, K);  \
+        return gnx_launch_status();                                                                              \
+    } while (0)
+        switch (S) {
+            case 4: GNX_DMA(4);
+            case 7: GNX_DMA(7);
+            case 8: GNX_DMA(8);
+            case 14: GNX_DMA(14);
+            case 16: GNX_DMA(16);
+            case 28: GNX_DMA(28);
+            case 32: GNX_DMA(32);
+            case 56: GNX_DMA(56);
+            case 64: GNX_DMA(64);
+            default: break;
+        }
+#undef GNX_DMA
+    }
     // ping-pong persistent form: whole K chunks, one 32-wide column tile, strip pair + weights fit the 160 KB LDS
     const size_t lds_pp = (2 * ((size_t)(C3_BM + 2 * S + 2) + 1 + 9 * 32) * LDK + LDK) * sizeof(float);
     if (fast && (K & 31) == 0 && N <= C3_BN && nj <= 9 && lds_pp <= 160 * 1024 && getenv("GNX_PINGPONG")) {

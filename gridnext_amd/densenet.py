@@ -274,11 +274,21 @@ class DenseNet(nn.Module):
                         sc1, sh1 = fold[layer.norm1]
                         sc2, sh2 = fold[layer.norm2]
                         t0 = self._probe_begin()
-                        L.call('gnx_conv1x1_bnrelu' + sfx, L.ptr(rows), c_total, L.ptr(layer.conv1.weight), L.ptr(bott),
-                               mid, M, mid, cin, L.ptr(sc1), L.ptr(sh1), 0, 0, st)
-                        t1 = self._probe_mark('conv1x1', t0)
-                        L.call('gnx_conv3x3_bnrelu' + sfx, L.ptr(bott), mid, L.ptr(w2[layer]), rows.data_ptr() + 4 * cin,
-                               c_total, M, self.growth_rate, mid, s, L.ptr(sc2), L.ptr(sh2), st)
+                        if sfx:
+                            L.call('gnx_conv1x1_bnrelu_f16', L.ptr(rows), c_total, L.ptr(layer.conv1.weight),
+                                   L.ptr(bott), mid, M, mid, cin, L.ptr(sc1), L.ptr(sh1), 0, 0, st)
+                            t1 = self._probe_mark('conv1x1', t0)
+                            L.call('gnx_conv3x3_bnrelu_f16', L.ptr(bott), mid, L.ptr(w2[layer]),
+                                   rows.data_ptr() + 4 * cin, c_total, M, self.growth_rate, mid, s, L.ptr(sc2),
+                                   L.ptr(sh2), st)
+                        else:
+                            # norm2 + relu2 ride on conv1's store: conv2 then takes its operand as it lies in HBM
+                            # (global -> LDS DMA, no prologue)
+                            L.call('gnx_conv1x1_bnrelu_act', L.ptr(rows), c_total, L.ptr(layer.conv1.weight),
+                                   L.ptr(bott), mid, M, mid, cin, L.ptr(sc1), L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), st)
+                            t1 = self._probe_mark('conv1x1', t0)
+                            L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2[layer]), rows.data_ptr() + 4 * cin,
+                                   c_total, M, self.growth_rate, mid, s, None, None, st)
                         self._probe_mark('conv3x3', t1)
                     if trans is not None:
                         nxt = bufs[bi + 1]

@@ -89,6 +89,11 @@ int gnx_gemm_f32(const float* A, long lda, int a_kmajor, const float* B, long ld
  * bnrelu_maxpool : norm0->relu0->pool0 (:106-110);  bnrelu_avgpool : norm_final->relu->adaptive_avg_pool (:153-156) */
 int gnx_conv1x1_bnrelu(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
                        const float* scale, const float* shift, int pool, int S_in, gnx_stream_t stream);
+/* conv1x1_bnrelu_act: conv1x1_bnrelu (pool = 0) storing relu(out_scale[n] * y + out_shift[n]) -- _DenseLayer's norm2->relu2
+ * (:38-39) folded into conv1's store in eval mode, so conv2 reads a ready operand (scale = shift = NULL below). */
+int gnx_conv1x1_bnrelu_act(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
+                           const float* scale, const float* shift, const float* out_scale, const float* out_shift,
+                           gnx_stream_t stream);
 int gnx_repack_conv3x3(const float* w, float* wr, int N, int K, gnx_stream_t stream);
 int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, float* out, long ldc, long M, int N, int K, int S,
                        const float* scale, const float* shift, gnx_stream_t stream);

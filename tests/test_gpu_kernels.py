@@ -256,9 +256,32 @@ def test_transition_pool_first(L, n, S, K, N):
     close(out.reshape(n, So, So, N).permute(0, 3, 1, 2), ref, rtol=2e-4)
 
 
+@pytest.mark.parametrize("M,K,N", [(1024, 64, 128), (300, 22, 12), (4096, 224, 128), (129, 96, 130)])
+def test_conv1x1_bnrelu_act(L, M, K, N):
+    """conv1 storing relu(bn2(.)): the eval forward's bottleneck, ready for the prologue-free conv3x3."""
+    g = torch.Generator().manual_seed(M + K + 1)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.1
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+    osc, osh = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.5
+    ref = torch.relu((torch.relu(A * sc + sh) @ W.t()) * osc + osh)
+    Ad, Wd, scd, shd, oscd, oshd = (v.to(DEV) for v in (A, W, sc, sh, osc, osh))
+    out = torch.full((M, N + 3), 7.0, device=DEV)
+    L.call('gnx_conv1x1_bnrelu_act', L.ptr(Ad), K, L.ptr(Wd), L.ptr(out), N + 3, M, N, K, L.ptr(scd), L.ptr(shd),
+           L.ptr(oscd), L.ptr(oshd), L.stream())
+    close(out[:, :N], ref, rtol=2e-4)
+    assert float(out[:, N:].min()) == 7.0
+    assert L.lib().gnx_conv1x1_bnrelu_act(L.ptr(Ad), K, L.ptr(Wd), L.ptr(out), N + 3, M, N, K, L.ptr(scd), L.ptr(shd),
+                                          None, None, L.stream()) != 0       # both output vectors are required
+
+
 @pytest.mark.parametrize("n,S,K,N,act", [(2, 8, 128, 32, True), (3, 4, 12, 6, True), (1, 32, 128, 32, True),
                                          (5, 7, 16, 4, False), (2, 14, 128, 32, True), (1, 56, 8, 4, True),
-                                         (33, 4, 128, 32, True), (1, 1, 8, 4, True), (2, 2, 128, 32, True)])
+                                         (33, 4, 128, 32, True), (1, 1, 8, 4, True), (2, 2, 128, 32, True),
+                                         # prologue-free inputs, 128 | M, N = 32, 32 | K: the LDS-DMA persistent kernel
+                                         (2, 8, 128, 32, False), (8, 16, 128, 32, False), (3, 32, 64, 32, False),
+                                         (1, 64, 32, 32, False), (600, 4, 96, 32, False), (40, 32, 128, 32, False),
+                                         (128, 7, 160, 32, False)])
 def test_conv3x3_bnrelu(L, n, S, K, N, act):
     g = torch.Generator().manual_seed(S * 100 + K)
     x = torch.randn(n, K, S, S, generator=g)

@@ -33,6 +33,7 @@ def main():
     ap.add_argument('--spots', type=int, default=4992)
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--only', default='')
+    ap.add_argument('--noact', action='store_true', help='conv3x3 without the BN+ReLU prologue')
     args = ap.parse_args()
     n = args.spots
     st = L.stream()
@@ -60,8 +61,9 @@ def main():
             ct = 256
             out = torch.empty(M, ct, device=DEV)
             sc, sh = torch.rand(128, device=DEV) + 0.5, torch.randn(128, device=DEV) * 0.1
+            scp, shp = (None, None) if args.noact else (L.ptr(sc), L.ptr(sh))
             ms = timeit(lambda: L.call('gnx_conv3x3_bnrelu', L.ptr(A), 128, L.ptr(Wr), out.data_ptr() + 4 * 64, ct, M,
-                                       32, 128, S, L.ptr(sc), L.ptr(sh), st), args.reps)
+                                       32, 128, S, scp, shp, st), args.reps)
             fl = 2.0 * M * 1152 * 32
             print("conv3x3 S=%2d M=%8d  %8.3f ms  %6.1f TFLOP/s" % (S, M, ms, fl / ms / 1e9))
             del A, out

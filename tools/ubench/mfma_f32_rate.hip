@@ -42,8 +42,8 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
 }
 
 template <int NACC, bool LDSREAD>
-void run(const char* name, int blocks_per_cu) {
-    const int iters = 2000, grid = 256 * blocks_per_cu;
+void run(const char* name, int blocks_per_cu, int iters = 2000) {
+    const int grid = 256 * blocks_per_cu;
     float* out;
     hipMalloc(&out, sizeof(float) * grid * 256);
     hipEvent_t s, e;
@@ -71,5 +71,10 @@ int main() {
     run<2, true>("2 acc + 2 ds_read_b128 per 4 mfma", 2);
     run<4, true>("4 acc + 2 ds_read_b128 per 4 mfma", 2);
     run<4, true>("4 acc + 2 ds_read_b128 per 4 mfma", 3);
+    // sustained: does the clock hold over 20..200 ms of back-to-back matrix work?
+    run<2, true>("sustained 2 acc + ds_read", 1, 20000);
+    run<2, true>("sustained 2 acc + ds_read", 1, 200000);
+    run<2, true>("sustained 2 acc + ds_read", 2, 100000);
+    run<4, false>("sustained 4 acc regs only", 1, 200000);
     return 0;
 }
