@@ -225,7 +225,9 @@ def _call_conv1x1(L, A, W, scale, shift, pool=0, S=0, ldc=None, col0=0):
 
 
 @pytest.mark.parametrize("M,K,N,act", [(1024, 64, 128, True), (300, 22, 12, True), (129, 96, 128, False),
-                                       (4096, 224, 128, True), (64, 1024, 512, True), (5, 3, 2, True)])
+                                       (4096, 224, 128, True), (64, 1024, 512, True), (5, 3, 2, True),
+                                       # whole 128 x 128 x 32 tiles: the LDS-DMA kernel (odd and even chunk counts)
+                                       (256, 96, 256, False), (384, 32, 128, True), (128, 1024, 128, True)])
 def test_conv1x1_bnrelu(L, M, K, N, act):
     g = torch.Generator().manual_seed(M + K)
     Afull = torch.randn(M, K + 8, generator=g)                   # leading dimension != K
