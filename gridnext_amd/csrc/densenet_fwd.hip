@@ -938,25 +938,31 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------ conv1x1, wave-specialised
-// For whole 128 x 128 x 32 tiles (128 | M, 128 | N, 32 | K, aligned operands).  8 waves per workgroup:
-//  * waves 4-7 are PRODUCERS: global -> registers (two chunks ahead, so HBM latency never reaches the barrier) ->
-//    BN+ReLU (activations only) -> ds_write into the group-of-16 layout of the conv3x3 DMA kernel.  The prologue depends
-//    on the consumer layer, so the producer layer cannot apply it; the weights take the same road (a DMA into LDS could
-//    only be issued one chunk ahead).
+// For whole 128 x 128 x 32 tiles (128 | M, 128 | N, 32 | K, aligned operands).  PERSISTENT workgroups of 8 waves, two per
+// CU, each walking its tiles (round-robin over the (M/128) x (N/128) tile grid, N fastest):
+//  * waves 4-7 are PRODUCERS: global -> registers (two chunks ahead) -> BN+ReLU (activations only) -> ds_write into the
+//    group-of-16 layout of the conv3x3 DMA kernel.  The prologue depends on the consumer layer, so the producer layer
+//    cannot apply it; the weights take the same road.  The producers' chunk stream runs straight across tile
+//    boundaries, so a tile's first chunks are already staged while the consumers store the previous tile.
 //  * waves 0-3 are CONSUMERS: per chunk 4 sub-steps of 4 inline-asm ds_read_b128 (base + immediate) and 16 MFMAs - no
 //    VALU, no VMEM, which is what the matrix pipe needs from its wave (tools/ubench/mfma_loop_variants.hip).
-//  * ONE s_barrier per chunk for all 8 waves, double-buffered LDS (64 KB: two workgroups per CU).
+//  * ONE s_barrier per chunk for all 8 waves, double-buffered LDS (64 KB + the BN vectors).
+// Why persistent: stamped (tools/ubench/ws_stamps.py), a one-tile-per-workgroup version kept the consumers' chunk loop at
+// ~95 % matrix-pipe occupancy (two workgroups covering each other's barrier waits) but lost ~14 % of the kernel OUTSIDE
+// the loop: workgroup launch, BN-vector copy, first-load latency and the store epilogue of every tile.
 // lane -> (row, 16-B chunk) for loads and LDS writes: row = lane & 15 (+16 per group), chunk = 4 * half + (lane >> 4):
 // a quarter-wave writes 256 contiguous bytes (conflict-free) and reads 64-B row segments.
 struct C1Stage {
     float4 a[4], w[4];
+    int k0;                        // first K index of the staged chunk (for the BN vectors at the stash)
 };
 constexpr int C1_KMAX = 2048;      // scale/shift vectors are staged in LDS up to this K
 
 template <bool ACT>
 __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restrict__ A, int lda,
                                                             const float* __restrict__ W, float* __restrict__ out,
-                                                            int ldc, int K, const float* __restrict__ scale,
+                                                            int ldc, int K, int tilesN, int T,
+                                                            const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ oscale,
                                                             const float* __restrict__ oshift) {
@@ -965,11 +971,13 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restr
     char* const lds = reinterpret_cast<char*>(lds_f);
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
     const int nk = K >> 5;
-    // Every global load a wave issues beside the MFMA waves costs matrix-pipe time in proportion to its bytes (measured,
-    // tools/ubench/mfma_2x2.hip: ~59 cycles per 1-KB wave load; LDS reads cost nothing), so the per-chunk scale/shift
-    // vectors come from an LDS copy made once per workgroup instead of four more 1-KB loads per producer wave and chunk.
+    const int G = gridDim.x;
+    const int mine = (T - (int)blockIdx.x + G - 1) / G;    // tiles of this workgroup (gridDim.x <= T)
+    const int total = mine * nk;                           // chunks = barriers, the same number for all 8 waves
+    // Every global load a wave issues beside the MFMA waves costs matrix-pipe time in proportion to its bytes, LDS reads
+    // do not (tools/ubench/mfma_2x2.hip): the per-chunk scale/shift vectors come from an LDS copy made once per
+    // workgroup instead of four more 1-KB loads per producer wave and chunk.
     float* sS = reinterpret_cast<float*>(lds + 4 * OPB);
     if (ACT) {
         for (int k = t; k < K; k += 512) { sS[k] = scale[k]; sS[K + k] = shift[k]; }
@@ -979,13 +987,6 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restr
     if (wave >= 4) {
         // ------------------------------------------------------------------------------------------ producer
         const int pw = wave - 4, lr = lane & 15, lc = lane >> 4;
-        // buffer loads (128-bit resource + 32-bit lane offset + scalar chunk offset): beside the MFMA waves a
-        // buffer_load_dwordx4 measured free where a global_load of any width cost 20-60 matrix-pipe cycles per
-        // instruction (tools/ubench/mfma_2x2.hip)
-        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(A + (long)m0 * lda), 0, (127 * lda + K) * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(W + (long)n0 * K), 0, 128 * K * 4, 0x00020000);
         const int voA0 = ((32 * pw + lr) * lda + 4 * lc) * 4, voA1 = voA0 + 64 * lda;
         const int voW0 = ((32 * pw + lr) * K + 4 * lc) * 4, voW1 = voW0 + 64 * K;
         char* st = lds + (2 * pw) * 2048 + lc * 256 + lr * 16;      // + rg * 2048 + half * 1024 (+ OPB for W)
@@ -995,8 +996,18 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restr
             return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
                                __uint_as_float(v[3]));
         };
-        auto load = [&](C1Stage& s, int kt) {
-            const int kb = kt < nk ? kt << 7 : 0;          // byte offset of the chunk; past the end: re-read chunk 0
+        // the producers' own (tile, chunk) iterator; behind the last chunk it re-reads the first tile into a buffer
+        // nobody reads again (branch-free)
+        int ptile = blockIdx.x, pkt = 0;
+        auto load = [&](C1Stage& s) {
+            const int tm = ptile / tilesN, tn = ptile - tm * tilesN;
+            // buffer loads (128-bit resource + 32-bit lane offset + scalar chunk offset)
+            const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(A + (long)tm * 128 * lda), 0, (127 * lda + K) * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(W + (long)tn * 128 * K), 0, 128 * K * 4, 0x00020000);
+            const int kb = pkt << 7;                       // byte offset of the chunk
+            s.k0 = pkt << 5;
             s.a[0] = bld(rA, voA0, kb);
             s.a[1] = bld(rA, voA0, kb + 64);
             s.a[2] = bld(rA, voA1, kb);
@@ -1005,12 +1016,14 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restr
             s.w[1] = bld(rW, voW0, kb + 64);
             s.w[2] = bld(rW, voW1, kb);
             s.w[3] = bld(rW, voW1, kb + 64);
+            if (++pkt == nk) { pkt = 0; ptile += G; }
+            if (ptile >= T) ptile = blockIdx.x;
         };
-        auto stash = [&](const C1Stage& s, int kt, int buf) {
+        auto stash = [&](const C1Stage& s, int buf) {
             char* d = st + buf * 2 * OPB;
             float4 sc[2], sh[2];
             if (ACT) {
-                const int k0 = (kt < nk ? kt << 5 : 0) + 4 * lc;
+                const int k0 = s.k0 + 4 * lc;
                 sc[0] = ld4(sS + k0);
                 sc[1] = ld4(sS + k0 + 16);
                 sh[0] = ld4(sS + K + k0);
@@ -1026,17 +1039,17 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restr
         };
         __builtin_amdgcn_s_setprio(3);
         C1Stage s0, s1;
-        load(s0, 0);
-        load(s1, 1);
-        stash(s0, 0, 0);
-        for (int kt = 0; kt < nk; kt += 2) {
-            lds_barrier();                                  // chunk kt published; consumers done with buffer 1
-            load(s0, kt + 2);
-            stash(s1, kt + 1, 1);
-            if (kt + 1 >= nk) break;
-            lds_barrier();                                  // chunk kt+1 published; consumers done with buffer 0
-            load(s1, kt + 3);
-            stash(s0, kt + 2, 0);
+        load(s0);
+        load(s1);
+        stash(s0, 0);
+        for (int g = 0; g < total; g += 2) {
+            lds_barrier();                                  // chunk g published; consumers done with buffer 1
+            load(s0);
+            stash(s1, 1);
+            if (g + 1 >= total) break;
+            lds_barrier();                                  // chunk g+1 published; consumers done with buffer 0
+            load(s1);
+            stash(s0, 0);
         }
         return;
     }
@@ -1047,50 +1060,54 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restr
     // rows 64 wm + 32 mt + i of A, 64 wn + 32 nt + i of B; mt / nt = +2 groups = +4096 B
     const unsigned fA = lb + (4 * wm + (i >> 4)) * 2048 + (i & 15) * 16 + h * 256;
     const unsigned fB = lb + OPB + (4 * wn + (i >> 4)) * 2048 + (i & 15) * 16 + h * 256;
-    f32x16 acc00, acc01, acc10, acc11;
+    int g = 0;
+    for (int tile = blockIdx.x; tile < T; tile += G) {
+        f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_barrier" ::: "memory");
-        const unsigned a = fA + (kt & 1) * 2 * OPB, b = fB + (kt & 1) * 2 * OPB;
-        f32x4 a0 = lds_read4<0>(a), a1 = lds_read4<4096>(a), b0 = lds_read4<0>(b), b1 = lds_read4<4096>(b);
-        static_for<0, 4>([&](auto s_c) {
-            constexpr int sstep = decltype(s_c)::value;
-            f32x4 na0, na1, nb0, nb1;
-            if constexpr (sstep < 3) {
-                na0 = lds_read4<(sstep + 1) * 512>(a);
-                na1 = lds_read4<(sstep + 1) * 512 + 4096>(a);
-                nb0 = lds_read4<(sstep + 1) * 512>(b);
-                nb1 = lds_read4<(sstep + 1) * 512 + 4096>(b);
-                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
-            }
+        for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            asm volatile("s_barrier" ::: "memory");
+            const unsigned a = fA + (g & 1) * 2 * OPB, b = fB + (g & 1) * 2 * OPB;
+            f32x4 a0 = lds_read4<0>(a), a1 = lds_read4<4096>(a), b0 = lds_read4<0>(b), b1 = lds_read4<4096>(b);
+            static_for<0, 4>([&](auto s_c) {
+                constexpr int sstep = decltype(s_c)::value;
+                f32x4 na0, na1, nb0, nb1;
+                if constexpr (sstep < 3) {
+                    na0 = lds_read4<(sstep + 1) * 512>(a);
+                    na1 = lds_read4<(sstep + 1) * 512 + 4096>(a);
+                    nb0 = lds_read4<(sstep + 1) * 512>(b);
+                    nb1 = lds_read4<(sstep + 1) * 512 + 4096>(b);
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+                }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b0[c], acc00, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b1[c], acc01, 0, 0, 0);
-                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b0[c], acc10, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b1[c], acc11, 0, 0, 0);
-            }
-            if constexpr (sstep < 3) { a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; }
-        });
-    }
-    auto store = [&](f32x16& acc, int mt, int nt) {
-        const int col = n0 + 64 * wn + 32 * nt + i;
-        if (oscale) {
-            const float osc = oscale[col], osh = oshift[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fmaxf(fmaf(acc[r], osc, osh), 0.f);
+                for (int c = 0; c < 4; ++c) {
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b0[c], acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b1[c], acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b0[c], acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b1[c], acc11, 0, 0, 0);
+                }
+                if constexpr (sstep < 3) { a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; }
+            });
         }
-        float* o = out + (long)(m0 + 64 * wm + 32 * mt + 4 * h) * ldc + col;
+        const int tm = tile / tilesN, tn = tile - tm * tilesN;
+        auto store = [&](f32x16& acc, int mt, int nt) {
+            const int col = tn * 128 + 64 * wn + 32 * nt + i;
+            if (oscale) {
+                const float osc = oscale[col], osh = oshift[col];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[(long)(((r & 3) + 8 * (r >> 2)) * ldc)] = acc[r];
-    };
-    store(acc00, 0, 0);
-    store(acc01, 0, 1);
-    store(acc10, 1, 0);
-    store(acc11, 1, 1);
+                for (int r = 0; r < 16; ++r) acc[r] = fmaxf(fmaf(acc[r], osc, osh), 0.f);
+            }
+            float* o = out + (long)(tm * 128 + 64 * wm + 32 * mt + 4 * h) * ldc + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(long)(((r & 3) + 8 * (r >> 2)) * ldc)] = acc[r];
+        };
+        store(acc00, 0, 0);
+        store(acc01, 0, 1);
+        store(acc10, 1, 0);
+        store(acc11, 1, 1);
+    }
 }
 
 // [N][K][3][3] (torch) -> [tap][N][K]
@@ -1394,12 +1411,15 @@ static int conv1x1_launch(const float* A, long lda, const float* W, float* out, 
                 return GNX_ERR_LAUNCH;
             conf = true;
         }
+        const int tilesN = N / 128;
+        const long T = (M / 128) * tilesN;
+        const int wgs = (int)(T < 512 ? T : 512);          // persistent: two workgroups per CU
         if (scale)
-            conv1x1_ws_kernel<true><<<grid, 512, lds_ws, stream>>>(A, (int)lda, W, out, (int)ldc, K, scale, shift,
-                                                                   oscale, oshift);
+            conv1x1_ws_kernel<true><<<wgs, 512, lds_ws, stream>>>(A, (int)lda, W, out, (int)ldc, K, tilesN, (int)T,
+                                                                  scale, shift, oscale, oshift);
         else
-            conv1x1_ws_kernel<false><<<grid, 512, lds_ws, stream>>>(A, (int)lda, W, out, (int)ldc, K, scale, shift,
-                                                                    oscale, oshift);
+            conv1x1_ws_kernel<false><<<wgs, 512, lds_ws, stream>>>(A, (int)lda, W, out, (int)ldc, K, tilesN, (int)T,
+                                                                   scale, shift, oscale, oshift);
         return gnx_launch_status();
     }
 #define GNX_C1(P, F)                                                                                               \

@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--only', default='')
     ap.add_argument('--noact', action='store_true', help='conv3x3 without the BN+ReLU prologue')
+    ap.add_argument('--const', action='store_true', help='constant operands (low bit toggling) instead of randn')
     args = ap.parse_args()
     n = args.spots
     st = L.stream()
@@ -45,10 +46,14 @@ def main():
             M = n * S * S
             A = torch.randn(M, ct, device=DEV)
             W = torch.randn(128, K, device=DEV) * 0.05
+            if args.const:
+                A.fill_(1.0)
+                W.fill_(0.05)
             out = torch.empty(M, 128, device=DEV)
             sc, sh = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
+            scp, shp = (None, None) if args.noact else (L.ptr(sc), L.ptr(sh))
             ms = timeit(lambda: L.call('gnx_conv1x1_bnrelu', L.ptr(A), ct, L.ptr(W), L.ptr(out), 128, M, 128, K,
-                                       L.ptr(sc), L.ptr(sh), 0, 0, st), args.reps)
+                                       scp, shp, 0, 0, st), args.reps)
             fl = 2.0 * M * K * 128
             byts = 4.0 * M * (K + 128)
             print("conv1x1 S=%2d K=%4d M=%8d  %8.3f ms  %6.1f TFLOP/s  %5.2f TB/s" % (S, K, M, ms, fl / ms / 1e9, byts / ms / 1e9))
