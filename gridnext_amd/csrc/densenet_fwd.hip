@@ -958,10 +958,10 @@ struct C1Stage {
 };
 constexpr int C1_KMAX = 2048;      // scale/shift vectors are staged in LDS up to this K
 
-template <bool ACT>
+template <bool ACT, bool POOL>
 __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restrict__ A, int lda,
                                                             const float* __restrict__ W, float* __restrict__ out,
-                                                            int ldc, int K, int tilesN, int T,
+                                                            int ldc, int K, int tilesN, int T, int S_in, long rows_in,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ oscale,
@@ -999,6 +999,80 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restr
         // the producers' own (tile, chunk) iterator; behind the last chunk it re-reads the first tile into a buffer
         // nobody reads again (branch-free)
         int ptile = blockIdx.x, pkt = 0;
+        if constexpr (POOL) {
+            // _Transition (densenet.py:47-54), pool-first: the staged row of pooled position m is the mean of the 4
+            // activated source rows (2oy + {0,1}, 2ox + {0,1}).  16 activation loads per lane and chunk: one register
+            // stage (the path is HBM-bound: 4x the bytes of the plain 1x1 for the same MFMA work).
+            const int So = S_in >> 1, So2 = So * So;
+            float4 pa[16], pwv[4];
+            int pk0 = 0;
+            auto srcrow = [&](int mrow) {              // pooled row index -> first of its 4 source rows
+                const int img = mrow / So2, rem = mrow - img * So2;
+                const int oy = rem / So, ox = rem - oy * So;
+                return ((long)img * S_in + 2 * oy) * S_in + 2 * ox;
+            };
+            auto loadp = [&]() {
+                const int tm = ptile / tilesN, tn = ptile - tm * tilesN;
+                const long base = srcrow(tm * 128);
+                long left = (rows_in - base) * lda - (lda - K);                 // floats behind the resource base
+                const long span = (long)(4 * 128 + 2 * S_in + 4) * lda;
+                if (left > span) left = span;
+                const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(A + base * lda), 0, (int)(left * 4), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(W + (long)tn * 128 * K), 0, 128 * K * 4, 0x00020000);
+                const int vo0 = (int)(srcrow(tm * 128 + 32 * pw + lr) - base) * lda * 4 + lc * 16;
+                const int vo1 = (int)(srcrow(tm * 128 + 32 * pw + lr + 16) - base) * lda * 4 + lc * 16;
+                const int kb = pkt << 7;
+                pk0 = pkt << 5;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {          // (row group, half)
+                    const int vo = (q >> 1) ? vo1 : vo0, so = kb + (q & 1) * 64;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)        // the 4 pooled sources
+                        pa[4 * q + u] = bld(rA, vo, so + ((u >> 1) * S_in + (u & 1)) * lda * 4);
+                }
+                pwv[0] = bld(rW, voW0, kb);
+                pwv[1] = bld(rW, voW0, kb + 64);
+                pwv[2] = bld(rW, voW1, kb);
+                pwv[3] = bld(rW, voW1, kb + 64);
+                if (++pkt == nk) { pkt = 0; ptile += G; }
+                if (ptile >= T) ptile = blockIdx.x;
+            };
+            auto stashp = [&](int buf) {
+                char* d = st + buf * 2 * OPB;
+                float4 sc[2], sh[2];
+                if (ACT) {
+                    const int k0 = pk0 + 4 * lc;
+                    sc[0] = ld4(sS + k0);
+                    sc[1] = ld4(sS + k0 + 16);
+                    sh[0] = ld4(sS + K + k0);
+                    sh[1] = ld4(sS + K + k0 + 16);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        float4 v = pa[4 * q + u];
+                        if (ACT) v = act4(v, sc[q & 1], sh[q & 1]);
+                        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                    }
+                    *reinterpret_cast<float4*>(d + (q >> 1) * 2048 + (q & 1) * 1024) =
+                        make_float4(0.25f * sum.x, 0.25f * sum.y, 0.25f * sum.z, 0.25f * sum.w);
+                    *reinterpret_cast<float4*>(d + OPB + (q >> 1) * 2048 + (q & 1) * 1024) = pwv[q];
+                }
+            };
+            __builtin_amdgcn_s_setprio(3);
+            loadp();
+            stashp(0);
+            for (int g = 0; g < total; ++g) {
+                lds_barrier();                              // chunk g published; consumers done with the other buffer
+                loadp();
+                stashp((g + 1) & 1);
+            }
+            return;
+        }
         auto load = [&](C1Stage& s) {
             const int tm = ptile / tilesN, tn = ptile - tm * tilesN;
             // buffer loads (128-bit resource + 32-bit lane offset + scalar chunk offset)
@@ -1398,15 +1472,17 @@ static int conv1x1_launch(const float* A, long lda, const float* W, float* out, 
     const int vecW = al16(W) && K % 4 == 0;
     dim3 grid(gnx_cdiv(M, C1_BM), gnx_cdiv(N, C1_BN));
     const bool fast = vecA && vecW;
-    if (!pool && fast && M % 128 == 0 && N % 128 == 0 && K % 32 == 0 && K <= C1_KMAX &&
-        M * (lda > ldc ? lda : ldc) < (1L << 31) && !getenv("GNX_NO_WS1")) {
+    if (fast && M % 128 == 0 && N % 128 == 0 && K % 32 == 0 && K <= C1_KMAX && (!pool || (S_in % 2 == 0 && scale)) &&
+        4 * M < (1L << 31) && lda < (1 << 16) && ldc < (1 << 16) && !getenv("GNX_NO_WS1")) {     // int row / lane offsets
         const size_t lds_ws = 4 * 128 * 32 * 4 + (scale ? 8 * (size_t)K : 0);
         static bool conf = false;
         if (!conf) {
             const int mx = 4 * 128 * 32 * 4 + 8 * C1_KMAX;
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<true>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<true, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<false>),
+                hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<false, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
                 return GNX_ERR_LAUNCH;
             conf = true;
@@ -1414,12 +1490,13 @@ static int conv1x1_launch(const float* A, long lda, const float* W, float* out, 
         const int tilesN = N / 128;
         const long T = (M / 128) * tilesN;
         const int wgs = (int)(T < 512 ? T : 512);          // persistent: two workgroups per CU
-        if (scale)
-            conv1x1_ws_kernel<true><<<wgs, 512, lds_ws, stream>>>(A, (int)lda, W, out, (int)ldc, K, tilesN, (int)T,
-                                                                  scale, shift, oscale, oshift);
-        else
-            conv1x1_ws_kernel<false><<<wgs, 512, lds_ws, stream>>>(A, (int)lda, W, out, (int)ldc, K, tilesN, (int)T,
-                                                                   scale, shift, oscale, oshift);
+#define GNX_WS(ACTV, POOLV)                                                                                          \
+    conv1x1_ws_kernel<ACTV, POOLV><<<wgs, 512, lds_ws, stream>>>(A, (int)lda, W, out, (int)ldc, K, tilesN, (int)T, \
+                                                                 S_in, 4 * M, scale, shift, oscale, oshift)
+        if (pool) GNX_WS(true, true);
+        else if (scale) GNX_WS(true, false);
+        else GNX_WS(false, false);
+#undef GNX_WS
         return gnx_launch_status();
     }
 #define GNX_C1(P, F)                                                                                               \

@@ -242,7 +242,10 @@ def test_conv1x1_bnrelu(L, M, K, N, act):
     close(out, ref, rtol=1e-4 * max(1, K ** 0.5 / 4))
 
 
-@pytest.mark.parametrize("n,S,K,N", [(3, 8, 64, 32), (2, 7, 10, 5), (1, 32, 256, 128)])
+@pytest.mark.parametrize("n,S,K,N", [(3, 8, 64, 32), (2, 7, 10, 5), (1, 32, 256, 128),
+                                     # whole tiles: the wave-specialised kernel with pooling producers (tiles across
+                                     # image boundaries, two column tiles, odd chunk count)
+                                     (8, 8, 96, 256), (4, 16, 64, 128), (40, 4, 1024, 512)])
 def test_transition_pool_first(L, n, S, K, N):
     g = torch.Generator().manual_seed(S + K)
     x = torch.randn(n, K, S, S, generator=g)
