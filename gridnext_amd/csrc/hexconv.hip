@@ -226,11 +226,20 @@ GNX_EXPORT int gnx_hexconv_bwd_data(const float* dy, const float* kernel0, const
     return gnx_launch_status();
 }
 
+// positions per workgroup of the weight-gradient kernel: aim at ~1024 workgroups (one 78 x 64 array at 128 positions
+// per workgroup was 39 workgroups on a 256-CU chip, 240 us per layer), whole LDS passes, at most 128
+static int hex_ppb(long npos) {
+    long ppb = (npos + 1023) / 1024;
+    ppb = (ppb + WG_CHUNK - 1) / WG_CHUNK * WG_CHUNK;
+    if (ppb < WG_CHUNK) ppb = WG_CHUNK;
+    if (ppb > 128) ppb = 128;
+    return (int)ppb;
+}
+
 // workspace floats needed by gnx_hexconv_bwd_weight
 GNX_EXPORT long gnx_hexconv_bwd_weight_workspace(int B, int H, int W, int I, int O) {
     const long npos = (long)B * H * W;
-    const int ppb = 128;
-    return (long)gnx_cdiv(npos, ppb) * (7L * O * I + O);
+    return (long)gnx_cdiv(npos, hex_ppb(npos)) * (7L * O * I + O);
 }
 
 GNX_EXPORT int gnx_hexconv_bwd_weight(const float* x, const float* dy, float* dkernel0, float* dkernel1,
@@ -240,7 +249,7 @@ GNX_EXPORT int gnx_hexconv_bwd_weight(const float* x, const float* dy, float* dk
         H <= 0 || W <= 0 || B < 0)
         return GNX_ERR_BAD_ARG;
     const long npos = (long)B * H * W;
-    const int ppb = 128;
+    const int ppb = hex_ppb(npos);
     const int nblk = gnx_cdiv(npos, ppb);
     const int nout = 7 * O * I + O;
     HexGeom g{B, H, W, mode};

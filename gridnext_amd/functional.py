@@ -200,6 +200,12 @@ class _Linear(Function):
                 for b in range(Bn):
                     L.call('gnx_gemm_f32', L.ptr(dy[b * S:]), lddy, 1, L.ptr(x[b]), S, 0, None, L.ptr(dw), K,
                            N, K, S, 1 if b else 0, L.stream())
+            elif M >= 2048:
+                # many spots, few features: the split-M slab kernel of the conv weight gradients (deterministic
+                # two-stage sum) instead of a GEMM whose whole grid is N/64 x K/64 <= 16 workgroups
+                ws = torch.empty(L.query('gnx_wgrad_workspace', M, N, K, 1), device=dev, dtype=F32)
+                L.call('gnx_wgrad_bnrelu', L.ptr(dy), lddy, L.ptr(x), ctx.ld, None, None, L.ptr(dw), L.ptr(ws),
+                       M, N, K, 0, 1, 0, 0, L.stream())
             else:
                 L.call('gnx_gemm_f32', L.ptr(dy), lddy, 1, L.ptr(x), ctx.ld, 1, None, L.ptr(dw), K, N, K, M, 0,
                        L.stream())
