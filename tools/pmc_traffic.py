@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch from two rocprofv3 PMC passes of bench.py (FETCH_SIZE and WRITE_SIZE need separate
+passes: they share TCC counter slots), corrected as MI355X_MICROARCH.md prescribes for gfx950:
+  * both counters tick in KiB;
+  * FETCH_SIZE reports half of the bytes of wide (16 B/lane) coalesced reads - global_load, buffer_load and
+    LDS-DMA alike - so it is doubled;  WRITE_SIZE is exact (calibration: the stem's 5.23 GB output).
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o r --output-format csv -- python3 bench.py ...
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write -o r --output-format csv -- python3 bench.py ...
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/rNNx_pmc_traffic.json
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+GROUPS = [                                   # first match wins
+    ('conv1x1', lambda n: 'conv1x1_ws_kernel<true, false>' in n or 'conv1x1_ws_kernel<false, false>' in n
+        or 'conv1x1_kernel<false' in n),
+    ('transition', lambda n: 'conv1x1_ws_kernel<true, true>' in n or 'conv1x1_kernel<true' in n),
+    ('conv3x3', lambda n: 'conv3x3_' in n),
+    ('stem', lambda n: 'conv_stem' in n),
+    ('maxpool', lambda n: 'maxpool' in n),
+]
+
+
+def collect(d, counter):
+    f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+    if not f:
+        raise SystemExit('no counter_collection.csv under ' + d)
+    per = collections.defaultdict(list)
+    by_dispatch = collections.defaultdict(float)
+    names = {}
+    for r in csv.DictReader(open(f[0])):
+        if r['Counter_Name'] != counter:
+            continue
+        by_dispatch[r['Dispatch_Id']] += float(r['Counter_Value'])
+        names[r['Dispatch_Id']] = r['Kernel_Name']
+    for did, v in by_dispatch.items():
+        for g, match in GROUPS:
+            if match(names[did]):
+                per[g].append(v * 1024.0)
+                break
+    return per
+
+
+def main():
+    fetch = collect(sys.argv[1], 'FETCH_SIZE')
+    write = collect(sys.argv[2], 'WRITE_SIZE')
+    out = {}
+    for g, _ in GROUPS:
+        if g not in fetch or g not in write:
+            continue
+        fb = 2.0 * sum(fetch[g]) / len(fetch[g])
+        wb = sum(write[g]) / len(write[g])
+        out[g] = {'launches': len(fetch[g]), 'fetch_bytes_per_launch_corrected': fb, 'write_bytes_per_launch': wb,
+                  'hbm_bytes_per_launch': fb + wb}
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == '__main__':
+    main()
