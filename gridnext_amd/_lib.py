@@ -35,6 +35,7 @@ SIGNATURES = {
     'gnx_conv3x3_bnrelu_f16': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
     'gnx_conv3x3_bnrelu': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
     'gnx_conv_stem': (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'gnx_conv_stem_bnrelu_maxpool': (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     'gnx_bnrelu_maxpool': (_I, [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
     'gnx_bnrelu_avgpool': (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _P]),
     'gnx_wgrad_workspace': (_L, [_L, _I, _I, _I]),
@@ -52,6 +53,7 @@ SIGNATURES = {
 
 _lib = None
 _ERRORS = {-1: 'bad argument', -2: 'kernel launch failed', -3: 'unsupported shape'}
+ERR_UNSUPPORTED = -3
 
 
 class HipExtensionMissing(RuntimeError):

@@ -970,14 +970,18 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
 // the loop: workgroup launch, BN-vector copy, first-load latency and the store epilogue of every tile.
 // lane -> (row, 16-B chunk) for loads and LDS writes: row = lane & 15 (+16 per group), chunk = 4 * half + (lane >> 4):
 // a quarter-wave writes 256 contiguous bytes (conflict-free) and reads 64-B row segments.
+#ifndef GNX_WS_STAMP
+#define GNX_WS_STAMP 0
+#endif
+template <int GP>                  // groups of 16 rows per producer wave
 struct C1Stage {
-    float4 a[4], w[4];
+    float4 a[2 * GP], w[2 * GP];
     int k0;                        // first K index of the staged chunk (for the BN vectors at the stash)
 };
 constexpr int C1_KMAX = 2048;      // scale/shift vectors are staged in LDS up to this K
 
-template <bool ACT, bool POOL>
-__global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restrict__ A, int lda,
+template <bool ACT, bool POOL, int NP>
+__global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_kernel(const float* __restrict__ A, int lda,
                                                             const float* __restrict__ W, float* __restrict__ out,
                                                             int ldc, int K, int tilesN, int T, int S_in, long rows_in,
                                                             const float* __restrict__ scale,
@@ -998,16 +1002,17 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restr
     // workgroup instead of four more 1-KB loads per producer wave and chunk.
     float* sS = reinterpret_cast<float*>(lds + 4 * OPB);
     if (ACT) {
-        for (int k = t; k < K; k += 512) { sS[k] = scale[k]; sS[K + k] = shift[k]; }
+        for (int k = t; k < K; k += 64 * (4 + NP)) { sS[k] = scale[k]; sS[K + k] = shift[k]; }
         __syncthreads();
     }
 
     if (wave >= 4) {
         // ------------------------------------------------------------------------------------------ producer
+        constexpr int GP = 8 / NP;                           // 16-row groups per producer wave (NP = 4: 2, NP = 8: 1)
         const int pw = wave - 4, lr = lane & 15, lc = lane >> 4;
-        const int voA0 = ((32 * pw + lr) * lda + 4 * lc) * 4, voA1 = voA0 + 64 * lda;
-        const int voW0 = ((32 * pw + lr) * K + 4 * lc) * 4, voW1 = voW0 + 64 * K;
-        char* st = lds + (2 * pw) * 2048 + lc * 256 + lr * 16;      // + rg * 2048 + half * 1024 (+ OPB for W)
+        const int voA0 = ((16 * GP * pw + lr) * lda + 4 * lc) * 4, voA1 = voA0 + 64 * lda;
+        const int voW0 = ((16 * GP * pw + lr) * K + 4 * lc) * 4, voW1 = voW0 + 64 * K;
+        char* st = lds + (GP * pw) * 2048 + lc * 256 + lr * 16;     // + rg * 2048 + half * 1024 (+ OPB for W)
         auto bld = [](const __amdgpu_buffer_rsrc_t& r, int vo, int so) {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
@@ -1018,6 +1023,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restr
         // nobody reads again (branch-free)
         int ptile = blockIdx.x, pkt = 0;
         if constexpr (POOL) {
+            static_assert(!POOL || NP == 4, "pooling producers own 32 rows each");
             // _Transition (densenet.py:47-54), pool-first: the staged row of pooled position m is the mean of the 4
             // activated source rows (2oy + {0,1}, 2ox + {0,1}).  16 activation loads per lane and chunk: one register
             // stage (the path is HBM-bound: 4x the bytes of the plain 1x1 for the same MFMA work).
@@ -1091,7 +1097,7 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restr
             }
             return;
         }
-        auto load = [&](C1Stage& s) {
+        auto load = [&](C1Stage<GP>& s) {
             const int tm = ptile / tilesN, tn = ptile - tm * tilesN;
             // buffer loads (128-bit resource + 32-bit lane offset + scalar chunk offset)
             const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
@@ -1100,18 +1106,22 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restr
                 const_cast<float*>(W + (long)tn * 128 * K), 0, 128 * K * 4, 0x00020000);
             const int kb = pkt << 7;                       // byte offset of the chunk
             s.k0 = pkt << 5;
-            s.a[0] = bld(rA, voA0, kb);
-            s.a[1] = bld(rA, voA0, kb + 64);
-            s.a[2] = bld(rA, voA1, kb);
-            s.a[3] = bld(rA, voA1, kb + 64);
-            s.w[0] = bld(rW, voW0, kb);
-            s.w[1] = bld(rW, voW0, kb + 64);
-            s.w[2] = bld(rW, voW1, kb);
-            s.w[3] = bld(rW, voW1, kb + 64);
+#pragma unroll
+            for (int q = 0; q < 2 * GP; ++q) s.a[q] = bld(rA, (q >> 1) ? voA1 : voA0, kb + (q & 1) * 64);
+#pragma unroll
+            for (int q = 0; q < 2 * GP; ++q) s.w[q] = bld(rW, (q >> 1) ? voW1 : voW0, kb + (q & 1) * 64);
             if (++pkt == nk) { pkt = 0; ptile += G; }
             if (ptile >= T) ptile = blockIdx.x;
         };
-        auto stash = [&](const C1Stage& s, int buf) {
+#if GNX_WS_STAMP
+        long seg[4] = {0, 0, 0, 0};
+        long seg_t = 0;
+#define GNX_SEG(i) do { const long now = __builtin_amdgcn_s_memtime(); seg[i] += now - seg_t; seg_t = now; } while (0)
+#else
+#define GNX_SEG(i)
+#endif
+        auto stash = [&](const C1Stage<GP>& s, int buf) {
+            GNX_SEG(0);                                     // barrier release -> loads issued
             char* d = st + buf * 2 * OPB;
             float4 sc[2], sh[2];
             if (ACT) {
@@ -1121,28 +1131,58 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restr
                 sh[0] = ld4(sS + K + k0);
                 sh[1] = ld4(sS + K + k0 + 16);
             }
+#if GNX_WS_STAMP
+            if (GP == 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            GNX_SEG(1);                                     // operands of the stash have arrived (loads + BN vectors)
+#endif
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 2 * GP; ++q) {
                 float4 v = s.a[q];
                 if (ACT) v = act4(v, sc[q & 1], sh[q & 1]);
                 *reinterpret_cast<float4*>(d + (q >> 1) * 2048 + (q & 1) * 1024) = v;
                 *reinterpret_cast<float4*>(d + OPB + (q >> 1) * 2048 + (q & 1) * 1024) = s.w[q];
             }
+            GNX_SEG(2);                                     // activation + LDS writes issued
+#if GNX_WS_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            GNX_SEG(3);                                     // LDS writes done
+#endif
         };
         __builtin_amdgcn_s_setprio(3);
-        C1Stage s0, s1;
+        C1Stage<GP> s0, s1;
         load(s0);
         load(s1);
         stash(s0, 0);
+#if GNX_WS_STAMP
+        long p_wait = 0;
+        const long p_begin = __builtin_amdgcn_s_memtime();
+#define GNX_PBAR() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long tb = __builtin_amdgcn_s_memtime(); \
+                        asm volatile("s_barrier" ::: "memory"); seg_t = __builtin_amdgcn_s_memtime(); p_wait += seg_t - tb; } while (0)
+#else
+#define GNX_PBAR() lds_barrier()
+#endif
         for (int g = 0; g < total; g += 2) {
-            lds_barrier();                                  // chunk g published; consumers done with buffer 1
+            GNX_PBAR();                                     // chunk g published; consumers done with buffer 1
             load(s0);
             stash(s1, 1);
             if (g + 1 >= total) break;
-            lds_barrier();                                  // chunk g+1 published; consumers done with buffer 0
+            GNX_PBAR();                                     // chunk g+1 published; consumers done with buffer 0
             load(s1);
             stash(s0, 0);
         }
+#undef GNX_PBAR
+#if GNX_WS_STAMP
+        if (lane == 0 && pw == 0) {      // debug build: producer wave 4 of each workgroup -> (barrier wait, total) cycles
+            const long p_total = __builtin_amdgcn_s_memtime() - p_begin;
+            float* dbg = out + (long)(blockIdx.x / tilesN) * 128 * ldc + (blockIdx.x % tilesN) * 128;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg[4 * ldc + 0] = (float)p_wait;
+            dbg[4 * ldc + 1] = (float)p_total;
+            dbg[4 * ldc + 2] = (float)total;
+            for (int q = 0; q < 4; ++q) dbg[4 * ldc + 3 + q] = (float)seg[q];
+        }
+#endif
         return;
     }
     // ---------------------------------------------------------------------------------------------- consumer
@@ -1153,12 +1193,22 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restr
     const unsigned fA = lb + (4 * wm + (i >> 4)) * 2048 + (i & 15) * 16 + h * 256;
     const unsigned fB = lb + OPB + (4 * wn + (i >> 4)) * 2048 + (i & 15) * 16 + h * 256;
     int g = 0;
+#if GNX_WS_STAMP
+    long c_wait = 0;
+    const long c_begin = __builtin_amdgcn_s_memtime();
+#endif
     for (int tile = blockIdx.x; tile < T; tile += G) {
         f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
         for (int kt = 0; kt < nk; ++kt, ++g) {
+#if GNX_WS_STAMP
+            const long tb0 = __builtin_amdgcn_s_memtime();
+#endif
             asm volatile("s_barrier" ::: "memory");
+#if GNX_WS_STAMP
+            c_wait += __builtin_amdgcn_s_memtime() - tb0;
+#endif
             const unsigned a = fA + (g & 1) * 2 * OPB, b = fB + (g & 1) * 2 * OPB;
             f32x4 a0 = lds_read4<0>(a), a1 = lds_read4<4096>(a), b0 = lds_read4<0>(b), b1 = lds_read4<4096>(b);
             static_for<0, 4>([&](auto s_c) {
@@ -1200,6 +1250,15 @@ __global__ __launch_bounds__(512, 4) void conv1x1_ws_kernel(const float* __restr
         store(acc10, 1, 0);
         store(acc11, 1, 1);
     }
+#if GNX_WS_STAMP
+    if (lane == 0) {                     // debug build: consumer waves -> (barrier wait, total) cycles over all their tiles
+        const long c_total = __builtin_amdgcn_s_memtime() - c_begin;
+        float* dbg = out + (long)(blockIdx.x / tilesN) * 128 * ldc + (blockIdx.x % tilesN) * 128;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg[wave * ldc + 0] = (float)c_wait;
+        dbg[wave * ldc + 1] = (float)c_total;
+    }
+#endif
 }
 
 // [N][K][3][3] (torch) -> [tap][N][K]
@@ -1389,6 +1448,150 @@ __global__ __launch_bounds__(256) void conv_stem_patch_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------ stem + BN + ReLU + maxpool
+// features.conv0 -> norm0 -> relu0 -> pool0 (densenet.py:105-110) in ONE kernel for the 128-px geometry (7x7 s2 p3 conv to a
+// 64-wide map, 3x3 s2 p1 max pool): the 5.2 GB conv0 output of an array never goes to HBM (the two-kernel path writes
+// it and reads it back: 4.9 + 1.4 ms).  A persistent workgroup sweeps an image top to bottom in tiles of 2 conv rows x 64
+// columns (= the 128 positions of the MFMA M dimension, full width: no horizontal halo); tile t yields conv rows 2t and
+// 2t+1, pooled row t = max over conv rows {2t-1, 2t, 2t+1} and columns {2px-1, 2px, 2px+1}.  Row 2t-1 is the previous
+// tile's second row: every thread owns the same (px, 4 channels) items in every tile, so that carry lives in registers.
+// relu >= 0, so "outside the map" contributes 0 exactly as in gnx_bnrelu_maxpool.
+constexpr int SP_LDT = 72;         // floats per position of the activated tile in LDS: 4 * 72 = 32 (mod 64) banks, so the
+                                   // two lane halves of an accumulator store (positions p and p + 4) hit disjoint banks
+__global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             float* __restrict__ out, long ldo, int H, int Wd, int O,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, long imgs) {
+    constexpr int CIN = 3, KH = 7, KW = 7, STRIDE = 2, PAD = 3, WO = 64;
+    constexpr int PH = STRIDE + KH, PW = (63 * STRIDE + 8 + 1 + 1) & ~1;       // 9 x 136 input patch per channel
+    constexpr int KT = CIN * KH * 8, LDB = KT + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Bs = lds;                          // [64][LDB] weights, kx zero-padded to 8
+    float* Ps = lds + 64 * LDB;               // [CIN][PH][PW]
+    float* Ts = Ps + CIN * PH * PW;           // [128 positions][SP_LDT] activated conv tile
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    for (int idx = t; idx < 64 * KT; idx += 256) {
+        const int n = idx / KT, rem = idx - n * KT;
+        const int kx = rem & 7, cky = rem >> 3;          // cky = c*KH + ky
+        float v = 0.f;
+        if (n < O && kx < KW) v = w[((long)n * CIN * KH + cky) * KW + kx];
+        Bs[n * LDB + rem] = v;
+    }
+    for (int idx = t; idx < CIN * PH * PW; idx += 256) Ps[idx] = 0.f;          // the pad columns stay zero for good
+    const int trow = 32 * wave + i;                       // this lane's position in the 2 x 64 tile
+    const float* pa = Ps + (STRIDE * (trow >> 6)) * PW + STRIDE * (trow & 63) + 4 * h;
+    const float* pb = Bs + i * LDB + 4 * h;
+    const float sc0 = i < O ? scale[i] : 0.f, sh0 = i < O ? shift[i] : 0.f;
+    const float sc1 = 32 + i < O ? scale[32 + i] : 0.f, sh1 = 32 + i < O ? shift[32 + i] : 0.f;
+    const int c4 = t & 15, pxa = t >> 4;                  // pooling items of this thread: (pxa, c4) and (pxa + 16, c4)
+    const int Ho2 = (H + 2 * PAD - KH) / STRIDE + 1;      // conv rows (== 64 for the 128-px stem), pooled rows Ho2 / 2
+    const int ntt = Ho2 / 2;
+
+    // Patch staging: 27 rows (3 channels x 9 input rows) of Wd = 128 floats = 864 16-B pieces, 4 per thread (the last
+    // partly idle), fetched one tile AHEAD into registers while the current tile multiplies.
+    float4 pre[4];
+    auto fetch_patch = [&](long img, int tt) {
+        const int iy0 = 2 * tt * STRIDE - PAD;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = t + 256 * q;
+            const int f4 = j & 31, py = (j >> 5) % PH, c = (j >> 5) / PH;
+            const int iy = iy0 + py;
+            pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < CIN * PH * 32 && iy >= 0 && iy < H) pre[q] = ld4(x + ((img * CIN + c) * H + iy) * (long)Wd + 4 * f4);
+        }
+    };
+    auto stash_patch = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = t + 256 * q;
+            if (j < CIN * PH * 32) {
+                float* d = Ps + (j >> 5) * PW + PAD + 4 * (j & 31);          // patch column = ix + PAD
+                d[0] = pre[q].x; d[1] = pre[q].y; d[2] = pre[q].z; d[3] = pre[q].w;
+            }
+        }
+    };
+    __syncthreads();                                      // Bs and the zeroed patch are in place
+    fetch_patch(blockIdx.x, 0);
+
+    for (long img = blockIdx.x; img < imgs; img += gridDim.x) {
+        float4 carry[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        for (int tt = 0; tt < ntt; ++tt) {
+            __syncthreads();                              // previous tile's fragment and Ts reads are done
+            stash_patch();
+            {
+                long nimg = img;
+                int nt2 = tt + 1;
+                if (nt2 == ntt) { nt2 = 0; nimg += gridDim.x; }
+                if (nimg >= imgs) nimg = blockIdx.x;       // past the end: a harmless re-read
+                fetch_patch(nimg, nt2);
+            }
+            asm volatile("" ::: "memory");                // keep the prefetch in front of the multiply
+            __syncthreads();
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            auto load_a = [&](int step) {
+                const float* ap = pa + ((step / KH) * PH + (step % KH)) * PW;
+                const float2 lo = *reinterpret_cast<const float2*>(ap);
+                const float2 hi = *reinterpret_cast<const float2*>(ap + 2);
+                return make_float4(lo.x, lo.y, hi.x, hi.y);
+            };
+            constexpr int NSTEP = CIN * KH;
+            float4 a = load_a(0), b0 = ld4(pb), b1 = ld4(pb + 32 * LDB);
+#pragma unroll
+            for (int step = 0; step < NSTEP; ++step) {
+                float4 na = a, nb0 = b0, nb1 = b1;
+                if (step + 1 < NSTEP) {
+                    na = load_a(step + 1);
+                    nb0 = ld4(pb + (step + 1) * 8);
+                    nb1 = ld4(pb + 32 * LDB + (step + 1) * 8);
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+                a = na; b0 = nb0; b1 = nb1;
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+            // norm0 + relu0 on the accumulators, tile to LDS (lane = channel, register = position)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+                Ts[rr * SP_LDT + i] = fmaxf(fmaf(acc0[r], sc0, sh0), 0.f);
+                Ts[rr * SP_LDT + 32 + i] = fmaxf(fmaf(acc1[r], sc1, sh1), 0.f);
+            }
+            __syncthreads();
+            // pool0: pooled row tt, two (px, 4-channel) items per thread
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int px = pxa + 16 * q;
+                float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;            // horizontal max of conv rows 2tt, 2tt+1
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int ox = 2 * px + dx;
+                    if (ox < 0) continue;                                        // ox <= 63 always
+                    const float4 v0 = ld4(&Ts[ox * SP_LDT + 4 * c4]);
+                    const float4 v1 = ld4(&Ts[(WO + ox) * SP_LDT + 4 * c4]);
+                    m0 = make_float4(fmaxf(m0.x, v0.x), fmaxf(m0.y, v0.y), fmaxf(m0.z, v0.z), fmaxf(m0.w, v0.w));
+                    m1 = make_float4(fmaxf(m1.x, v1.x), fmaxf(m1.y, v1.y), fmaxf(m1.z, v1.z), fmaxf(m1.w, v1.w));
+                }
+                const float4 cv = carry[q];
+                const float4 o4 = make_float4(fmaxf(fmaxf(cv.x, m0.x), m1.x), fmaxf(fmaxf(cv.y, m0.y), m1.y),
+                                              fmaxf(fmaxf(cv.z, m0.z), m1.z), fmaxf(fmaxf(cv.w, m0.w), m1.w));
+                carry[q] = m1;
+                if (4 * c4 < O)
+                    *reinterpret_cast<float4*>(out + ((img * (Ho2 / 2) + tt) * (long)(WO / 2) + px) * ldo + 4 * c4) = o4;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ BN+ReLU+maxpool 3x3 s2 p1
 __global__ __launch_bounds__(256) void bnrelu_maxpool_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out,
                                                              long ldo, long Mout, int C, int Hi, int Wi, int Ho, int Wo,
@@ -1496,24 +1699,32 @@ static int conv1x1_launch(const float* A, long lda, const float* W, float* out, 
         static bool conf = false;
         if (!conf) {
             const int mx = 4 * 128 * 32 * 4 + 8 * C1_KMAX;
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<true, false>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<true, false, 4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<false, false>),
+                hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<false, false, 4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<true, true>),
+                hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<true, false, 8>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<false, false, 8>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<true, true, 4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
                 return GNX_ERR_LAUNCH;
             conf = true;
         }
         const int tilesN = N / 128;
         const long T = (M / 128) * tilesN;
-        const int wgs = (int)(T < 512 ? T : 512);          // persistent: two workgroups per CU
-#define GNX_WS(ACTV, POOLV)                                                                                          \
-    conv1x1_ws_kernel<ACTV, POOLV><<<wgs, 512, lds_ws, stream>>>(A, (int)lda, W, out, (int)ldc, K, tilesN, (int)T, \
-                                                                 S_in, 4 * M, scale, shift, oscale, oshift)
-        if (pool) GNX_WS(true, true);
-        else if (scale) GNX_WS(true, false);
-        else GNX_WS(false, false);
+        // NP = producer waves: 4 (two 8-wave workgroups per CU) or 8 (one 12-wave workgroup per CU)
+        static const int np8 = getenv("GNX_WS_NP8") ? 1 : 0;
+        const int np = (!pool && np8) ? 8 : 4;
+        const int per_cu = np == 4 ? 2 : 1;
+        const int wgs = (int)(T < 256 * per_cu ? T : 256 * per_cu);
+#define GNX_WS(ACTV, POOLV, NPV)                                                                                     \
+    conv1x1_ws_kernel<ACTV, POOLV, NPV><<<wgs, 64 * (4 + NPV), lds_ws, stream>>>(                                     \
+        A, (int)lda, W, out, (int)ldc, K, tilesN, (int)T, S_in, 4 * M, scale, shift, oscale, oshift)
+        if (pool) GNX_WS(true, true, 4);
+        else if (scale) { if (np == 8) GNX_WS(true, false, 8); else GNX_WS(true, false, 4); }
+        else { if (np == 8) GNX_WS(false, false, 8); else GNX_WS(false, false, 4); }
 #undef GNX_WS
         return gnx_launch_status();
     }
@@ -1689,6 +1900,33 @@ GNX_EXPORT int gnx_conv_stem(const float* x, const float* w, float* out, long ld
     const size_t lds_bytes = (size_t)(ST_BM + ST_BN) * (KH * 8 + 4) * sizeof(float);
     dim3 grid(gnx_cdiv(M, ST_BM), gnx_cdiv(O, ST_BN));
     conv_stem_kernel<<<grid, 256, lds_bytes, stream>>>(x, w, out, ldc, M, Cin, H, W, Ho, Wo, O, KH, KW, stride, pad);
+    return gnx_launch_status();
+}
+
+// x [imgs][3][H][W] (NCHW patches), w [O][3][7][7] -> out [imgs*(Ho/2)*(Wo/2)][O] (ldo):
+// maxpool3x3s2p1(relu(scale * conv7x7s2p3(x) + shift)) without the intermediate map.  Supported geometry: Cin = 3, the
+// conv output is 64 wide and even-high (128-px patches), O <= 64 and O % 4 == 0; anything else returns
+// GNX_ERR_UNSUPPORTED and the caller runs gnx_conv_stem + gnx_bnrelu_maxpool.
+GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool(const float* x, const float* w, float* out, long ldo, long imgs, int Cin,
+                                            int H, int W, int O, int KH, int KW, int stride, int pad, const float* scale,
+                                            const float* shift, hipStream_t stream) {
+    if (!x || !w || !out || !scale || !shift || imgs < 0 || Cin <= 0 || O <= 0 || H <= 0 || W <= 0 || ldo < O)
+        return GNX_ERR_BAD_ARG;
+    if (Cin != 3 || KH != 7 || KW != 7 || stride != 2 || pad != 3 || O > 64 || O % 4 != 0 || ldo % 4 != 0 || !al16(out))
+        return GNX_ERR_UNSUPPORTED;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    if (Wo != 64 || W != 128 || Ho % 2 != 0 || Ho <= 0 || !al16(x)) return GNX_ERR_UNSUPPORTED;    // 16-B row pieces
+    if (imgs == 0) return GNX_OK;
+    const size_t lds_bytes = ((size_t)64 * (3 * 7 * 8 + 4) + (size_t)3 * 9 * 136 + (size_t)128 * SP_LDT) * sizeof(float);
+    static bool conf = false;
+    if (!conf) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return GNX_ERR_LAUNCH;
+        conf = true;
+    }
+    const int grid = (int)(imgs < 256 ? imgs : 256);
+    conv_stem_pool_kernel<<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale, shift, imgs);
     return gnx_launch_status();
 }
 

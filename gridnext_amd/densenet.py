@@ -238,7 +238,7 @@ class DenseNet(nn.Module):
         bufs = [torch.empty((chunk * s * s, c_total), device=dev, dtype=F32)
                 for (_, _, _, c_total), s in zip(self._blocks, sizes)]
         bott = torch.empty((chunk * sizes[0] * sizes[0], mid), device=dev, dtype=F32)
-        stem_out = torch.empty((chunk * hs * hs, c0), device=dev, dtype=F32) if hs is not None else None
+        stem_out = None                                         # conv0 map: only the unfused stem needs it
         feats = torch.empty((N, self.num_features), device=dev, dtype=F32)
         w0 = conv0.weight.detach().contiguous()
 
@@ -265,10 +265,19 @@ class DenseNet(nn.Module):
                                    3, 3, 1, 1, st)
                         else:
                             sc, sh = fold[self.features.norm0]
-                            L.call('gnx_conv_stem', L.ptr(xu), L.ptr(w0), L.ptr(stem_out), c0, nu, 3, P, P, c0,
-                                   7, 7, 2, 3, st)
-                            L.call('gnx_bnrelu_maxpool', L.ptr(stem_out), c0, L.ptr(rows), c_total, nu, c0, hs, hs,
-                                   L.ptr(sc), L.ptr(sh), st)
+                            # conv0 -> norm0 -> relu0 -> pool0 in one kernel where the geometry allows (128-px
+                            # patches): the conv0 map (5.2 GB per array) then never touches HBM
+                            rc = L.query('gnx_conv_stem_bnrelu_maxpool', L.ptr(xu), L.ptr(w0), L.ptr(rows), c_total, nu,
+                                         3, P, P, c0, 7, 7, 2, 3, L.ptr(sc), L.ptr(sh), st)
+                            if rc == L.ERR_UNSUPPORTED:
+                                if stem_out is None:
+                                    stem_out = torch.empty((chunk * hs * hs, c0), device=dev, dtype=F32)
+                                L.call('gnx_conv_stem', L.ptr(xu), L.ptr(w0), L.ptr(stem_out), c0, nu, 3, P, P, c0,
+                                       7, 7, 2, 3, st)
+                                L.call('gnx_bnrelu_maxpool', L.ptr(stem_out), c0, L.ptr(rows), c_total, nu, c0, hs, hs,
+                                       L.ptr(sc), L.ptr(sh), st)
+                            elif rc != 0:
+                                raise RuntimeError("gnx_conv_stem_bnrelu_maxpool failed (%d)" % rc)
                     for li, layer in enumerate(layers):
                         cin = c_in + li * self.growth_rate
                         sc1, sh1 = fold[layer.norm1]

@@ -1,5 +1,5 @@
-"""Reads the consumer-wave stamps of a -DGNX_WS_STAMP=1 build of conv1x1_ws_kernel (GNX_LIB=tools/ubench/build/libws_stamp.so):
-how many cycles of the chunk loop the MFMA waves spend waiting at the per-chunk barrier."""
+"""Reads the wave stamps of a -DGNX_WS_STAMP=1 build of conv1x1_ws_kernel (GNX_LIB=tools/ubench/build/libws_stamp.so):
+cycles the consumer (MFMA) waves and producer wave 4 of every persistent workgroup spend waiting at the per-chunk barrier."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -12,10 +12,15 @@ for S, K, ct in [(32, 224, 256), (16, 480, 512), (8, 992, 1024)]:
     out = torch.empty(M, 128, device=DEV)
     sc, sh = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
     for _ in range(30):
-        L.call('gnx_conv1x1_bnrelu', L.ptr(A), ct, L.ptr(W), L.ptr(out), 128, M, 128, K, L.ptr(sc), L.ptr(sh), 0, 0, L.stream())
+        L.call('gnx_conv1x1_bnrelu', L.ptr(A), ct, L.ptr(W), L.ptr(out), 128, M, 128, K, (L.ptr(sc) if os.environ.get('WS_ACT', '1') == '1' else None), (L.ptr(sh) if os.environ.get('WS_ACT', '1') == '1' else None), 0, 0, L.stream())
     torch.cuda.synchronize()
-    o = out.view(M // 128, 128, 128)[:, :4, :2].double().cpu()       # [tile][wave][bar,total]
-    bar, tot = o[..., 0].mean().item(), o[..., 1].mean().item()
-    nk = K // 32
-    print("S=%2d K=%4d: chunk loop %8.0f cycles/tile (%6.0f per chunk; 64 MFMAs = 4096), at barriers %8.0f (%4.1f%%)"
-          % (S, K, tot, tot / nk, bar, 100 * bar / tot))
+    nwg = min(M // 128, 512)
+    o = out.view(M // 128, 128, 128)[:nwg, :5, :7].double().cpu()       # [workgroup = its first tile][wave 0-3, producer][..]
+    cw, ct_ = o[:, :4, 0].mean().item(), o[:, :4, 1].mean().item()
+    pw, pt, chunks = o[:, 4, 0].mean().item(), o[:, 4, 1].mean().item(), o[:, 4, 2].mean().item()
+    print("S=%2d K=%4d: %5.0f chunks/workgroup; consumer %7.0f cycles/chunk (ideal 2 x 4096 shared by two workgroups), at "
+          "barriers %4.1f%%; producer at barriers %4.1f%% (work %6.0f cycles/chunk)"
+          % (S, K, chunks, ct_ / chunks, 100 * cw / ct_, 100 * pw / pt, (pt - pw) / chunks))
+    seg = [o[:, 4, 3 + q].mean().item() / chunks for q in range(4)]
+    print("      producer cycles/chunk: issue loads %5.0f | wait operands %5.0f | BN+ReLU + issue ds_write %5.0f | wait ds_write %5.0f"
+          % tuple(seg))
