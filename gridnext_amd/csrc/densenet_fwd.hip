@@ -789,10 +789,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 // KC = K elements per chunk (32: 128-B LDS rows, 1 workgroup per CU; 16: 64-B rows, half the LDS, 2 workgroups per CU
 // whose barriers, prologues and stores then hide behind each other's MFMAs).  With KC = 16 a group of 16 rows is 1 KB
 // (chunk c at c * 256, four chunks) and one DMA instruction writes a whole group.
-template <int S, int NW, int KC>
+// NK1 (data-gradient shape: K == KC = 32 input channels, N = 32 * NT output channels, NT even): a tile's chunks are its
+// NT column tiles instead of K chunks - the strip is re-fetched (L2) with each column tile's weights, every chunk starts
+// from zero accumulators and ends with its 16 stores.
+template <int S, int NW, int KC, bool NK1 = false>
 __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __restrict__ A, int lda,
                                                               const float* __restrict__ Wr, float* __restrict__ out,
-                                                              int ldc, int M, int K) {
+                                                              int ldc, int M, int K, int N) {
     constexpr int BM = 32 * NW;
     constexpr int strip = BM + 2 * S + 2;
     constexpr int SR = (strip + 15) & ~15;                 // strip rows padded to whole groups of 16
@@ -810,7 +813,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     for (int z = t; z < 512; z += 64 * NW) reinterpret_cast<float*>(lds + ZB)[z] = 0.f;
     const int T = M / BM;
-    const int nk2 = K / (2 * KC);                          // pairs of chunks
+    const int nk2 = NK1 ? N / 64 : K / (2 * KC);           // pairs of chunks (NK1: of column tiles)
     int G = gridDim.x;                                     // pinned in an SGPR: no s_load may sit among the counted
     asm volatile("" : "+s"(G));                            // lgkmcnt waits of the fragment reads
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (round-robin dispatch), each XCD has its own L2.  In every FULL
@@ -848,20 +851,22 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
             const int row0 = ntile * BM - S - 1 + 16 * grp;                    // first strip row of the group
             char* d = dst + grp * GB + part * 1024;
             if (__builtin_expect(row0 >= 0 && row0 + 15 < M, 1)) {
-                const char* sb = reinterpret_cast<const char*>(A + (long)row0 * lda + KC * nchunk + 16 * part);
+                const char* sb = reinterpret_cast<const char*>(A + (long)row0 * lda + (NK1 ? 0 : KC * nchunk) + 16 * part);
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(sb + voffA), (float*)d, 16, 0, 0);
             } else {
                 // array ends: rows outside [0, M) are only ever "read" by masked taps, any in-range row will do
                 int Pr = row0 + (lane & 15);
                 Pr = Pr < 0 ? 0 : (Pr >= M ? M - 1 : Pr);
-                __builtin_amdgcn_global_load_lds(A + (long)Pr * lda + KC * nchunk + 16 * part + 4 * (lane >> 4),
+                __builtin_amdgcn_global_load_lds(A + (long)Pr * lda + (NK1 ? 0 : KC * nchunk) + 16 * part + 4 * (lane >> 4),
                                                  (float*)d, 16, 0, 0);
             }
         } else {
             const int p = wave + NW * (slot - NSA);                            // weight group p / PPG = 2 tap + (n >> 4)
             if ((NPW % NW) && slot == NSA + NSW - 1 && p >= NPW) return;
             const int grp = p / PPG, part = p % PPG;
-            const char* sb = reinterpret_cast<const char*>(Wr + (long)(grp * 16) * K + KC * nchunk + 16 * part);
+            // weight rows [tap][N][K]: tap = grp >> 1, n = 32 * (column tile) + 16 * (grp & 1) + lane row
+            const char* sb = reinterpret_cast<const char*>(
+                Wr + (long)((grp >> 1) * N + (NK1 ? 32 * nchunk : 0) + (grp & 1) * 16) * K + (NK1 ? 0 : KC * nchunk) + 16 * part);
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(sb + voffW),
                                              (float*)(dst + SR * ROWB + grp * GB + part * 1024), 16, 0, 0);
         }
@@ -901,8 +906,18 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
-        auto do_chunk = [&](auto par_c) {
+        auto store16 = [&](int col0) {
+            float* o = out + (long)(tile * BM + 32 * wave + 4 * h) * ldc + col0 + i;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(long)(((r & 3) + 8 * (r >> 2)) * ldc)] = acc0[r] + acc1[r];     // exactly 16 stores
+            stored = true;
+        };
+        auto do_chunk = [&](auto par_c, int ct) {
             constexpr int par = decltype(par_c)::value;
+            if constexpr (NK1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            }
             // this wave's DMAs into the current buffer have landed (the 16 stores of a just-finished tile may stay in
             // flight: they are younger than those DMAs and vmcnt retires in order)
             if (stored) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -942,15 +957,13 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
                 if constexpr (step < STEPS - 1) { a = na; bq = nb; }
             });
             advance_next();
+            if constexpr (NK1) store16(32 * ct);
         };
         for (int c2 = 0; c2 < nk2; ++c2) {
-            do_chunk(std::integral_constant<int, 0>{});
-            do_chunk(std::integral_constant<int, 1>{});
+            do_chunk(std::integral_constant<int, 0>{}, 2 * c2);
+            do_chunk(std::integral_constant<int, 1>{}, 2 * c2 + 1);
         }
-        float* o = out + (long)(tile * BM + 32 * wave + 4 * h) * ldc + i;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[(long)(((r & 3) + 8 * (r >> 2)) * ldc)] = acc0[r] + acc1[r];     // exactly 16 stores
-        stored = true;
+        if constexpr (!NK1) store16(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -983,8 +996,8 @@ constexpr int C1_KMAX = 2048;      // scale/shift vectors are staged in LDS up t
 template <bool ACT, bool POOL, int NP>
 __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_kernel(const float* __restrict__ A, int lda,
                                                             const float* __restrict__ W, float* __restrict__ out,
-                                                            int ldc, int K, int tilesN, int T, int S_in, long rows_in,
-                                                            const float* __restrict__ scale,
+                                                            int ldc, int K, int N, int tilesN, int T, int S_in,
+                                                            long rows_in, const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ oscale,
                                                             const float* __restrict__ oshift) {
@@ -1044,7 +1057,8 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
                 const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float*>(A + base * lda), 0, (int)(left * 4), 0x00020000);
                 const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float*>(W + (long)tn * 128 * K), 0, 128 * K * 4, 0x00020000);
+                    const_cast<float*>(W + (long)tn * 128 * K), 0, (N - tn * 128 < 128 ? N - tn * 128 : 128) * K * 4,
+                    0x00020000);          // rows past N read as 0 (buffer bounds check): ragged last column tile
                 const int vo0 = (int)(srcrow(tm * 128 + 32 * pw + lr) - base) * lda * 4 + lc * 16;
                 const int vo1 = (int)(srcrow(tm * 128 + 32 * pw + lr + 16) - base) * lda * 4 + lc * 16;
                 const int kb = pkt << 7;
@@ -1103,7 +1117,8 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
             const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(A + (long)tm * 128 * lda), 0, (127 * lda + K) * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(W + (long)tn * 128 * K), 0, 128 * K * 4, 0x00020000);
+                const_cast<float*>(W + (long)tn * 128 * K), 0, (N - tn * 128 < 128 ? N - tn * 128 : 128) * K * 4,
+                    0x00020000);          // rows past N read as 0 (buffer bounds check): ragged last column tile
             const int kb = pkt << 7;                       // byte offset of the chunk
             s.k0 = pkt << 5;
 #pragma unroll
@@ -1236,6 +1251,7 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
         const int tm = tile / tilesN, tn = tile - tm * tilesN;
         auto store = [&](f32x16& acc, int mt, int nt) {
             const int col = tn * 128 + 64 * wn + 32 * nt + i;
+            if (col - i >= N) return;                      // 32 | N: whole fragments in or out
             if (oscale) {
                 const float osc = oscale[col], osh = oshift[col];
 #pragma unroll
@@ -1693,7 +1709,7 @@ static int conv1x1_launch(const float* A, long lda, const float* W, float* out, 
     const int vecW = al16(W) && K % 4 == 0;
     dim3 grid(gnx_cdiv(M, C1_BM), gnx_cdiv(N, C1_BN));
     const bool fast = vecA && vecW;
-    if (fast && M % 128 == 0 && N % 128 == 0 && K % 32 == 0 && K <= C1_KMAX && (!pool || (S_in % 2 == 0 && scale)) &&
+    if (fast && M % 128 == 0 && N % 32 == 0 && K % 32 == 0 && K <= C1_KMAX && (!pool || (S_in % 2 == 0 && scale)) &&
         4 * M < (1L << 31) && lda < (1 << 16) && ldc < (1 << 16) && !getenv("GNX_NO_WS1")) {     // int row / lane offsets
         const size_t lds_ws = 4 * 128 * 32 * 4 + (scale ? 8 * (size_t)K : 0);
         static bool conf = false;
@@ -1712,7 +1728,7 @@ static int conv1x1_launch(const float* A, long lda, const float* W, float* out, 
                 return GNX_ERR_LAUNCH;
             conf = true;
         }
-        const int tilesN = N / 128;
+        const int tilesN = (N + 127) / 128;
         const long T = (M / 128) * tilesN;
         // NP = producer waves: 4 (two 8-wave workgroups per CU) or 8 (one 12-wave workgroup per CU)
         static const int np8 = getenv("GNX_WS_NP8") ? 1 : 0;
@@ -1721,7 +1737,7 @@ static int conv1x1_launch(const float* A, long lda, const float* W, float* out, 
         const int wgs = (int)(T < 256 * per_cu ? T : 256 * per_cu);
 #define GNX_WS(ACTV, POOLV, NPV)                                                                                     \
     conv1x1_ws_kernel<ACTV, POOLV, NPV><<<wgs, 64 * (4 + NPV), lds_ws, stream>>>(                                     \
-        A, (int)lda, W, out, (int)ldc, K, tilesN, (int)T, S_in, 4 * M, scale, shift, oscale, oshift)
+        A, (int)lda, W, out, (int)ldc, K, N, tilesN, (int)T, S_in, 4 * M, scale, shift, oscale, oshift)
         if (pool) GNX_WS(true, true, 4);
         else if (scale) { if (np == 8) GNX_WS(true, false, 8); else GNX_WS(true, false, 4); }
         else { if (np == 8) GNX_WS(false, false, 8); else GNX_WS(false, false, 4); }
@@ -1805,18 +1821,18 @@ GNX_EXPORT int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, flo
             if (variant == 2 && M % 256 == 0 && K % 64 == 0) {                                                   \
                 const long wgs = M / 256 > 256 ? 256 : M / 256;                                                  \
                 conv3x3_dma_kernel<SS, 8, 32><<<(int)wgs, 512, 0, stream>>>(A, (int)lda, Wr, out, (int)ldc,      \
-                                                                            (int)M, K);                          \
+                                                                            (int)M, K, N);                       \
                 return gnx_launch_status();                                                                      \
             }                                                                                                    \
         }                                                                                                        \
         if (variant == 1 && K % 64 == 0) {                                                                       \
             const long wgs = M / 128 > 256 ? 256 : M / 128;                                                      \
             conv3x3_dma_kernel<SS, 4, 32><<<(int)wgs, 256, 0, stream>>>(A, (int)lda, Wr, out, (int)ldc, (int)M,  \
-                                                                        K);                                      \
+                                                                        K, N);                                   \
             return gnx_launch_status();                                                                          \
         }                                                                                                        \
         const long wgs = M / 128 > 512 ? 512 : M / 128;                                                          \
-        conv3x3_dma_kernel<SS, 4, 16><<<(int)wgs, 256, 0, stream>>>(A, (int)lda, Wr, out, (int)ldc, (int)M, K);  \
+        conv3x3_dma_kernel<SS, 4, 16><<<(int)wgs, 256, 0, stream>>>(A, (int)lda, Wr, out, (int)ldc, (int)M, K, N);\
         return gnx_launch_status();                                                                              \
     } while (0)
         switch (S) {
@@ -1832,6 +1848,38 @@ GNX_EXPORT int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, flo
             default: break;
         }
 #undef GNX_DMA
+    }
+    // the same kernel in its data-gradient shape (dX = conv3x3(dY, W^T): K = 32 channels in, N = 128 out): column tiles
+    // of 32 take the place of K chunks
+    if (!scale && fast && K == 32 && (N & 63) == 0 && (M % C3_BM) == 0 && M * (lda > ldc ? lda : ldc) < (1L << 31) &&
+        !getenv("GNX_NO_DMA")) {
+#define GNX_DMAG(SS)                                                                                             \
+    do {                                                                                                         \
+        if constexpr (SS <= 32) {                                                                                \
+            if (M % 256 == 0 && M / 256 >= 1024) {                                                               \
+                conv3x3_dma_kernel<SS, 8, 32, true><<<256, 512, 0, stream>>>(A, (int)lda, Wr, out, (int)ldc,     \
+                                                                             (int)M, K, N);                      \
+                return gnx_launch_status();                                                                      \
+            }                                                                                                    \
+        }                                                                                                        \
+        const long wgs = M / 128 > 256 ? 256 : M / 128;                                                          \
+        conv3x3_dma_kernel<SS, 4, 32, true><<<(int)wgs, 256, 0, stream>>>(A, (int)lda, Wr, out, (int)ldc,        \
+                                                                          (int)M, K, N);                         \
+        return gnx_launch_status();                                                                              \
+    } while (0)
+        switch (S) {
+            case 4: GNX_DMAG(4);
+            case 7: GNX_DMAG(7);
+            case 8: GNX_DMAG(8);
+            case 14: GNX_DMAG(14);
+            case 16: GNX_DMAG(16);
+            case 28: GNX_DMAG(28);
+            case 32: GNX_DMAG(32);
+            case 56: GNX_DMAG(56);
+            case 64: GNX_DMAG(64);
+            default: break;
+        }
+#undef GNX_DMAG
     }
     // ping-pong persistent form: whole K chunks, one 32-wide column tile, strip pair + weights fit the 160 KB LDS
     const size_t lds_pp = (2 * ((size_t)(C3_BM + 2 * S + 2) + 1 + 9 * 32) * LDK + LDK) * sizeof(float);

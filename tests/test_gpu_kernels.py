@@ -227,7 +227,9 @@ def _call_conv1x1(L, A, W, scale, shift, pool=0, S=0, ldc=None, col0=0):
 @pytest.mark.parametrize("M,K,N,act", [(1024, 64, 128, True), (300, 22, 12, True), (129, 96, 128, False),
                                        (4096, 224, 128, True), (64, 1024, 512, True), (5, 3, 2, True),
                                        # whole 128 x 128 x 32 tiles: the LDS-DMA kernel (odd and even chunk counts)
-                                       (256, 96, 256, False), (384, 32, 128, True), (128, 1024, 128, True)])
+                                       (256, 96, 256, False), (384, 32, 128, True), (128, 1024, 128, True),
+                                       # ragged last column tile (32 | N): the data-gradient shapes N = channels-in
+                                       (256, 128, 96, False), (128, 128, 160, True), (640, 128, 352, False)])
 def test_conv1x1_bnrelu(L, M, K, N, act):
     g = torch.Generator().manual_seed(M + K)
     Afull = torch.randn(M, K + 8, generator=g)                   # leading dimension != K
@@ -261,7 +263,7 @@ def test_transition_pool_first(L, n, S, K, N):
     close(out.reshape(n, So, So, N).permute(0, 3, 1, 2), ref, rtol=2e-4)
 
 
-@pytest.mark.parametrize("M,K,N", [(1024, 64, 128), (300, 22, 12), (4096, 224, 128), (129, 96, 130)])
+@pytest.mark.parametrize("M,K,N", [(1024, 64, 128), (300, 22, 12), (4096, 224, 128), (129, 96, 130), (256, 64, 96)])
 def test_conv1x1_bnrelu_act(L, M, K, N):
     """conv1 storing relu(bn2(.)): the eval forward's bottleneck, ready for the prologue-free conv3x3."""
     g = torch.Generator().manual_seed(M + K + 1)
@@ -286,7 +288,10 @@ def test_conv1x1_bnrelu_act(L, M, K, N):
                                          # prologue-free inputs, 128 | M, N = 32, 32 | K: the LDS-DMA persistent kernel
                                          (2, 8, 128, 32, False), (8, 16, 128, 32, False), (3, 32, 64, 32, False),
                                          (1, 64, 32, 32, False), (600, 4, 96, 32, False), (40, 32, 128, 32, False),
-                                         (128, 7, 160, 32, False)])
+                                         (128, 7, 160, 32, False),
+                                         # data-gradient shape (K = 32 in, N = 64 / 128 out): column tiles as chunks
+                                         (2, 8, 32, 128, False), (8, 16, 32, 64, False), (40, 32, 32, 128, False),
+                                         (256, 32, 32, 128, False), (64, 7, 32, 128, False)])
 def test_conv3x3_bnrelu(L, n, S, K, N, act):
     g = torch.Generator().manual_seed(S * 100 + K)
     x = torch.randn(n, K, S, S, generator=g)
