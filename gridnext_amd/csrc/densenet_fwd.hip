@@ -1010,6 +1010,17 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
     const int G = gridDim.x;
     const int mine = (T - (int)blockIdx.x + G - 1) / G;    // tiles of this workgroup (gridDim.x <= T)
     const int total = mine * nk;                           // chunks = barriers, the same number for all 8 waves
+    // Workgroup -> tile order.  With several column tiles per row tile (transitions: N = 256 / 512) the column tiles of one
+    // row tile read the same (4x pooled) activation rows: put them on the SAME XCD (workgroup b runs on XCD b % 8, one L2
+    // per XCD) so those rows come from HBM once - measured 6.6 GB per transition launch before, 1.9x the algorithmic bytes.
+    // Full rounds of G tiles only; a partial last round keeps the plain order (every workgroup with blockIdx.x < rest works).
+    const int bx = blockIdx.x;
+    const int jmap = (tilesN > 1 && G % (8 * tilesN) == 0)
+                         ? tilesN * ((bx & 7) + 8 * (bx / (8 * tilesN))) + (bx >> 3) % tilesN : bx;
+    auto tile_of = [&](int round) {
+        const int base = round * G;
+        return base + (base + G <= T ? jmap : bx);
+    };
     // Every global load a wave issues beside the MFMA waves costs matrix-pipe time in proportion to its bytes, LDS reads
     // do not (tools/ubench/mfma_2x2.hip): the per-chunk scale/shift vectors come from an LDS copy made once per
     // workgroup instead of four more 1-KB loads per producer wave and chunk.
@@ -1034,7 +1045,7 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
         };
         // the producers' own (tile, chunk) iterator; behind the last chunk it re-reads the first tile into a buffer
         // nobody reads again (branch-free)
-        int ptile = blockIdx.x, pkt = 0;
+        int pround = 0, ptile = tile_of(0), pkt = 0;
         if constexpr (POOL) {
             static_assert(!POOL || NP == 4, "pooling producers own 32 rows each");
             // _Transition (densenet.py:47-54), pool-first: the staged row of pooled position m is the mean of the 4
@@ -1074,8 +1085,8 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
                 pwv[1] = bld(rW, voW0, kb + 64);
                 pwv[2] = bld(rW, voW1, kb);
                 pwv[3] = bld(rW, voW1, kb + 64);
-                if (++pkt == nk) { pkt = 0; ptile += G; }
-                if (ptile >= T) ptile = blockIdx.x;
+                if (++pkt == nk) { pkt = 0; ptile = tile_of(++pround); }
+                if (ptile >= T) ptile = bx;
             };
             auto stashp = [&](int buf) {
                 char* d = st + buf * 2 * OPB;
@@ -1125,8 +1136,8 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
             for (int q = 0; q < 2 * GP; ++q) s.a[q] = bld(rA, (q >> 1) ? voA1 : voA0, kb + (q & 1) * 64);
 #pragma unroll
             for (int q = 0; q < 2 * GP; ++q) s.w[q] = bld(rW, (q >> 1) ? voW1 : voW0, kb + (q & 1) * 64);
-            if (++pkt == nk) { pkt = 0; ptile += G; }
-            if (ptile >= T) ptile = blockIdx.x;
+            if (++pkt == nk) { pkt = 0; ptile = tile_of(++pround); }
+            if (ptile >= T) ptile = bx;
         };
 #if GNX_WS_STAMP
         long seg[4] = {0, 0, 0, 0};
@@ -1212,7 +1223,7 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
     long c_wait = 0;
     const long c_begin = __builtin_amdgcn_s_memtime();
 #endif
-    for (int tile = blockIdx.x; tile < T; tile += G) {
+    for (int round = 0, tile = tile_of(0); tile < T; tile = tile_of(++round)) {
         f32x16 acc00, acc01, acc10, acc11;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }

@@ -17,9 +17,9 @@ import os
 import sys
 
 GROUPS = [                                   # first match wins
-    ('conv1x1', lambda n: 'conv1x1_ws_kernel<true, false>' in n or 'conv1x1_ws_kernel<false, false>' in n
+    ('conv1x1', lambda n: 'conv1x1_ws_kernel<true, false' in n or 'conv1x1_ws_kernel<false, false' in n
         or 'conv1x1_kernel<false' in n),
-    ('transition', lambda n: 'conv1x1_ws_kernel<true, true>' in n or 'conv1x1_kernel<true' in n),
+    ('transition', lambda n: 'conv1x1_ws_kernel<true, true' in n or 'conv1x1_kernel<true' in n),
     ('conv3x3', lambda n: 'conv3x3_' in n),
     ('stem', lambda n: 'conv_stem' in n),
     ('maxpool', lambda n: 'maxpool' in n),
