@@ -172,6 +172,163 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dY
     }
 }
 
+// Register-prefetched form for the common case (no pooling, 16-B aligned operands, 4 | K, a whole 32*NT-wide column tile,
+// strip <= 256 * NX / 32 rows): the next tile's dY rows and X strip are fetched into registers (branch-free: clamped
+// addresses, zeroed at the stash) while the current tile multiplies, so the global latency the plain kernel exposes once per
+// 64 positions hides behind the 128 (1x1) / 288 (3x3) MFMAs of a tile.  Same slab layout, same fixed summation order.
+template <int T, int NT, int NX>
+__global__ __launch_bounds__(256) void wgrad_pf_kernel(const float* __restrict__ dY, long lddy,
+                                                       const float* __restrict__ X, long ldx,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       float* __restrict__ slabs, long M, int N, int K, int S,
+                                                       long tiles_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int halo = (T == 9) ? S + 1 : 0;
+    const int strip = WG_BM + 2 * halo;
+    constexpr int LDY = 32 * NT, NLY = WG_BM * (LDY / 4) / 256;
+    float* Ys = lds;                               // [WG_BM][LDY]
+    float* Xs = lds + WG_BM * LDY;                 // [strip][LDX]
+    unsigned* Vm = reinterpret_cast<unsigned*>(Xs + strip * LDX);   // [WG_BM] tap-validity bits (T == 9)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    const int n0 = blockIdx.y * 32 * NT;
+    const int kbase = blockIdx.z * WG_KR;
+    const int kc = kbase + 32 * wave;              // this wave's 32 k columns
+    const bool has_act = scale != nullptr;
+    const long ntiles = (M + WG_BM - 1) / WG_BM;
+    const long tile0 = (long)blockIdx.x * tiles_per_split;
+    const long tile1 = min(tile0 + tiles_per_split, ntiles);
+    if (tile0 >= tile1) {                          // an empty split still owes its (zero) slab
+        const int k = kc + i;
+        if (k < K)
+            for (int a = 0; a < T * NT; ++a) {
+                const int tap = (T == 1) ? 0 : a, nt = (T == 1) ? a : 0;
+                float* dst = slabs + ((long)blockIdx.x * T + tap) * N * K;
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (n < N) dst[(long)n * K + k] = 0.f;
+                }
+            }
+        return;
+    }
+
+    f32x16 acc[T * NT];
+#pragma unroll
+    for (int a = 0; a < T * NT; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    // this thread's X column quad is the same in every tile (256 % 32 == 0)
+    const int q = t & 31;
+    const int kq = kbase + 4 * q;
+    const bool kok = kq < K;                       // 4 | K: the whole quad is in or out
+    const int kld = kok ? kq : 0;
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_act) { sc4 = *reinterpret_cast<const float4*>(scale + kld); sh4 = *reinterpret_cast<const float4*>(shift + kld); }
+    float4 ry[NLY], rx[NX];
+    auto fetch = [&](long tile) {
+        const long m0 = tile * WG_BM;
+#pragma unroll
+        for (int j = 0; j < NLY; ++j) {
+            const int idx = t + 256 * j;
+            const int r = idx / (LDY / 4), c4 = idx - r * (LDY / 4);
+            long m = m0 + r;
+            m = m < M ? m : M - 1;
+            ry[j] = *reinterpret_cast<const float4*>(dY + m * lddy + n0 + 4 * c4);
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int r = (t >> 5) + 8 * j;        // strip row of piece t + 256 j
+            long pp = m0 - halo + r;
+            pp = pp < 0 ? 0 : (pp < M ? pp : M - 1);
+            rx[j] = *reinterpret_cast<const float4*>(X + pp * ldx + kld);       // rows past the strip: a harmless re-read
+        }
+    };
+    auto stash = [&](long tile) {
+        const long m0 = tile * WG_BM;
+#pragma unroll
+        for (int j = 0; j < NLY; ++j) {
+            const int idx = t + 256 * j;
+            const int r = idx / (LDY / 4), c4 = idx - r * (LDY / 4);
+            float4 v = ry[j];
+            if (m0 + r >= M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(&Ys[r * LDY + 4 * c4]) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int r = (t >> 5) + 8 * j;
+            if (r < strip) {
+                const long pp = m0 - halo + r;
+                float4 v = rx[j];
+                if (has_act)
+                    v = make_float4(act1(v.x, sc4.x, sh4.x), act1(v.y, sc4.y, sh4.y), act1(v.z, sc4.z, sh4.z),
+                                    act1(v.w, sc4.w, sh4.w));
+                if (!kok || pp < 0 || pp >= M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&Xs[r * LDX + 4 * q]) = v;
+            }
+        }
+        if (T == 9) {
+            for (int r = t; r < WG_BM; r += 256) {
+                const long m = m0 + r;
+                unsigned mask = 0;
+                if (m < M) {
+                    const int rem = (int)(m % ((long)S * S));
+                    const int y = rem / S, x = rem - y * S;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                        if (yy >= 0 && yy < S && xx >= 0 && xx < S) mask |= 1u << tap;
+                    }
+                }
+                Vm[r] = mask;
+            }
+        }
+    };
+
+    fetch(tile0);
+    for (long tile = tile0; tile < tile1; ++tile) {
+        __syncthreads();                           // the previous tile's fragment reads are done
+        stash(tile);
+        __syncthreads();
+        fetch(tile + 1 < tile1 ? tile + 1 : tile); // branch-free; the last one is a harmless re-read
+        asm volatile("" ::: "memory");             // keep the prefetch in front of the multiply
+#pragma unroll 4
+        for (int mm = 0; mm < WG_BM; mm += 2) {
+            const float a = Ys[(mm + h) * LDY + i];
+            if (T == 9) {
+                const unsigned vm = Vm[mm + h];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int off = (S + 1) + (tap / 3 - 1) * S + (tap % 3 - 1);
+                    const float b = Xs[(mm + h + off) * LDX + 32 * wave + i];
+                    const float am = ((vm >> tap) & 1u) ? a : 0.f;
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(am, b, acc[tap], 0, 0, 0);
+                }
+            } else {
+                const float b = Xs[(mm + h) * LDX + 32 * wave + i];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0], 0, 0, 0);
+#pragma unroll
+                for (int nt = 1; nt < NT; ++nt) {
+                    const float an = Ys[(mm + h) * LDY + 32 * nt + i];
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(an, b, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int k = kc + i;
+    if (k < K) {
+#pragma unroll
+        for (int a = 0; a < T * NT; ++a) {
+            const int tap = (T == 1) ? 0 : a, nt = (T == 1) ? a : 0;
+            float* dst = slabs + ((long)blockIdx.x * T + tap) * N * K;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (n < N) dst[(long)n * K + k] = acc[a][r];
+            }
+        }
+    }
+}
+
 // dW (torch layout [N][K][T]) = fixed-order sum over splits of slab[split][tap][n][k]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, int T, int N, int K,
                                     float* __restrict__ dW, int accumulate) {
@@ -417,9 +574,29 @@ GNX_EXPORT int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long
         wgrad_kernel<T, NTT, P><<<grid, 256, lds_bytes, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, N, K, S, \
                                                              tps, vec, vecY);                                      \
     } while (0)
-    if (taps == 9) GNX_WG(9, 1, false);
+    // register-prefetched form where the shape allows (see wgrad_pf_kernel)
+    const bool pf = !pool && vec && vecY && K % 4 == 0 && N % (32 * nt) == 0 && !getenv("GNX_NO_WGRAD_PF");
+#define GNX_WGPF(T, NTT, NXX)                                                                                         \
+    do {                                                                                                              \
+        static size_t conf = 0;                                                                                       \
+        if (lds_bytes > conf) {                                                                                       \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_pf_kernel<T, NTT, NXX>),                      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)        \
+                return GNX_ERR_LAUNCH;                                                                                \
+            conf = lds_bytes;                                                                                         \
+        }                                                                                                             \
+        wgrad_pf_kernel<T, NTT, NXX><<<grid, 256, lds_bytes, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M,  \
+                                                                       N, K, S, tps);                                 \
+    } while (0)
+    const int strip_rows = WG_BM + 2 * halo;
+    if (pf && taps == 1) GNX_WGPF(1, 4, 8);
+    else if (pf && taps == 9 && strip_rows <= 8 * 10) GNX_WGPF(9, 1, 10);       // S <= 7
+    else if (pf && taps == 9 && strip_rows <= 8 * 13) GNX_WGPF(9, 1, 13);       // S <= 16
+    else if (pf && taps == 9 && strip_rows <= 8 * 17) GNX_WGPF(9, 1, 17);       // S <= 32
+    else if (taps == 9) GNX_WG(9, 1, false);
     else if (pool) GNX_WG(1, 4, true);
     else GNX_WG(1, 4, false);
+#undef GNX_WGPF
 #undef GNX_WG
     const long total = (long)taps * N * K;
     wgrad_reduce_kernel<<<gnx_cdiv(total, 256), 256, 0, stream>>>(workspace, nsplit, taps, N, K, dW, accumulate);
