@@ -589,10 +589,12 @@ GNX_EXPORT int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long
                                                                        N, K, S, tps);                                 \
     } while (0)
     const int strip_rows = WG_BM + 2 * halo;
+    // 3x3: the 144 accumulator registers + a prefetched strip (68 more) leave one wave per SIMD - measured slower (56 vs
+    // 51 ms per step) than the plain kernel at two workgroups per CU, so only GNX_WGRAD_PF9 enables it
+    static const bool pf9 = getenv("GNX_WGRAD_PF9") != nullptr;
     if (pf && taps == 1) GNX_WGPF(1, 4, 8);
-    else if (pf && taps == 9 && strip_rows <= 8 * 10) GNX_WGPF(9, 1, 10);       // S <= 7
-    else if (pf && taps == 9 && strip_rows <= 8 * 13) GNX_WGPF(9, 1, 13);       // S <= 16
-    else if (pf && taps == 9 && strip_rows <= 8 * 17) GNX_WGPF(9, 1, 17);       // S <= 32
+    else if (pf && pf9 && taps == 9 && strip_rows <= 8 * 13) GNX_WGPF(9, 1, 13);       // S <= 16
+    else if (pf && pf9 && taps == 9 && strip_rows <= 8 * 17) GNX_WGPF(9, 1, 17);       // S <= 32
     else if (taps == 9) GNX_WG(9, 1, false);
     else if (pool) GNX_WG(1, 4, true);
     else GNX_WG(1, 4, false);
