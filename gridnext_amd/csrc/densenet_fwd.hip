@@ -517,229 +517,6 @@ __global__ __launch_bounds__(256) void conv3x3_pipe_kernel(const float* __restri
     }
 }
 
-// ------------------------------------------------------------------------------------------------ conv3x3, ping-pong form
-// EXPERIMENTAL (enabled with GNX_PINGPONG=1; r01 measurement: 110-118 TFLOP/s, no better than the pipe kernel because
-// hipcc still places a wait right behind the memory role's loads - see fetch() - so that role is as long as the
-// compute phase it hides behind).  Kept for the next round: with the loads hidden (LDS-DMA or asm) this schedule has
-// every SIMD's matrix pipe owned by exactly one wave at any time.
-// Same arithmetic and LDS images as conv3x3_pipe_kernel, different schedule.  PMC showed the two co-resident 4-wave
-// workgroups of that kernel run in lockstep (both in their MFMA phase, then both in their load/activate/LDS-write phase),
-// capping matrix-core utilisation at ~73 %.  Here ONE persistent 8-wave workgroup per CU holds two independent tile
-// pipelines (waves 0-3 and 4-7, one wave of each per SIMD) that are offset by exactly one phase: between two barriers
-// one half multiplies its K-chunk out of LDS while the other half writes its next chunk to LDS (BN+ReLU applied), stores
-// its finished tile and issues the global loads it will need two phases later.  Each SIMD therefore always has exactly
-// one wave in an MFMA phase, and all non-MFMA work is hidden behind the partner's 144 MFMAs.
-#ifdef GNX_PP_STAMPS
-__device__ unsigned long long gnx_pp_stamps[8192];
-#endif
-
-template <int NJ, bool ACT>
-__global__ __launch_bounds__(512) void conv3x3_pp_kernel(const float* __restrict__ A, long lda,
-                                                         const float* __restrict__ Wr, float* __restrict__ out,
-                                                         long ldc, long M, int N, int K, int S,
-                                                         const float* __restrict__ scale,
-                                                         const float* __restrict__ shift) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int strip = C3_BM + 2 * S + 2;
-    // wave-uniform by construction AND provably so for the compiler (readfirstlane): the role branch below becomes a
-    // scalar branch and s_setprio lands only on the waves that take it
-    const int half = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >> 8;
-    const int t = threadIdx.x & 255, lane = t & 63, hw = t >> 6, h = lane >> 5, i = lane & 31;
-    const int half_floats = (strip + 1 + 9 * 32) * LDK;       // strip rows + one trash row + weight rows
-    float* As = lds + half * half_floats;
-    float* Bs = As + (strip + 1) * LDK;
-    float* Zs = lds + 2 * half_floats;
-    if (threadIdx.x < LDK) Zs[threadIdx.x] = 0.f;
-    const int zoff = (int)(Zs - As);
-    const int kq = t & 7, r0 = t >> 3;
-    const long T = (M + C3_BM - 1) / C3_BM;
-    const int nk = K >> 5;
-    const long tstep = 2L * gridDim.x;
-    const int nload = r0 < N ? r0 : N - 1;
-    const bool nok = r0 < N;
-    // LDS write offsets of this thread's strip rows; rows past the strip go to the trash row (no branch in the hot loop)
-    int woff[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int row = r0 + 32 * j;
-        woff[j] = (row < strip ? row : strip) * LDK + 4 * kq;
-    }
-
-    long m_tile = 2L * blockIdx.x + half;      // tile whose chunks the memory role is feeding
-    int mc = 0;
-    long c_tile = m_tile;                      // tile the compute role is multiplying
-    int cc = 0;
-    long e_tile = 0;                           // finished tile waiting to be stored
-    bool regs_loaded = false, regs_interior = false, lds_ready = false, epi_pending = false;
-
-    f32x16 acc0, acc1, outv;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; outv[r] = 0.f; }
-    int aoff[9];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) aoff[tap] = zoff;
-
-    float4 ra[NJ], rb[9], sc4, sh4;
-    auto is_interior = [&](long tile) {
-        const long base = tile * C3_BM - S - 1;
-        return base >= 0 && base + (long)NJ * 32 <= M && N >= C3_BN;
-    };
-    // ONE load sequence, at ONE place in the loop: with several definition sites (prologue + loop, or fast/slow
-    // variants) the register allocator inserts copies of the freshly loaded registers right behind the loads, and
-    // every such copy needs the data, i.e. a wait that exposes the whole memory latency inside the memory phase.
-    auto fetch = [&](long tile, int chunk) {
-        const long base = tile * C3_BM - S - 1;
-        const int kc = 32 * chunk + 4 * kq;
-        if (ACT) { sc4 = ld4(scale + kc); sh4 = ld4(shift + kc); }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            long Pr = base + r0 + 32 * j;
-            Pr = Pr < 0 ? 0 : (Pr >= M ? M - 1 : Pr);
-            ra[j] = ld4(A + Pr * lda + kc);
-        }
-        const float* wp = Wr + (long)nload * K + kc;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) rb[j] = ld4(wp + (long)j * N * K);
-    };
-    auto stash = [&](long tile, bool inter) {
-        if (inter) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                float4 v = ra[j];
-                if (ACT) v = act4(v, sc4, sh4);
-                *reinterpret_cast<float4*>(As + woff[j]) = v;
-            }
-#pragma unroll
-            for (int j = 0; j < 9; ++j) *reinterpret_cast<float4*>(&Bs[(r0 + 32 * j) * LDK + 4 * kq]) = rb[j];
-            return;
-        }
-        const long base = tile * C3_BM - S - 1;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const long Pr = base + r0 + 32 * j;
-            float4 v = ra[j];
-            if (ACT) v = act4(v, sc4, sh4);
-            if (!(Pr >= 0 && Pr < M)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(As + woff[j]) = v;
-        }
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            float4 v = rb[j];
-            if (!nok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&Bs[(r0 + 32 * j) * LDK + 4 * kq]) = v;
-        }
-    };
-
-    const long my_pairs = (T > 2L * blockIdx.x) ? (T - 2L * blockIdx.x + tstep - 1) / tstep : 0;
-    const long phases = 2L * nk * my_pairs + 5;
-    __syncthreads();                                   // zero row visible
-    const float* bbase = &Bs[i * LDK + 4 * h];
-
-    for (long ph = 0; ph < phases; ++ph) {
-        const bool mem_role = ((ph + half) & 1) == 0;
-#ifdef GNX_PP_STAMPS
-        unsigned long long st0 = clock64(), sta = st0, stb = st0;
-#endif
-        if (mem_role) {
-            // The memory role is a few hundred instructions; without priority it is starved of issue slots by the
-            // partner wave's back-to-back MFMAs on the same SIMD (measured: ~90 cycles per instruction) and becomes
-            // LONGER than the compute phase it is supposed to hide behind.
-            __builtin_amdgcn_s_setprio(3);
-            // order: LDS write (consumes the prefetch registers) -> next prefetch -> store of the finished tile
-            if (regs_loaded) {
-                stash(m_tile, regs_interior);
-                lds_ready = true;
-                regs_loaded = false;
-                if (++mc == nk) { mc = 0; m_tile += tstep; }
-            }
-#ifdef GNX_PP_STAMPS
-            sta = clock64();
-#endif
-            if (m_tile < T) {
-                if (mc == 0) regs_interior = is_interior(m_tile);
-                fetch(m_tile, mc);
-                regs_loaded = true;
-            }
-#ifdef GNX_PP_STAMPS
-            stb = clock64();
-#endif
-            if (epi_pending) {
-                float* o = out + (e_tile * C3_BM + 32 * hw + 4 * h) * ldc + i;
-                if ((e_tile + 1) * C3_BM <= M && N >= C3_BN) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2)) * ldc] = outv[r];
-                } else if (i < N) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rr = (r & 3) + 8 * (r >> 2);
-                        if (e_tile * C3_BM + 32 * hw + 4 * h + rr < M) o[rr * ldc] = outv[r];
-                    }
-                }
-                epi_pending = false;
-            }
-            __builtin_amdgcn_s_setprio(0);
-        } else if (lds_ready) {
-            if (cc == 0) {
-                const long P = c_tile * C3_BM + 32 * hw + i;
-                unsigned mask = 0;
-                if (P < M) {
-                    const int rem = (int)(P % ((long)S * S));
-                    const int y = rem / S, x = rem - y * S;
-#pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) {
-                        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-                        if (yy >= 0 && yy < S && xx >= 0 && xx < S) mask |= 1u << tap;
-                    }
-                }
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int off = (S + 1) + (tap / 3 - 1) * S + (tap % 3 - 1);
-                    aoff[tap] = ((mask >> tap) & 1u) ? (32 * hw + i + off) * LDK + 4 * h : zoff;
-                }
-            }
-            float4 a = ld4(As + aoff[0]), b = ld4(bbase);
-#pragma unroll
-            for (int step = 0; step < 36; ++step) {
-                float4 na = a, nb = b;
-                if (step < 35) {
-                    const int ntap = (step + 1) >> 2, ns = (step + 1) & 3;
-                    na = ld4(As + aoff[ntap] + 8 * ns);
-                    nb = ld4(bbase + ntap * 32 * LDK + 8 * ns);
-                }
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc1, 0, 0, 0);
-                a = na; b = nb;
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            }
-            lds_ready = false;
-            if (++cc == nk) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { outv[r] = acc0[r] + acc1[r]; acc0[r] = 0.f; acc1[r] = 0.f; }
-                epi_pending = true;
-                e_tile = c_tile;
-                cc = 0;
-                c_tile += tstep;
-            }
-        }
-#ifdef GNX_PP_STAMPS
-        unsigned long long st1 = clock64();
-        lds_barrier();
-        unsigned long long st2 = clock64();
-        if (blockIdx.x == 7 && lane == 0 && hw == 0 && ph < 1000) {
-            gnx_pp_stamps[(ph * 2 + half) * 4 + 0] = st0;
-            gnx_pp_stamps[(ph * 2 + half) * 4 + 1] = st1;
-            gnx_pp_stamps[(ph * 2 + half) * 4 + 2] = mem_role ? sta : st2;
-            gnx_pp_stamps[(ph * 2 + half) * 4 + 3] = mem_role ? (stb | (1ull << 63)) : 0;
-        }
-#else
-        lds_barrier();
-#endif
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ conv3x3, LDS-DMA form
 // For inputs that need NO prologue (scale == nullptr: the eval forward stores the bottleneck already activated, see
 // gnx_conv1x1_bnrelu's output activation).  The strip rows and the weight rows of a 32-wide K chunk go global -> LDS
@@ -762,7 +539,6 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(const float* __restrict
 // A quarter-wave of a ds_read_b128 (16 consecutive rows, one c) then covers all 64 banks exactly once, and the four
 // k-subchunks of a lane are base + {0, 512, 1024, 1536}.  One DMA instruction (64 lanes x 16 B, lane-linear in LDS)
 // writes half a group: 16 rows x 4 chunks; lane L fetches row (L & 15), chunk 4 * half + (L >> 4).
-constexpr int DMA_ROWB = 128;      // bytes per LDS row (32 floats of K)
 #ifndef GNX_DMA_DBG
 #define GNX_DMA_DBG 0
 #endif
@@ -1819,11 +1595,11 @@ GNX_EXPORT int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, flo
     } while (0)
     const bool fast = vecA && vecW;      // aligned pointers/leading dimensions and K % 4 == 0
     // LDS-DMA persistent form for prologue-free inputs (the eval forward's pre-activated bottleneck)
-    if (!scale && fast && N == C3_BN && (K & 31) == 0 && (M % C3_BM) == 0 && M * (lda > ldc ? lda : ldc) < (1L << 31) &&
+    if (!scale && fast && N == C3_BN && (K & 63) == 0 && (M % C3_BM) == 0 && M * (lda > ldc ? lda : ldc) < (1L << 31) &&
         !getenv("GNX_NO_DMA")) {
-        // variant: 0 = 4 waves, KC 16, 2 workgroups per CU; 1 = 4 waves, KC 32; 2 = 8 waves, KC 32.  Measured sustained
-        // (tools/kbench.py --noact --reps 300): 2 wins wherever its 256-row tiles fill the chip (139 vs 133 TFLOP/s),
-        // 1 where they quantise badly (S = 4 at 4992 spots: 82 vs 107).
+        // variant 1 = 4 waves (128-row tiles), 2 = 8 waves (256-row tiles).  Measured sustained (tools/kbench.py --noact
+        // --reps 300): 2 wins wherever its tiles fill the chip (139 vs 133 TFLOP/s), 1 where they quantise badly (S = 4 at
+        // 4992 spots: 82 vs 107).  (A third variant - 64-B LDS rows, two 4-wave workgroups per CU - measured like 1.)
         static const int forced = getenv("GNX_DMA_VARIANT") ? atoi(getenv("GNX_DMA_VARIANT")) : -1;
         const int variant = forced >= 0 ? forced : (M / 256 >= 1024 ? 2 : 1);
 #define GNX_DMA(SS)                                                                                              \
@@ -1836,14 +1612,9 @@ GNX_EXPORT int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, flo
                 return gnx_launch_status();                                                                      \
             }                                                                                                    \
         }                                                                                                        \
-        if (variant == 1 && K % 64 == 0) {                                                                       \
-            const long wgs = M / 128 > 256 ? 256 : M / 128;                                                      \
-            conv3x3_dma_kernel<SS, 4, 32><<<(int)wgs, 256, 0, stream>>>(A, (int)lda, Wr, out, (int)ldc, (int)M,  \
-                                                                        K, N);                                   \
-            return gnx_launch_status();                                                                          \
-        }                                                                                                        \
-        const long wgs = M / 128 > 512 ? 512 : M / 128;                                                          \
-        conv3x3_dma_kernel<SS, 4, 16><<<(int)wgs, 256, 0, stream>>>(A, (int)lda, Wr, out, (int)ldc, (int)M, K, N);\
+        const long wgs = M / 128 > 256 ? 256 : M / 128;                                                          \
+        conv3x3_dma_kernel<SS, 4, 32><<<(int)wgs, 256, 0, stream>>>(A, (int)lda, Wr, out, (int)ldc, (int)M, K,   \
+                                                                    N);                                          \
         return gnx_launch_status();                                                                              \
     } while (0)
         switch (S) {
@@ -1891,37 +1662,6 @@ GNX_EXPORT int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, flo
             default: break;
         }
 #undef GNX_DMAG
-    }
-    // ping-pong persistent form: whole K chunks, one 32-wide column tile, strip pair + weights fit the 160 KB LDS
-    const size_t lds_pp = (2 * ((size_t)(C3_BM + 2 * S + 2) + 1 + 9 * 32) * LDK + LDK) * sizeof(float);
-    if (fast && (K & 31) == 0 && N <= C3_BN && nj <= 9 && lds_pp <= 160 * 1024 && getenv("GNX_PINGPONG")) {
-        const long T = (M + C3_BM - 1) / C3_BM;
-        long wgs = (T + 1) / 2;
-        if (wgs > 256) wgs = 256;
-#define GNX_PP(NJ, ACTV)                                                                                               \
-    do {                                                                                                            \
-        static size_t conf = 0;                                                                                     \
-        if (lds_pp > conf) {                                                                                        \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_pp_kernel<NJ, ACTV>),                     \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp) != hipSuccess)         \
-                return GNX_ERR_LAUNCH;                                                                              \
-            conf = lds_pp;                                                                                          \
-        }                                                                                                           \
-        conv3x3_pp_kernel<NJ, ACTV><<<(int)wgs, 512, lds_pp, stream>>>(A, lda, Wr, out, ldc, M, N, K, S, scale, shift); \
-    } while (0)
-        if (scale) {
-            if (nj <= 5) GNX_PP(5, true);
-            else if (nj == 6) GNX_PP(6, true);
-            else if (nj == 7) GNX_PP(7, true);
-            else GNX_PP(9, true);
-        } else {
-            if (nj <= 5) GNX_PP(5, false);
-            else if (nj == 6) GNX_PP(6, false);
-            else if (nj == 7) GNX_PP(7, false);
-            else GNX_PP(9, false);
-        }
-#undef GNX_PP
-        return gnx_launch_status();
     }
     if (fast && nj <= 5) GNX_PIPE(5);
     else if (fast && nj == 6) GNX_PIPE(6);
@@ -2021,8 +1761,3 @@ GNX_EXPORT int gnx_bnrelu_avgpool(const float* in, long ldi, float* out, long ld
     return gnx_launch_status();
 }
 
-#ifdef GNX_PP_STAMPS
-GNX_EXPORT int gnx_debug_pp_stamps(unsigned long long* host_dst, int n) {
-    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(gnx_pp_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -2;
-}
-#endif
