@@ -142,6 +142,122 @@ __global__ __launch_bounds__(NTHR) void k(float* out, int iters, float seed, con
     for (int r = 0; r < 16; ++r) s += acc00[r] + acc01[r] + acc10[r] + acc11[r];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+
+// ---- How long does a producer wave's own instruction stream take next to two saturated MFMA waves per SIMD?
+// OP: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_max_f32, 3 v_max_i32 (integer ReLU on float bits), 4 v_and_b32, 5 v_med3_f32,
+// 6 ds_read_b128.  Each producer wave times 64 dependent-free instructions of that kind per chunk with s_memtime.
+template <int OP>
+__global__ __launch_bounds__(512) void klat(float* out, long* cyc, int iters, float seed) {
+    __shared__ __attribute__((aligned(16))) char lds[65536];
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) ((float*)lds)[i] = seed + i * 1e-6f;
+    __syncthreads();
+    if (threadIdx.x >= 256) {
+        float v[16];
+        for (int j = 0; j < 16; ++j) v[j] = seed * (j + 1);
+        long tot = 0;
+        for (int it = 0; it < iters; ++it) {
+            const long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (OP == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[j]) : "v"(1.0001f), "v"(seed));
+                    if (OP == 2) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[j]) : "v"(seed));
+                    if (OP == 3) asm volatile("v_max_i32 %0, %0, %1" : "+v"(v[j]) : "v"(0));
+                    if (OP == 4) asm volatile("v_and_b32 %0, %0, %1" : "+v"(v[j]) : "v"(0x7fffffff));
+                    if (OP == 5) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(v[j]) : "v"(-1e30f), "v"(1e30f));
+                }
+            if (OP == 1) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        f2 x = {v[2 * j], v[2 * j + 1]};
+                        const f2 a = {1.0001f, 1.0001f}, b = {seed, seed};
+                        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
+                        v[2 * j] = x[0]; v[2 * j + 1] = x[1];
+                    }
+            }
+            if (OP == 6) {
+                f32x4 g[16];
+                const unsigned a = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)lds + (threadIdx.x - 256) * 16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) g[j] = lds_read4<0>(a + (j & 3) * 4096);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                v[0] += g[0][0] + g[15][3];
+            }
+            asm volatile("s_nop 0" ::: "memory");
+            tot += __builtin_amdgcn_s_memtime() - t0;
+            asm volatile("s_barrier" ::: "memory");
+        }
+        float sacc = 0.f;
+        for (int j = 0; j < 16; ++j) sacc += v[j];
+        if (sacc == 12345.678f) out[0] = sacc;
+        if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + ((threadIdx.x - 256) >> 6)] = tot;
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned lb = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)lds;
+    const unsigned fA = lb + (4 * wm + (i >> 4)) * 2048 + (i & 15) * 16 + h * 256;
+    const unsigned fB = lb + 16384 + (4 * wn + (i >> 4)) * 2048 + (i & 15) * 16 + h * 256;
+    f32x16 acc00, acc01, acc10, acc11;
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("s_barrier" ::: "memory");
+        const unsigned a = fA + (it & 1) * 32768, b = fB + (it & 1) * 32768;
+        f32x4 a0 = lds_read4<0>(a), a1 = lds_read4<4096>(a), b0 = lds_read4<0>(b), b1 = lds_read4<4096>(b);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 na0, na1, nb0, nb1;
+            if (s < 3) {
+                na0 = lds_read4<512>(a + 512 * s); na1 = lds_read4<512 + 4096>(a + 512 * s);
+                nb0 = lds_read4<512>(b + 512 * s); nb1 = lds_read4<512 + 4096>(b + 512 * s);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b0[c], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b1[c], acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b0[c], acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b1[c], acc11, 0, 0, 0);
+            }
+            if (s < 3) { a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; }
+        }
+    }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += acc00[r] + acc01[r] + acc10[r] + acc11[r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int OP>
+void runlat(const char* name) {
+    const int grid = 512, iters = 4000;
+    float* out; long* cyc;
+    (void)hipMalloc(&out, sizeof(float) * grid * 256);
+    (void)hipMalloc(&cyc, sizeof(long) * grid * 4);
+    hipEvent_t s, e;
+    (void)hipEventCreate(&s); (void)hipEventCreate(&e);
+    klat<OP><<<grid, 512>>>(out, cyc, 10, 0.5f);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(s);
+    klat<OP><<<grid, 512>>>(out, cyc, iters, 0.5f);
+    (void)hipEventRecord(e);
+    (void)hipEventSynchronize(e);
+    float ms; (void)hipEventElapsedTime(&ms, s, e);
+    static long h[2048];
+    (void)hipMemcpy(h, cyc, sizeof(long) * grid * 4, hipMemcpyDeviceToHost);
+    double tot = 0; for (int q = 0; q < grid * 4; ++q) tot += h[q];
+    double flops = (double)grid * 4 * iters * 64 * 4096.0;
+    printf("%-40s : MFMA waves %7.1f TFLOP/s; producer: %6.0f cycles per 64 instructions (%5.1f each)\n", name,
+           flops / ms / 1e9, tot / (grid * 4) / iters, tot / (grid * 4) / iters / 64);
+    (void)hipFree(out); (void)hipFree(cyc);
+}
 template <int MODE, int NTHR, int PW = 0>
 void run(const char* name, int bpc, int iters) {
     iters *= g_scale;
@@ -186,5 +302,12 @@ int main(int argc, char** argv) {
     run<2, 512, 1024>("producers: 16 dwordx4 hitting L1", 2, 10000);
     run<2, 512, 7>("producers: all three", 2, 10000);
     run<2, 512, 15>("producers: all three, setprio 3", 2, 10000);
+    runlat<0>("64 v_fma_f32 / chunk");
+    runlat<1>("64 v_pk_fma_f32 / chunk");
+    runlat<2>("64 v_max_f32 / chunk");
+    runlat<3>("64 v_max_i32 / chunk");
+    runlat<4>("64 v_and_b32 / chunk");
+    runlat<5>("64 v_med3_f32 / chunk");
+    runlat<6>("64 ds_read_b128 / chunk");
     return 0;
 }
