@@ -146,7 +146,8 @@ __global__ __launch_bounds__(NTHR) void k(float* out, int iters, float seed, con
 // ---- How long does a producer wave's own instruction stream take next to two saturated MFMA waves per SIMD?
 // OP: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_max_f32, 3 v_max_i32 (integer ReLU on float bits), 4 v_and_b32, 5 v_med3_f32,
 // 6 ds_read_b128.  Each producer wave times 64 dependent-free instructions of that kind per chunk with s_memtime.
-template <int OP>
+// MF: 0 = consumers use v_mfma_f32_32x32x2_f32 (64 cycles each), 1 = v_mfma_f32_16x16x4_f32 (32 cycles each, twice as many)
+template <int OP, int MF = 0>
 __global__ __launch_bounds__(512) void klat(float* out, long* cyc, int iters, float seed) {
     __shared__ __attribute__((aligned(16))) char lds[65536];
     for (int i = threadIdx.x; i < 16384; i += blockDim.x) ((float*)lds)[i] = seed + i * 1e-6f;
@@ -205,6 +206,35 @@ __global__ __launch_bounds__(512) void klat(float* out, long* cyc, int iters, fl
     const unsigned lb = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)lds;
     const unsigned fA = lb + (4 * wm + (i >> 4)) * 2048 + (i & 15) * 16 + h * 256;
     const unsigned fB = lb + 16384 + (4 * wn + (i >> 4)) * 2048 + (i & 15) * 16 + h * 256;
+    if (MF == 1) {
+        // 64 x 64 wave tile out of 16 x 16 x 4 MFMAs: 4 A + 4 B fragments (16 rows x 16 k per ds_read_b128), 16 accumulators
+        f32x4 acc[4][4];
+        for (int x = 0; x < 4; ++x) for (int y = 0; y < 4; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned gA = lb + (4 * wm) * 2048 + (lane & 15) * 16 + (lane >> 4) * 256;
+        const unsigned gB = lb + 16384 + (4 * wn) * 2048 + (lane & 15) * 16 + (lane >> 4) * 256;
+        for (int it = 0; it < iters; ++it) {
+            asm volatile("s_barrier" ::: "memory");
+            const unsigned a = gA + (it & 1) * 32768, b = gB + (it & 1) * 32768;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {                  // two 16-k halves of the 32-k chunk
+                f32x4 fa[4], fb[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) { fa[x] = lds_read4<0>(a + x * 2048 + s * 1024); fb[x] = lds_read4<0>(b + x * 2048 + s * 1024); }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+#pragma unroll
+                        for (int y = 0; y < 4; ++y)
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[x][c], fb[y][c], acc[x][y], 0, 0, 0);
+            }
+        }
+        float s = 0.f;
+        for (int x = 0; x < 4; ++x) for (int y = 0; y < 4; ++y) s += acc[x][y][0] + acc[x][y][3];
+        out[blockIdx.x * 256 + threadIdx.x] = s;
+        return;
+    }
     f32x16 acc00, acc01, acc10, acc11;
     for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
     for (int it = 0; it < iters; ++it) {
@@ -235,7 +265,7 @@ __global__ __launch_bounds__(512) void klat(float* out, long* cyc, int iters, fl
     for (int r = 0; r < 16; ++r) s += acc00[r] + acc01[r] + acc10[r] + acc11[r];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
-template <int OP>
+template <int OP, int MF = 0>
 void runlat(const char* name) {
     const int grid = 512, iters = 4000;
     float* out; long* cyc;
@@ -243,10 +273,10 @@ void runlat(const char* name) {
     (void)hipMalloc(&cyc, sizeof(long) * grid * 4);
     hipEvent_t s, e;
     (void)hipEventCreate(&s); (void)hipEventCreate(&e);
-    klat<OP><<<grid, 512>>>(out, cyc, 10, 0.5f);
+    klat<OP, MF><<<grid, 512>>>(out, cyc, 10, 0.5f);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(s);
-    klat<OP><<<grid, 512>>>(out, cyc, iters, 0.5f);
+    klat<OP, MF><<<grid, 512>>>(out, cyc, iters, 0.5f);
     (void)hipEventRecord(e);
     (void)hipEventSynchronize(e);
     float ms; (void)hipEventElapsedTime(&ms, s, e);
@@ -309,5 +339,9 @@ int main(int argc, char** argv) {
     runlat<4>("64 v_and_b32 / chunk");
     runlat<5>("64 v_med3_f32 / chunk");
     runlat<6>("64 ds_read_b128 / chunk");
+    runlat<0, 1>("16x16x4 consumers: 64 v_fma_f32 / chunk");
+    runlat<1, 1>("16x16x4 consumers: 64 v_pk_fma_f32 / chunk");
+    runlat<2, 1>("16x16x4 consumers: 64 v_max_f32 / chunk");
+    runlat<6, 1>("16x16x4 consumers: 64 ds_read_b128 / chunk");
     return 0;
 }
