@@ -487,13 +487,17 @@ __global__ __launch_bounds__(256) void maxpool_bwd_vec4_kernel(const float* __re
 // ---- stem conv weight gradient: dW[o][c][ky][kx] = sum_{img,oy,ox} dS[(img,oy,ox)][o] * x[img][c][oy*st+ky-pad][ox*st+kx-pad]
 // Workgroup = 8x16 output tile; the input patch is staged like the forward; wave w reduces positions 32w..32w+31 of the
 // tile into 2 (o-tiles) x CIN x 2 (k-tiles of 32 over ky*8+kx) accumulators and the four waves write separate slabs.
-template <int STRIDE, int KH, int CIN>
+// FAST (7x7 s2 p3 stem, 4 | W, O == 64, whole 8x16 tiles, 16-B aligned operands): the patch rows and the dS tile are
+// fetched as 16-B pieces one tile AHEAD into registers while the current tile multiplies (the plain form stages 42 scalar
+// loads per thread synchronously: 47 us per tile against 5 us of MFMA work).  The patch then starts at the 16-B aligned
+// column 32 tx - 4 (one left of ix0 = 32 tx - 3) and is 44 floats wide.
+template <int STRIDE, int KH, int CIN, bool FAST = false>
 __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dS,
                                                           long ldd, float* __restrict__ slabs, int H, int Wd, int Ho,
                                                           int Wo, int O, int KW, int pad, int tiles_x, int tiles_y,
                                                           long ntiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int PH = 7 * STRIDE + KH, PW = (15 * STRIDE + 8 + 1) & ~1;
+    constexpr int PH = 7 * STRIDE + KH, PW = FAST ? 44 : (15 * STRIDE + 8 + 1) & ~1;
     constexpr int KT = KH * 8;                      // k index inside a channel: ky*8 + kx
     constexpr int NKT = (KT + 31) / 32;
     float* Ps = lds;                                // [CIN][PH][PW] (+ slack row for the padded k lanes)
@@ -514,8 +518,38 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
     for (int q = 0; q < NKT; ++q) {
         const int k = 32 * q + i;
         const int ky = k < KT ? k >> 3 : 0, kx = k < KT ? k & 7 : 0;
-        koff[q] = ky * PW + kx;
+        koff[q] = ky * PW + kx + (FAST ? 1 : 0);
     }
+    float4 rp[3], rd[8];                            // FAST: next tile's patch pieces and dS pieces
+    auto tile_geo = [&](long tile, long& img, int& oy0, int& ox0) {
+        img = tile / ((long)tiles_x * tiles_y);
+        const int trem = (int)(tile - img * tiles_x * tiles_y);
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        oy0 = ty * 8;
+        ox0 = tx * 16;
+    };
+    auto fetch = [&](long tile) {
+        long img; int oy0, ox0;
+        tile_geo(tile, img, oy0, ox0);
+        const int iy0 = oy0 * STRIDE - pad, ixb0 = ox0 * STRIDE - 4;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int item = t + 256 * j;
+            const int rowc = item / 11, j4 = item - rowc * 11;
+            const int c = rowc / PH, py = rowc - c * PH;
+            const int iy = iy0 + py, ixb = ixb0 + 4 * j4;
+            rp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (item < CIN * PH * 11 && iy >= 0 && iy < H && ixb >= 0 && ixb + 3 < Wd)
+                rp[j] = *reinterpret_cast<const float4*>(x + ((img * CIN + c) * H + iy) * (long)Wd + ixb);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int item = t + 256 * j;
+            const int r = item >> 4, o4 = item & 15;
+            rd[j] = *reinterpret_cast<const float4*>(dS + ((img * Ho + oy0 + (r >> 4)) * (long)Wo + ox0 + (r & 15)) * ldd + 4 * o4);
+        }
+    };
+    if (FAST) fetch(blockIdx.x);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long img = tile / ((long)tiles_x * tiles_y);
         const int trem = (int)(tile - img * tiles_x * tiles_y);
@@ -523,6 +557,19 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
         const int oy0 = ty * 8, ox0 = tx * 16;
         const int iy0 = oy0 * STRIDE - pad, ix0 = ox0 * STRIDE - pad;
         __syncthreads();
+        if (FAST) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int item = t + 256 * j;
+                if (item < CIN * PH * 11) *reinterpret_cast<float4*>(&Ps[4 * item]) = rp[j];       // [row][11 pieces]
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(&Ds[4 * (t + 256 * j)]) = rd[j];
+            __syncthreads();
+            const long nxt = tile + gridDim.x;
+            fetch(nxt < ntiles ? nxt : tile);          // branch-free; the last one is a harmless re-read
+            asm volatile("" ::: "memory");             // keep the prefetch in front of the multiply
+        } else {
         for (int idx = t; idx < CIN * PH * PW; idx += 256) {
             const int px = idx % PW, py = (idx / PW) % PH, c = idx / (PW * PH);
             const int iy = iy0 + py, ix = ix0 + px;
@@ -538,6 +585,7 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
             Ds[idx] = v;
         }
         __syncthreads();
+        }
         for (int mm = 0; mm < 32; mm += 2) {
             const int r = 32 * wave + mm + h;            // tile position handled by this lane half
             const int poff = (STRIDE * (r >> 4)) * PW + STRIDE * (r & 15);
@@ -730,7 +778,13 @@ GNX_EXPORT int gnx_conv0_wgrad(const float* x, const float* dS, long ldd, float*
     const int blocks = (int)(ntiles < 512 ? ntiles : 512);
     const int PH = 7 * stride + KH, PW = (15 * stride + 8 + 1) & ~1;
     const size_t lds_bytes = ((size_t)3 * PH * PW + 64 + 128 * 64) * sizeof(float);
-    if (stride == 2)
+    const bool fastld = stride == 2 && pad == 3 && W % 4 == 0 && O == 64 && Ho % 8 == 0 && Wo % 16 == 0 && ldd % 4 == 0 &&
+                        al16b(x) && al16b(dS) && !getenv("GNX_NO_CONV0_PF");
+    if (fastld) {
+        const size_t lds_fast = ((size_t)3 * PH * 44 + 64 + 128 * 64) * sizeof(float);
+        conv0_wgrad_kernel<2, 7, 3, true><<<blocks, 256, lds_fast, stream>>>(x, dS, ldd, workspace, H, W, Ho, Wo, O, KW,
+                                                                             pad, tiles_x, tiles_y, ntiles);
+    } else if (stride == 2)
         conv0_wgrad_kernel<2, 7, 3><<<blocks, 256, lds_bytes, stream>>>(x, dS, ldd, workspace, H, W, Ho, Wo, O, KW, pad,
                                                                         tiles_x, tiles_y, ntiles);
     else
