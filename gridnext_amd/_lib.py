@@ -34,6 +34,8 @@ SIGNATURES = {
     'gnx_conv1x1_bnrelu_f16': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _I, _I, _P]),
     'gnx_conv3x3_bnrelu_f16': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
     'gnx_conv3x3_bnrelu': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
+    'gnx_winograd_conv3x3_weights': (_I, [_P, _P, _I, _I, _P]),
+    'gnx_conv3x3_winograd': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _P]),
     'gnx_conv_stem': (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'gnx_conv_stem_bnrelu_maxpool': (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     'gnx_bnrelu_maxpool': (_I, [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P]),

@@ -1064,6 +1064,205 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ conv3x3, Winograd F(2,3) along x
+// The 3x3 convolution of a pre-activated operand with 1.5x fewer multiplies: along a row, two neighbouring outputs
+//   y0 = d0 g0 + d1 g1 + d2 g2,  y1 = d1 g0 + d2 g1 + d3 g2      (d = 4 consecutive inputs, g = the 3 taps of one kernel row)
+// are  y0 = m0 + m1 + m2,  y1 = m1 - m2 - m3  with
+//   m0 = (d0 - d2) g0,  m1 = (d1 + d2) (g0 + g1 + g2)/2,  m2 = (d2 - d1) (g0 - g1 + g2)/2,  m3 = (d1 - d3) g2:
+// 4 multiplies instead of 6, summed over the 3 kernel rows and all channels BEFORE the output transform, so a wave keeps 4
+// accumulators M0..M3 for its 32 output PAIRS x 32 channels and runs 12 "taps" (3 rows x 4) instead of 18 per pair.
+// Per K chunk (16 channels) the workgroup first turns the DMA'd strip into the four transformed arrays
+// V0..V3[pair][k] in LDS (VALU phase: nothing else of this workgroup runs on the matrix pipe meanwhile, so the VALU
+// stream is not starved), then multiplies out of V and the transformed weights U[row][xi][n][k] (gnx_winograd_conv3x3
+// _weights; DMA'd).  S must be a power of two (pairs never straddle an image row; 256-pixel tiles start at x = 0 mod S);
+// the zero padding left and right of a row is applied in the transform, above and below by pointing the (row, xi) fragment
+// bases of a masked row at a zero region, as in the direct kernel.  Differences from the direct sum are rounding only
+// (coefficients 1 and 1/2).
+template <int S>
+__global__ __launch_bounds__(256) void conv3x3_wino_kernel(const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ Wu, float* __restrict__ out,
+                                                          int ldc, int M, int K) {
+    constexpr int BM = 256, NPAIR = 128;                  // pixels / output pairs per tile (4 waves x 32 pairs)
+    constexpr int RAWN = BM + 2 * S + 2, SRAW = (RAWN + 15) & ~15;        // raw strip pixels [P0 - S - 1, P0 + BM + S + 1)
+    constexpr int NV = NPAIR + S, NVR = (NV + 15) & ~15;                   // V pairs [P0 - S, P0 + BM + S) / 2
+    constexpr int RAWB = SRAW * 64, UB = 12 * 32 * 64, VB = NVR * 64;      // bytes: raw chunk, U chunk, one V_xi array
+    constexpr int OFF_RAW = 0, OFF_U = 2 * RAWB, OFF_V = OFF_U + 2 * UB, OFF_Z = OFF_V + 4 * VB;
+    static_assert(OFF_Z + 1024 <= 160 * 1024, "LDS");
+    constexpr int NPR = SRAW / 16, NPU = 24;               // DMA pieces (16 rows x 64 B) per chunk
+    constexpr int NSR = (NPR + 3) / 4, NSU = NPU / 4;      // slots per wave
+    static_assert(NSR + NSU <= 24, "one DMA slot per MFMA step");
+    __shared__ __attribute__((aligned(16))) char lds[OFF_Z + 1024];
+    const int t = threadIdx.x, lane = t & 63, h = lane >> 5, i = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    for (int z = t; z < 256; z += 256) reinterpret_cast<float*>(lds + OFF_Z)[z] = 0.f;
+    const int T = M / BM;
+    const int nk2 = K >> 5;                                // pairs of 16-channel chunks
+    int G = gridDim.x;
+    asm volatile("" : "+s"(G));
+    const int bx = blockIdx.x;
+    const int bid = (G & 7) == 0 ? (bx & 7) * (G >> 3) + (bx >> 3) : bx;       // XCD-aware order, as the direct kernel
+    auto tile_of = [&](int round) {
+        const int base = round * G;
+        return base + (base + G <= T ? bid : bx);
+    };
+    const unsigned lb = lds_addr(lds);
+
+    // ---- DMA side (16 rows x 4 chunks per piece: lane -> row lane & 15, 16-B chunk lane >> 4)
+    const unsigned voffA = ((unsigned)(lane & 15) * lda + 4 * (lane >> 4)) * 4u;
+    const unsigned voffU = ((unsigned)(lane & 15) * K + 4 * (lane >> 4)) * 4u;
+    int nround = 0, ntile = tile_of(0), nchunk = 0;
+    auto issue_slot = [&](auto slot_c, int buf) {
+        constexpr int slot = decltype(slot_c)::value;
+        if constexpr (slot < NSR) {
+            const int p = wave + 4 * slot;
+            if ((NPR % 4) && slot == NSR - 1 && p >= NPR) return;
+            const int row0 = ntile * BM - S - 1 + 16 * p;
+            char* d = lds + OFF_RAW + buf * RAWB + p * 1024;
+            if (__builtin_expect(row0 >= 0 && row0 + 15 < M, 1)) {
+                const char* sb = reinterpret_cast<const char*>(A + (long)row0 * lda + 16 * nchunk);
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(sb + voffA), (float*)d, 16, 0, 0);
+            } else {                                       // array ends: any in-range row (only masked rows use it)
+                int Pr = row0 + (lane & 15);
+                Pr = Pr < 0 ? 0 : (Pr >= M ? M - 1 : Pr);
+                __builtin_amdgcn_global_load_lds(A + (long)Pr * lda + 16 * nchunk + 4 * (lane >> 4), (float*)d, 16, 0, 0);
+            }
+        } else {
+            const int p = wave + 4 * (slot - NSR);         // U group p: tap p >> 1, rows 16 (p & 1) ..
+            const char* sb = reinterpret_cast<const char*>(Wu + (long)(16 * p) * K + 16 * nchunk);
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(sb + voffU),
+                                             (float*)(lds + OFF_U + buf * UB + p * 1024), 16, 0, 0);
+        }
+    };
+    auto advance_next = [&]() {
+        if (++nchunk == 2 * nk2) { nchunk = 0; ntile = tile_of(++nround); }
+        if (ntile >= T) ntile = bid;
+    };
+    static_for<0, NSR + NSU>([&](auto sc) { issue_slot(sc, 0); });
+    advance_next();
+
+    // ---- transform side: item = (V pair jp, 16-B chunk c), jp fastest across lanes
+    constexpr int NIT = (NVR * 4 + 255) / 256;
+    // ---- fragment side
+    const int r = 32 * wave + i;                           // output pair of this lane within the tile
+    const unsigned fU = lb + OFF_U + (i >> 4) * 1024 + (i & 15) * 16 + h * 256;
+
+    bool stored = false;
+    for (int round = 0, tile = tile_of(0); tile < T; tile = tile_of(++round)) {
+        const int P = tile * BM + 2 * r;
+        const int y = (P % (S * S)) / S;
+        unsigned bV[12];                                   // (row dy, xi) fragment bases; masked rows -> zero region
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int jp = r + S / 2 + (dy - 1) * (S / 2);
+            const bool ok = (dy == 1) || (dy == 0 ? y > 0 : y < S - 1);
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi)
+                bV[dy * 4 + xi] = ok ? lb + OFF_V + xi * VB + (jp >> 4) * 1024 + (jp & 15) * 16 + h * 256 : lb + OFF_Z;
+        }
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[xi][q][e] = 0.f;
+
+        auto do_chunk = [&](auto par_c) {
+            constexpr int par = decltype(par_c)::value;
+            if (stored) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      // the 32 stores of a finished tile may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stored = false;
+            asm volatile("s_barrier" ::: "memory");       // chunk's raw strip + U visible; V and the other buffers free
+            // input transform: V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3 (d0 / d3 zero beside the row ends)
+            {
+                const char* raw = lds + OFF_RAW + par * RAWB;
+#pragma unroll
+                for (int j = 0; j < NIT; ++j) {
+                    const int it = t + 256 * j;
+                    const int c = it / NVR, jp = it - c * NVR;
+                    if (it < NVR * 4 && jp < NV) {             // pairs past NV are never read
+                        const int xin = (2 * jp) & (S - 1);
+                        auto rd = [&](int q) {
+                            return *reinterpret_cast<const float4*>(raw + (q >> 4) * 1024 + c * 256 + (q & 15) * 16);
+                        };
+                        float4 d0 = rd(2 * jp), d1 = rd(2 * jp + 1), d2 = rd(2 * jp + 2), d3 = rd(2 * jp + 3);
+                        if (xin == 0) d0 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (xin + 2 == S) d3 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        char* v = lds + OFF_V + (jp >> 4) * 1024 + c * 256 + (jp & 15) * 16;
+                        *reinterpret_cast<float4*>(v) = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
+                        *reinterpret_cast<float4*>(v + VB) = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
+                        *reinterpret_cast<float4*>(v + 2 * VB) = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
+                        *reinterpret_cast<float4*>(v + 3 * VB) = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");       // V visible
+            const unsigned bU = fU + par * UB;
+            auto rdA = [&](auto e_c) {                     // step e = 2 * tap + s2
+                constexpr int e = decltype(e_c)::value;
+                return lds_read4<(e & 1) * 512>(bV[e >> 1]);
+            };
+            auto rdB = [&](auto e_c) {
+                constexpr int e = decltype(e_c)::value;
+                return lds_read4<(e >> 1) * 2048 + (e & 1) * 512>(bU);
+            };
+            f32x4 a = rdA(std::integral_constant<int, 0>{}), bq = rdB(std::integral_constant<int, 0>{});
+            static_for<0, 24>([&](auto step_c) {
+                constexpr int step = decltype(step_c)::value;
+                constexpr int xi = (step >> 1) & 3;
+                f32x4 na, nb;
+                if constexpr (step < 23) {
+                    na = rdA(std::integral_constant<int, step + 1>{});
+                    nb = rdB(std::integral_constant<int, step + 1>{});
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(bq));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(bq));
+                }
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bq[0], acc[xi][0], 0, 0, 0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], bq[1], acc[xi][1], 0, 0, 0);
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], bq[2], acc[xi][0], 0, 0, 0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], bq[3], acc[xi][1], 0, 0, 0);
+                if constexpr (step < NSR + NSU) issue_slot(step_c, par ^ 1);
+                if constexpr (step < 23) { a = na; bq = nb; }
+            });
+            advance_next();
+        };
+        for (int c2 = 0; c2 < nk2; ++c2) {
+            do_chunk(std::integral_constant<int, 0>{});
+            do_chunk(std::integral_constant<int, 1>{});
+        }
+        // output transform: y(2p) = M0 + M1 + M2, y(2p+1) = M1 - M2 - M3
+        float* o = out + (long)(tile * BM + 2 * (32 * wave + 4 * h)) * ldc + i;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float m0 = acc[0][0][e] + acc[0][1][e], m1 = acc[1][0][e] + acc[1][1][e];
+            const float m2 = acc[2][0][e] + acc[2][1][e], m3 = acc[3][0][e] + acc[3][1][e];
+            const long row = 2 * ((e & 3) + 8 * (e >> 2));
+            o[row * ldc] = (m0 + m1) + m2;
+            o[(row + 1) * ldc] = (m1 - m2) - m3;
+        }
+        stored = true;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// g [N][K][3][3] (torch) -> U [row dy][xi][N][K]: U0 = g0, U1 = (g0 + g1 + g2)/2, U2 = (g0 - g1 + g2)/2, U3 = g2 (along kx)
+__global__ void winograd_weights_kernel(const float* __restrict__ w, float* __restrict__ wu, int N, int K) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)3 * N * K;
+    if (idx >= total) return;
+    const int k = (int)(idx % K), n = (int)((idx / K) % N), dy = (int)(idx / ((long)K * N));
+    const float* g = w + ((long)n * K + k) * 9 + dy * 3;
+    const float g0 = g[0], g1 = g[1], g2 = g[2];
+    const long nk = (long)N * K;
+    float* u = wu + (long)dy * 4 * nk + (long)n * K + k;
+    u[0] = g0;
+    u[nk] = 0.5f * ((g0 + g2) + g1);
+    u[2 * nk] = 0.5f * ((g0 + g2) - g1);
+    u[3 * nk] = g2;
+}
+
 // [N][K][3][3] (torch) -> [tap][N][K]
 __global__ void repack3x3_kernel(const float* __restrict__ w, float* __restrict__ wr, int N, int K) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1559,6 +1758,40 @@ GNX_EXPORT int gnx_repack_conv3x3(const float* w, float* wr, int N, int K, hipSt
     if (!w || !wr || N <= 0 || K <= 0) return GNX_ERR_BAD_ARG;
     repack3x3_kernel<<<gnx_cdiv(9L * N * K, 256), 256, 0, stream>>>(w, wr, N, K);
     return gnx_launch_status();
+}
+
+// w [N][K][3][3] -> wu [3][4][N][K] (12 N K floats): the Winograd F(2,3)-along-x transform of the weights
+GNX_EXPORT int gnx_winograd_conv3x3_weights(const float* w, float* wu, int N, int K, hipStream_t stream) {
+    if (!w || !wu || N <= 0 || K <= 0) return GNX_ERR_BAD_ARG;
+    winograd_weights_kernel<<<gnx_cdiv(3L * N * K, 256), 256, 0, stream>>>(w, wu, N, K);
+    return gnx_launch_status();
+}
+
+// out[M][32] (ldc) = conv3x3_pad1(A[M = imgs*S*S][K] (lda)) for an operand that needs no prologue, with Winograd F(2,3)
+// along x (1.5x fewer matrix operations than the direct form; results differ by rounding only).  Shapes: N == 32,
+// 32 | K, S in {4, 8, 16, 32, 64}, 256 | M, 16-B aligned operands; anything else returns GNX_ERR_UNSUPPORTED (use
+// gnx_conv3x3_bnrelu with scale = shift = NULL and the [tap][N][K] weights).
+GNX_EXPORT int gnx_conv3x3_winograd(const float* A, long lda, const float* Wu, float* out, long ldc, long M, int N, int K,
+                                    int S, hipStream_t stream) {
+    if (!A || !Wu || !out || M < 0 || N <= 0 || K <= 0 || S <= 0 || lda < K || ldc < N || (M % ((long)S * S)) != 0)
+        return GNX_ERR_BAD_ARG;
+    if (N != 32 || (K & 31) != 0 || (M & 255) != 0 || !al16(A) || !al16(Wu) || lda % 4 != 0 ||
+        M * (lda > ldc ? lda : ldc) >= (1L << 31))
+        return GNX_ERR_UNSUPPORTED;
+    if (M == 0) return GNX_OK;
+    const long wgs = M / 256 > 256 ? 256 : M / 256;
+#define GNX_WINO(SS)                                                                                        \
+    conv3x3_wino_kernel<SS><<<(int)wgs, 256, 0, stream>>>(A, (int)lda, Wu, out, (int)ldc, (int)M, K);        \
+    return gnx_launch_status()
+    switch (S) {
+        case 4: GNX_WINO(4);
+        case 8: GNX_WINO(8);
+        case 16: GNX_WINO(16);
+        case 32: GNX_WINO(32);
+        case 64: GNX_WINO(64);
+        default: return GNX_ERR_UNSUPPORTED;
+    }
+#undef GNX_WINO
 }
 
 // out[M][N] (ldc) = conv3x3_pad1(act(A[M = imgs*S*S][K] (lda))) with weights repacked to [tap][N][K]

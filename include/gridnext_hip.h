@@ -97,6 +97,12 @@ int gnx_conv1x1_bnrelu_act(const float* A, long lda, const float* W, float* out,
 int gnx_repack_conv3x3(const float* w, float* wr, int N, int K, gnx_stream_t stream);
 int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, float* out, long ldc, long M, int N, int K, int S,
                        const float* scale, const float* shift, gnx_stream_t stream);
+/* conv2 (:41) of a pre-activated bottleneck with Winograd F(2,3) along x: 12 matrix "taps" per output pair instead of 18.
+ * Same result as gnx_conv3x3_bnrelu(scale = shift = NULL) up to rounding; weights from gnx_winograd_conv3x3_weights
+ * ([N][K][3][3] -> [3][4][N][K]).  GNX_ERR_UNSUPPORTED outside N == 32, 32 | K, S in {4, 8, 16, 32, 64}, 256 | M. */
+int gnx_winograd_conv3x3_weights(const float* w, float* wu, int N, int K, gnx_stream_t stream);
+int gnx_conv3x3_winograd(const float* A, long lda, const float* Wu, float* out, long ldc, long M, int N, int K, int S,
+                         gnx_stream_t stream);
 int gnx_conv_stem(const float* x, const float* w, float* out, long ldc, long imgs, int Cin, int H, int W, int O,
                   int KH, int KW, int stride, int pad, gnx_stream_t stream);
 /* conv0 -> norm0 -> relu0 -> pool0 (:105-110) fused for the 128-px geometry (conv map 64 wide): the conv0 map never goes to

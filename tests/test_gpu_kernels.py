@@ -332,6 +332,31 @@ def test_stem_fused_with_norm0_relu0_pool0(L, n, O):
                    L.ptr(scd), L.ptr(shd), L.stream()) == L.ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("n,S,K", [(16, 4, 32), (4, 8, 128), (8, 16, 64), (1, 32, 128), (40, 32, 128), (1, 64, 32),
+                                   (4160, 4, 128)])
+def test_conv3x3_winograd(L, n, S, K):
+    """Winograd F(2,3)-along-x form of conv2 on a pre-activated operand == the direct 3x3 convolution (rounding only)."""
+    N = 32
+    g = torch.Generator().manual_seed(S * 10 + K)
+    x = torch.randn(n, K, S, S, generator=g)
+    W = torch.randn(N, K, 3, 3, generator=g) * 0.1
+    ref = F.conv2d(x.double(), W.double(), padding=1).float()
+    A = x.permute(0, 2, 3, 1).reshape(-1, K).contiguous().to(DEV)
+    Wd = W.to(DEV)
+    Wu = torch.empty((12, N, K), device=DEV)
+    L.call('gnx_winograd_conv3x3_weights', L.ptr(Wd), L.ptr(Wu), N, K, L.stream())
+    g0, g1, g2 = W[..., 0], W[..., 1], W[..., 2]                         # [N][K][ky]
+    Uref = torch.stack([g0, 0.5 * ((g0 + g2) + g1), 0.5 * ((g0 + g2) - g1), g2], 0)     # [xi][N][K][ky]
+    close(Wu.view(3, 4, N, K), Uref.permute(3, 0, 1, 2), rtol=1e-6, what='transformed weights')
+    ldc = N + 4
+    out = torch.full((n * S * S, ldc), 7.0, device=DEV)
+    L.call('gnx_conv3x3_winograd', L.ptr(A), K, L.ptr(Wu), out.data_ptr() + 4 * 2, ldc, n * S * S, N, K, S, L.stream())
+    close(out[:, 2:2 + N].reshape(n, S, S, N).permute(0, 3, 1, 2), ref, rtol=2e-4)
+    assert float(out[:, :2].min()) == 7.0 and float(out[:, 2 + N:].min()) == 7.0
+    assert L.query('gnx_conv3x3_winograd', L.ptr(A), K, L.ptr(Wu), L.ptr(out), ldc, n * S * S, 16, K, S,
+                   L.stream()) == L.ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("n,P,O,KH,stride,pad", [(3, 32, 8, 7, 2, 3), (2, 128, 64, 7, 2, 3), (2, 16, 10, 3, 1, 1),
                                                  (1, 30, 24, 7, 2, 3)])
 def test_stem_conv_and_pools(L, n, P, O, KH, stride, pad):

@@ -35,6 +35,7 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--noact', action='store_true', help='conv3x3 without the BN+ReLU prologue')
     ap.add_argument('--const', action='store_true', help='constant operands (low bit toggling) instead of randn')
+    ap.add_argument('--wino', action='store_true', help='conv3x3 in its Winograd F(2,3) form (prologue-free operand)')
     args = ap.parse_args()
     n = args.spots
     st = L.stream()
@@ -67,10 +68,17 @@ def main():
             out = torch.empty(M, ct, device=DEV)
             sc, sh = torch.rand(128, device=DEV) + 0.5, torch.randn(128, device=DEV) * 0.1
             scp, shp = (None, None) if args.noact else (L.ptr(sc), L.ptr(sh))
-            ms = timeit(lambda: L.call('gnx_conv3x3_bnrelu', L.ptr(A), 128, L.ptr(Wr), out.data_ptr() + 4 * 64, ct, M,
-                                       32, 128, S, scp, shp, st), args.reps)
+            if args.wino:
+                Wt = torch.randn(32, 128, 3, 3, device=DEV) * 0.05
+                Wu = torch.empty(12, 32, 128, device=DEV)
+                L.call('gnx_winograd_conv3x3_weights', L.ptr(Wt), L.ptr(Wu), 32, 128, st)
+                ms = timeit(lambda: L.call('gnx_conv3x3_winograd', L.ptr(A), 128, L.ptr(Wu), out.data_ptr() + 4 * 64, ct,
+                                           M, 32, 128, S, st), args.reps)
+            else:
+                ms = timeit(lambda: L.call('gnx_conv3x3_bnrelu', L.ptr(A), 128, L.ptr(Wr), out.data_ptr() + 4 * 64, ct,
+                                           M, 32, 128, S, scp, shp, st), args.reps)
             fl = 2.0 * M * 1152 * 32
-            print("conv3x3 S=%2d M=%8d  %8.3f ms  %6.1f TFLOP/s" % (S, M, ms, fl / ms / 1e9))
+            print("conv3x3 S=%2d M=%8d  %8.3f ms  %6.1f TFLOP/s (direct-conv FLOPs)" % (S, M, ms, fl / ms / 1e9))
             del A, out
     if args.only in ('', 'stem'):
         x = torch.rand(n, 3, 128, 128, device=DEV)
