@@ -60,6 +60,8 @@ class DenseNet(nn.Module):
         self.bn_size, self.small_inputs, self.classify = bn_size, small_inputs, classify
         self.atonce = None          # spots per chunk in eval mode (None = auto)
         self.mfma = 'f32'           # 'f16': fp16 matrix-core operands in the eval forward (BASELINE config 5)
+        self.winograd = True        # eval forward: conv2 as Winograd F(2,3) along x where the shape allows (fp32 path;
+                                    # same arithmetic type, 1.5x fewer matrix operations, rounding-level differences)
         self.l3_blocking = False    # option: run each dense block over Infinity-Cache-sized sub-ranges of spots
                                     # (measured r01: slower - 15x more, smaller launches; kept for experiments)
         self.l3_budget = 160 * 1024 * 1024
@@ -160,6 +162,24 @@ class DenseNet(nn.Module):
         self._cache['w2'] = (key, table)
         return table
 
+    def _winograd_conv2(self):
+        """{layer: conv2 weight as Winograd F(2,3)-along-x factors [3][4][growth][mid]} refreshed with the weights."""
+        layers = [l for _, ls, _, _ in self._blocks for l in ls]
+        key = tuple(l.conv2.weight._version for l in layers) + (str(layers[0].conv2.weight.device),)
+        hit = self._cache.get('w2u')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        table = {}
+        st = L.stream()
+        for l in layers:
+            w = l.conv2.weight
+            n, k = w.shape[0], w.shape[1]
+            wu = torch.empty((12, n, k), device=w.device, dtype=F32)
+            L.call('gnx_winograd_conv3x3_weights', L.ptr(w.detach().contiguous()), L.ptr(wu), n, k, st)
+            table[l] = wu
+        self._cache['w2u'] = (key, table)
+        return table
+
     def _geometry(self, P):
         if self.small_inputs:
             hs, s = None, P
@@ -226,6 +246,7 @@ class DenseNet(nn.Module):
         st = L.stream()
         fold = self._folded_eval()
         w2 = self._repacked_conv2()
+        w2u = self._winograd_conv2() if (self.winograd and self.mfma == 'f32') else None
         if self.mfma not in ('f32', 'f16'):
             raise ValueError("DenseNet.mfma must be 'f32' or 'f16'")
         sfx = '_f16' if self.mfma == 'f16' else ''
@@ -296,8 +317,19 @@ class DenseNet(nn.Module):
                             L.call('gnx_conv1x1_bnrelu_act', L.ptr(rows), c_total, L.ptr(layer.conv1.weight),
                                    L.ptr(bott), mid, M, mid, cin, L.ptr(sc1), L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), st)
                             t1 = self._probe_mark('conv1x1', t0)
-                            L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2[layer]), rows.data_ptr() + 4 * cin,
-                                   c_total, M, self.growth_rate, mid, s, None, None, st)
+                            # conv2 on the ready operand: Winograd F(2,3) along x (1.5x fewer matrix operations, rounding-
+                            # level differences) for the maps whose size alone guarantees whole 256-position tiles
+                            # (S = 16, 32, 64), so that the choice - and with it every output bit - does not depend on
+                            # how many spots a call or a chunk holds; else the direct LDS-DMA kernel
+                            rc = L.ERR_UNSUPPORTED
+                            if w2u is not None and (s * s) % 256 == 0:
+                                rc = L.query('gnx_conv3x3_winograd', L.ptr(bott), mid, L.ptr(w2u[layer]),
+                                             rows.data_ptr() + 4 * cin, c_total, M, self.growth_rate, mid, s, st)
+                                if rc not in (0, L.ERR_UNSUPPORTED):
+                                    raise RuntimeError("gnx_conv3x3_winograd failed (%d)" % rc)
+                            if rc == L.ERR_UNSUPPORTED:
+                                L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2[layer]),
+                                       rows.data_ptr() + 4 * cin, c_total, M, self.growth_rate, mid, s, None, None, st)
                         self._probe_mark('conv3x3', t1)
                     if trans is not None:
                         nxt = bufs[bi + 1]
