@@ -48,13 +48,13 @@ def conv3x3_flops_per_spot(patch):
 
 
 def conv3x3_executed_flops_per_spot(patch):
-    """Matrix FLOPs the conv2 launches actually execute: the maps with 256 | S*S (S = 16, 32, 64) run Winograd F(2,3) along
-    x - 12 instead of 18 multiply-accumulate "taps" per output pair, i.e. 2/3 of the direct count."""
+    """Matrix FLOPs the conv2 launches actually execute: power-of-two maps of 8 x 8 and up run Winograd F(2,3) along x -
+    12 instead of 18 multiply-accumulate "taps" per output pair, i.e. 2/3 of the direct count."""
     s = ((patch + 6 - 7) // 2 + 1 + 2 - 3) // 2 + 1
     total = 0
     for n_layers in DENSENET121['block_config']:
         f = n_layers * s * s * 2 * (9 * 128) * 32
-        total += f * 2 // 3 if (s * s) % 256 == 0 else f
+        total += f * 2 // 3 if (s >= 8 and (s & (s - 1)) == 0) else f
         s //= 2
     return total
 
@@ -255,8 +255,8 @@ def main():
             # execute fewer: report the executed rate next to it
             k3 = kern['conv3x3']
             ex = conv3x3_executed_flops_per_spot(args.patch) * H * W * args.steps
-            k3["kernel"] = "conv3x3_wino_kernel (S = 16, 32, 64) + conv3x3_dma_kernel (S = 4, 8)"
-            k3["algorithm"] = ("Winograd F(2,3) along x where 256 | S*S: 2/3 of the direct multiply-adds; `achieved` and "
+            k3["kernel"] = "conv3x3_wino_kernel (S >= 8) + conv3x3_dma_kernel (S = 4)"
+            k3["algorithm"] = ("Winograd F(2,3) along x for maps of 8 x 8 and up: 2/3 of the direct multiply-adds; `achieved` and "
                                "`frac` count direct-convolution FLOPs, `executed_*` the matrix FLOPs actually issued")
             k3["executed_achieved"] = ex / (k3["ms_per_step"] * args.steps * 1e-3) / 1e12
             k3["executed_frac"] = k3["executed_achieved"] / PEAK_F32_MATRIX_TFLOPS

@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(const float* __restri
     const int t = threadIdx.x, lane = t & 63, h = lane >> 5, i = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     for (int z = t; z < 256; z += 256) reinterpret_cast<float*>(lds + OFF_Z)[z] = 0.f;
-    const int T = M / BM;
+    const int T = (M + BM - 1) / BM;                       // the last tile may be ragged (stores guarded, loads clamped)
     const int nk2 = K >> 5;                                // pairs of 16-channel chunks
     int G = gridDim.x;
     asm volatile("" : "+s"(G));
@@ -1239,8 +1239,10 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(const float* __restri
             const float m0 = acc[0][0][e] + acc[0][1][e], m1 = acc[1][0][e] + acc[1][1][e];
             const float m2 = acc[2][0][e] + acc[2][1][e], m3 = acc[3][0][e] + acc[3][1][e];
             const long row = 2 * ((e & 3) + 8 * (e >> 2));
-            o[row * ldc] = (m0 + m1) + m2;
-            o[(row + 1) * ldc] = (m1 - m2) - m3;
+            if (tile * BM + 2 * (32 * wave + 4 * h) + row < M) {       // M is even: both pixels of a pair are in or out
+                o[row * ldc] = (m0 + m1) + m2;
+                o[(row + 1) * ldc] = (m1 - m2) - m3;
+            }
         }
         stored = true;
     }
@@ -1769,17 +1771,17 @@ GNX_EXPORT int gnx_winograd_conv3x3_weights(const float* w, float* wu, int N, in
 
 // out[M][32] (ldc) = conv3x3_pad1(A[M = imgs*S*S][K] (lda)) for an operand that needs no prologue, with Winograd F(2,3)
 // along x (1.5x fewer matrix operations than the direct form; results differ by rounding only).  Shapes: N == 32,
-// 32 | K, S in {4, 8, 16, 32, 64}, 256 | M, 16-B aligned operands; anything else returns GNX_ERR_UNSUPPORTED (use
+// 32 | K, S in {4, 8, 16, 32, 64}, 16-B aligned operands; anything else returns GNX_ERR_UNSUPPORTED (use
 // gnx_conv3x3_bnrelu with scale = shift = NULL and the [tap][N][K] weights).
 GNX_EXPORT int gnx_conv3x3_winograd(const float* A, long lda, const float* Wu, float* out, long ldc, long M, int N, int K,
                                     int S, hipStream_t stream) {
     if (!A || !Wu || !out || M < 0 || N <= 0 || K <= 0 || S <= 0 || lda < K || ldc < N || (M % ((long)S * S)) != 0)
         return GNX_ERR_BAD_ARG;
-    if (N != 32 || (K & 31) != 0 || (M & 255) != 0 || !al16(A) || !al16(Wu) || lda % 4 != 0 ||
+    if (N != 32 || (K & 31) != 0 || !al16(A) || !al16(Wu) || lda % 4 != 0 ||
         M * (lda > ldc ? lda : ldc) >= (1L << 31))
         return GNX_ERR_UNSUPPORTED;
     if (M == 0) return GNX_OK;
-    const long wgs = M / 256 > 256 ? 256 : M / 256;
+    const long wgs = (M + 255) / 256 > 256 ? 256 : (M + 255) / 256;
 #define GNX_WINO(SS)                                                                                        \
     conv3x3_wino_kernel<SS><<<(int)wgs, 256, 0, stream>>>(A, (int)lda, Wu, out, (int)ldc, (int)M, K);        \
     return gnx_launch_status()

@@ -318,11 +318,11 @@ class DenseNet(nn.Module):
                                    L.ptr(bott), mid, M, mid, cin, L.ptr(sc1), L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), st)
                             t1 = self._probe_mark('conv1x1', t0)
                             # conv2 on the ready operand: Winograd F(2,3) along x (1.5x fewer matrix operations, rounding-
-                            # level differences) for the maps whose size alone guarantees whole 256-position tiles
-                            # (S = 16, 32, 64), so that the choice - and with it every output bit - does not depend on
-                            # how many spots a call or a chunk holds; else the direct LDS-DMA kernel
+                            # level differences) for maps of 8 x 8 and up (4 x 4 measured faster direct).  The choice
+                            # depends on the map size only - never on how many spots a call or a chunk holds - so chunked
+                            # and unchunked evaluation stay bit-identical.
                             rc = L.ERR_UNSUPPORTED
-                            if w2u is not None and (s * s) % 256 == 0:
+                            if w2u is not None and s >= 8:
                                 rc = L.query('gnx_conv3x3_winograd', L.ptr(bott), mid, L.ptr(w2u[layer]),
                                              rows.data_ptr() + 4 * cin, c_total, M, self.growth_rate, mid, s, st)
                                 if rc not in (0, L.ERR_UNSUPPORTED):

@@ -99,7 +99,7 @@ int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, float* out, lo
                        const float* scale, const float* shift, gnx_stream_t stream);
 /* conv2 (:41) of a pre-activated bottleneck with Winograd F(2,3) along x: 12 matrix "taps" per output pair instead of 18.
  * Same result as gnx_conv3x3_bnrelu(scale = shift = NULL) up to rounding; weights from gnx_winograd_conv3x3_weights
- * ([N][K][3][3] -> [3][4][N][K]).  GNX_ERR_UNSUPPORTED outside N == 32, 32 | K, S in {4, 8, 16, 32, 64}, 256 | M. */
+ * ([N][K][3][3] -> [3][4][N][K]).  GNX_ERR_UNSUPPORTED outside N == 32, 32 | K, S in {4, 8, 16, 32, 64}. */
 int gnx_winograd_conv3x3_weights(const float* w, float* wu, int N, int K, gnx_stream_t stream);
 int gnx_conv3x3_winograd(const float* A, long lda, const float* Wu, float* out, long ldc, long M, int N, int K, int S,
                          gnx_stream_t stream);

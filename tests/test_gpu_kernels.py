@@ -333,7 +333,7 @@ def test_stem_fused_with_norm0_relu0_pool0(L, n, O):
 
 
 @pytest.mark.parametrize("n,S,K", [(16, 4, 32), (4, 8, 128), (8, 16, 64), (1, 32, 128), (40, 32, 128), (1, 64, 32),
-                                   (4160, 4, 128)])
+                                   (4160, 4, 128), (5, 8, 64), (3, 4, 32), (1001, 8, 32)])      # last three: ragged last tile
 def test_conv3x3_winograd(L, n, S, K):
     """Winograd F(2,3)-along-x form of conv2 on a pre-activated operand == the direct 3x3 convolution (rounding only)."""
     N = 32
