@@ -1078,6 +1078,9 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
 // the zero padding left and right of a row is applied in the transform, above and below by pointing the (row, xi) fragment
 // bases of a masked row at a zero region, as in the direct kernel.  Differences from the direct sum are rounding only
 // (coefficients 1 and 1/2).
+#ifndef GNX_WINO_DBG
+#define GNX_WINO_DBG 0        // ablations for tools/kbench.py: 1 = no input transform, 2 = no DMA after the first chunk
+#endif
 template <int S>
 __global__ __launch_bounds__(256) void conv3x3_wino_kernel(const float* __restrict__ A, int lda,
                                                           const float* __restrict__ Wu, float* __restrict__ out,
@@ -1174,6 +1177,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(const float* __restri
             stored = false;
             asm volatile("s_barrier" ::: "memory");       // chunk's raw strip + U visible; V and the other buffers free
             // input transform: V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3 (d0 / d3 zero beside the row ends)
+#if GNX_WINO_DBG != 1
             {
                 const char* raw = lds + OFF_RAW + par * RAWB;
 #pragma unroll
@@ -1182,20 +1186,24 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(const float* __restri
                     const int c = it / NVR, jp = it - c * NVR;
                     if (it < NVR * 4 && jp < NV) {             // pairs past NV are never read
                         const int xin = (2 * jp) & (S - 1);
-                        auto rd = [&](int q) {
-                            return *reinterpret_cast<const float4*>(raw + (q >> 4) * 1024 + c * 256 + (q & 15) * 16);
-                        };
-                        float4 d0 = rd(2 * jp), d1 = rd(2 * jp + 1), d2 = rd(2 * jp + 2), d3 = rd(2 * jp + 3);
-                        if (xin == 0) d0 = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (xin + 2 == S) d3 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        // the zero padding beside the row ends: read the zero region instead of the neighbour (an address
+                        // choice the compiler hoists out of every loop - no select on the data)
+                        auto at = [&](int q) { return raw + (q >> 4) * 1024 + c * 256 + (q & 15) * 16; };
+                        const char* zr = lds + OFF_Z;
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        struct F4 { f2 lo, hi; };
+                        auto rd = [&](const char* p) { return *reinterpret_cast<const F4*>(p); };
+                        const F4 d0 = rd(xin == 0 ? zr : at(2 * jp)), d1 = rd(at(2 * jp + 1)), d2 = rd(at(2 * jp + 2)),
+                                 d3 = rd(xin + 2 == S ? zr : at(2 * jp + 3));
                         char* v = lds + OFF_V + (jp >> 4) * 1024 + c * 256 + (jp & 15) * 16;
-                        *reinterpret_cast<float4*>(v) = make_float4(d0.x - d2.x, d0.y - d2.y, d0.z - d2.z, d0.w - d2.w);
-                        *reinterpret_cast<float4*>(v + VB) = make_float4(d1.x + d2.x, d1.y + d2.y, d1.z + d2.z, d1.w + d2.w);
-                        *reinterpret_cast<float4*>(v + 2 * VB) = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
-                        *reinterpret_cast<float4*>(v + 3 * VB) = make_float4(d1.x - d3.x, d1.y - d3.y, d1.z - d3.z, d1.w - d3.w);
+                        *reinterpret_cast<F4*>(v) = F4{d0.lo - d2.lo, d0.hi - d2.hi};
+                        *reinterpret_cast<F4*>(v + VB) = F4{d1.lo + d2.lo, d1.hi + d2.hi};
+                        *reinterpret_cast<F4*>(v + 2 * VB) = F4{d2.lo - d1.lo, d2.hi - d1.hi};
+                        *reinterpret_cast<F4*>(v + 3 * VB) = F4{d1.lo - d3.lo, d1.hi - d3.hi};
                     }
                 }
             }
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             asm volatile("s_barrier" ::: "memory");       // V visible
             const unsigned bU = fU + par * UB;
@@ -1223,7 +1231,9 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(const float* __restri
                 acc[xi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], bq[1], acc[xi][1], 0, 0, 0);
                 acc[xi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], bq[2], acc[xi][0], 0, 0, 0);
                 acc[xi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], bq[3], acc[xi][1], 0, 0, 0);
+#if GNX_WINO_DBG != 2
                 if constexpr (step < NSR + NSU) issue_slot(step_c, par ^ 1);
+#endif
                 if constexpr (step < 23) { a = na; bq = nb; }
             });
             advance_next();
