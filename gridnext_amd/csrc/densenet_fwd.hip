@@ -1111,7 +1111,11 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(const float* __restri
     const unsigned lb = lds_addr(lds);
 
     // ---- DMA side (16 rows x 4 chunks per piece: lane -> row lane & 15, 16-B chunk lane >> 4)
-    const unsigned voffA = ((unsigned)(lane & 15) * lda + 4 * (lane >> 4)) * 4u;
+    // Raw-strip pieces with an odd index are stored rotated by one 16-B slot: the transform reads every OTHER pixel
+    // (q = 2 jp + e), 16 lanes = 32 pixels = two pieces x the same 8 slots - a 2-way bank conflict on all its reads
+    // unless the second piece's slots are shifted.  A wave's pieces all have the parity of its wave index.
+    const int pix = ((lane & 15) - (wave & 1)) & 15;       // pixel of the piece this lane fetches into slot lane & 15
+    const unsigned voffA = ((unsigned)pix * lda + 4 * (lane >> 4)) * 4u;
     const unsigned voffU = ((unsigned)(lane & 15) * K + 4 * (lane >> 4)) * 4u;
     int nround = 0, ntile = tile_of(0), nchunk = 0;
     auto issue_slot = [&](auto slot_c, int buf) {
@@ -1125,7 +1129,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(const float* __restri
                 const char* sb = reinterpret_cast<const char*>(A + (long)row0 * lda + 16 * nchunk);
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(sb + voffA), (float*)d, 16, 0, 0);
             } else {                                       // array ends: any in-range row (only masked rows use it)
-                int Pr = row0 + (lane & 15);
+                int Pr = row0 + pix;
                 Pr = Pr < 0 ? 0 : (Pr >= M ? M - 1 : Pr);
                 __builtin_amdgcn_global_load_lds(A + (long)Pr * lda + 16 * nchunk + 4 * (lane >> 4), (float*)d, 16, 0, 0);
             }
@@ -1188,7 +1192,9 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(const float* __restri
                         const int xin = (2 * jp) & (S - 1);
                         // the zero padding beside the row ends: read the zero region instead of the neighbour (an address
                         // choice the compiler hoists out of every loop - no select on the data)
-                        auto at = [&](int q) { return raw + (q >> 4) * 1024 + c * 256 + (q & 15) * 16; };
+                        auto at = [&](int q) {
+                            return raw + (q >> 4) * 1024 + c * 256 + (((q & 15) + ((q >> 4) & 1)) & 15) * 16;
+                        };
                         const char* zr = lds + OFF_Z;
                         typedef float f2 __attribute__((ext_vector_type(2)));
                         struct F4 { f2 lo, hi; };
