@@ -66,6 +66,26 @@ def test_densenet121_closed_form_eval():
             assert torch.equal(out.argmax(1).cpu(), ref.argmax(1))
 
 
+def test_densenet121_winograd_conv2_vs_direct_conv2():
+    """The eval forward's Winograd conv2 (maps of 8 x 8 and up) against its direct conv2: rounding-level differences only."""
+    import gridnext_amd as ga
+    from oracle import densenet as odn
+    cfg = odn.DenseNetCfg(num_classes=8, **odn.DENSENET121)
+    m = ga.DenseNet(num_classes=8, **odn.DENSENET121)
+    m.load_state_dict(odn.closed_form_state(cfg))
+    m.to(DEV).eval()
+    x = odn.closed_form_images(6, 128).to(DEV)
+    with torch.no_grad():
+        assert m.winograd
+        a = m(x)
+        m.winograd = False
+        b = m(x)
+        m.winograd = True
+    close(a, b, rtol=2e-5, what='winograd vs direct')
+    assert torch.equal(a.argmax(1), b.argmax(1))
+    assert not torch.equal(a, b)          # i.e. the switch does select a different kernel
+
+
 def test_densenet121_many_spots_vs_oracle():
     """A few hundred spots through the chunked path (ragged last chunk) vs the fp32 CPU oracle."""
     import gridnext_amd as ga
