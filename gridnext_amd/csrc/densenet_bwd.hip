@@ -1,7 +1,7 @@
 // DenseNet-BC backward kernels (gfx950, exact fp32 on the matrix cores).
 //
 // Autograd of /root/reference/gridnext/densenet.py is torch's; these kernels compute the same gradients:
-//   data gradients of conv1x1 / conv3x3 reuse the FORWARD kernels of densenet_fwd.hip with transformed weights
+//   data gradients of conv1x1 / conv3x3 reuse the FORWARD kernels of conv1x1.hip / conv3x3.hip with transformed weights
 //     (gnx_transpose_weight: W[N][K] -> [K][N];  gnx_repack_conv3x3_bwd: W[N][K][3][3] -> [flipped tap][K][N]);
 //   gnx_wgrad_bnrelu   : weight gradient of conv1x1 (taps=1, optionally through the transition's 2x2 average) and
 //                        conv3x3 (taps=9): dW[tap][n][k] = sum_m dY[m][n] * act(X)[nbr(m,tap)][k], the BN+ReLU of the

@@ -1,6 +1,6 @@
 // fp16-MFMA variants of the two DenseNet conv kernels (BASELINE.json config 5: "fp16 MFMA conv path").
 //
-// Same contract as gnx_conv1x1_bnrelu / gnx_conv3x3_bnrelu (densenet_fwd.hip): fp32 activations and weights in HBM,
+// Same contract as gnx_conv1x1_bnrelu / gnx_conv3x3_bnrelu (conv1x1.hip, conv3x3.hip): fp32 activations and weights in HBM,
 // fp32 BN+ReLU prologue, fp32 accumulation, fp32 outputs.  Only the MFMA operands are narrowed: values are rounded to
 // IEEE fp16 as they are written to LDS and multiplied with v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate), so the
 // result differs from the fp32 path by operand rounding (~2^-11 relative per product); tests state the tolerance and

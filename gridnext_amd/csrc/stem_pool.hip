@@ -1,0 +1,501 @@
+// DenseNet-BC forward: stem (conv0, optionally fused with norm0/relu0/pool0), BN+ReLU+maxpool, BN+ReLU+global average
+// pool (densenet.py:98-112, :153-156).
+#include "fwd_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ stem conv (NCHW in, NHWC out)
+// out[(img,oy,ox)][o] = sum_{c,ky,kx} x[img][c][oy*st+ky-pad][ox*st+kx-pad] * w[o][c][ky][kx]
+// im2col is built in LDS one input channel at a time: K-chunk = KH x 8 (kx padded to 8 with zero weights).
+constexpr int ST_BM = 128, ST_BN = 64;
+
+__global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ out, long ldc, long M, int Cin, int H,
+                                                        int Wd, int Ho, int Wo, int O, int KH, int KW, int stride,
+                                                        int pad) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int KC = KH * 8, LD = KC + 4;
+    float* As = lds;                 // [128][LD]
+    float* Bs = lds + ST_BM * LD;    // [64][LD]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long m0 = (long)blockIdx.x * ST_BM;
+    const int n0 = blockIdx.y * ST_BN;
+    const int kx = t & 7, rr = t >> 3;
+
+    long ibase[4];
+    int iy0[4], ix0[4];
+    bool rok[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const long row = m0 + rr + 32 * p;
+        rok[p] = row < M;
+        const long img = row / ((long)Ho * Wo);
+        const int rem = (int)(row - img * Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        ibase[p] = img * Cin * (long)H * Wd;
+        iy0[p] = oy * stride - pad;
+        ix0[p] = ox * stride - pad + kx;
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    for (int c = 0; c < Cin; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool xok = rok[p] && kx < KW && ix0[p] >= 0 && ix0[p] < Wd;
+            const float* xc = x + ibase[p] + (long)c * H * Wd;
+            for (int ky = 0; ky < KH; ++ky) {
+                const int iy = iy0[p] + ky;
+                float v = 0.f;
+                if (xok && iy >= 0 && iy < H) v = xc[(long)iy * Wd + ix0[p]];
+                As[(rr + 32 * p) * LD + ky * 8 + kx] = v;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int o = n0 + rr + 32 * p;
+            for (int ky = 0; ky < KH; ++ky) {
+                float v = 0.f;
+                if (o < O && kx < KW) v = w[(((long)o * Cin + c) * KH + ky) * KW + kx];
+                Bs[(rr + 32 * p) * LD + ky * 8 + kx] = v;
+            }
+        }
+        __syncthreads();
+        for (int s = 0; s < KH; ++s) {
+            const float4 a0 = ld4(&As[(64 * wm + i) * LD + 8 * s + 4 * h]);
+            const float4 a1 = ld4(&As[(64 * wm + 32 + i) * LD + 8 * s + 4 * h]);
+            const float4 b = ld4(&Bs[(32 * wn + i) * LD + 8 * s + 4 * h]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc[1], 0, 0, 0);
+        }
+    }
+    const int col = n0 + 32 * wn + i;
+    if (col < O) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = m0 + 64 * wm + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) out[row * ldc + col] = acc[mt][r];
+            }
+    }
+}
+
+// Patch-resident form of the stem conv (used for the two stems DenseNet has: 7x7 s2 p3 and 3x3 s1 p1, 3 input channels).
+// A workgroup owns an 8x16 tile of output positions: the input patch it needs (all channels, zero-padded borders) is
+// staged into LDS once with coalesced loads, and the MFMA A-fragments are read STRAIGHT from that patch - the four
+// consecutive kx of a fragment are four consecutive floats of a patch row - so no im2col image is ever built.  The whole
+// weight tensor ([O<=64][Cin][KH][8], kx zero-padded to 8) lives in LDS for the lifetime of the (persistent) workgroup.
+template <int STRIDE, int KH, int CIN>
+__global__ __launch_bounds__(256) void conv_stem_patch_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              float* __restrict__ out, long ldc, int Cin, int H, int Wd,
+                                                              int Ho, int Wo, int O, int KW, int pad, int tiles_x,
+                                                              int tiles_y, long ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PH = 7 * STRIDE + KH, PW = (15 * STRIDE + 8 + 1) & ~1;
+    const int KT = Cin * KH * 8, LDB = KT + 4;
+    float* Bs = lds;                          // [64][LDB]
+    float* Ps = lds + 64 * LDB;               // [Cin][PH][PW]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    for (int idx = t; idx < 64 * KT; idx += 256) {
+        const int n = idx / KT, rem = idx - n * KT;
+        const int kx = rem & 7, cky = rem >> 3;          // cky = c*KH + ky
+        float v = 0.f;
+        if (n < O && kx < KW) v = w[((long)n * Cin * KH + cky) * KW + kx];
+        Bs[n * LDB + rem] = v;
+    }
+    const int trow = 32 * wave + i;                       // this lane's row of the 128-position tile
+    const int oyl = trow >> 4, oxl = trow & 15;
+    const float* pa = Ps + (STRIDE * oyl) * PW + STRIDE * oxl + 4 * h;
+    const float* pb = Bs + i * LDB + 4 * h;
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long img = tile / ((long)tiles_x * tiles_y);
+        const int trem = (int)(tile - img * tiles_x * tiles_y);
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int oy0 = ty * 8, ox0 = tx * 16;
+        const int iy0 = oy0 * STRIDE - pad, ix0 = ox0 * STRIDE - pad;
+        __syncthreads();                                  // previous tile's fragment reads (and the Bs fill) are done
+        for (int idx = t; idx < Cin * PH * PW; idx += 256) {
+            const int px = idx % PW, py = (idx / PW) % PH, c = idx / (PW * PH);
+            const int iy = iy0 + py, ix = ix0 + px;
+            float v = 0.f;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < Wd) v = x[((img * Cin + c) * H + iy) * (long)Wd + ix];
+            Ps[idx] = v;
+        }
+        __syncthreads();
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        auto load_a = [&](int step) {
+            const float* ap = pa + ((step / KH) * PH + (step % KH)) * PW;
+            if (STRIDE % 2 == 0) {
+                const float2 lo = *reinterpret_cast<const float2*>(ap);
+                const float2 hi = *reinterpret_cast<const float2*>(ap + 2);
+                return make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+            return make_float4(ap[0], ap[1], ap[2], ap[3]);
+        };
+        constexpr int NSTEP = CIN * KH;
+        float4 a = load_a(0), b0 = ld4(pb), b1 = ld4(pb + 32 * LDB);
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) {
+            float4 na = a, nb0 = b0, nb1 = b1;
+            if (step + 1 < NSTEP) {
+                na = load_a(step + 1);
+                nb0 = ld4(pb + (step + 1) * 8);
+                nb1 = ld4(pb + 32 * LDB + (step + 1) * 8);
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+            a = na; b0 = nb0; b1 = nb1;
+            __builtin_amdgcn_sched_group_barrier(0x100, STRIDE % 2 == 0 ? 4 : 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rr = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int oy = oy0 + (rr >> 4), ox = ox0 + (rr & 15);
+            if (oy < Ho && ox < Wo) {
+                float* o = out + ((img * Ho + oy) * (long)Wo + ox) * ldc;
+                if (i < O) o[i] = acc0[r];
+                if (32 + i < O) o[32 + i] = acc1[r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ stem + BN + ReLU + maxpool
+// features.conv0 -> norm0 -> relu0 -> pool0 (densenet.py:105-110) in ONE kernel for the 128-px geometry (7x7 s2 p3 conv to a
+// 64-wide map, 3x3 s2 p1 max pool): the 5.2 GB conv0 output of an array never goes to HBM (the two-kernel path writes
+// it and reads it back: 4.9 + 1.4 ms).  A persistent workgroup sweeps an image top to bottom in tiles of 2 conv rows x 64
+// columns (= the 128 positions of the MFMA M dimension, full width: no horizontal halo); tile t yields conv rows 2t and
+// 2t+1, pooled row t = max over conv rows {2t-1, 2t, 2t+1} and columns {2px-1, 2px, 2px+1}.  Row 2t-1 is the previous
+// tile's second row: every thread owns the same (px, 4 channels) items in every tile, so that carry lives in registers.
+// relu >= 0, so "outside the map" contributes 0 exactly as in gnx_bnrelu_maxpool.
+constexpr int SP_LDT = 72;         // floats per position of the activated tile in LDS: 4 * 72 = 32 (mod 64) banks, so the
+                                   // two lane halves of an accumulator store (positions p and p + 4) hit disjoint banks
+__global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             float* __restrict__ out, long ldo, int H, int Wd, int O,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, long imgs) {
+    constexpr int CIN = 3, KH = 7, KW = 7, STRIDE = 2, PAD = 3, WO = 64;
+    constexpr int PH = STRIDE + KH, PW = (63 * STRIDE + 8 + 1 + 1) & ~1;       // 9 x 136 input patch per channel
+    constexpr int KT = CIN * KH * 8, LDB = KT + 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Bs = lds;                          // [64][LDB] weights, kx zero-padded to 8
+    float* Ps = lds + 64 * LDB;               // [CIN][PH][PW]
+    float* Ts = Ps + CIN * PH * PW;           // [128 positions][SP_LDT] activated conv tile
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    for (int idx = t; idx < 64 * KT; idx += 256) {
+        const int n = idx / KT, rem = idx - n * KT;
+        const int kx = rem & 7, cky = rem >> 3;          // cky = c*KH + ky
+        float v = 0.f;
+        if (n < O && kx < KW) v = w[((long)n * CIN * KH + cky) * KW + kx];
+        Bs[n * LDB + rem] = v;
+    }
+    for (int idx = t; idx < CIN * PH * PW; idx += 256) Ps[idx] = 0.f;          // the pad columns stay zero for good
+    const int trow = 32 * wave + i;                       // this lane's position in the 2 x 64 tile
+    const float* pa = Ps + (STRIDE * (trow >> 6)) * PW + STRIDE * (trow & 63) + 4 * h;
+    const float* pb = Bs + i * LDB + 4 * h;
+    const float sc0 = i < O ? scale[i] : 0.f, sh0 = i < O ? shift[i] : 0.f;
+    const float sc1 = 32 + i < O ? scale[32 + i] : 0.f, sh1 = 32 + i < O ? shift[32 + i] : 0.f;
+    const int c4 = t & 15, pxa = t >> 4;                  // pooling items of this thread: (pxa, c4) and (pxa + 16, c4)
+    const int Ho2 = (H + 2 * PAD - KH) / STRIDE + 1;      // conv rows (== 64 for the 128-px stem), pooled rows Ho2 / 2
+    const int ntt = Ho2 / 2;
+
+    // Patch staging: 27 rows (3 channels x 9 input rows) of Wd = 128 floats = 864 16-B pieces, 4 per thread (the last
+    // partly idle), fetched one tile AHEAD into registers while the current tile multiplies.
+    float4 pre[4];
+    auto fetch_patch = [&](long img, int tt) {
+        const int iy0 = 2 * tt * STRIDE - PAD;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = t + 256 * q;
+            const int f4 = j & 31, py = (j >> 5) % PH, c = (j >> 5) / PH;
+            const int iy = iy0 + py;
+            pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < CIN * PH * 32 && iy >= 0 && iy < H) pre[q] = ld4(x + ((img * CIN + c) * H + iy) * (long)Wd + 4 * f4);
+        }
+    };
+    auto stash_patch = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = t + 256 * q;
+            if (j < CIN * PH * 32) {
+                float* d = Ps + (j >> 5) * PW + PAD + 4 * (j & 31);          // patch column = ix + PAD
+                d[0] = pre[q].x; d[1] = pre[q].y; d[2] = pre[q].z; d[3] = pre[q].w;
+            }
+        }
+    };
+    __syncthreads();                                      // Bs and the zeroed patch are in place
+    fetch_patch(blockIdx.x, 0);
+
+    for (long img = blockIdx.x; img < imgs; img += gridDim.x) {
+        float4 carry[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        for (int tt = 0; tt < ntt; ++tt) {
+            __syncthreads();                              // previous tile's fragment and Ts reads are done
+            stash_patch();
+            {
+                long nimg = img;
+                int nt2 = tt + 1;
+                if (nt2 == ntt) { nt2 = 0; nimg += gridDim.x; }
+                if (nimg >= imgs) nimg = blockIdx.x;       // past the end: a harmless re-read
+                fetch_patch(nimg, nt2);
+            }
+            asm volatile("" ::: "memory");                // keep the prefetch in front of the multiply
+            __syncthreads();
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            auto load_a = [&](int step) {
+                const float* ap = pa + ((step / KH) * PH + (step % KH)) * PW;
+                const float2 lo = *reinterpret_cast<const float2*>(ap);
+                const float2 hi = *reinterpret_cast<const float2*>(ap + 2);
+                return make_float4(lo.x, lo.y, hi.x, hi.y);
+            };
+            constexpr int NSTEP = CIN * KH;
+            float4 a = load_a(0), b0 = ld4(pb), b1 = ld4(pb + 32 * LDB);
+#pragma unroll
+            for (int step = 0; step < NSTEP; ++step) {
+                float4 na = a, nb0 = b0, nb1 = b1;
+                if (step + 1 < NSTEP) {
+                    na = load_a(step + 1);
+                    nb0 = ld4(pb + (step + 1) * 8);
+                    nb1 = ld4(pb + 32 * LDB + (step + 1) * 8);
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+                a = na; b0 = nb0; b1 = nb1;
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+            // norm0 + relu0 on the accumulators, tile to LDS (lane = channel, register = position)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+                Ts[rr * SP_LDT + i] = fmaxf(fmaf(acc0[r], sc0, sh0), 0.f);
+                Ts[rr * SP_LDT + 32 + i] = fmaxf(fmaf(acc1[r], sc1, sh1), 0.f);
+            }
+            __syncthreads();
+            // pool0: pooled row tt, two (px, 4-channel) items per thread
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int px = pxa + 16 * q;
+                float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;            // horizontal max of conv rows 2tt, 2tt+1
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int ox = 2 * px + dx;
+                    if (ox < 0) continue;                                        // ox <= 63 always
+                    const float4 v0 = ld4(&Ts[ox * SP_LDT + 4 * c4]);
+                    const float4 v1 = ld4(&Ts[(WO + ox) * SP_LDT + 4 * c4]);
+                    m0 = make_float4(fmaxf(m0.x, v0.x), fmaxf(m0.y, v0.y), fmaxf(m0.z, v0.z), fmaxf(m0.w, v0.w));
+                    m1 = make_float4(fmaxf(m1.x, v1.x), fmaxf(m1.y, v1.y), fmaxf(m1.z, v1.z), fmaxf(m1.w, v1.w));
+                }
+                const float4 cv = carry[q];
+                const float4 o4 = make_float4(fmaxf(fmaxf(cv.x, m0.x), m1.x), fmaxf(fmaxf(cv.y, m0.y), m1.y),
+                                              fmaxf(fmaxf(cv.z, m0.z), m1.z), fmaxf(fmaxf(cv.w, m0.w), m1.w));
+                carry[q] = m1;
+                if (4 * c4 < O)
+                    *reinterpret_cast<float4*>(out + ((img * (Ho2 / 2) + tt) * (long)(WO / 2) + px) * ldo + 4 * c4) = o4;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BN+ReLU+maxpool 3x3 s2 p1
+__global__ __launch_bounds__(256) void bnrelu_maxpool_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out,
+                                                             long ldo, long Mout, int C, int Hi, int Wi, int Ho, int Wo,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift) {
+    const long total = Mout * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long row = idx / C;
+        const int c = (int)(idx - row * C);
+        const long img = row / ((long)Ho * Wo);
+        const int rem = (int)(row - img * Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        const float sc = scale[c], sh = shift[c];
+        float m = 0.f;     // relu output is >= 0 and the window always holds a valid tap
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int iy = 2 * oy + dy;
+            if (iy < 0 || iy >= Hi) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int ix = 2 * ox + dx;
+                if (ix < 0 || ix >= Wi) continue;
+                m = fmaxf(m, fmaf(in[((img * Hi + iy) * Wi + ix) * ldi + c], sc, sh));
+            }
+        }
+        out[row * ldo + c] = m;
+    }
+}
+
+// same, 4 channels per thread with 16-B accesses (C % 4 == 0, aligned pointers / leading dimensions)
+__global__ __launch_bounds__(256) void bnrelu_maxpool_vec4_kernel(const float* __restrict__ in, long ldi,
+                                                                  float* __restrict__ out, long ldo, long Mout, int C4,
+                                                                  int Hi, int Wi, int Ho, int Wo,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift) {
+    const long total = Mout * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long row = idx / C4;
+        const int c = 4 * (int)(idx - row * C4);
+        const long img = row / ((long)Ho * Wo);
+        const int rem = (int)(row - img * Ho * Wo);
+        const int oy = rem / Wo, ox = rem - oy * Wo;
+        const float4 sc = ld4(scale + c), sh = ld4(shift + c);
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int iy = 2 * oy + dy;
+            if (iy < 0 || iy >= Hi) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int ix = 2 * ox + dx;
+                if (ix < 0 || ix >= Wi) continue;
+                const float4 v = ld4(in + ((img * Hi + iy) * Wi + ix) * ldi + c);
+                m.x = fmaxf(m.x, fmaf(v.x, sc.x, sh.x));
+                m.y = fmaxf(m.y, fmaf(v.y, sc.y, sh.y));
+                m.z = fmaxf(m.z, fmaf(v.z, sc.z, sh.z));
+                m.w = fmaxf(m.w, fmaf(v.w, sc.w, sh.w));
+            }
+        }
+        *reinterpret_cast<float4*>(out + row * ldo + c) = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BN+ReLU+global average pool
+// out[img][c] = mean over the S2 positions of relu(x*scale+shift)
+__global__ __launch_bounds__(256) void bnrelu_avgpool_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out,
+                                                             long ldo, int C, int S2, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const long img = blockIdx.x;
+    float acc = 0.f;
+    if (c < C) {
+        const float sc = scale[c], sh = shift[c];
+        for (int r = rl; r < S2; r += 4) acc += fmaxf(fmaf(in[(img * S2 + r) * ldi + c], sc, sh), 0.f);
+    }
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < C)
+        out[img * ldo + c] = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) / (float)S2;
+}
+
+}  // namespace
+
+// x [imgs][Cin][H][W] (NCHW, as the datasets deliver patches) -> out [imgs*Ho*Wo][O] channels-last (ldc)
+GNX_EXPORT int gnx_conv_stem(const float* x, const float* w, float* out, long ldc, long imgs, int Cin, int H, int W,
+                             int O, int KH, int KW, int stride, int pad, hipStream_t stream) {
+    if (!x || !w || !out || imgs < 0 || Cin <= 0 || O <= 0 || KH <= 0 || KH > 7 || KW <= 0 || KW > 8 || stride <= 0 ||
+        ldc < O)
+        return GNX_ERR_BAD_ARG;
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return GNX_ERR_BAD_ARG;
+    const long M = imgs * Ho * Wo;
+    if (M == 0) return GNX_OK;
+    if (O <= 64 && Cin == 3 && ((stride == 2 && KH == 7 && KW == 7) || (stride == 1 && KH == 3 && KW == 3))) {
+        const int tiles_x = gnx_cdiv(Wo, 16), tiles_y = gnx_cdiv(Ho, 8);
+        const long ntiles = imgs * tiles_x * tiles_y;
+        const int PH = 7 * stride + KH, PW = (15 * stride + 8 + 1) & ~1;
+        const size_t lds2 = ((size_t)64 * (Cin * KH * 8 + 4) + (size_t)Cin * PH * PW) * sizeof(float);
+        const int grid2 = (int)(ntiles < 256 * 3 ? ntiles : 256 * 3);
+        if (stride == 2)
+            conv_stem_patch_kernel<2, 7, 3><<<grid2, 256, lds2, stream>>>(x, w, out, ldc, Cin, H, W, Ho, Wo, O, KW, pad,
+                                                                      tiles_x, tiles_y, ntiles);
+        else
+            conv_stem_patch_kernel<1, 3, 3><<<grid2, 256, lds2, stream>>>(x, w, out, ldc, Cin, H, W, Ho, Wo, O, KW, pad,
+                                                                      tiles_x, tiles_y, ntiles);
+        return gnx_launch_status();
+    }
+    const size_t lds_bytes = (size_t)(ST_BM + ST_BN) * (KH * 8 + 4) * sizeof(float);
+    dim3 grid(gnx_cdiv(M, ST_BM), gnx_cdiv(O, ST_BN));
+    conv_stem_kernel<<<grid, 256, lds_bytes, stream>>>(x, w, out, ldc, M, Cin, H, W, Ho, Wo, O, KH, KW, stride, pad);
+    return gnx_launch_status();
+}
+
+// x [imgs][3][H][W] (NCHW patches), w [O][3][7][7] -> out [imgs*(Ho/2)*(Wo/2)][O] (ldo):
+// maxpool3x3s2p1(relu(scale * conv7x7s2p3(x) + shift)) without the intermediate map.  Supported geometry: Cin = 3, the
+// conv output is 64 wide and even-high (128-px patches), O <= 64 and O % 4 == 0; anything else returns
+// GNX_ERR_UNSUPPORTED and the caller runs gnx_conv_stem + gnx_bnrelu_maxpool.
+GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool(const float* x, const float* w, float* out, long ldo, long imgs, int Cin,
+                                            int H, int W, int O, int KH, int KW, int stride, int pad, const float* scale,
+                                            const float* shift, hipStream_t stream) {
+    if (!x || !w || !out || !scale || !shift || imgs < 0 || Cin <= 0 || O <= 0 || H <= 0 || W <= 0 || ldo < O)
+        return GNX_ERR_BAD_ARG;
+    if (Cin != 3 || KH != 7 || KW != 7 || stride != 2 || pad != 3 || O > 64 || O % 4 != 0 || ldo % 4 != 0 || !al16(out))
+        return GNX_ERR_UNSUPPORTED;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    if (Wo != 64 || W != 128 || Ho % 2 != 0 || Ho <= 0 || !al16(x)) return GNX_ERR_UNSUPPORTED;    // 16-B row pieces
+    if (imgs == 0) return GNX_OK;
+    const size_t lds_bytes = ((size_t)64 * (3 * 7 * 8 + 4) + (size_t)3 * 9 * 136 + (size_t)128 * SP_LDT) * sizeof(float);
+    static bool conf = false;
+    if (!conf) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return GNX_ERR_LAUNCH;
+        conf = true;
+    }
+    const int grid = (int)(imgs < 256 ? imgs : 256);
+    conv_stem_pool_kernel<<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale, shift, imgs);
+    return gnx_launch_status();
+}
+
+// in [imgs*Hi*Wi][C] (ldi) -> out [imgs*Ho*Wo][C] (ldo): max over 3x3 s2 p1 windows of relu(in*scale+shift)
+GNX_EXPORT int gnx_bnrelu_maxpool(const float* in, long ldi, float* out, long ldo, long imgs, int C, int Hi, int Wi,
+                                  const float* scale, const float* shift, hipStream_t stream) {
+    if (!in || !out || !scale || !shift || imgs < 0 || C <= 0 || Hi <= 0 || Wi <= 0 || ldi < C || ldo < C)
+        return GNX_ERR_BAD_ARG;
+    const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+    const long Mout = imgs * Ho * Wo;
+    if (Mout == 0) return GNX_OK;
+    if (C % 4 == 0 && ldi % 4 == 0 && ldo % 4 == 0 && al16(in) && al16(out) && al16(scale) && al16(shift)) {
+        long blocks = (Mout * (C / 4) + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        bnrelu_maxpool_vec4_kernel<<<(int)blocks, 256, 0, stream>>>(in, ldi, out, ldo, Mout, C / 4, Hi, Wi, Ho, Wo,
+                                                                     scale, shift);
+        return gnx_launch_status();
+    }
+    long blocks = (Mout * C + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    bnrelu_maxpool_kernel<<<(int)blocks, 256, 0, stream>>>(in, ldi, out, ldo, Mout, C, Hi, Wi, Ho, Wo, scale, shift);
+    return gnx_launch_status();
+}
+
+// in [imgs*S2][C] (ldi) -> out [imgs][C] (ldo): mean over positions of relu(in*scale+shift)
+GNX_EXPORT int gnx_bnrelu_avgpool(const float* in, long ldi, float* out, long ldo, long imgs, int C, int S2,
+                                  const float* scale, const float* shift, hipStream_t stream) {
+    if (!in || !out || !scale || !shift || imgs < 0 || C <= 0 || S2 <= 0 || ldi < C || ldo < C) return GNX_ERR_BAD_ARG;
+    if (imgs == 0) return GNX_OK;
+    if (imgs > 2147483647L) return GNX_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)imgs, gnx_cdiv(C, 64));
+    bnrelu_avgpool_kernel<<<grid, 256, 0, stream>>>(in, ldi, out, ldo, C, S2, scale, shift);
+    return gnx_launch_status();
+}

@@ -7,7 +7,7 @@ Drop-in for `gridnext.densenet.DenseNet` (/root/reference/gridnext/densenet.py:7
 
 The module tree below holds PARAMETERS ONLY (stock torch containers, so `.to()`, `.train()`, `state_dict()`
 and optimizers behave as for the reference).  `forward` does not call them: it drives the hand-written gfx950
-kernels of csrc/densenet_fwd.hip through the C ABI:
+kernels of csrc/conv1x1.hip, conv3x3.hip and stem_pool.hip through the C ABI:
   * activations are channels-last matrices [spots*S*S, C]; a dense block is ONE buffer, each layer writes its
     `growth_rate` columns in place, so the reference's `torch.cat` (:14, :75) never happens;
   * BN+ReLU are folded into the operand load of the following conv; the transition averages 2x2 first;
