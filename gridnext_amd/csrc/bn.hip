@@ -272,9 +272,15 @@ __global__ __launch_bounds__(256) void bn_bwd_eval_fused_kernel(const float* __r
             float ds[4] = {dv.x, dv.y, dv.z, dv.w}, o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (relu && fmaf(xs[e], scs[e], shs[e]) <= 0.f) ds[e] = 0.f;
+                float xe = xs[e];
+                if (relu == 2) {                            // x holds a = relu(scale x + shift): mask = a > 0, and where
+                    if (xe <= 0.f) ds[e] = 0.f;             // the mask is set x = (a - shift) / scale (scale != 0)
+                    xe = (xe - shs[e]) / scs[e];
+                } else if (relu && fmaf(xe, scs[e], shs[e]) <= 0.f) {
+                    ds[e] = 0.f;
+                }
                 s1[e] += ds[e];
-                s2[e] = fmaf(ds[e], (xs[e] - mus[e]) * iss[e], s2[e]);
+                s2[e] = fmaf(ds[e], (xe - mus[e]) * iss[e], s2[e]);
                 o[e] = scs[e] * ds[e];
             }
             if (dx) {
@@ -380,6 +386,7 @@ GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long 
                              reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(scale) |
                              reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(save_mean) |
                              reinterpret_cast<uintptr_t>(save_invstd)) & 15) == 0;
+        if (relu == 2 && (training || !v4all)) return GNX_ERR_UNSUPPORTED;     // activated-input form: eval statistics only
         if (!training && v4all) {
             // one pass: dx and the dgamma/dbeta column sums together
             bn_bwd_eval_fused_kernel<<<grid, 256, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale, shift, save_mean,

@@ -45,6 +45,13 @@ def _bn(model_bn, X_ptr, ld, M, training, dev, st):
     return stats
 
 
+def gammas_nonzero(model):
+    """True when no norm2 weight of the network is exactly zero: one device reduction and one host read per forward (the
+    activated-bottleneck form of the training forward cannot recover x_hat where gamma == 0)."""
+    w = torch.cat([l.norm2.weight.detach().reshape(-1) for _, ls, _, _ in model._blocks for l in ls])
+    return bool((w != 0).all().item())
+
+
 class _DenseNetFn(Function):
     @staticmethod
     def forward(ctx, model, x, *params):
@@ -75,7 +82,8 @@ class _DenseNetFn(Function):
             L.call('gnx_bnrelu_maxpool', L.ptr(stem_out), c0, L.ptr(bufs[0]), ld1, N, c0, hs, hs, L.ptr(s0[0]),
                    L.ptr(s0[1]), st)
             tape.stem_out, tape.stats0 = stem_out, s0
-        tape.layers = []          # per block: list of (bott, stats1, stats2, w2 repacked)
+        tape.layers = []          # per block: list of (bott, stats1, stats2, bottleneck stored activated?)
+        act_ok = (not training) and gammas_nonzero(model)
         tape.trans = []           # per block: stats of the transition BN (or None)
         for bi, ((c_in, layers, trans, c_total), s) in enumerate(zip(model._blocks, sizes)):
             buf = bufs[bi]
@@ -85,14 +93,32 @@ class _DenseNetFn(Function):
                 cin = c_in + li * g
                 s1 = _bn(layer.norm1, L.ptr(buf), c_total, M, training, dev, st)
                 bott = torch.empty((M, mid), device=dev, dtype=F32)
-                L.call('gnx_conv1x1_bnrelu', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid, M, mid,
-                       cin, L.ptr(s1[0]), L.ptr(s1[1]), 0, 0, st)
-                s2 = _bn(layer.norm2, L.ptr(bott), mid, M, training, dev, st)
-                w2 = torch.empty((9, g, mid), device=dev, dtype=F32)
-                L.call('gnx_repack_conv3x3', L.ptr(layer.conv2.weight.detach().contiguous()), L.ptr(w2), g, mid, st)
-                L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2), _cols(buf, cin), c_total, M, g, mid, s,
-                       L.ptr(s2[0]), L.ptr(s2[1]), st)
-                recs.append((bott, s1, s2))
+                w2c = layer.conv2.weight.detach().contiguous()
+                # Eval statistics (training.py:126 puts f in eval mode even when it is trained): norm2's affine map is known
+                # before conv1 runs, so the bottleneck is stored ACTIVATED - conv2 then runs its prologue-free LDS-DMA
+                # form and its weight gradient needs no prologue; the BN adjoint recovers mask and
+                # x_hat from the activated values (needs scale != 0, i.e. gamma != 0, checked once per layer).
+                activated = act_ok
+                if activated:
+                    s2 = _bn(layer.norm2, None, mid, M, False, dev, st)
+                    L.call('gnx_conv1x1_bnrelu_act', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid, M,
+                           mid, cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s2[0]), L.ptr(s2[1]), st)
+                    # the direct form, not Winograd: a rounding-level change of a pre-activation that sits exactly at 0
+                    # flips a ReLU mask of the next layer and with it a visible part of a gradient (measured on the
+                    # closed-form test net: 1 % of one norm1.bias gradient); the frozen eval forward has no such cliff
+                    w2 = torch.empty((9, g, mid), device=dev, dtype=F32)
+                    L.call('gnx_repack_conv3x3', L.ptr(w2c), L.ptr(w2), g, mid, st)
+                    L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2), _cols(buf, cin), c_total, M, g, mid, s,
+                           None, None, st)
+                else:
+                    L.call('gnx_conv1x1_bnrelu', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid, M, mid,
+                           cin, L.ptr(s1[0]), L.ptr(s1[1]), 0, 0, st)
+                    s2 = _bn(layer.norm2, L.ptr(bott), mid, M, training, dev, st)
+                    w2 = torch.empty((9, g, mid), device=dev, dtype=F32)
+                    L.call('gnx_repack_conv3x3', L.ptr(w2c), L.ptr(w2), g, mid, st)
+                    L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2), _cols(buf, cin), c_total, M, g, mid, s,
+                           L.ptr(s2[0]), L.ptr(s2[1]), st)
+                recs.append((bott, s1, s2, activated))
             tape.layers.append(recs)
             if trans is not None:
                 nxt = bufs[bi + 1]
@@ -142,12 +168,12 @@ class _DenseNetFn(Function):
             grads[p] = t
             return t
 
-        def bn_bwd(bn, stats, dy_ptr, lddy, x_ptr, ldx, dx_ptr, lddx, M, C, dx_acc):
+        def bn_bwd(bn, stats, dy_ptr, lddy, x_ptr, ldx, dx_ptr, lddx, M, C, dx_acc, relu=1):
             dg = new_like(bn.weight) if want(bn.weight) else None
             db = new_like(bn.bias) if want(bn.bias) else None
             ws = torch.empty(L.query('gnx_bn_workspace', M, C), device=dev, dtype=F32)
             L.call('gnx_bn_relu_bwd', dy_ptr, lddy, x_ptr, ldx, dx_ptr, lddx, M, C, L.ptr(stats[0]), L.ptr(stats[1]),
-                   L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(dg), L.ptr(db), 1, 1 if training else 0, 0, dx_acc,
+                   L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(dg), L.ptr(db), relu, 1 if training else 0, 0, dx_acc,
                    L.ptr(ws), st)
 
         def wgrad(w, dy_ptr, lddy, x_ptr, ldx, stats, M, Nn, K, S, taps, pool):
@@ -155,8 +181,9 @@ class _DenseNetFn(Function):
                 return
             dw = new_like(w)
             ws = torch.empty(L.query('gnx_wgrad_workspace', M, Nn, K, taps), device=dev, dtype=F32)
-            L.call('gnx_wgrad_bnrelu', dy_ptr, lddy, x_ptr, ldx, L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(dw), L.ptr(ws),
-                   M, Nn, K, S, taps, pool, 0, st)
+            sc, sh = (L.ptr(stats[0]), L.ptr(stats[1])) if stats is not None else (None, None)
+            L.call('gnx_wgrad_bnrelu', dy_ptr, lddy, x_ptr, ldx, sc, sh, L.ptr(dw), L.ptr(ws), M, Nn, K, S, taps, pool, 0,
+                   st)
 
         # ---- classifier
         c_last = model.num_features
@@ -201,16 +228,18 @@ class _DenseNetFn(Function):
             tC = torch.empty((M, c_total), device=dev, dtype=F32)
             for li in range(len(layers) - 1, -1, -1):
                 layer = layers[li]
-                bott, s1, s2 = tape.layers[bi][li]
+                bott, s1, s2, activated = tape.layers[bi][li]
                 cin = c_in + li * g
                 dy2 = _cols(dbuf, cin)
-                # conv2: weight gradient, then data gradient (adjoint conv with flipped taps)
-                wgrad(layer.conv2.weight, dy2, c_total, L.ptr(bott), mid, s2, M, g, mid, s, 9, 0)
+                # conv2: weight gradient (no prologue when the bottleneck was stored activated), then data gradient
+                # (adjoint conv with flipped taps)
+                wgrad(layer.conv2.weight, dy2, c_total, L.ptr(bott), mid, None if activated else s2, M, g, mid, s, 9, 0)
                 wb = torch.empty((9, mid, g), device=dev, dtype=F32)
                 L.call('gnx_repack_conv3x3_bwd', L.ptr(layer.conv2.weight.detach().contiguous()), L.ptr(wb), g, mid, st)
                 L.call('gnx_conv3x3_bnrelu', dy2, c_total, L.ptr(wb), L.ptr(tA), mid, M, mid, g, s, None, None, st)
                 # norm2 + relu2
-                bn_bwd(layer.norm2, s2, L.ptr(tA), mid, L.ptr(bott), mid, L.ptr(tB), mid, M, mid, 0)
+                bn_bwd(layer.norm2, s2, L.ptr(tA), mid, L.ptr(bott), mid, L.ptr(tB), mid, M, mid, 0,
+                       relu=2 if activated else 1)
                 # conv1
                 wgrad(layer.conv1.weight, L.ptr(tB), mid, L.ptr(buf), c_total, s1, M, mid, cin, s, 1, 0)
                 w1t = torch.empty((cin, mid), device=dev, dtype=F32)

@@ -53,6 +53,8 @@ int gnx_bn_fold_eval(int C, const float* gamma, const float* beta, const float* 
                      float* save_invstd, gnx_stream_t stream);
 int gnx_scale_shift_relu(const float* x, long ldx, float* y, long ldy, long M, int C, const float* scale,
                          const float* shift, int relu, gnx_stream_t stream);
+/* relu: 0 = plain BN, 1 = BN -> ReLU with x the BN input, 2 = BN -> ReLU with x holding the ACTIVATED output
+ * relu(scale x + shift) (eval statistics only, scale != 0: the forward stored the bottleneck that way). */
 int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long ldx, float* dx, long lddx, long M, int C,
                     const float* scale, const float* shift, const float* save_mean, const float* save_invstd,
                     float* dgamma, float* dbeta, int relu, int training, int accumulate, int dx_accumulate,
