@@ -34,7 +34,7 @@ H, W, GENES, CLASSES = 78, 64, 2000, 8
 DENSENET121 = dict(growth_rate=32, block_config=(6, 12, 24, 16), num_init_features=64, bn_size=4, drop_rate=0,
                    small_inputs=False)
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PMC_TRAFFIC_FILE = 'r01h_pmc_traffic.json'
+PMC_TRAFFIC_FILE = 'r01i_pmc_traffic.json'
 
 
 def conv3x3_flops_per_spot(patch):
