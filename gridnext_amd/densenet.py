@@ -335,7 +335,9 @@ class DenseNet(nn.Module):
                         nxt = bufs[bi + 1]
                         so = s // 2
                         sct, sht = fold[trans.norm]
-                        L.call('gnx_conv1x1_bnrelu' + sfx, L.ptr(rows), c_total, L.ptr(trans.conv.weight),
+                        # transitions are HBM-bound (4x the input bytes of their output): the fp32 wave-specialised
+                        # kernel serves both matrix precisions
+                        L.call('gnx_conv1x1_bnrelu', L.ptr(rows), c_total, L.ptr(trans.conv.weight),
                                L.ptr(nxt[u0 * so * so:]), nxt.shape[1], nu * so * so, trans.conv.out_channels,
                                c_total, L.ptr(sct), L.ptr(sht), 1, s, st)
             scf, shf = fold[self.features.norm_final]
