@@ -192,12 +192,19 @@ __global__ __launch_bounds__(256) void conv_stem_patch_kernel(const float* __res
 // relu >= 0, so "outside the map" contributes 0 exactly as in gnx_bnrelu_maxpool.
 constexpr int SP_LDT = 72;         // floats per position of the activated tile in LDS: 4 * 72 = 32 (mod 64) banks, so the
                                    // two lane halves of an accumulator store (positions p and p + 4) hit disjoint banks
+// WO = width of the conv0 map: 64 (128-px patches: tiles of 2 rows, one pooled row each, one carried row) or 128
+// (256-px patches: tiles of 1 row; a pooled row is emitted on every odd conv row from the two carried rows and the new one).
+template <int WO>
 __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              float* __restrict__ out, long ldo, int H, int Wd, int O,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift, long imgs) {
-    constexpr int CIN = 3, KH = 7, KW = 7, STRIDE = 2, PAD = 3, WO = 64;
-    constexpr int PH = STRIDE + KH, PW = (63 * STRIDE + 8 + 1 + 1) & ~1;       // 9 x 136 input patch per channel
+    constexpr int CIN = 3, KH = 7, KW = 7, STRIDE = 2, PAD = 3;
+    constexpr int RT = 128 / WO;                          // conv rows per tile
+    constexpr int PH = STRIDE * (RT - 1) + KH, PW = ((WO - 1) * STRIDE + 8 + 1 + 1) & ~1;      // input patch per channel
+    constexpr int F4R = WO * STRIDE / 4;                  // 16-B pieces per input row (row width 2 WO)
+    constexpr int NPC = CIN * PH * F4R, NPRE = (NPC + 255) / 256;       // patch pieces, per thread
+    constexpr int NIT = (WO / 2) * 16 / 256;              // pooling items per thread: (pooled x, 4 channels)
     constexpr int KT = CIN * KH * 8, LDB = KT + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Bs = lds;                          // [64][LDB] weights, kx zero-padded to 8
@@ -212,35 +219,35 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __rest
         Bs[n * LDB + rem] = v;
     }
     for (int idx = t; idx < CIN * PH * PW; idx += 256) Ps[idx] = 0.f;          // the pad columns stay zero for good
-    const int trow = 32 * wave + i;                       // this lane's position in the 2 x 64 tile
-    const float* pa = Ps + (STRIDE * (trow >> 6)) * PW + STRIDE * (trow & 63) + 4 * h;
+    const int trow = 32 * wave + i;                       // this lane's position in the RT x WO tile
+    const float* pa = Ps + (STRIDE * (trow / WO)) * PW + STRIDE * (trow % WO) + 4 * h;
     const float* pb = Bs + i * LDB + 4 * h;
     const float sc0 = i < O ? scale[i] : 0.f, sh0 = i < O ? shift[i] : 0.f;
     const float sc1 = 32 + i < O ? scale[32 + i] : 0.f, sh1 = 32 + i < O ? shift[32 + i] : 0.f;
-    const int c4 = t & 15, pxa = t >> 4;                  // pooling items of this thread: (pxa, c4) and (pxa + 16, c4)
-    const int Ho2 = (H + 2 * PAD - KH) / STRIDE + 1;      // conv rows (== 64 for the 128-px stem), pooled rows Ho2 / 2
-    const int ntt = Ho2 / 2;
+    const int c4 = t & 15, pxa = t >> 4;                  // pooling items of this thread: (pxa + 16 q, c4)
+    const int Ho2 = (H + 2 * PAD - KH) / STRIDE + 1;      // conv rows (even), pooled rows Ho2 / 2
+    const int ntt = Ho2 / RT;                             // tiles per image
 
-    // Patch staging: 27 rows (3 channels x 9 input rows) of Wd = 128 floats = 864 16-B pieces, 4 per thread (the last
-    // partly idle), fetched one tile AHEAD into registers while the current tile multiplies.
-    float4 pre[4];
+    // Patch staging: CIN * PH input rows of 2 WO floats as 16-B pieces, fetched one tile AHEAD into registers while the
+    // current tile multiplies.
+    float4 pre[NPRE];
     auto fetch_patch = [&](long img, int tt) {
-        const int iy0 = 2 * tt * STRIDE - PAD;
+        const int iy0 = RT * tt * STRIDE - PAD;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NPRE; ++q) {
             const int j = t + 256 * q;
-            const int f4 = j & 31, py = (j >> 5) % PH, c = (j >> 5) / PH;
+            const int f4 = j % F4R, py = (j / F4R) % PH, c = (j / F4R) / PH;
             const int iy = iy0 + py;
             pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < CIN * PH * 32 && iy >= 0 && iy < H) pre[q] = ld4(x + ((img * CIN + c) * H + iy) * (long)Wd + 4 * f4);
+            if (j < NPC && iy >= 0 && iy < H) pre[q] = ld4(x + ((img * CIN + c) * H + iy) * (long)Wd + 4 * f4);
         }
     };
     auto stash_patch = [&]() {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NPRE; ++q) {
             const int j = t + 256 * q;
-            if (j < CIN * PH * 32) {
-                float* d = Ps + (j >> 5) * PW + PAD + 4 * (j & 31);          // patch column = ix + PAD
+            if (j < NPC) {
+                float* d = Ps + (j / F4R) * PW + PAD + 4 * (j % F4R);        // patch column = ix + PAD
                 d[0] = pre[q].x; d[1] = pre[q].y; d[2] = pre[q].z; d[3] = pre[q].w;
             }
         }
@@ -249,7 +256,9 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __rest
     fetch_patch(blockIdx.x, 0);
 
     for (long img = blockIdx.x; img < imgs; img += gridDim.x) {
-        float4 carry[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        float4 carry[NIT], carry2[NIT];                   // horizontal maxima of the last (and, WO = 128, second-last) row
+#pragma unroll
+        for (int q = 0; q < NIT; ++q) carry[q] = carry2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int tt = 0; tt < ntt; ++tt) {
             __syncthreads();                              // previous tile's fragment and Ts reads are done
             stash_patch();
@@ -301,26 +310,41 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __rest
                 Ts[rr * SP_LDT + 32 + i] = fmaxf(fmaf(acc1[r], sc1, sh1), 0.f);
             }
             __syncthreads();
-            // pool0: pooled row tt, two (px, 4-channel) items per thread
+            // pool0
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < NIT; ++q) {
                 const int px = pxa + 16 * q;
-                float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;            // horizontal max of conv rows 2tt, 2tt+1
+                float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;            // horizontal maxima of the tile's rows
 #pragma unroll
                 for (int dx = -1; dx <= 1; ++dx) {
                     const int ox = 2 * px + dx;
-                    if (ox < 0) continue;                                        // ox <= 63 always
+                    if (ox < 0) continue;                                        // ox <= WO - 1 always
                     const float4 v0 = ld4(&Ts[ox * SP_LDT + 4 * c4]);
-                    const float4 v1 = ld4(&Ts[(WO + ox) * SP_LDT + 4 * c4]);
                     m0 = make_float4(fmaxf(m0.x, v0.x), fmaxf(m0.y, v0.y), fmaxf(m0.z, v0.z), fmaxf(m0.w, v0.w));
-                    m1 = make_float4(fmaxf(m1.x, v1.x), fmaxf(m1.y, v1.y), fmaxf(m1.z, v1.z), fmaxf(m1.w, v1.w));
+                    if (RT == 2) {
+                        const float4 v1 = ld4(&Ts[(WO + ox) * SP_LDT + 4 * c4]);
+                        m1 = make_float4(fmaxf(m1.x, v1.x), fmaxf(m1.y, v1.y), fmaxf(m1.z, v1.z), fmaxf(m1.w, v1.w));
+                    }
                 }
-                const float4 cv = carry[q];
-                const float4 o4 = make_float4(fmaxf(fmaxf(cv.x, m0.x), m1.x), fmaxf(fmaxf(cv.y, m0.y), m1.y),
-                                              fmaxf(fmaxf(cv.z, m0.z), m1.z), fmaxf(fmaxf(cv.w, m0.w), m1.w));
-                carry[q] = m1;
-                if (4 * c4 < O)
-                    *reinterpret_cast<float4*>(out + ((img * (Ho2 / 2) + tt) * (long)(WO / 2) + px) * ldo + 4 * c4) = o4;
+                if (RT == 2) {                            // rows 2tt, 2tt+1 + the carried row 2tt-1 -> pooled row tt
+                    const float4 cv = carry[q];
+                    const float4 o4 = make_float4(fmaxf(fmaxf(cv.x, m0.x), m1.x), fmaxf(fmaxf(cv.y, m0.y), m1.y),
+                                                  fmaxf(fmaxf(cv.z, m0.z), m1.z), fmaxf(fmaxf(cv.w, m0.w), m1.w));
+                    carry[q] = m1;
+                    if (4 * c4 < O)
+                        *reinterpret_cast<float4*>(out + ((img * (Ho2 / 2) + tt) * (long)(WO / 2) + px) * ldo + 4 * c4) = o4;
+                } else {                                  // one row per tile: emit pooled row (tt-1)/2 on odd rows
+                    if (tt & 1) {
+                        const float4 c2 = carry2[q], c1 = carry[q];
+                        const float4 o4 = make_float4(fmaxf(fmaxf(c2.x, c1.x), m0.x), fmaxf(fmaxf(c2.y, c1.y), m0.y),
+                                                      fmaxf(fmaxf(c2.z, c1.z), m0.z), fmaxf(fmaxf(c2.w, c1.w), m0.w));
+                        if (4 * c4 < O)
+                            *reinterpret_cast<float4*>(out + ((img * (Ho2 / 2) + (tt >> 1)) * (long)(WO / 2) + px) * ldo +
+                                                       4 * c4) = o4;
+                    }
+                    carry2[q] = carry[q];
+                    carry[q] = m0;
+                }
             }
         }
     }
@@ -443,7 +467,7 @@ GNX_EXPORT int gnx_conv_stem(const float* x, const float* w, float* out, long ld
 
 // x [imgs][3][H][W] (NCHW patches), w [O][3][7][7] -> out [imgs*(Ho/2)*(Wo/2)][O] (ldo):
 // maxpool3x3s2p1(relu(scale * conv7x7s2p3(x) + shift)) without the intermediate map.  Supported geometry: Cin = 3, the
-// conv output is 64 wide and even-high (128-px patches), O <= 64 and O % 4 == 0; anything else returns
+// conv output is 64 or 128 wide and even-high (128- / 256-px patches), O <= 64 and O % 4 == 0; anything else returns
 // GNX_ERR_UNSUPPORTED and the caller runs gnx_conv_stem + gnx_bnrelu_maxpool.
 GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool(const float* x, const float* w, float* out, long ldo, long imgs, int Cin,
                                             int H, int W, int O, int KH, int KW, int stride, int pad, const float* scale,
@@ -453,18 +477,31 @@ GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool(const float* x, const float* w, floa
     if (Cin != 3 || KH != 7 || KW != 7 || stride != 2 || pad != 3 || O > 64 || O % 4 != 0 || ldo % 4 != 0 || !al16(out))
         return GNX_ERR_UNSUPPORTED;
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-    if (Wo != 64 || W != 128 || Ho % 2 != 0 || Ho <= 0 || !al16(x)) return GNX_ERR_UNSUPPORTED;    // 16-B row pieces
+    if ((Wo != 64 && Wo != 128) || W != 2 * Wo || Ho % 2 != 0 || Ho <= 0 || !al16(x))
+        return GNX_ERR_UNSUPPORTED;                        // 16-B row pieces, whole 128-position tiles
     if (imgs == 0) return GNX_OK;
-    const size_t lds_bytes = ((size_t)64 * (3 * 7 * 8 + 4) + (size_t)3 * 9 * 136 + (size_t)128 * SP_LDT) * sizeof(float);
-    static bool conf = false;
-    if (!conf) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return GNX_ERR_LAUNCH;
-        conf = true;
-    }
+    const int RT = 128 / Wo, PH = 2 * (RT - 1) + 7, PW = ((Wo - 1) * 2 + 8 + 2) & ~1;
+    const size_t lds_bytes = ((size_t)64 * (3 * 7 * 8 + 4) + (size_t)3 * PH * PW + (size_t)128 * SP_LDT) * sizeof(float);
     const int grid = (int)(imgs < 256 ? imgs : 256);
-    conv_stem_pool_kernel<<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale, shift, imgs);
+    if (Wo == 64) {
+        static bool conf = false;
+        if (!conf) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel<64>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+                return GNX_ERR_LAUNCH;
+            conf = true;
+        }
+        conv_stem_pool_kernel<64><<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale, shift, imgs);
+    } else {
+        static bool conf = false;
+        if (!conf) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel<128>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+                return GNX_ERR_LAUNCH;
+            conf = true;
+        }
+        conv_stem_pool_kernel<128><<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale, shift, imgs);
+    }
     return gnx_launch_status();
 }
 

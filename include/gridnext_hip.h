@@ -107,8 +107,8 @@ int gnx_conv3x3_winograd(const float* A, long lda, const float* Wu, float* out, 
                          gnx_stream_t stream);
 int gnx_conv_stem(const float* x, const float* w, float* out, long ldc, long imgs, int Cin, int H, int W, int O,
                   int KH, int KW, int stride, int pad, gnx_stream_t stream);
-/* conv0 -> norm0 -> relu0 -> pool0 (:105-110) fused for the 128-px geometry (conv map 64 wide): the conv0 map never goes to
- * HBM.  Returns GNX_ERR_UNSUPPORTED for any other geometry: run gnx_conv_stem + gnx_bnrelu_maxpool then. */
+/* conv0 -> norm0 -> relu0 -> pool0 (:105-110) fused for the 128- and 256-px geometries (conv map 64 or 128 wide, even
+ * height, W = 2 Wo): the conv0 map never goes to HBM.  Returns GNX_ERR_UNSUPPORTED for any other geometry: run gnx_conv_stem + gnx_bnrelu_maxpool then. */
 int gnx_conv_stem_bnrelu_maxpool(const float* x, const float* w, float* out, long ldo, long imgs, int Cin, int H, int W,
                                  int O, int KH, int KW, int stride, int pad, const float* scale, const float* shift,
                                  gnx_stream_t stream);

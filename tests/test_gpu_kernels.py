@@ -312,20 +312,22 @@ def test_conv3x3_bnrelu(L, n, S, K, N, act):
     assert float(out[:, :3].min()) == 7.0 and float(out[:, 3 + N:].min()) == 7.0     # neighbours untouched
 
 
-@pytest.mark.parametrize("n,O", [(3, 64), (300, 64), (2, 32)])
-def test_stem_fused_with_norm0_relu0_pool0(L, n, O):
-    """conv0 -> norm0 -> relu0 -> pool0 in one kernel (128-px geometry) vs torch; other geometries must say UNSUPPORTED."""
+@pytest.mark.parametrize("n,O,P", [(3, 64, 128), (300, 64, 128), (2, 32, 128), (3, 64, 256), (270, 64, 256), (2, 32, 256)])
+def test_stem_fused_with_norm0_relu0_pool0(L, n, O, P):
+    """conv0 -> norm0 -> relu0 -> pool0 in one kernel (128- and 256-px geometry) vs torch; other geometries must say
+    UNSUPPORTED."""
     g = torch.Generator().manual_seed(n + O)
-    x = torch.rand(n, 3, 128, 128, generator=g)
+    x = torch.rand(n, 3, P, P, generator=g)
     W = torch.randn(O, 3, 7, 7, generator=g) * 0.1
     sc, sh = torch.rand(O, generator=g) + 0.5, torch.randn(O, generator=g) * 0.2
     ref = F.max_pool2d(torch.relu(F.conv2d(x, W, stride=2, padding=3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)),
                        3, 2, 1)
     xd, Wd, scd, shd = x.to(DEV), W.to(DEV), sc.to(DEV), sh.to(DEV)
-    out = torch.full((n * 32 * 32, O + 8), 7.0, device=DEV)
-    L.call('gnx_conv_stem_bnrelu_maxpool', L.ptr(xd), L.ptr(Wd), L.ptr(out), O + 8, n, 3, 128, 128, O, 7, 7, 2, 3,
+    Q = P // 4
+    out = torch.full((n * Q * Q, O + 8), 7.0, device=DEV)
+    L.call('gnx_conv_stem_bnrelu_maxpool', L.ptr(xd), L.ptr(Wd), L.ptr(out), O + 8, n, 3, P, P, O, 7, 7, 2, 3,
            L.ptr(scd), L.ptr(shd), L.stream())
-    close(out[:, :O].reshape(n, 32, 32, O).permute(0, 3, 1, 2), ref, rtol=1e-4)
+    close(out[:, :O].reshape(n, Q, Q, O).permute(0, 3, 1, 2), ref, rtol=1e-4)
     assert float(out[:, O:].min()) == 7.0
     x64 = torch.rand(2, 3, 64, 64, device=DEV)
     assert L.query('gnx_conv_stem_bnrelu_maxpool', L.ptr(x64), L.ptr(Wd), L.ptr(out), O + 8, 2, 3, 64, 64, O, 7, 7, 2, 3,
