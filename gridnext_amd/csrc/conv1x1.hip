@@ -550,6 +550,288 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ conv1x1, LDS-clamp form
+// The eval forward's _DenseLayer norm1 -> relu1 -> conv1 (-> norm2 -> relu2) with NO vector ALU work on the staging side.
+//   relu(sc x + sh) = sc clamp(x) + sh,  clamp(x) = max(x, t) for sc > 0, min(x, t) for sc < 0,  t = -sh / sc,
+// so with Wf[n][k] = W[n][k] sc[k] and b[n] = sum_k W[n][k] sh[k] (conv1x1_fold_kernel, once per weight/BN update)
+//   y[m][n] = sum_k Wf[n][k] clamp_k(x[m][k]) + b[n].
+// The producers of conv1x1_ws_kernel are bounded by their VALU issue rate beside the MFMA waves (one slot per ~120
+// cycles whatever the instruction; tools/ubench/mfma_2x2.hip), and a VALU clamp changes nothing about that.  LDS
+// instructions are issued every ~19 cycles in the same place, and the LDS has float atomics: here the raw activations go
+// global -> LDS by DMA (no registers) and are clamped IN the LDS by ds_max_f32 / ds_min_f32 against per-lane bounds
+// (16 + 16 per producer wave and chunk, ~780 cycles against the consumers' 4 096).  Per chunk and producer wave: 8 DMA
+// instructions, 4 16-B loads of bounds, 32 LDS atomics, no VALU.
+// LDS: three A stages (consumed | being clamped | DMA in flight) + two B stages (consumed | in flight: weights come from
+// L2), 16 KB each = 80 KB, two workgroups per CU.  vmcnt retires in order, so per window the issue order is
+// B(q+1), bounds(q+2), A(q+2): `vmcnt(12)` = A(q+1) and its bounds have landed, `vmcnt(8)` = B(q+1) has.
+template <int OFF, int MIN>
+__device__ __forceinline__ void lds_fclamp(unsigned addr, float v) {
+    if (MIN) asm volatile("ds_min_f32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+    else asm volatile("ds_max_f32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+struct C1Bounds { f32x4 lo0, lo1, hi0, hi1; };              // this lane's 8 k of a chunk: k = 4 c + (lane & 3), c = 0..7
+
+__global__ __launch_bounds__(512, 4) void conv1x1_clamp_kernel(const float* __restrict__ A, int lda,
+                                                               const float* __restrict__ Wf,
+                                                               const float* __restrict__ bounds, float* __restrict__ out,
+                                                               int ldc, int K, int N, int tilesN, int T,
+                                                               const float* __restrict__ oscale,
+                                                               const float* __restrict__ oshift) {
+    constexpr int OPB = 128 * 32 * 4;                      // bytes of one operand chunk
+    constexpr int BOFF = 3 * OPB;                          // the two B stages lie behind the three A stages
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    char* const lds = reinterpret_cast<char*>(lds_f);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nk = K >> 5;
+    const int G = gridDim.x;
+    const int bx = blockIdx.x;
+    const int mine = (T - bx + G - 1) / G;                 // tiles of this workgroup (gridDim.x <= T)
+    const int total = mine * nk;                           // chunks = barriers, the same number for all 8 waves
+    const int jmap = (tilesN > 1 && G % (8 * tilesN) == 0)
+                         ? tilesN * ((bx & 7) + 8 * (bx / (8 * tilesN))) + (bx >> 3) % tilesN : bx;
+    auto tile_of = [&](int round) {
+        const int base = round * G;
+        return base + (base + G <= T ? jmap : bx);
+    };
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------------------------------ producer
+        const int pw = wave - 4;
+        const unsigned voA = ((unsigned)(lane & 15) * lda + 4 * (lane >> 4)) * 4u;      // per-lane constant byte offsets
+        const unsigned voW = ((unsigned)(lane & 15) * K + 4 * (lane >> 4)) * 4u;
+        const unsigned vob = (lane & 3) * 32u;             // this lane's 8 bounds within a chunk's 32 (bytes)
+        const unsigned cl = lds_addr(lds) + pw * 4096 + lane * 4;                       // clamp address in stage 0
+        // (tile, chunk) iterators; behind the last chunk they re-read this workgroup's first tile into stages nobody reads
+        struct It { int round, tile, kt; };
+        It ia = {0, tile_of(0), 0}, ib = ia;
+        auto advance = [&](It& it) {
+            if (++it.kt == nk) { it.kt = 0; it.tile = tile_of(++it.round); }
+            if (it.tile >= T) it.tile = bx;
+        };
+        // DMA as BUFFER loads (128-bit resource in SGPRs + per-lane constant 32-bit offset + scalar offset): beside saturated
+        // MFMA waves a global_load costs the matrix pipe ~40 cycles per wave-instruction, a buffer_load nothing
+        // (tools/ubench/mfma_2x2.hip: 16 per chunk -> 117 / 130 (LDS form) against 152 TFLOP/s) - and no VALU address
+        // arithmetic either.  M0 = LDS destination of lane 0; the scalar offset moves only the source.
+        auto dma4 = [&](const __amdgpu_buffer_rsrc_t& r, int so, int rowskip, unsigned vo, unsigned m0) {
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         ::"s"(m0), "v"(vo), "s"(r), "s"(so) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         ::"s"(m0 + 1024), "v"(vo), "s"(r), "s"(so + 64) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         ::"s"(m0 + 2048), "v"(vo), "s"(r), "s"(so + rowskip) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         ::"s"(m0 + 3072), "v"(vo), "s"(r), "s"(so + rowskip + 64) : "memory", "m0");
+        };
+        const unsigned ldsb = lds_addr(lds) + pw * 4096;
+        auto issue_a = [&](int stage) {
+            const int tm = ia.tile / tilesN;
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(A + ((long)tm * 128 + 32 * pw) * lda), 0, (31 * lda + K) * 4, 0x00020000);
+            dma4(r, ia.kt << 7, lda * 64, voA, ldsb + stage * OPB);
+            advance(ia);
+        };
+        auto issue_b = [&](int stage) {
+            const int tn = ib.tile % tilesN;
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(Wf + ((long)tn * 128 + 32 * pw) * K), 0, 32 * K * 4, 0x00020000);
+            dma4(r, ib.kt << 7, K * 64, voW, ldsb + BOFF + stage * OPB);
+            advance(ib);
+        };
+        // bounds of the chunk `ia` points at: asm loads, so they keep their place in the vmcnt order
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bounds), 0, 8 * K, 0x00020000);
+        auto load_bounds = [&](C1Bounds& b) {
+            const int so = ia.kt << 7, soh = so + 4 * K;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(b.lo0) : "v"(vob), "s"(rb), "s"(so) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(b.lo1) : "v"(vob), "s"(rb), "s"(so) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(b.hi0) : "v"(vob), "s"(rb), "s"(soh) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(b.hi1) : "v"(vob), "s"(rb), "s"(soh) : "memory");
+        };
+#if GNX_WS_STAMP
+        long seg[4] = {0, 0, 0, 0};
+        long seg_t = 0, p_wait = 0;
+#endif
+        auto clamp = [&](int stage, C1Bounds& b) {
+            // A(stage) and b have landed once at most 12 younger VMEM operations are outstanding
+            asm volatile("s_waitcnt vmcnt(12)" : "+v"(b.lo0), "+v"(b.lo1), "+v"(b.hi0), "+v"(b.hi1)::"memory");
+            const unsigned a = cl + stage * OPB;
+            static_for<0, 16>([&](auto ic) {                // instruction i: rows 16 (i >> 3) + (lane >> 2), k = 4 (i & 7) + (lane & 3)
+                constexpr int i = decltype(ic)::value, c = i & 7;
+                lds_fclamp<256 * i, 0>(a, c < 4 ? b.lo0[c & 3] : b.lo1[c & 3]);
+                lds_fclamp<256 * i, 1>(a, c < 4 ? b.hi0[c & 3] : b.hi1[c & 3]);
+            });
+        };
+#if GNX_WS_STAMP
+#define GNX_PBAR() do { asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); GNX_SEG(3); const long tb = __builtin_amdgcn_s_memtime(); \
+                        asm volatile("s_barrier" ::: "memory"); seg_t = __builtin_amdgcn_s_memtime(); p_wait += seg_t - tb; } while (0)
+#else
+#define GNX_PBAR() lds_barrier()
+#endif
+        __builtin_amdgcn_s_setprio(3);
+        C1Bounds b0, b1;
+        issue_b(0);
+        load_bounds(b0);
+        issue_a(0);
+        load_bounds(b1);
+        issue_a(1);
+        {
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(b0.lo0), "+v"(b0.lo1), "+v"(b0.hi0), "+v"(b0.hi1)::"memory");
+            static_for<0, 16>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, c = i & 7;
+                lds_fclamp<256 * i, 0>(cl, c < 4 ? b0.lo0[c & 3] : b0.lo1[c & 3]);
+                lds_fclamp<256 * i, 1>(cl, c < 4 ? b0.hi0[c & 3] : b0.hi1[c & 3]);
+            });
+        }
+        int s3 = 0;                                         // q % 3
+#if GNX_WS_STAMP
+        const long p_begin = __builtin_amdgcn_s_memtime();
+        seg_t = p_begin;
+#endif
+        for (int q = 0; q < total; q += 2) {
+            GNX_PBAR();                                     // chunk q published; consumers are done with chunk q-1
+            int s1 = s3 + 1 == 3 ? 0 : s3 + 1, s2 = s1 + 1 == 3 ? 0 : s1 + 1;
+            issue_b((q + 1) & 1);
+            GNX_SEG(0);
+            load_bounds(b0);
+            GNX_SEG(1);
+            issue_a(s2);
+            GNX_SEG(2);
+            clamp(s1, b1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                 // B(q+1) has landed
+            s3 = s1;
+            if (q + 1 >= total) break;
+            GNX_PBAR();
+            s1 = s3 + 1 == 3 ? 0 : s3 + 1; s2 = s1 + 1 == 3 ? 0 : s1 + 1;
+            issue_b(q & 1);
+            GNX_SEG(0);
+            load_bounds(b1);
+            GNX_SEG(1);
+            issue_a(s2);
+            GNX_SEG(2);
+            clamp(s1, b0);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            s3 = s1;
+        }
+#undef GNX_PBAR
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // no DMA may outlive the workgroup's LDS
+#if GNX_WS_STAMP
+        if (lane == 0 && pw == 0) {      // debug build: producer wave 4 of each workgroup -> (barrier wait, total) cycles
+            const long p_total = __builtin_amdgcn_s_memtime() - p_begin;
+            float* dbg = out + (long)(blockIdx.x / tilesN) * 128 * ldc + (blockIdx.x % tilesN) * 128;
+            dbg[4 * ldc + 0] = (float)p_wait;
+            dbg[4 * ldc + 1] = (float)p_total;
+            dbg[4 * ldc + 2] = (float)total;
+            for (int q = 0; q < 4; ++q) dbg[4 * ldc + 3 + q] = (float)seg[q];
+        }
+#endif
+        return;
+    }
+    // ---------------------------------------------------------------------------------------------- consumer
+    const int h = lane >> 5, i = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned lb = lds_addr(lds);
+    const unsigned fA = lb + (4 * wm + (i >> 4)) * 2048 + (i & 15) * 16 + h * 256;
+    const unsigned fB = lb + BOFF + (4 * wn + (i >> 4)) * 2048 + (i & 15) * 16 + h * 256;
+    int g = 0, g3 = 0;
+#if GNX_WS_STAMP
+    long c_wait = 0;
+    const long c_begin = __builtin_amdgcn_s_memtime();
+#endif
+    for (int round = 0, tile = tile_of(0); tile < T; tile = tile_of(++round)) {
+        f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+#if GNX_WS_STAMP
+            const long tb0 = __builtin_amdgcn_s_memtime();
+#endif
+            asm volatile("s_barrier" ::: "memory");
+#if GNX_WS_STAMP
+            c_wait += __builtin_amdgcn_s_memtime() - tb0;
+#endif
+            const unsigned a = fA + g3 * OPB, b = fB + (g & 1) * OPB;
+            g3 = g3 + 1 == 3 ? 0 : g3 + 1;
+            f32x4 a0 = lds_read4<0>(a), a1 = lds_read4<4096>(a), b0 = lds_read4<0>(b), b1 = lds_read4<4096>(b);
+            static_for<0, 4>([&](auto s_c) {
+                constexpr int sstep = decltype(s_c)::value;
+                f32x4 na0, na1, nb0, nb1;
+                if constexpr (sstep < 3) {
+                    na0 = lds_read4<(sstep + 1) * 512>(a);
+                    na1 = lds_read4<(sstep + 1) * 512 + 4096>(a);
+                    nb0 = lds_read4<(sstep + 1) * 512>(b);
+                    nb1 = lds_read4<(sstep + 1) * 512 + 4096>(b);
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b0[c], acc00, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b1[c], acc01, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b0[c], acc10, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b1[c], acc11, 0, 0, 0);
+                }
+                if constexpr (sstep < 3) { a0 = na0; a1 = na1; b0 = nb0; b1 = nb1; }
+            });
+        }
+        const int tm = tile / tilesN, tn = tile - tm * tilesN;
+        auto store = [&](f32x16& acc, int mt, int nt) {
+            const int col = tn * 128 + 64 * wn + 32 * nt + i;
+            const float osc = oscale[col], osh = oshift[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaxf(fmaf(acc[r], osc, osh), 0.f);
+            float* o = out + (long)(tm * 128 + 64 * wm + 32 * mt + 4 * h) * ldc + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(long)(((r & 3) + 8 * (r >> 2)) * ldc)] = acc[r];
+        };
+        store(acc00, 0, 0);
+        store(acc01, 0, 1);
+        store(acc10, 1, 0);
+        store(acc11, 1, 1);
+    }
+#if GNX_WS_STAMP
+    if (lane == 0) {                     // debug build: consumer waves -> (barrier wait, total) cycles over all their tiles
+        const long c_total = __builtin_amdgcn_s_memtime() - c_begin;
+        float* dbg = out + (long)(blockIdx.x / tilesN) * 128 * ldc + (blockIdx.x % tilesN) * 128;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg[wave * ldc + 0] = (float)c_wait;
+        dbg[wave * ldc + 1] = (float)c_total;
+    }
+#endif
+}
+
+// Wf[n][k] = W[n][k] sc[k];  bounds[0][.] / [1][.] = lower / upper clamp per k, stored per 32-k chunk as [k & 3][k >> 2]
+// (a producer lane's 8 values contiguous);  out_shift_f[n] = out_scale[n] * sum_k W[n][k] sh[k] + out_shift[n].
+// Channels whose scale is 0 (or so small that -sh/sc is not finite) are constants relu(sh): weight 0, value into the sum.
+__global__ __launch_bounds__(256) void conv1x1_fold_kernel(const float* __restrict__ W, const float* __restrict__ sc,
+                                                           const float* __restrict__ sh,
+                                                           const float* __restrict__ osc, const float* __restrict__ osh,
+                                                           float* __restrict__ Wf, float* __restrict__ bounds,
+                                                           float* __restrict__ oshf, int N, int K) {
+    __shared__ double red[256];
+    const int n = blockIdx.x, t = threadIdx.x;
+    double sum = 0.0;
+    for (int k = t; k < K; k += 256) {
+        const float s = sc[k], b = sh[k], tt = -b / s;
+        const bool ok = s != 0.f && fabsf(tt) <= 3.0e38f;          // false for NaN too
+        const float w = W[(long)n * K + k];
+        Wf[(long)n * K + k] = ok ? w * s : 0.f;
+        sum += (double)w * (double)(ok ? b : fmaxf(b, 0.f));
+        if (n == 0) {
+            const int pos = (k & ~31) + (k & 3) * 8 + ((k & 31) >> 2);
+            bounds[pos] = ok && s > 0.f ? tt : -INFINITY;
+            bounds[K + pos] = ok && s < 0.f ? tt : INFINITY;
+        }
+    }
+    red[t] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) red[t] += red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) oshf[n] = (float)((double)osc[n] * red[0] + (double)osh[n]);
+}
+
 }  // namespace
 
 // out[M][N] (ldc) = act(A[M][K] (lda)) . W[N][K]^T ; pool != 0: A is on an S_in x S_in grid per image and M counts the
@@ -623,4 +905,44 @@ GNX_EXPORT int gnx_conv1x1_bnrelu_act(const float* A, long lda, const float* W, 
                                       const float* out_shift, hipStream_t stream) {
     if (!out_scale || !out_shift) return GNX_ERR_BAD_ARG;
     return conv1x1_launch(A, lda, W, out, ldc, M, N, K, scale, shift, 0, 0, out_scale, out_shift, stream);
+}
+
+// Fold norm1 (scale, shift: the PRODUCER-side BN of this conv) and the consumer's norm2 (out_scale, out_shift) into the
+// operands of gnx_conv1x1_clamped_act: Wf [N][K], bounds [2][K], out_shift_f [N].  32 | K.  Once per weight / BN update.
+GNX_EXPORT int gnx_conv1x1_fold_clamp(const float* W, const float* scale, const float* shift, const float* out_scale,
+                                      const float* out_shift, float* Wf, float* bounds, float* out_shift_f, int N, int K,
+                                      hipStream_t stream) {
+    if (!W || !scale || !shift || !out_scale || !out_shift || !Wf || !bounds || !out_shift_f || N <= 0 || K <= 0)
+        return GNX_ERR_BAD_ARG;
+    if (K % 32 != 0) return GNX_ERR_UNSUPPORTED;
+    conv1x1_fold_kernel<<<N, 256, 0, stream>>>(W, scale, shift, out_scale, out_shift, Wf, bounds, out_shift_f, N, K);
+    return gnx_launch_status();
+}
+
+// out[m][n] = relu(out_scale[n] * sum_k Wf[n][k] clamp_k(A[m][k]) + out_shift_f[n]) == gnx_conv1x1_bnrelu_act on the
+// unfolded operands up to rounding (conv1x1_clamp_kernel).  Whole tiles only: 128 | M, 128 | N, 32 | K, 16-B aligned
+// operands; anything else returns GNX_ERR_UNSUPPORTED (run gnx_conv1x1_bnrelu_act then).
+GNX_EXPORT int gnx_conv1x1_clamped_act(const float* A, long lda, const float* Wf, const float* bounds, float* out, long ldc,
+                                       long M, int N, int K, const float* out_scale, const float* out_shift_f,
+                                       hipStream_t stream) {
+    if (!A || !Wf || !bounds || !out || !out_scale || !out_shift_f || M < 0 || N <= 0 || K <= 0 || lda < K || ldc < N)
+        return GNX_ERR_BAD_ARG;
+    if (M % 128 != 0 || N % 128 != 0 || K % 32 != 0 || !al16(A) || !al16(Wf) || !al16(bounds) || lda % 4 != 0 ||
+        M >= (1L << 29) || lda >= (1 << 16) || ldc >= (1 << 16) || getenv("GNX_NO_CLAMP1"))
+        return GNX_ERR_UNSUPPORTED;
+    if (M == 0) return GNX_OK;
+    constexpr int lds_bytes = 5 * 128 * 32 * 4;
+    static bool conf = false;
+    if (!conf) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_clamp_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return GNX_ERR_LAUNCH;
+        conf = true;
+    }
+    const int tilesN = N / 128;
+    const long T = (M / 128) * tilesN;
+    const int wgs = (int)(T < 512 ? T : 512);
+    conv1x1_clamp_kernel<<<wgs, 512, lds_bytes, stream>>>(A, (int)lda, Wf, bounds, out, (int)ldc, K, N, tilesN, (int)T,
+                                                          out_scale, out_shift_f);
+    return gnx_launch_status();
 }

@@ -340,6 +340,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
     // next chunk's DMA state.  Past this workgroup's last tile the DMA re-reads its first tile into the buffer nobody
     // will read: cheaper than a branch around every slot.  gridDim.x <= T: every workgroup owns at least one tile.
     int nround = 0, ntile = tile_of(0), nchunk = 0;
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wr), 0, 9 * N * K * 4, 0x00020000);
     auto issue_slot = [&](auto slot_c, char* dst) {
         constexpr int slot = decltype(slot_c)::value;
         if constexpr (slot < NSA) {
@@ -349,8 +350,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
             const int row0 = ntile * BM - S - 1 + 16 * grp;                    // first strip row of the group
             char* d = dst + grp * GB + part * 1024;
             if (__builtin_expect(row0 >= 0 && row0 + 15 < M, 1)) {
-                const char* sb = reinterpret_cast<const char*>(A + (long)row0 * lda + (NK1 ? 0 : KC * nchunk) + 16 * part);
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(sb + voffA), (float*)d, 16, 0, 0);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(A + (long)row0 * lda), 0, (15 * lda + K) * 4, 0x00020000);
+                dma16_buf(rs, voffA, ((NK1 ? 0 : KC * nchunk) + 16 * part) * 4, lds_addr(d));
             } else {
                 // array ends: rows outside [0, M) are only ever "read" by masked taps, any in-range row will do
                 int Pr = row0 + (lane & 15);
@@ -363,10 +365,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
             if ((NPW % NW) && slot == NSA + NSW - 1 && p >= NPW) return;
             const int grp = p / PPG, part = p % PPG;
             // weight rows [tap][N][K]: tap = grp >> 1, n = 32 * (column tile) + 16 * (grp & 1) + lane row
-            const char* sb = reinterpret_cast<const char*>(
-                Wr + (long)((grp >> 1) * N + (NK1 ? 32 * nchunk : 0) + (grp & 1) * 16) * K + (NK1 ? 0 : KC * nchunk) + 16 * part);
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(sb + voffW),
-                                             (float*)(dst + SR * ROWB + grp * GB + part * 1024), 16, 0, 0);
+            dma16_buf(rW, voffW,
+                      (((grp >> 1) * N + (NK1 ? 32 * nchunk : 0) + (grp & 1) * 16) * K + (NK1 ? 0 : KC * nchunk) + 16 * part) * 4,
+                      lds_addr(dst + SR * ROWB + grp * GB + part * 1024));
         }
     };
     auto advance_next = [&]() {
@@ -520,6 +521,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(const float* __restri
     const unsigned voffA = ((unsigned)pix * lda + 4 * (lane >> 4)) * 4u;
     const unsigned voffU = ((unsigned)(lane & 15) * K + 4 * (lane >> 4)) * 4u;
     int nround = 0, ntile = tile_of(0), nchunk = 0;
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wu), 0, 12 * 32 * K * 4, 0x00020000);
     auto issue_slot = [&](auto slot_c, int buf) {
         constexpr int slot = decltype(slot_c)::value;
         if constexpr (slot < NSR) {
@@ -528,8 +530,9 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(const float* __restri
             const int row0 = ntile * BM - S - 1 + 16 * p;
             char* d = lds + OFF_RAW + buf * RAWB + p * 1024;
             if (__builtin_expect(row0 >= 0 && row0 + 15 < M, 1)) {
-                const char* sb = reinterpret_cast<const char*>(A + (long)row0 * lda + 16 * nchunk);
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(sb + voffA), (float*)d, 16, 0, 0);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(A + (long)row0 * lda), 0, (15 * lda + K) * 4, 0x00020000);
+                dma16_buf(rs, voffA, 64 * nchunk, lds_addr(d));
             } else {                                       // array ends: any in-range row (only masked rows use it)
                 int Pr = row0 + pix;
                 Pr = Pr < 0 ? 0 : (Pr >= M ? M - 1 : Pr);
@@ -537,9 +540,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(const float* __restri
             }
         } else {
             const int p = wave + 4 * (slot - NSR);         // U group p: tap p >> 1, rows 16 (p & 1) ..
-            const char* sb = reinterpret_cast<const char*>(Wu + (long)(16 * p) * K + 16 * nchunk);
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(sb + voffU),
-                                             (float*)(lds + OFF_U + buf * UB + p * 1024), 16, 0, 0);
+            dma16_buf(rU, voffU, (16 * p * K + 16 * nchunk) * 4, lds_addr(lds + OFF_U + buf * UB + p * 1024));
         }
     };
     auto advance_next = [&]() {

@@ -52,6 +52,14 @@ __device__ __forceinline__ f32x4 lds_read4(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
+// 1 KB of LDS-DMA (16 B per lane, LDS destination lds_dst + 16 lane) through a BUFFER resource: source = resource base +
+// per-lane offset voff + scalar offset soff.  Beside saturated MFMA waves the global_load_lds form of the same transfer costs
+// the matrix pipe ~40 cycles per wave-instruction, the buffer form nothing (tools/ubench/mfma_2x2.hip: 16 per chunk and
+// wave -> 129 against 150 TFLOP/s); bytes past the resource's extent read as zero.
+__device__ __forceinline__ void dma16_buf(const __amdgpu_buffer_rsrc_t& r, unsigned voff, int soff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff) : "memory", "m0");
+}
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {

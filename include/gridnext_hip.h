@@ -96,6 +96,17 @@ int gnx_conv1x1_bnrelu(const float* A, long lda, const float* W, float* out, lon
 int gnx_conv1x1_bnrelu_act(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
                            const float* scale, const float* shift, const float* out_scale, const float* out_shift,
                            gnx_stream_t stream);
+/* The same operation with norm1 folded into the operands (eval mode, weights frozen): relu(sc x + sh) = sc clamp(x) + sh,
+ * clamp = max(., -sh/sc) for sc > 0, min for sc < 0.  gnx_conv1x1_fold_clamp makes Wf[N][K] = W sc, bounds[2][K] (private
+ * order) and out_shift_f[N] = out_scale (W . sh) + out_shift once per weight / BN update; gnx_conv1x1_clamped_act then
+ * streams the raw activations global -> LDS by DMA and clamps them there with LDS float atomics (no vector ALU work beside
+ * the matrix waves).  Equal to gnx_conv1x1_bnrelu_act up to rounding.  Whole tiles only (128 | M, 128 | N, 32 | K,
+ * 16-B aligned): GNX_ERR_UNSUPPORTED otherwise -- call gnx_conv1x1_bnrelu_act then. */
+int gnx_conv1x1_fold_clamp(const float* W, const float* scale, const float* shift, const float* out_scale,
+                           const float* out_shift, float* Wf, float* bounds, float* out_shift_f, int N, int K,
+                           gnx_stream_t stream);
+int gnx_conv1x1_clamped_act(const float* A, long lda, const float* Wf, const float* bounds, float* out, long ldc, long M,
+                            int N, int K, const float* out_scale, const float* out_shift_f, gnx_stream_t stream);
 int gnx_repack_conv3x3(const float* w, float* wr, int N, int K, gnx_stream_t stream);
 int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, float* out, long ldc, long M, int N, int K, int S,
                        const float* scale, const float* shift, gnx_stream_t stream);

@@ -282,6 +282,39 @@ def test_conv1x1_bnrelu_act(L, M, K, N):
                                           None, None, L.stream()) != 0       # both output vectors are required
 
 
+@pytest.mark.parametrize("M,K,N,lda", [(128, 32, 128, 32), (1024, 64, 128, 256), (4096, 224, 128, 256), (128 * 700, 96, 128, 128),
+                                       (2048, 992, 128, 1024), (1280, 160, 256, 160)])
+def test_conv1x1_clamped_act(L, M, K, N, lda):
+    """norm1 folded into conv1's operands, the ReLU done as a clamp inside the LDS: == relu(bn2(conv1(relu(bn1(x))))) up to
+    rounding, with negative, zero and denormal-small scales among the channels; ragged shapes must say UNSUPPORTED."""
+    g = torch.Generator().manual_seed(M + K + 2)
+    A = torch.randn(M, lda, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.1
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+    sc[1::5] *= -1.0                                           # gamma < 0: the clamp is a min
+    sc[2::7] = 0.0                                             # gamma = 0: the channel is the constant relu(shift)
+    sc[3] = 1e-42                                              # -shift/scale overflows: treated like gamma = 0
+    osc, osh = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.5
+    ref = torch.relu((torch.relu(A[:, :K].double() * sc.double() + sh.double()) @ W.double().t()) * osc.double() + osh.double())
+    Ad, Wd, scd, shd, oscd, oshd = (v.to(DEV) for v in (A, W, sc, sh, osc, osh))
+    Wf, bounds, oshf = torch.empty(N, K, device=DEV), torch.empty(2, K, device=DEV), torch.empty(N, device=DEV)
+    L.call('gnx_conv1x1_fold_clamp', L.ptr(Wd), L.ptr(scd), L.ptr(shd), L.ptr(oscd), L.ptr(oshd), L.ptr(Wf), L.ptr(bounds),
+           L.ptr(oshf), N, K, L.stream())
+    out = torch.full((M, N + 4), 7.0, device=DEV)
+    L.call('gnx_conv1x1_clamped_act', L.ptr(Ad), lda, L.ptr(Wf), L.ptr(bounds), L.ptr(out), N + 4, M, N, K, L.ptr(oscd),
+           L.ptr(oshf), L.stream())
+    close(out[:, :N].double(), ref, rtol=2e-4)
+    assert float(out[:, N:].min()) == 7.0
+    # same answer as the unfolded kernel, to rounding
+    out2 = torch.empty((M, N), device=DEV)
+    L.call('gnx_conv1x1_bnrelu_act', L.ptr(Ad), lda, L.ptr(Wd), L.ptr(out2), N, M, N, K, L.ptr(scd), L.ptr(shd),
+           L.ptr(oscd), L.ptr(oshd), L.stream())
+    close(out[:, :N], out2, rtol=2e-4)
+    for m, n, k in ((M - 64, N, K), (M, N - 32, K), (M, N, K - 16)):
+        assert L.query('gnx_conv1x1_clamped_act', L.ptr(Ad), lda, L.ptr(Wf), L.ptr(bounds), L.ptr(out), N + 4, m, n, k,
+                       L.ptr(oscd), L.ptr(oshf), L.stream()) == L.ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("n,S,K,N,act", [(2, 8, 128, 32, True), (3, 4, 12, 6, True), (1, 32, 128, 32, True),
                                          (5, 7, 16, 4, False), (2, 14, 128, 32, True), (1, 56, 8, 4, True),
                                          (33, 4, 128, 32, True), (1, 1, 8, 4, True), (2, 2, 128, 32, True),

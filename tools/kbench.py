@@ -35,6 +35,7 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--noact', action='store_true', help='conv3x3 without the BN+ReLU prologue')
     ap.add_argument('--const', action='store_true', help='constant operands (low bit toggling) instead of randn')
+    ap.add_argument('--clamp', action='store_true', help='conv1x1 in its folded LDS-clamp form (gnx_conv1x1_clamped_act)')
     ap.add_argument('--wino', action='store_true', help='conv3x3 in its Winograd F(2,3) form (prologue-free operand)')
     args = ap.parse_args()
     n = args.spots
@@ -53,8 +54,16 @@ def main():
             out = torch.empty(M, 128, device=DEV)
             sc, sh = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
             scp, shp = (None, None) if args.noact else (L.ptr(sc), L.ptr(sh))
-            ms = timeit(lambda: L.call('gnx_conv1x1_bnrelu', L.ptr(A), ct, L.ptr(W), L.ptr(out), 128, M, 128, K,
-                                       scp, shp, 0, 0, st), args.reps)
+            if args.clamp:
+                osc, osh = torch.rand(128, device=DEV) + 0.5, torch.randn(128, device=DEV) * 0.1
+                Wf, bounds, oshf = torch.empty(128, K, device=DEV), torch.empty(2, K, device=DEV), torch.empty(128, device=DEV)
+                L.call('gnx_conv1x1_fold_clamp', L.ptr(W), L.ptr(sc), L.ptr(sh), L.ptr(osc), L.ptr(osh), L.ptr(Wf),
+                       L.ptr(bounds), L.ptr(oshf), 128, K, st)
+                ms = timeit(lambda: L.call('gnx_conv1x1_clamped_act', L.ptr(A), ct, L.ptr(Wf), L.ptr(bounds), L.ptr(out), 128,
+                                           M, 128, K, L.ptr(osc), L.ptr(oshf), st), args.reps)
+            else:
+                ms = timeit(lambda: L.call('gnx_conv1x1_bnrelu', L.ptr(A), ct, L.ptr(W), L.ptr(out), 128, M, 128, K,
+                                           scp, shp, 0, 0, st), args.reps)
             fl = 2.0 * M * K * 128
             byts = 4.0 * M * (K + 128)
             print("conv1x1 S=%2d K=%4d M=%8d  %8.3f ms  %6.1f TFLOP/s  %5.2f TB/s" % (S, K, M, ms, fl / ms / 1e9, byts / ms / 1e9))

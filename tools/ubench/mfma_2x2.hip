@@ -12,10 +12,23 @@ __device__ __forceinline__ f32x4 lds_read4(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
+template <int OFF, int MIN>
+__device__ __forceinline__ void lds_fmax(unsigned addr, float v) {          // LDS[addr + OFF] = max/min(LDS[..], v)
+    if (MIN) asm volatile("ds_min_f32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+    else asm volatile("ds_max_f32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int I, int N, int BOTH>
+__device__ __forceinline__ void lds_fmax_seq(unsigned addr, const float* v) {
+    if constexpr (I < N) {
+        lds_fmax<I * 256, 0>(addr, v[I & 15]);
+        if constexpr (BOTH) lds_fmax<I * 256, 1>(addr, v[(I + 7) & 15]);
+        lds_fmax_seq<I + 1, N, BOTH>(addr, v);
+    }
+}
 // MODE 0: as the kernel (a0 feeds two consecutive MFMAs).  1: order changed so consecutive MFMAs share no source
 // register.  2: mode 0 + s_barrier per chunk.
 // PW (producer work per chunk, waves 4-7): bit 0 = 64 v_fma_f32, bit 1 = 8 ds_write_b128, bit 2 = 16 global_load_dwordx4,
-// bit 3 = run the producer at s_setprio 3
+// bit 3 = run the producer at s_setprio 3, bits 4.. = load variants (see the code)
 template <int MODE, int NTHR, int PW = 0>
 __global__ __launch_bounds__(NTHR) void k(float* out, int iters, float seed, const float* src = nullptr) {
     __shared__ __attribute__((aligned(16))) char lds[65536];
@@ -60,6 +73,16 @@ __global__ __launch_bounds__(NTHR) void k(float* out, int iters, float seed, con
                     u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, ((it * 16 + j) & 15) * 4096, 0);
                     g[j] = make_float4(__int_as_float(r[0]), __int_as_float(r[1]), __int_as_float(r[2]), __int_as_float(r[3]));
                 }
+            }
+            if (PW & 2048) {        // 16 buffer_load_dwordx4 ... lds (DMA through a buffer resource)
+                __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<char*>(reinterpret_cast<const char*>(src)) + (size_t)blockIdx.x * 65536, 0, 65536, 0x00020000);
+                const unsigned vo = (threadIdx.x - 256) * 16;
+                const unsigned m0b = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)lds + 32768 + ((threadIdx.x - 256) >> 6) * 4096);
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                                 ::"s"(m0b + (j & 3) * 1024), "v"(vo), "s"(rsrc), "s"(((it * 16 + j) & 15) * 4096) : "memory", "m0");
             }
             if (PW & 512) {         // 16 dwordx2 loads
 #pragma unroll
@@ -145,19 +168,41 @@ __global__ __launch_bounds__(NTHR) void k(float* out, int iters, float seed, con
 
 // ---- How long does a producer wave's own instruction stream take next to two saturated MFMA waves per SIMD?
 // OP: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_max_f32, 3 v_max_i32 (integer ReLU on float bits), 4 v_and_b32, 5 v_med3_f32,
-// 6 ds_read_b128.  Each producer wave times 64 dependent-free instructions of that kind per chunk with s_memtime.
+// 6 ds_read_b128, 7 ds_max_f32 (LDS float atomic), 8 ds_max_f32 + ds_min_f32, 9 = 16 of each.  Each producer wave times 64 dependent-free instructions of that kind per chunk with s_memtime.
 // MF: 0 = consumers use v_mfma_f32_32x32x2_f32 (64 cycles each), 1 = v_mfma_f32_16x16x4_f32 (32 cycles each, twice as many)
 template <int OP, int MF = 0>
-__global__ __launch_bounds__(512) void klat(float* out, long* cyc, int iters, float seed) {
+__global__ __launch_bounds__(512) void klat(float* out, long* cyc, int iters, float seed, const float* src = nullptr, long* cyc2 = nullptr) {
     __shared__ __attribute__((aligned(16))) char lds[65536];
     for (int i = threadIdx.x; i < 16384; i += blockDim.x) ((float*)lds)[i] = seed + i * 1e-6f;
     __syncthreads();
     if (threadIdx.x >= 256) {
         float v[16];
         for (int j = 0; j < 16; ++j) v[j] = seed * (j + 1);
-        long tot = 0;
+        long tot = 0, tot2 = 0;
         for (int it = 0; it < iters; ++it) {
             const long t0 = __builtin_amdgcn_s_memtime();
+            if (OP >= 10 && OP <= 13) {
+                // VMEM issue time: 16 loads of 1 KB per wave-instruction, streaming (each chunk a fresh 16 KB per wave)
+                // 10 global_load_dwordx4, 11 global_load_lds_dwordx4 (DMA), 12 global_load_dword (256 B), 13 dwordx4 from L2
+                const long slot = ((long)(blockIdx.x * 4 + ((threadIdx.x - 256) >> 6)) * iters + (OP == 13 ? 0 : it)) & 131071;
+                const float* p = src + slot * 4096 + (threadIdx.x & 63) * 4;
+                f32x4 g[16];
+                char* d = lds + ((threadIdx.x - 256) >> 6) * 16384;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (OP == 10 || OP == 13) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(g[j]) : "v"(p + j * 256) : "memory");
+                    if (OP == 12) asm volatile("global_load_dword %0, %1, off" : "=v"(g[j][0]) : "v"(p + j * 256) : "memory");
+                    if (OP == 11) __builtin_amdgcn_global_load_lds(p + j * 256, (float*)(d + j * 1024), 16, 0, 0);
+                }
+                asm volatile("s_nop 0" ::: "memory");
+                const long t1 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                tot2 += __builtin_amdgcn_s_memtime() - t1;
+                if (OP != 11) for (int j = 0; j < 16; ++j) asm volatile("" :: "v"(g[j]));
+                tot += t1 - t0;
+                asm volatile("s_barrier" ::: "memory");
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -191,6 +236,13 @@ __global__ __launch_bounds__(512) void klat(float* out, long* cyc, int iters, fl
                 }
                 v[0] += g[0][0] + g[15][3];
             }
+            if (OP == 7 || OP == 8 || OP == 9) {          // LDS float atomics: 64 x (256 B per wave-instruction, conflict-free)
+                const unsigned a = (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)lds +
+                                   ((threadIdx.x - 256) >> 6) * 16384 + (threadIdx.x & 63) * 4;
+                if (OP == 9) { lds_fmax_seq<0, 16, 1>(a, v); }     // what a chunk needs: 16 max + 16 min
+                else lds_fmax_seq<0, 64, OP == 8>(a, v);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             asm volatile("s_nop 0" ::: "memory");
             tot += __builtin_amdgcn_s_memtime() - t0;
             asm volatile("s_barrier" ::: "memory");
@@ -199,6 +251,7 @@ __global__ __launch_bounds__(512) void klat(float* out, long* cyc, int iters, fl
         for (int j = 0; j < 16; ++j) sacc += v[j];
         if (sacc == 12345.678f) out[0] = sacc;
         if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + ((threadIdx.x - 256) >> 6)] = tot;
+        if (cyc2 && (threadIdx.x & 63) == 0) cyc2[blockIdx.x * 4 + ((threadIdx.x - 256) >> 6)] = tot2;
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, i = lane & 31;
@@ -265,6 +318,33 @@ __global__ __launch_bounds__(512) void klat(float* out, long* cyc, int iters, fl
     for (int r = 0; r < 16; ++r) s += acc00[r] + acc01[r] + acc10[r] + acc11[r];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+template <int OP>
+void runvmem(const char* name) {
+    const int grid = 512, iters = 2000;
+    float* out; long* cyc; long* cyc2;
+    static float* src = nullptr;
+    if (!src) { (void)hipMalloc(&src, 131072ull * 16384 + 65536); (void)hipMemset(src, 0, 131072ull * 16384 + 65536); }
+    (void)hipMalloc(&out, sizeof(float) * grid * 256);
+    (void)hipMalloc(&cyc, sizeof(long) * grid * 4);
+    (void)hipMalloc(&cyc2, sizeof(long) * grid * 4);
+    hipEvent_t s, e;
+    (void)hipEventCreate(&s); (void)hipEventCreate(&e);
+    klat<OP, 0><<<grid, 512>>>(out, cyc, 10, 0.5f, src, cyc2);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(s);
+    klat<OP, 0><<<grid, 512>>>(out, cyc, iters, 0.5f, src, cyc2);
+    (void)hipEventRecord(e);
+    (void)hipEventSynchronize(e);
+    float ms; (void)hipEventElapsedTime(&ms, s, e);
+    static long h[2048], h2[2048];
+    (void)hipMemcpy(h, cyc, sizeof(long) * grid * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h2, cyc2, sizeof(long) * grid * 4, hipMemcpyDeviceToHost);
+    double tot = 0, tot2 = 0; for (int q = 0; q < grid * 4; ++q) { tot += h[q]; tot2 += h2[q]; }
+    double flops = (double)grid * 4 * iters * 64 * 4096.0;
+    printf("%-40s : MFMA waves %7.1f TFLOP/s; producer: %6.0f cycles to issue 16 (%5.1f each), then %6.0f until landed\n", name,
+           flops / ms / 1e9, tot / (grid * 4) / iters, tot / (grid * 4) / iters / 16, tot2 / (grid * 4) / iters);
+    (void)hipFree(out); (void)hipFree(cyc); (void)hipFree(cyc2);
+}
 template <int OP, int MF = 0>
 void runlat(const char* name) {
     const int grid = 512, iters = 4000;
@@ -313,6 +393,7 @@ void run(const char* name, int bpc, int iters) {
 int main(int argc, char** argv) {
     if (argc > 1) g_scale = atoi(argv[1]);
     run<0, 256>("warm-up", 2, 20000);
+    if (argc > 2) goto lat;
     run<0, 256>("0 kernel order (a0 feeds 2 consecutive MFMAs)", 1, 10000);
     run<0, 256>("0 kernel order", 2, 10000);
     run<1, 256>("1 no shared source between consecutive MFMAs", 1, 10000);
@@ -328,10 +409,12 @@ int main(int argc, char** argv) {
     run<2, 512, 64>("producers: 16 ds_read_b128 / chunk", 2, 10000);
     run<2, 512, 128>("producers: 16 dwordx4, saddr + voffset", 2, 10000);
     run<2, 512, 256>("producers: 16 buffer_load_dwordx4", 2, 10000);
+    run<2, 512, 2048>("producers: 16 buffer_load_dwordx4 lds (DMA)", 2, 10000);
     run<2, 512, 512>("producers: 16 global_load_dwordx2", 2, 10000);
     run<2, 512, 1024>("producers: 16 dwordx4 hitting L1", 2, 10000);
     run<2, 512, 7>("producers: all three", 2, 10000);
     run<2, 512, 15>("producers: all three, setprio 3", 2, 10000);
+lat:
     runlat<0>("64 v_fma_f32 / chunk");
     runlat<1>("64 v_pk_fma_f32 / chunk");
     runlat<2>("64 v_max_f32 / chunk");
@@ -339,6 +422,14 @@ int main(int argc, char** argv) {
     runlat<4>("64 v_and_b32 / chunk");
     runlat<5>("64 v_med3_f32 / chunk");
     runlat<6>("64 ds_read_b128 / chunk");
+    runlat<7>("64 ds_max_f32 / chunk");
+    runlat<8>("64 ds_max_f32 + 64 ds_min_f32 / chunk");
+    runlat<9>("16 ds_max_f32 + 16 ds_min_f32 / chunk");
+    runvmem<10>("16 global_load_dwordx4 (HBM) / chunk");
+    runvmem<11>("16 global_load_lds_dwordx4 (HBM) / chunk");
+    runvmem<12>("16 global_load_dword (HBM) / chunk");
+    runvmem<13>("16 global_load_dwordx4 (L2) / chunk");
+    if (argc > 2) return 0;
     runlat<0, 1>("16x16x4 consumers: 64 v_fma_f32 / chunk");
     runlat<1, 1>("16x16x4 consumers: 64 v_pk_fma_f32 / chunk");
     runlat<2, 1>("16x16x4 consumers: 64 v_max_f32 / chunk");

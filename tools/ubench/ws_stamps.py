@@ -11,7 +11,16 @@ for S, K, ct in [(32, 224, 256), (16, 480, 512), (8, 992, 1024)]:
     W = torch.randn(128, K, device=DEV) * 0.05
     out = torch.empty(M, 128, device=DEV)
     sc, sh = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
+    if os.environ.get('WS_CLAMP'):
+        osc, osh = torch.rand(128, device=DEV) + 0.5, torch.randn(128, device=DEV) * 0.1
+        Wf, bounds, oshf = torch.empty(128, K, device=DEV), torch.empty(2, K, device=DEV), torch.empty(128, device=DEV)
+        L.call('gnx_conv1x1_fold_clamp', L.ptr(W), L.ptr(sc), L.ptr(sh), L.ptr(osc), L.ptr(osh), L.ptr(Wf), L.ptr(bounds),
+               L.ptr(oshf), 128, K, L.stream())
     for _ in range(30):
+        if os.environ.get('WS_CLAMP'):
+            L.call('gnx_conv1x1_clamped_act', L.ptr(A), ct, L.ptr(Wf), L.ptr(bounds), L.ptr(out), 128, M, 128, K, L.ptr(osc),
+                   L.ptr(oshf), L.stream())
+            continue
         L.call('gnx_conv1x1_bnrelu', L.ptr(A), ct, L.ptr(W), L.ptr(out), 128, M, 128, K, (L.ptr(sc) if os.environ.get('WS_ACT', '1') == '1' else None), (L.ptr(sh) if os.environ.get('WS_ACT', '1') == '1' else None), 0, 0, L.stream())
     torch.cuda.synchronize()
     nwg = min(M // 128, 512)
