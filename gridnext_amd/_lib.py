@@ -35,6 +35,8 @@ SIGNATURES = {
     'gnx_repack_conv3x3': (_I, [_P, _P, _I, _I, _P]),
     'gnx_conv1x1_bnrelu_f16': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _I, _I, _P]),
     'gnx_conv3x3_bnrelu_f16': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
+    'gnx_conv1x1_bnrelu_f16_act16': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _P, _P, _P]),
+    'gnx_conv3x3_f16_dma': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _P]),
     'gnx_conv3x3_bnrelu': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
     'gnx_winograd_conv3x3_weights': (_I, [_P, _P, _I, _I, _P]),
     'gnx_conv3x3_winograd': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _P]),

@@ -290,7 +290,11 @@ __global__ __launch_bounds__(256) void conv3x3_pipe_kernel(const float* __restri
 // NK1 (data-gradient shape: K == KC = 32 input channels, N = 32 * NT output channels, NT even): a tile's chunks are its
 // NT column tiles instead of K chunks - the strip is re-fetched (L2) with each column tile's weights, every chunk starts
 // from zero accumulators and ends with its 16 stores.
-template <int S, int NW, int KC, bool NK1 = false>
+// H16 (config 5's fp16 path): the operands are fp16 in HBM - the activated bottleneck gnx_conv1x1_bnrelu_f16_act16 stores and
+// the tap-major weights rounded once.  Two halves are one "float" to everything but the multiply: A / Wr / lda / K are passed
+// in float units (K/2, lda/2), a 128-B LDS row holds 64 channels, and a fragment read (16 B = 8 consecutive k of a lane's
+// row; the two lane halves 16 k) feeds ONE v_mfma_f32_32x32x16_f16 where the fp32 form issues four 32x32x2.
+template <int S, int NW, int KC, bool NK1 = false, bool H16 = false>
 __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __restrict__ A, int lda,
                                                               const float* __restrict__ Wr, float* __restrict__ out,
                                                               int ldc, int M, int K, int N) {
@@ -446,10 +450,17 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(bq));
                 }
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bq[0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], bq[1], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], bq[2], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], bq[3], acc1, 0, 0, 0);
+                if constexpr (H16) {
+                    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+                    const half8 ah = __builtin_bit_cast(half8, a), bh = __builtin_bit_cast(half8, bq);
+                    if constexpr (step & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc0, 0, 0, 0);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bq[0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], bq[1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], bq[2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], bq[3], acc1, 0, 0, 0);
+                }
 #if GNX_DMA_DBG != 1
                 if constexpr (step < NSA + NSW) issue_slot(step_c, nxt);
 #endif
@@ -844,4 +855,46 @@ GNX_EXPORT int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, flo
     else conv3x3_kernel<<<grid, 256, lds_bytes, stream>>>(A, lda, Wr, out, ldc, M, N, K, S, scale, shift, vecA, vecW);
 #undef GNX_PIPE
     return gnx_launch_status();
+}
+
+// conv3x3 (pad 1) of an fp16, already activated operand (config 5): A16 [M][K] halves (lda16), Wr16 [9][N][K] halves
+// (gnx_repack_conv3x3's layout rounded to fp16), fp32 accumulation, fp32 out [M][N] (ldc).  conv3x3_dma_kernel in its H16
+// form: N == 32, 128 | K, 128 | M, 16-B aligned; S as the fp32 DMA path.  Anything else: GNX_ERR_UNSUPPORTED.
+GNX_EXPORT int gnx_conv3x3_f16_dma(const void* A16, long lda16, const void* Wr16, float* out, long ldc, long M, int N, int K,
+                                   int S, hipStream_t stream) {
+    if (!A16 || !Wr16 || !out || M < 0 || N <= 0 || K <= 0 || S <= 0 || lda16 < K || ldc < N || (M % ((long)S * S)) != 0)
+        return GNX_ERR_BAD_ARG;
+    if (N != C3_BN || (K & 127) != 0 || (M % C3_BM) != 0 || (lda16 & 7) != 0 || !al16(A16) || !al16(Wr16) ||
+        M * (lda16 > ldc ? lda16 : ldc) >= (1L << 31))
+        return GNX_ERR_UNSUPPORTED;
+    if (M == 0) return GNX_OK;
+    const float* A = reinterpret_cast<const float*>(A16);
+    const float* Wr = reinterpret_cast<const float*>(Wr16);
+    const int Kf = K / 2, ldaf = (int)(lda16 / 2);
+    const int variant = M / 256 >= 1024 ? 2 : 1;
+#define GNX_DMAH(SS)                                                                                             \
+    do {                                                                                                         \
+        if constexpr (SS <= 32) {                                                                                \
+            if (variant == 2 && M % 256 == 0) {                                                                  \
+                const long wgs = M / 256 > 256 ? 256 : M / 256;                                                  \
+                conv3x3_dma_kernel<SS, 8, 32, false, true><<<(int)wgs, 512, 0, stream>>>(A, ldaf, Wr, out,       \
+                                                                                         (int)ldc, (int)M, Kf, N); \
+                return gnx_launch_status();                                                                      \
+            }                                                                                                    \
+        }                                                                                                        \
+        const long wgs = M / 128 > 256 ? 256 : M / 128;                                                          \
+        conv3x3_dma_kernel<SS, 4, 32, false, true><<<(int)wgs, 256, 0, stream>>>(A, ldaf, Wr, out, (int)ldc,     \
+                                                                                 (int)M, Kf, N);                 \
+        return gnx_launch_status();                                                                              \
+    } while (0)
+    switch (S) {
+        case 4: GNX_DMAH(4);
+        case 8: GNX_DMAH(8);
+        case 16: GNX_DMAH(16);
+        case 32: GNX_DMAH(32);
+        case 64: GNX_DMAH(64);
+        default: break;
+    }
+#undef GNX_DMAH
+    return GNX_ERR_UNSUPPORTED;
 }

@@ -26,13 +26,18 @@ __device__ __forceinline__ half4 to_h4(float4 v) {
 __device__ __forceinline__ half8 ldh8(const _Float16* p) { return *reinterpret_cast<const half8*>(p); }
 
 // ---- conv1x1: 128x128 tile, 4 waves x (64x64), K chunks of 32; requires aligned pointers and K % 4 == 0
-template <bool POOL>
+// OUT16: the store applies the consumer's BN + ReLU and rounds to fp16 (out is _Float16 [M][N], ldc in halves): the
+// bottleneck as conv3x3_dma_kernel<.., H16> takes it.
+template <bool POOL, bool OUT16 = false>
 __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restrict__ A, long lda,
                                                           const float* __restrict__ W, float* __restrict__ out, long ldc,
                                                           long M, int N, int K, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, int S_in) {
-    __shared__ __attribute__((aligned(16))) _Float16 As[128 * LDH];
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[128 * LDH];
+                                                          const float* __restrict__ shift, int S_in,
+                                                          const float* __restrict__ oscale = nullptr,
+                                                          const float* __restrict__ oshift = nullptr) {
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * 128 * LDH];
+    _Float16* const As = smem;
+    _Float16* const Bs = smem + 128 * LDH;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, i = lane & 31;
     const int kq = t & 7, r0 = t >> 3;
@@ -65,6 +70,60 @@ __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restric
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int nkt = (K + 31) / 32;
+    auto mfma_chunk = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const half8 a0 = ldh8(&As[(64 * wm + i) * LDH + 16 * s + 8 * h]);
+            const half8 a1 = ldh8(&As[(64 * wm + 32 + i) * LDH + 16 * s + 8 * h]);
+            const half8 b0 = ldh8(&Bs[(64 * wn + i) * LDH + 16 * s + 8 * h]);
+            const half8 b1 = ldh8(&Bs[(64 * wn + 32 + i) * LDH + 16 * s + 8 * h]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    };
+    if constexpr (!POOL) {
+        // register-prefetched: chunk kt+1's global loads are in flight while chunk kt is converted, staged and multiplied
+        // (the kernel streams the fp32 block buffer: it is HBM-bound, the matrix phase is 1/16 of the fp32 kernel's)
+        float4 va[4], vb[4];
+        auto fetch = [&](int kt) {
+            const int k = kt * 32 + 4 * kq;
+            const int kc = k < K ? k : 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                va[p] = ld4(A + src[p] + kc);
+                const int n = n0 + r0 + 32 * p;
+                vb[p] = ld4(W + (long)(n < N ? n : N - 1) * K + kc);
+            }
+        };
+        fetch(0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int k = kt * 32 + 4 * kq;
+            const bool kok = k < K;
+            const int kc = kok ? k : 0;
+            float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (has_act) { sc4 = ld4(scale + kc); sh4 = ld4(shift + kc); }
+            __syncthreads();                               // the previous chunk's fragment reads are done
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float4 v = va[p];
+                if (has_act) {
+                    v.x = act1(v.x, sc4.x, sh4.x); v.y = act1(v.y, sc4.y, sh4.y);
+                    v.z = act1(v.z, sc4.z, sh4.z); v.w = act1(v.w, sc4.w, sh4.w);
+                }
+                if (!(rok[p] && kok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 w = vb[p];
+                if (!(n0 + r0 + 32 * p < N && kok)) w = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<half4*>(&As[(r0 + 32 * p) * LDH + 4 * kq]) = to_h4(v);
+                *reinterpret_cast<half4*>(&Bs[(r0 + 32 * p) * LDH + 4 * kq]) = to_h4(w);
+            }
+            __syncthreads();
+            fetch(kt + 1 < nkt ? kt + 1 : kt);             // branch-free; the last one is a harmless re-read
+            asm volatile("" ::: "memory");                 // keep the prefetch in front of the multiply
+            mfma_chunk();
+        }
+    } else
     for (int kt = 0; kt < nkt; ++kt) {
         const int k = kt * 32 + 4 * kq;
         const bool kok = k < K;
@@ -106,17 +165,36 @@ __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restric
             *reinterpret_cast<half4*>(&Bs[(r0 + 32 * p) * LDH + 4 * kq]) = to_h4(vb[p]);
         }
         __syncthreads();
+        mfma_chunk();
+    }
+    if constexpr (OUT16) {
+        // activated, rounded, and turned through the LDS (free after the K loop) so that a lane stores 16 B (8 channels of a
+        // row) instead of 2: each wave owns [32 rows][64 + 8 halves] for its 32 x 64 half tile, one pass per mt (8 | N)
+        constexpr int LDO = 72;
+        _Float16* const Os = smem + wave * 32 * LDO;
+        _Float16* const o16 = reinterpret_cast<_Float16*>(out);
+        __syncthreads();                                   // everyone is done with the last chunk's fragments
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const half8 a0 = ldh8(&As[(64 * wm + i) * LDH + 16 * s + 8 * h]);
-            const half8 a1 = ldh8(&As[(64 * wm + 32 + i) * LDH + 16 * s + 8 * h]);
-            const half8 b0 = ldh8(&Bs[(64 * wn + i) * LDH + 16 * s + 8 * h]);
-            const half8 b1 = ldh8(&Bs[(64 * wn + 32 + i) * LDH + 16 * s + 8 * h]);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int col = n0 + 64 * wn + 32 * nt + i;
+                const float osc = col < N ? oscale[col] : 0.f, osh = col < N ? oshift[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Os[((r & 3) + 8 * (r >> 2) + 4 * h) * LDO + 32 * nt + i] =
+                        (_Float16)fmaxf(fmaf(acc[mt][nt][r], osc, osh), 0.f);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {                  // 32 rows x 8 pieces of 16 B
+                const int piece = lane + 64 * p, rr = piece >> 3, c8 = piece & 7;
+                const long row = m0 + 64 * wm + 32 * mt + rr;
+                const int col = n0 + 64 * wn + 8 * c8;
+                if (row < M && col < N)
+                    *reinterpret_cast<half8*>(o16 + row * ldc + col) = *reinterpret_cast<const half8*>(&Os[rr * LDO + 8 * c8]);
+            }
         }
+        return;
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -248,5 +326,23 @@ GNX_EXPORT int gnx_conv3x3_bnrelu_f16(const float* A, long lda, const float* Wr,
     if (lds_bytes > 64 * 1024) return GNX_ERR_UNSUPPORTED;
     dim3 grid(gnx_cdiv(M, 128), gnx_cdiv(N, 32));
     conv3x3_f16_kernel<<<grid, 256, lds_bytes, stream>>>(A, lda, Wr, out, ldc, M, N, K, S, scale, shift);
+    return gnx_launch_status();
+}
+
+// gnx_conv1x1_bnrelu_f16 (pool = 0) storing the bottleneck ACTIVATED and in fp16: out16[m][n] = fp16(relu(out_scale[n] *
+// y[m][n] + out_shift[n])), ldc16 in halves - the operand of gnx_conv3x3_f16_dma.
+GNX_EXPORT int gnx_conv1x1_bnrelu_f16_act16(const float* A, long lda, const float* W, void* out16, long ldc16, long M, int N,
+                                            int K, const float* scale, const float* shift, const float* out_scale,
+                                            const float* out_shift, hipStream_t stream) {
+    if (!A || !W || !out16 || !out_scale || !out_shift || M < 0 || N <= 0 || K <= 0 || lda < K || ldc16 < N ||
+        (!scale) != (!shift))
+        return GNX_ERR_BAD_ARG;
+    if (!(al16h(A) && al16h(W) && al16h(out16) && lda % 4 == 0 && K % 4 == 0 && N % 8 == 0 && ldc16 % 8 == 0 &&
+          (!scale || (al16h(scale) && al16h(shift)))))
+        return GNX_ERR_UNSUPPORTED;
+    if (M == 0) return GNX_OK;
+    dim3 grid(gnx_cdiv(M, 128), gnx_cdiv(N, 128));
+    conv1x1_f16_kernel<false, true><<<grid, 256, 0, stream>>>(A, lda, W, reinterpret_cast<float*>(out16), ldc16, M, N, K,
+                                                              scale, shift, 0, out_scale, out_shift);
     return gnx_launch_status();
 }

@@ -162,6 +162,22 @@ class DenseNet(nn.Module):
         self._cache['w2'] = (key, table)
         return table
 
+    def _repacked_conv2_f16(self):
+        """{layer: the tap-major conv2 weight rounded to fp16} (config 5's DMA conv2), refreshed with the weights."""
+        w2 = self._repacked_conv2()
+        hit = self._cache.get('w2h')
+        if hit is not None and hit[0] is w2:
+            return hit[1]
+        table = {l: w.to(torch.float16) for l, w in w2.items()}
+        self._cache['w2h'] = (w2, table)
+        return table
+
+    def _f16_dma_ok(self, M, s, mid, c_total):
+        """Shapes gnx_conv3x3_f16_dma takes (conv3x3.hip): growth 32, 128 | mid, power-of-two maps 4..64, whole 128-row
+        tiles, 32-bit element offsets."""
+        return (self.growth_rate == 32 and mid % 128 == 0 and s in (4, 8, 16, 32, 64) and M % 128 == 0
+                and M * max(mid, c_total) < 2 ** 31)
+
     def _winograd_conv2(self):
         """{layer: conv2 weight as Winograd F(2,3)-along-x factors [3][4][growth][mid]} refreshed with the weights."""
         layers = [l for _, ls, _, _ in self._blocks for l in ls]
@@ -247,6 +263,7 @@ class DenseNet(nn.Module):
         fold = self._folded_eval()
         w2 = self._repacked_conv2()
         w2u = self._winograd_conv2() if (self.winograd and self.mfma == 'f32') else None
+        w2h = self._repacked_conv2_f16() if self.mfma == 'f16' else None
         if self.mfma not in ('f32', 'f16'):
             raise ValueError("DenseNet.mfma must be 'f32' or 'f16'")
         sfx = '_f16' if self.mfma == 'f16' else ''
@@ -259,6 +276,7 @@ class DenseNet(nn.Module):
         bufs = [torch.empty((chunk * s * s, c_total), device=dev, dtype=F32)
                 for (_, _, _, c_total), s in zip(self._blocks, sizes)]
         bott = torch.empty((chunk * sizes[0] * sizes[0], mid), device=dev, dtype=F32)
+        bott16 = bott.view(torch.float16)                       # the same memory as [rows][2 mid] halves (fp16 path)
         stem_out = None                                         # conv0 map: only the unfused stem needs it
         feats = torch.empty((N, self.num_features), device=dev, dtype=F32)
         w0 = conv0.weight.detach().contiguous()
@@ -304,7 +322,15 @@ class DenseNet(nn.Module):
                         sc1, sh1 = fold[layer.norm1]
                         sc2, sh2 = fold[layer.norm2]
                         t0 = self._probe_begin()
-                        if sfx:
+                        if sfx and self._f16_dma_ok(M, s, mid, c_total):
+                            # fp16 bottleneck: conv1 stores it activated and rounded, conv2 streams it by DMA.  The choice
+                            # depends on the map size and channel counts only (128 | M holds for every whole spot)
+                            L.call('gnx_conv1x1_bnrelu_f16_act16', L.ptr(rows), c_total, L.ptr(layer.conv1.weight),
+                                   L.ptr(bott16, torch.float16), mid, M, mid, cin, L.ptr(sc1), L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), st)
+                            t1 = self._probe_mark('conv1x1', t0)
+                            L.call('gnx_conv3x3_f16_dma', L.ptr(bott16, torch.float16), mid, L.ptr(w2h[layer], torch.float16),
+                                   rows.data_ptr() + 4 * cin, c_total, M, self.growth_rate, mid, s, st)
+                        elif sfx:
                             L.call('gnx_conv1x1_bnrelu_f16', L.ptr(rows), c_total, L.ptr(layer.conv1.weight),
                                    L.ptr(bott), mid, M, mid, cin, L.ptr(sc1), L.ptr(sh1), 0, 0, st)
                             t1 = self._probe_mark('conv1x1', t0)

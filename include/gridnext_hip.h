@@ -134,6 +134,15 @@ int gnx_conv1x1_bnrelu_f16(const float* A, long lda, const float* W, float* out,
                            const float* scale, const float* shift, int pool, int S_in, gnx_stream_t stream);
 int gnx_conv3x3_bnrelu_f16(const float* A, long lda, const float* Wr, float* out, long ldc, long M, int N, int K, int S,
                            const float* scale, const float* shift, gnx_stream_t stream);
+/* Config 5 with the bottleneck kept in fp16: conv1 stores it activated (the consumer's norm2 -> relu2, :38-39) and rounded to
+ * fp16 [M][N] (ldc16 in halves); conv2 then streams it and the fp16 tap-major weights (gnx_repack_conv3x3's layout rounded
+ * once) global -> LDS by DMA and multiplies with v_mfma_f32_32x32x16_f16, fp32 accumulation, fp32 output.
+ * gnx_conv3x3_f16_dma: N == 32, 128 | K, 128 | M, S in {4, 8, 16, 32, 64}, 16-B aligned; else GNX_ERR_UNSUPPORTED. */
+int gnx_conv1x1_bnrelu_f16_act16(const float* A, long lda, const float* W, void* out16, long ldc16, long M, int N, int K,
+                                 const float* scale, const float* shift, const float* out_scale, const float* out_shift,
+                                 gnx_stream_t stream);
+int gnx_conv3x3_f16_dma(const void* A16, long lda16, const void* Wr16, float* out, long ldc, long M, int N, int K, int S,
+                        gnx_stream_t stream);
 
 /* ---- DenseNet-BC backward (the gradients torch.autograd derives for gridnext/densenet.py) -----------------------------
  * Data gradients reuse gnx_conv1x1_bnrelu / gnx_conv3x3_bnrelu with weights transformed by gnx_transpose_weight

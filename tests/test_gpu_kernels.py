@@ -345,6 +345,51 @@ def test_conv3x3_bnrelu(L, n, S, K, N, act):
     assert float(out[:, :3].min()) == 7.0 and float(out[:, 3 + N:].min()) == 7.0     # neighbours untouched
 
 
+@pytest.mark.parametrize("M,K,N", [(1024, 64, 128), (300, 24, 16), (4096, 224, 128), (77, 96, 200)])
+def test_conv1x1_f16_act16(L, M, K, N):
+    """Config 5: conv1 with fp16 MFMA operands storing the bottleneck activated and rounded to fp16."""
+    g = torch.Generator().manual_seed(M + K + 3)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.1
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+    osc, osh = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.5
+    act = torch.relu(A * sc + sh).half().double()                  # operands as the kernel rounds them
+    ref = torch.relu((act @ W.half().double().t()) * osc.double() + osh.double())
+    Ad, Wd, scd, shd, oscd, oshd = (v.to(DEV) for v in (A, W, sc, sh, osc, osh))
+    ldc = (N + 15) // 8 * 8
+    out = torch.full((M, ldc), 7.0, device=DEV, dtype=torch.float16)
+    L.call('gnx_conv1x1_bnrelu_f16_act16', L.ptr(Ad), K, L.ptr(Wd), L.ptr(out, torch.float16), ldc, M, N, K, L.ptr(scd), L.ptr(shd),
+           L.ptr(oscd), L.ptr(oshd), L.stream())
+    close(out[:, :N].double(), ref, rtol=1.5e-3)                   # fp16 rounding of the stored value: 2^-11
+    assert float(out[:, N:].float().min()) == 7.0
+
+
+@pytest.mark.parametrize("n,S", [(8, 4), (2, 8), (1, 16), (40, 32), (4, 64), (256, 32), (4992, 4)])
+def test_conv3x3_f16_dma(L, n, S):
+    """Config 5: conv2 on the fp16 bottleneck, both operands global -> LDS by DMA, v_mfma_f32_32x32x16_f16, fp32
+    accumulation: equal to the convolution of the same fp16 values up to fp32 summation order."""
+    K, N = 128, 32
+    g = torch.Generator().manual_seed(n * 100 + S)
+    x16 = torch.relu(torch.randn(n, K, S, S, generator=g)).half()
+    W = torch.randn(N, K, 3, 3, generator=g) * 0.05
+    Wd = W.to(DEV)
+    Wr = torch.empty(9, N, K, device=DEV)
+    L.call('gnx_repack_conv3x3', L.ptr(Wd), L.ptr(Wr), N, K, L.stream())
+    Wr16 = Wr.half()
+    if n * S * S <= 65536:
+        ref = F.conv2d(x16.double(), W.half().double(), padding=1)
+    else:                                                          # the large cases: fp32 reference on the GPU
+        ref = F.conv2d(x16.to(DEV).float(), W.half().float().to(DEV), padding=1).cpu()
+    A16 = x16.permute(0, 2, 3, 1).reshape(-1, K).contiguous().to(DEV)
+    ldc = N + 8
+    out = torch.full((n * S * S, ldc), 7.0, device=DEV)
+    L.call('gnx_conv3x3_f16_dma', L.ptr(A16, torch.float16), K, L.ptr(Wr16, torch.float16), out.data_ptr() + 4 * 4, ldc, n * S * S, N, K, S, L.stream())
+    close(out[:, 4:4 + N].reshape(n, S, S, N).permute(0, 3, 1, 2), ref, rtol=2e-4)
+    assert float(out[:, :4].min()) == 7.0 and float(out[:, 4 + N:].min()) == 7.0
+    assert L.query('gnx_conv3x3_f16_dma', L.ptr(A16, torch.float16), K, L.ptr(Wr16, torch.float16), L.ptr(out), ldc, n * S * S, 24, K, S,
+                   L.stream()) == L.ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("n,O,P", [(3, 64, 128), (300, 64, 128), (2, 32, 128), (3, 64, 256), (270, 64, 256), (2, 32, 256)])
 def test_stem_fused_with_norm0_relu0_pool0(L, n, O, P):
     """conv0 -> norm0 -> relu0 -> pool0 in one kernel (128- and 256-px geometry) vs torch; other geometries must say
