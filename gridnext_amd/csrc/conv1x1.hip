@@ -522,6 +522,10 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
             });
         }
         const int tm = tile / tilesN, tn = tile - tm * tilesN;
+        // BUFFER stores: like the loads, a global_store issued beside MFMA waves costs the matrix pipe, a buffer_store does
+        // not (resource = this tile's 128 output rows; lane offset constant, row offset scalar)
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (long)tm * 128 * ldc, 0, 128 * ldc * 4,
+                                                                            0x00020000);
         auto store = [&](f32x16& acc, int mt, int nt) {
             const int col = tn * 128 + 64 * wn + 32 * nt + i;
             if (col - i >= N) return;                      // 32 | N: whole fragments in or out
@@ -530,9 +534,11 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = fmaxf(fmaf(acc[r], osc, osh), 0.f);
             }
-            float* o = out + (long)(tm * 128 + 64 * wm + 32 * mt + 4 * h) * ldc + col;
+            const int vo = ((64 * wm + 4 * h) * ldc + col) * 4;
+            const int so = 32 * mt * ldc * 4;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[(long)(((r & 3) + 8 * (r >> 2)) * ldc)] = acc[r];
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), ro, vo, so + ((r & 3) + 8 * (r >> 2)) * ldc * 4, 0);
         };
         store(acc00, 0, 0);
         store(acc01, 0, 1);

@@ -410,9 +410,13 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
         auto store16 = [&](int col0) {
-            float* o = out + (long)(tile * BM + 32 * wave + 4 * h) * ldc + col0 + i;
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (long)tile * BM * ldc, 0, BM * ldc * 4,
+                                                                                0x00020000);
+            const int vo = ((32 * wave + 4 * h) * ldc + col0 + i) * 4;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[(long)(((r & 3) + 8 * (r >> 2)) * ldc)] = acc0[r] + acc1[r];     // exactly 16 stores
+            for (int r = 0; r < 16; ++r)                   // exactly 16 (buffer) stores
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc0[r] + acc1[r]), ro, vo,
+                                                      ((r & 3) + 8 * (r >> 2)) * ldc * 4, 0);
             stored = true;
         };
         auto do_chunk = [&](auto par_c, int ct) {
@@ -663,15 +667,20 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(const float* __restri
             do_chunk(std::integral_constant<int, 1>{});
         }
         // output transform: y(2p) = M0 + M1 + M2, y(2p+1) = M1 - M2 - M3
-        float* o = out + (long)(tile * BM + 2 * (32 * wave + 4 * h)) * ldc + i;
+        // buffer stores (free beside MFMA waves where a global_store is not); the resource ends with the array, so the rows
+        // a ragged last tile does not have are dropped by the bounds check: always exactly 32 stores
+        {
+            const int left = M - tile * BM;
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+                out + (long)tile * BM * ldc, 0, (left < BM ? left : BM) * ldc * 4, 0x00020000);
+            const int vo = (2 * (32 * wave + 4 * h) * ldc + i) * 4;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float m0 = acc[0][0][e] + acc[0][1][e], m1 = acc[1][0][e] + acc[1][1][e];
-            const float m2 = acc[2][0][e] + acc[2][1][e], m3 = acc[3][0][e] + acc[3][1][e];
-            const long row = 2 * ((e & 3) + 8 * (e >> 2));
-            if (tile * BM + 2 * (32 * wave + 4 * h) + row < M) {       // M is even: both pixels of a pair are in or out
-                o[row * ldc] = (m0 + m1) + m2;
-                o[(row + 1) * ldc] = (m1 - m2) - m3;
+            for (int e = 0; e < 16; ++e) {
+                const float m0 = acc[0][0][e] + acc[0][1][e], m1 = acc[1][0][e] + acc[1][1][e];
+                const float m2 = acc[2][0][e] + acc[2][1][e], m3 = acc[3][0][e] + acc[3][1][e];
+                const int row = 2 * ((e & 3) + 8 * (e >> 2));
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((m0 + m1) + m2), ro, vo, row * ldc * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((m1 - m2) - m3), ro, vo, (row + 1) * ldc * 4, 0);
             }
         }
         stored = true;
