@@ -227,6 +227,31 @@ __global__ __launch_bounds__(256) void wgrad_pf_kernel(const float* __restrict__
     float4 ry[NLY], rx[NX];
     auto fetch = [&](long tile) {
         const long m0 = tile * WG_BM;
+        if constexpr (T == 1) {
+            // BUFFER loads (a global_load issued by a wave that also multiplies costs the matrix pipe ~40 cycles, a
+            // buffer_load nothing: tools/ubench/mfma_2x2.hip).  One resource per tile and operand; rows past M read 0.
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const long left = M - m0;
+            const int rows = (int)(left < WG_BM ? left : WG_BM);
+            const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(dY + m0 * lddy), 0, (int)(((long)(rows - 1) * lddy + N) * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(X + m0 * ldx), 0, (int)(((long)(rows - 1) * ldx + K) * 4), 0x00020000);
+            constexpr int RPJ = 256 / (LDY / 4);           // dY rows per 256 pieces
+            const int c4 = t % (LDY / 4), r0y = t / (LDY / 4);
+            const int voy = (int)((r0y * lddy + n0 + 4 * c4) * 4), vox = (int)(((t >> 5) * ldx + kld) * 4);
+#pragma unroll
+            for (int j = 0; j < NLY; ++j) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rY, voy, (int)(j * RPJ * lddy * 4), 0);
+                ry[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            }
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rX, vox, (int)(j * 8 * ldx * 4), 0);
+                rx[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NLY; ++j) {
             const int idx = t + 256 * j;
