@@ -255,14 +255,26 @@ struct C1Stage {
 };
 constexpr int C1_KMAX = 2048;      // scale/shift vectors are staged in LDS up to this K
 
-template <bool ACT, bool POOL, int NP>
+// DGBN (training backward: conv1's data gradient fused with norm1 -> relu1's backward): A = dL/d(conv1 out) [M][K = 128],
+// W = conv1 weight transposed [N = cin][K]; the store, instead of writing the product g0[m][c], reads the layer's input
+// x[m][c] (bn.x, the block buffer) and the block gradient out[m][c], and writes
+//   out[m][c] += sc[c] g[m][c],   g = g0 where sc[c] x + sh[c] > 0, else 0            (densenet.py:35-37 backwards)
+// and the column sums sum_m g, sum_m g xhat (xhat = (x - mean) invstd) of each 64-row half tile go to bn.slab
+// [2 M/128][2][N] for dbeta / dgamma.  Five passes over [M][cin] (write g0, read g0, read x, read + write the gradient) become
+// three.
+struct C1BnBwd {
+    const float* x; int ldx;
+    const float* sc; const float* sh; const float* mean; const float* inv;
+    float* slab;
+};
+template <bool ACT, bool POOL, int NP, bool DGBN = false>
 __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_kernel(const float* __restrict__ A, int lda,
                                                             const float* __restrict__ W, float* __restrict__ out,
                                                             int ldc, int K, int N, int tilesN, int T, int S_in,
                                                             long rows_in, const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ oscale,
-                                                            const float* __restrict__ oshift) {
+                                                            const float* __restrict__ oshift, C1BnBwd bn = C1BnBwd()) {
     constexpr int OPB = 128 * 32 * 4;                      // bytes of one operand chunk
     extern __shared__ __attribute__((aligned(16))) float lds_f[];  // [buffer][A | B] then scale[K], shift[K]
     char* const lds = reinterpret_cast<char*>(lds_f);
@@ -540,6 +552,46 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
             for (int r = 0; r < 16; ++r)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), ro, vo, so + ((r & 3) + 8 * (r >> 2)) * ldc * 4, 0);
         };
+        if constexpr (DGBN) {
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(bn.x + (long)tm * 128 * bn.ldx), 0, 128 * bn.ldx * 4, 0x00020000);
+            auto bwd = [&](f32x16& a0, f32x16& a1, int nt) {           // the two row halves (mt = 0, 1) of column fragment nt
+                const int col = tn * 128 + 64 * wn + 32 * nt + i;
+                if (col - i >= N) return;
+                const float sc = bn.sc[col], sh = bn.sh[col], mu = bn.mean[col], is = bn.inv[col];
+                const int vox = ((64 * wm + 4 * h) * bn.ldx + col) * 4, vod = ((64 * wm + 4 * h) * ldc + col) * 4;
+                float sb = 0.f, sg = 0.f;
+                auto half = [&](f32x16& acc, int mt) {
+                    float xv[16], dv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = 32 * mt + (r & 3) + 8 * (r >> 2);
+                        xv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vox, row * bn.ldx * 4, 0));
+                        dv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, vod, row * ldc * 4, 0));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = 32 * mt + (r & 3) + 8 * (r >> 2);
+                        const float g = fmaf(xv[r], sc, sh) > 0.f ? acc[r] : 0.f;
+                        sb += g;
+                        sg = fmaf(g, (xv[r] - mu) * is, sg);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(g, sc, dv[r])), ro, vod, row * ldc * 4, 0);
+                    }
+                };
+                half(a0, 0);
+                half(a1, 1);
+                sb += __shfl_xor(sb, 32);
+                sg += __shfl_xor(sg, 32);
+                if (h == 0) {
+                    float* sl = bn.slab + ((long)(2 * tm + wm) * 2) * N + col;
+                    sl[0] = sb;
+                    sl[N] = sg;
+                }
+            };
+            bwd(acc00, acc10, 0);
+            bwd(acc01, acc11, 1);
+            continue;
+        }
         store(acc00, 0, 0);
         store(acc01, 0, 1);
         store(acc10, 1, 0);
@@ -554,6 +606,39 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
         dbg[wave * ldc + 1] = (float)c_total;
     }
 #endif
+}
+
+// slab[nblk][2][C] -> part[R][2][C]: block y sums its contiguous share of the slabs in a fixed order (bn_bwd_reduce_kernel
+// of bn.hip then finishes over the R rows)
+__global__ __launch_bounds__(256) void slab_fold_kernel(const float* __restrict__ slab, long nblk, int C, int R,
+                                                        float* __restrict__ part) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long per = (nblk + R - 1) / R, b0 = blockIdx.y * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C)
+        for (long b = b0 + sl; b < b1; b += 4) {
+            s1 += slab[(b * 2 + 0) * C + c];
+            s2 += slab[(b * 2 + 1) * C + c];
+        }
+    red[0][sl][cl] = s1;
+    red[1][sl][cl] = s2;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        part[((long)blockIdx.y * 2 + 0) * C + c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        part[((long)blockIdx.y * 2 + 1) * C + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    }
+}
+// out[c] (+)= sum over the R rows of part[.][q][c], fixed order
+__global__ void slab_finish_kernel(const float* __restrict__ part, int R, int C, float* dbeta, float* dgamma,
+                                   int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < R; ++b) { s1 += part[((long)b * 2 + 0) * C + c]; s2 += part[((long)b * 2 + 1) * C + c]; }
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + s2 : s2;
 }
 
 // ------------------------------------------------------------------------------------------------ conv1x1, LDS-clamp form
@@ -621,13 +706,13 @@ __global__ __launch_bounds__(512, 4) void conv1x1_clamp_kernel(const float* __re
         // arithmetic either.  M0 = LDS destination of lane 0; the scalar offset moves only the source.
         auto dma4 = [&](const __amdgpu_buffer_rsrc_t& r, int so, int rowskip, unsigned vo, unsigned m0) {
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         ::"s"(m0), "v"(vo), "s"(r), "s"(so) : "memory", "m0");
+                         ::"s"(m0), "v"(vo), "s"(r), "s"(so) : "memory");
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         ::"s"(m0 + 1024), "v"(vo), "s"(r), "s"(so + 64) : "memory", "m0");
+                         ::"s"(m0 + 1024), "v"(vo), "s"(r), "s"(so + 64) : "memory");
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         ::"s"(m0 + 2048), "v"(vo), "s"(r), "s"(so + rowskip) : "memory", "m0");
+                         ::"s"(m0 + 2048), "v"(vo), "s"(r), "s"(so + rowskip) : "memory");
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         ::"s"(m0 + 3072), "v"(vo), "s"(r), "s"(so + rowskip + 64) : "memory", "m0");
+                         ::"s"(m0 + 3072), "v"(vo), "s"(r), "s"(so + rowskip + 64) : "memory");
         };
         const unsigned ldsb = lds_addr(lds) + pw * 4096;
         auto issue_a = [&](int stage) {
@@ -950,5 +1035,52 @@ GNX_EXPORT int gnx_conv1x1_clamped_act(const float* A, long lda, const float* Wf
     const int wgs = (int)(T < 512 ? T : 512);
     conv1x1_clamp_kernel<<<wgs, 512, lds_bytes, stream>>>(A, (int)lda, Wf, bounds, out, (int)ldc, K, N, tilesN, (int)T,
                                                           out_scale, out_shift_f);
+    return gnx_launch_status();
+}
+
+// floats of workspace gnx_conv1x1_dgrad_bnrelu_bwd needs
+constexpr int C1_DGBN_R = 128;
+GNX_EXPORT long gnx_conv1x1_dgrad_bn_workspace(long M, int N) {
+    return (2 * (M / 128) * 2 + (long)C1_DGBN_R * 2) * (long)N;
+}
+
+// conv1's data gradient fused with norm1 -> relu1's backward (eval statistics), accumulated into the block gradient:
+//   dX[m][c] += scale[c] g[m][c],  g = (dY . Wt^T)[m][c] where scale[c] X[m][c] + shift[c] > 0, else 0     (c < N = cin)
+//   dbeta[c] (+)= sum_m g,  dgamma[c] (+)= sum_m g (X - mean) invstd
+// == gnx_conv1x1_bnrelu(dY, Wt) followed by gnx_bn_relu_bwd(relu = 1, training = 0, dx_accumulate = 1), in three passes over
+// [M][N] instead of five.  dY [M][K] (lddy), Wt [N][K] (gnx_transpose_weight), X / dX [M][>= N] (ldx / lddx).
+// Whole tiles only (128 | M, 32 | N, 32 | K, aligned): GNX_ERR_UNSUPPORTED otherwise - run the two calls then.
+GNX_EXPORT int gnx_conv1x1_dgrad_bnrelu_bwd(const float* dY, long lddy, const float* Wt, const float* X, long ldx, float* dX,
+                                            long lddx, long M, int N, int K, const float* scale, const float* shift,
+                                            const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                            int accumulate, float* workspace, hipStream_t stream) {
+    if (!dY || !Wt || !X || !dX || !scale || !shift || !mean || !invstd || !workspace || M < 0 || N <= 0 || K <= 0 ||
+        lddy < K || ldx < N || lddx < N)
+        return GNX_ERR_BAD_ARG;
+    if (M % 128 != 0 || N % 32 != 0 || K % 32 != 0 || K > C1_KMAX || !al16(dY) || !al16(Wt) || lddy % 4 != 0 ||
+        4 * M >= (1L << 31) || lddy >= (1 << 16) || ldx >= (1 << 16) || lddx >= (1 << 16))
+        return GNX_ERR_UNSUPPORTED;
+    if (M == 0) return GNX_OK;
+    const size_t lds_ws = 4 * 128 * 32 * 4;
+    static bool conf = false;
+    if (!conf) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_ws_kernel<false, false, 4, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 32 * 4 + 8 * C1_KMAX) != hipSuccess)
+            return GNX_ERR_LAUNCH;
+        conf = true;
+    }
+    const int tilesN = (N + 127) / 128;
+    const long T = (M / 128) * tilesN;
+    const int wgs = (int)(T < 512 ? T : 512);
+    float* slab = workspace;
+    float* part = workspace + 2 * (M / 128) * 2 * (long)N;
+    C1BnBwd bn = {X, (int)ldx, scale, shift, mean, invstd, slab};
+    conv1x1_ws_kernel<false, false, 4, true><<<wgs, 512, lds_ws, stream>>>(dY, (int)lddy, Wt, dX, (int)lddx, K, N, tilesN,
+                                                                           (int)T, 0, 4 * M, nullptr, nullptr, nullptr,
+                                                                           nullptr, bn);
+    if (dgamma || dbeta) {
+        slab_fold_kernel<<<dim3(gnx_cdiv(N, 64), C1_DGBN_R), 256, 0, stream>>>(slab, 2 * (M / 128), N, C1_DGBN_R, part);
+        slab_finish_kernel<<<gnx_cdiv(N, 64), 64, 0, stream>>>(part, C1_DGBN_R, N, dbeta, dgamma, accumulate);
+    }
     return gnx_launch_status();
 }

@@ -361,8 +361,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
                 // array ends: rows outside [0, M) are only ever "read" by masked taps, any in-range row will do
                 int Pr = row0 + (lane & 15);
                 Pr = Pr < 0 ? 0 : (Pr >= M ? M - 1 : Pr);
-                __builtin_amdgcn_global_load_lds(A + (long)Pr * lda + (NK1 ? 0 : KC * nchunk) + 16 * part + 4 * (lane >> 4),
-                                                 (float*)d, 16, 0, 0);
+                dma16_global(A + (long)Pr * lda + (NK1 ? 0 : KC * nchunk) + 16 * part + 4 * (lane >> 4), lds_addr(d));
             }
         } else {
             const int p = wave + NW * (slot - NSA);                            // weight group p / PPG = 2 tap + (n >> 4)
@@ -551,7 +550,7 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(const float* __restri
             } else {                                       // array ends: any in-range row (only masked rows use it)
                 int Pr = row0 + pix;
                 Pr = Pr < 0 ? 0 : (Pr >= M ? M - 1 : Pr);
-                __builtin_amdgcn_global_load_lds(A + (long)Pr * lda + 16 * nchunk + 4 * (lane >> 4), (float*)d, 16, 0, 0);
+                dma16_global(A + (long)Pr * lda + 16 * nchunk + 4 * (lane >> 4), lds_addr(d));
             }
         } else {
             const int p = wave + 4 * (slot - NSR);         // U group p: tap p >> 1, rows 16 (p & 1) ..

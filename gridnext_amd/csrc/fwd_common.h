@@ -58,7 +58,12 @@ __device__ __forceinline__ f32x4 lds_read4(unsigned addr) {
 // wave -> 129 against 150 TFLOP/s); bytes past the resource's extent read as zero.
 __device__ __forceinline__ void dma16_buf(const __amdgpu_buffer_rsrc_t& r, unsigned voff, int soff, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff) : "memory", "m0");
+                 ::"s"(lds_dst), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+// The same transfer with per-lane 64-bit addresses (array ends, where rows are clamped per lane).  M0 is written inside the
+// asm statements only: no kernel mixes these helpers with the compiler's own LDS-DMA builtin, which keeps M0 itself.
+__device__ __forceinline__ void dma16_global(const float* lane_src, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_dst), "v"(lane_src) : "memory");
 }
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {

@@ -244,10 +244,23 @@ class _DenseNetFn(Function):
                 wgrad(layer.conv1.weight, L.ptr(tB), mid, L.ptr(buf), c_total, s1, M, mid, cin, s, 1, 0)
                 w1t = torch.empty((cin, mid), device=dev, dtype=F32)
                 L.call('gnx_transpose_weight', L.ptr(layer.conv1.weight.detach().contiguous()), L.ptr(w1t), mid, cin, st)
-                L.call('gnx_conv1x1_bnrelu', L.ptr(tB), mid, L.ptr(w1t), L.ptr(tC), c_total, M, cin, mid, None, None,
-                       0, 0, st)
-                # norm1 + relu1, accumulated into the block-buffer gradient
-                bn_bwd(layer.norm1, s1, L.ptr(tC), c_total, L.ptr(buf), c_total, L.ptr(dbuf), c_total, M, cin, 1)
+                # conv1's data gradient + norm1/relu1 backward, accumulated into the block-buffer gradient: one kernel where
+                # the statistics are the running ones and the tiles are whole (3 passes over [M][cin] instead of 5)
+                rc = L.ERR_UNSUPPORTED
+                if not training:
+                    bn1 = layer.norm1
+                    dg = new_like(bn1.weight) if want(bn1.weight) else None
+                    db = new_like(bn1.bias) if want(bn1.bias) else None
+                    ws = torch.empty(L.query('gnx_conv1x1_dgrad_bn_workspace', M, cin), device=dev, dtype=F32)
+                    rc = L.query('gnx_conv1x1_dgrad_bnrelu_bwd', L.ptr(tB), mid, L.ptr(w1t), L.ptr(buf), c_total,
+                                 L.ptr(dbuf), c_total, M, cin, mid, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s1[2]), L.ptr(s1[3]),
+                                 L.ptr(dg), L.ptr(db), 0, L.ptr(ws), st)
+                    if rc not in (0, L.ERR_UNSUPPORTED):
+                        raise RuntimeError("gnx_conv1x1_dgrad_bnrelu_bwd failed (%d)" % rc)
+                if rc == L.ERR_UNSUPPORTED:
+                    L.call('gnx_conv1x1_bnrelu', L.ptr(tB), mid, L.ptr(w1t), L.ptr(tC), c_total, M, cin, mid, None, None,
+                           0, 0, st)
+                    bn_bwd(layer.norm1, s1, L.ptr(tC), c_total, L.ptr(buf), c_total, L.ptr(dbuf), c_total, M, cin, 1)
                 tape.layers[bi][li] = None
             del tA, tB, tC
             if bi > 0:

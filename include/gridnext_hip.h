@@ -96,6 +96,15 @@ int gnx_conv1x1_bnrelu(const float* A, long lda, const float* W, float* out, lon
 int gnx_conv1x1_bnrelu_act(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
                            const float* scale, const float* shift, const float* out_scale, const float* out_shift,
                            gnx_stream_t stream);
+/* Training backward of norm1 -> relu1 -> conv1 (:35-37) w.r.t. the layer input, eval statistics: conv1's data gradient
+ * dY . Wt^T (Wt = gnx_transpose_weight of conv1.weight) fused with the BN + ReLU backward and accumulated into the block
+ * gradient dX[:, :N]; dbeta / dgamma from per-tile column sums (fixed order).  Same result as gnx_conv1x1_bnrelu followed by
+ * gnx_bn_relu_bwd(relu = 1, training = 0, dx_accumulate = 1).  Whole tiles only, else GNX_ERR_UNSUPPORTED. */
+long gnx_conv1x1_dgrad_bn_workspace(long M, int N);
+int gnx_conv1x1_dgrad_bnrelu_bwd(const float* dY, long lddy, const float* Wt, const float* X, long ldx, float* dX, long lddx,
+                                 long M, int N, int K, const float* scale, const float* shift, const float* mean,
+                                 const float* invstd, float* dgamma, float* dbeta, int accumulate, float* workspace,
+                                 gnx_stream_t stream);
 /* The same operation with norm1 folded into the operands (eval mode, weights frozen): relu(sc x + sh) = sc clamp(x) + sh,
  * clamp = max(., -sh/sc) for sc > 0, min for sc < 0.  gnx_conv1x1_fold_clamp makes Wf[N][K] = W sc, bounds[2][K] (private
  * order) and out_shift_f[N] = out_scale (W . sh) + out_shift once per weight / BN update; gnx_conv1x1_clamped_act then

@@ -282,6 +282,52 @@ def test_conv1x1_bnrelu_act(L, M, K, N):
                                           None, None, L.stream()) != 0       # both output vectors are required
 
 
+@pytest.mark.parametrize("M,N,ld", [(128, 64, 64), (1024, 96, 256), (128 * 600, 224, 256), (2048, 992, 1024)])
+def test_conv1x1_dgrad_fused_with_bn_relu_backward(L, M, N, ld):
+    """conv1's data gradient with norm1 -> relu1's backward in its store == the two separate kernels (dX accumulated into the
+    block gradient, dgamma, dbeta), eval statistics; ragged shapes must say UNSUPPORTED."""
+    K = 128
+    g = torch.Generator().manual_seed(M + N)
+    dY = torch.randn(M, K, generator=g).to(DEV)
+    W1 = (torch.randn(K, N, generator=g) * 0.1).to(DEV)                  # conv1.weight [mid][cin]
+    Wt = W1.t().contiguous()
+    X = torch.randn(M, ld, generator=g).to(DEV)
+    dX0 = torch.randn(M, ld, generator=g).to(DEV)
+    gamma, beta = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.3
+    gamma[1::6] *= -1.0
+    mean, var = torch.randn(N, generator=g) * 0.2, torch.rand(N, generator=g) + 0.5
+    inv = 1.0 / torch.sqrt(var + 1e-5)
+    sc, sh = (gamma * inv).to(DEV), (beta - mean * gamma * inv).to(DEV)
+    meand, invd = mean.to(DEV), inv.to(DEV)
+    # the two-kernel form
+    tC = torch.empty(M, ld, device=DEV)
+    L.call('gnx_conv1x1_bnrelu', L.ptr(dY), K, L.ptr(Wt), L.ptr(tC), ld, M, N, K, None, None, 0, 0, L.stream())
+    dX_ref = dX0.clone()
+    dg_ref, db_ref = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    ws = torch.empty(L.query('gnx_bn_workspace', M, N), device=DEV)
+    L.call('gnx_bn_relu_bwd', L.ptr(tC), ld, L.ptr(X), ld, L.ptr(dX_ref), ld, M, N, L.ptr(sc), L.ptr(sh), L.ptr(meand),
+           L.ptr(invd), L.ptr(dg_ref), L.ptr(db_ref), 1, 0, 0, 1, L.ptr(ws), L.stream())
+    # fused
+    dX = dX0.clone()
+    dg, db = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    ws2 = torch.empty(L.query('gnx_conv1x1_dgrad_bn_workspace', M, N), device=DEV)
+    L.call('gnx_conv1x1_dgrad_bnrelu_bwd', L.ptr(dY), K, L.ptr(Wt), L.ptr(X), ld, L.ptr(dX), ld, M, N, K, L.ptr(sc),
+           L.ptr(sh), L.ptr(meand), L.ptr(invd), L.ptr(dg), L.ptr(db), 0, L.ptr(ws2), L.stream())
+    close(dX[:, :N], dX_ref[:, :N], rtol=1e-5)
+    assert torch.equal(dX[:, N:], dX0[:, N:])                           # columns past cin untouched
+    close(dg, dg_ref, rtol=2e-5, atol=1e-3)
+    close(db, db_ref, rtol=2e-5, atol=1e-3)
+    # against torch autograd on a slice (double)
+    m = min(M, 512)
+    xs = X[:m, :N].double().cpu().requires_grad_(True)
+    z = torch.relu(xs * sc.double().cpu() + sh.double().cpu()) @ W1.double().cpu().t()
+    z.backward(dY[:m].double().cpu())
+    close(dX[:m, :N] - dX0[:m, :N], xs.grad, rtol=1e-4)
+    assert L.query('gnx_conv1x1_dgrad_bnrelu_bwd', L.ptr(dY), K, L.ptr(Wt), L.ptr(X), ld, L.ptr(dX), ld, M - 64, N, K,
+                   L.ptr(sc), L.ptr(sh), L.ptr(meand), L.ptr(invd), L.ptr(dg), L.ptr(db), 0, L.ptr(ws2),
+                   L.stream()) == L.ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("M,K,N,lda", [(128, 32, 128, 32), (1024, 64, 128, 256), (4096, 224, 128, 256), (128 * 700, 96, 128, 128),
                                        (2048, 992, 128, 1024), (1280, 160, 256, 160)])
 def test_conv1x1_clamped_act(L, M, K, N, lda):
