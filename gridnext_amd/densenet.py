@@ -293,6 +293,8 @@ class DenseNet(nn.Module):
                 fit = max(1, self.l3_budget // (4 * per_spot))
                 fill = -(-512 * 128 // (s * s))
                 sub = n if not self.l3_blocking else max(1, min(n, max(fit, fill)))
+                if sub >= 8:
+                    sub -= sub % 8                          # whole 128-row tiles down to the 4 x 4 maps (16 rows per spot)
                 for u0 in range(0, n, sub):
                     nu = min(sub, n - u0)
                     rows = buf[u0 * s * s:(u0 + nu) * s * s]
