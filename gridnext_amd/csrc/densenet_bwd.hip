@@ -364,6 +364,13 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit,
     // four independent partial sums keep several loads in flight; combined in a fixed order
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int sp = 0;
+    for (; sp + 15 < nsplit; sp += 16) {                   // the same four chains, 16 loads in flight
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = slabs[(long)(sp + u) * total + idx];
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+    }
     for (; sp + 3 < nsplit; sp += 4) {
         s0 += slabs[(long)sp * total + idx];
         s1 += slabs[(long)(sp + 1) * total + idx];

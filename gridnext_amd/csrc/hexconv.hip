@@ -185,8 +185,18 @@ __global__ void hexconv_reduce_weight_kernel(const float* __restrict__ partial, 
     const int nout = 7 * O * I + O;
     const int out = blockIdx.x * blockDim.x + threadIdx.x;
     if (out >= nout) return;
+    // slabs added in index order, their loads issued 16 at a time (a plain loop over ~1000 slabs is one memory round trip
+    // per term: 74 us for 29 MB)
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * nout + out];
+    int b = 0;
+    for (; b + 16 <= nblk; b += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)(b + u) * nout + out];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; b < nblk; ++b) s += partial[(size_t)b * nout + out];
     float* dst;
     if (out < 7 * O * I) {
         const int i = out % I, o = (out / I) % O, t = out / (O * I);
