@@ -58,7 +58,7 @@ __device__ __forceinline__ float load_w(const float* k0, const float* k1, int I,
     return t < 3 ? k0[(o * I + i) * 3 + t] : k1[(o * I + i) * 4 + (t - 3)];
 }
 
-constexpr int POS_PER_BLOCK = 64;
+constexpr int POS_PER_BLOCK = 16;      // 312 workgroups on a 78 x 64 grid (64 per block left 178 CUs idle: 38 us per launch)
 
 // y[pos][o] = bias[o] + sum_t sum_i W_t[o][i] * x[nbr_t(pos)][i]
 __global__ __launch_bounds__(256) void hexconv_fwd_kernel(
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void hexconv_fwd_kernel(
     const int npos = g.B * g.H * g.W;
     const int base = blockIdx.x * POS_PER_BLOCK;
     if (o >= O) return;
+    const bool vec = (I & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     const float bo = bias ? bias[o] : 0.f;
     for (int pl = pl0; pl < POS_PER_BLOCK; pl += pstep) {
         const int pos = base + pl;
@@ -86,7 +87,17 @@ __global__ __launch_bounds__(256) void hexconv_fwd_kernel(
             if (n < 0) continue;
             const float* xr = x + (size_t)n * I;
             const float* wr = wl + t * I * O + o;
-            for (int i = 0; i < I; ++i) acc = fmaf(wr[i * O], xr[i], acc);
+            if (vec) {                                      // 16-B loads of the neighbour's row, same order of the adds
+                for (int i = 0; i < I; i += 4) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xr + i);
+                    acc = fmaf(wr[i * O], xv.x, acc);
+                    acc = fmaf(wr[(i + 1) * O], xv.y, acc);
+                    acc = fmaf(wr[(i + 2) * O], xv.z, acc);
+                    acc = fmaf(wr[(i + 3) * O], xv.w, acc);
+                }
+            } else {
+                for (int i = 0; i < I; ++i) acc = fmaf(wr[i * O], xr[i], acc);
+            }
         }
         y[(size_t)pos * O + o] = acc;
     }
@@ -106,6 +117,7 @@ __global__ __launch_bounds__(256) void hexconv_bwd_data_kernel(
     const int npos = g.B * g.H * g.W;
     const int base = blockIdx.x * POS_PER_BLOCK;
     if (i >= I) return;
+    const bool vec = (O & 3) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
     for (int pl = pl0; pl < POS_PER_BLOCK; pl += pstep) {
         const int pos = base + pl;
         if (pos >= npos) break;
@@ -117,7 +129,17 @@ __global__ __launch_bounds__(256) void hexconv_bwd_data_kernel(
             if (s < 0) continue;
             const float* dr = dy + (size_t)s * O;
             const float* wr = wl + t * I * O + i;
-            for (int o = 0; o < O; ++o) acc = fmaf(wr[o * I], dr[o], acc);
+            if (vec) {
+                for (int o = 0; o < O; o += 4) {
+                    const float4 dv = *reinterpret_cast<const float4*>(dr + o);
+                    acc = fmaf(wr[o * I], dv.x, acc);
+                    acc = fmaf(wr[(o + 1) * I], dv.y, acc);
+                    acc = fmaf(wr[(o + 2) * I], dv.z, acc);
+                    acc = fmaf(wr[(o + 3) * I], dv.w, acc);
+                }
+            } else {
+                for (int o = 0; o < O; ++o) acc = fmaf(wr[o * I], dr[o], acc);
+            }
         }
         dx[(size_t)pos * I + i] = acc;
     }
@@ -132,6 +154,7 @@ __global__ __launch_bounds__(256) void hexconv_bwd_weight_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dys = lds;                          // [WG_CHUNK][O]
     float* xs = lds + WG_CHUNK * O;            // [WG_CHUNK][7][I]
+    __shared__ int nbrs[WG_CHUNK * 7];
     const int nout = 7 * O * I + O;
     const int npos = g.B * g.H * g.W;
     const int base = blockIdx.x * pos_per_block;
@@ -140,21 +163,28 @@ __global__ __launch_bounds__(256) void hexconv_bwd_weight_kernel(
 #pragma unroll
     for (int j = 0; j < MAXACC; ++j) acc[j] = 0.f;
     for (int c0 = 0; c0 < pos_per_block; c0 += WG_CHUNK) {
+        const int cnt = pos_per_block - c0 < WG_CHUNK ? pos_per_block - c0 : WG_CHUNK;      // positions of this pass
         __syncthreads();
-        for (int idx = threadIdx.x; idx < WG_CHUNK * O; idx += blockDim.x) {
+        for (int idx = threadIdx.x; idx < cnt * O; idx += blockDim.x) {
             const int pos = base + c0 + idx / O;
             dys[idx] = pos < npos ? dy[(size_t)pos * O + idx % O] : 0.f;
         }
-        for (int idx = threadIdx.x; idx < WG_CHUNK * 7 * I; idx += blockDim.x) {
-            const int i = idx % I, t = (idx / I) % 7, pl = idx / (7 * I);
+        // neighbour rows once per (position, tap) - not once per staged element - then row copies
+        if (threadIdx.x < cnt * 7) {
+            const int t = threadIdx.x % 7, pl = threadIdx.x / 7;
             const int pos = base + c0 + pl;
-            float v = 0.f;
+            int n = -1;
             if (pos < npos) {
                 const int xx = pos % g.W, yy = (pos / g.W) % g.H, b = pos / (g.W * g.H);
-                const int n = g.nbr(b, yy, xx, t);
-                if (n >= 0) v = x[(size_t)n * I + i];
+                n = g.nbr(b, yy, xx, t);
             }
-            xs[idx] = v;
+            nbrs[threadIdx.x] = n;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < cnt * 7 * I; idx += blockDim.x) {
+            const int q = idx / I, i = idx - q * I;           // q = pl * 7 + t
+            const int n = nbrs[q];
+            xs[idx] = n >= 0 ? x[(size_t)n * I + i] : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -163,10 +193,10 @@ __global__ __launch_bounds__(256) void hexconv_bwd_weight_kernel(
             float a = acc[j];
             if (out < 7 * O * I) {
                 const int i = out % I, o = (out / I) % O, t = out / (O * I);
-                for (int pl = 0; pl < WG_CHUNK; ++pl) a = fmaf(dys[pl * O + o], xs[(pl * 7 + t) * I + i], a);
+                for (int pl = 0; pl < cnt; ++pl) a = fmaf(dys[pl * O + o], xs[(pl * 7 + t) * I + i], a);
             } else if (out < nout) {
                 const int o = out - 7 * O * I;
-                for (int pl = 0; pl < WG_CHUNK; ++pl) a += dys[pl * O + o];
+                for (int pl = 0; pl < cnt; ++pl) a += dys[pl * O + o];
             }
             acc[j] = a;
         }
