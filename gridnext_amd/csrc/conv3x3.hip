@@ -294,7 +294,8 @@ __global__ __launch_bounds__(256) void conv3x3_pipe_kernel(const float* __restri
 // the tap-major weights rounded once.  Two halves are one "float" to everything but the multiply: A / Wr / lda / K are passed
 // in float units (K/2, lda/2), a 128-B LDS row holds 64 channels, and a fragment read (16 B = 8 consecutive k of a lane's
 // row; the two lane halves 16 k) feeds ONE v_mfma_f32_32x32x16_f16 where the fp32 form issues four 32x32x2.
-template <int S, int NW, int KC, bool NK1 = false, bool H16 = false>
+// O16: the output is fp16 too ([M][N] halves, ldc in halves): config 5 with fp16 block buffers.
+template <int S, int NW, int KC, bool NK1 = false, bool H16 = false, bool O16 = false>
 __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __restrict__ A, int lda,
                                                               const float* __restrict__ Wr, float* __restrict__ out,
                                                               int ldc, int M, int K, int N) {
@@ -409,6 +410,20 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
         auto store16 = [&](int col0) {
+            if constexpr (O16) {
+                _Float16* o16 = reinterpret_cast<_Float16*>(out);
+                const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(o16 + (long)tile * BM * ldc, 0,
+                                                                                    BM * ldc * 2, 0x00020000);
+                const int vo = ((32 * wave + 4 * h) * ldc + col0 + i) * 2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {             // exactly 16 (buffer) stores
+                    const _Float16 hv = (_Float16)(acc0[r] + acc1[r]);
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, hv), ro, vo,
+                                                          ((r & 3) + 8 * (r >> 2)) * ldc * 2, 0);
+                }
+                stored = true;
+                return;
+            }
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (long)tile * BM * ldc, 0, BM * ldc * 4,
                                                                                 0x00020000);
             const int vo = ((32 * wave + 4 * h) * ldc + col0 + i) * 4;
@@ -868,8 +883,9 @@ GNX_EXPORT int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, flo
 // conv3x3 (pad 1) of an fp16, already activated operand (config 5): A16 [M][K] halves (lda16), Wr16 [9][N][K] halves
 // (gnx_repack_conv3x3's layout rounded to fp16), fp32 accumulation, fp32 out [M][N] (ldc).  conv3x3_dma_kernel in its H16
 // form: N == 32, 128 | K, 128 | M, 16-B aligned; S as the fp32 DMA path.  Anything else: GNX_ERR_UNSUPPORTED.
-GNX_EXPORT int gnx_conv3x3_f16_dma(const void* A16, long lda16, const void* Wr16, float* out, long ldc, long M, int N, int K,
-                                   int S, hipStream_t stream) {
+template <bool O16>
+static int conv3x3_f16_dma_launch(const void* A16, long lda16, const void* Wr16, float* out, long ldc, long M, int N, int K,
+                                  int S, hipStream_t stream) {
     if (!A16 || !Wr16 || !out || M < 0 || N <= 0 || K <= 0 || S <= 0 || lda16 < K || ldc < N || (M % ((long)S * S)) != 0)
         return GNX_ERR_BAD_ARG;
     if (N != C3_BN || (K & 127) != 0 || (M % C3_BM) != 0 || (lda16 & 7) != 0 || !al16(A16) || !al16(Wr16) ||
@@ -885,13 +901,13 @@ GNX_EXPORT int gnx_conv3x3_f16_dma(const void* A16, long lda16, const void* Wr16
         if constexpr (SS <= 32) {                                                                                \
             if (variant == 2 && M % 256 == 0) {                                                                  \
                 const long wgs = M / 256 > 256 ? 256 : M / 256;                                                  \
-                conv3x3_dma_kernel<SS, 8, 32, false, true><<<(int)wgs, 512, 0, stream>>>(A, ldaf, Wr, out,       \
+                conv3x3_dma_kernel<SS, 8, 32, false, true, O16><<<(int)wgs, 512, 0, stream>>>(A, ldaf, Wr, out,       \
                                                                                          (int)ldc, (int)M, Kf, N); \
                 return gnx_launch_status();                                                                      \
             }                                                                                                    \
         }                                                                                                        \
         const long wgs = M / 128 > 256 ? 256 : M / 128;                                                          \
-        conv3x3_dma_kernel<SS, 4, 32, false, true><<<(int)wgs, 256, 0, stream>>>(A, ldaf, Wr, out, (int)ldc,     \
+        conv3x3_dma_kernel<SS, 4, 32, false, true, O16><<<(int)wgs, 256, 0, stream>>>(A, ldaf, Wr, out, (int)ldc,     \
                                                                                  (int)M, Kf, N);                 \
         return gnx_launch_status();                                                                              \
     } while (0)
@@ -905,4 +921,14 @@ GNX_EXPORT int gnx_conv3x3_f16_dma(const void* A16, long lda16, const void* Wr16
     }
 #undef GNX_DMAH
     return GNX_ERR_UNSUPPORTED;
+}
+
+GNX_EXPORT int gnx_conv3x3_f16_dma(const void* A16, long lda16, const void* Wr16, float* out, long ldc, long M, int N, int K,
+                                   int S, hipStream_t stream) {
+    return conv3x3_f16_dma_launch<false>(A16, lda16, Wr16, out, ldc, M, N, K, S, stream);
+}
+// the same with an fp16 output [M][N] (ldc16 in halves): config 5 with fp16 block buffers
+GNX_EXPORT int gnx_conv3x3_f16_dma_h(const void* A16, long lda16, const void* Wr16, void* out16, long ldc16, long M, int N,
+                                     int K, int S, hipStream_t stream) {
+    return conv3x3_f16_dma_launch<true>(A16, lda16, Wr16, reinterpret_cast<float*>(out16), ldc16, M, N, K, S, stream);
 }

@@ -24,11 +24,22 @@ __device__ __forceinline__ half4 to_h4(float4 v) {
     return r;
 }
 __device__ __forceinline__ half8 ldh8(const _Float16* p) { return *reinterpret_cast<const half8*>(p); }
+// 4 consecutive activations at element offset `off` of a matrix stored as fp32 or (IN16) fp16
+template <bool IN16>
+__device__ __forceinline__ float4 lda4(const float* A, long off) {
+    if constexpr (IN16) {
+        const half4 h = *reinterpret_cast<const half4*>(reinterpret_cast<const _Float16*>(A) + off);
+        return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    } else {
+        return ld4(A + off);
+    }
+}
 
 // ---- conv1x1: 128x128 tile, 4 waves x (64x64), K chunks of 32; requires aligned pointers and K % 4 == 0
 // OUT16: the store applies the consumer's BN + ReLU and rounds to fp16 (out is _Float16 [M][N], ldc in halves): the
 // bottleneck as conv3x3_dma_kernel<.., H16> takes it.
-template <bool POOL, bool OUT16 = false>
+// IN16: A holds fp16 activations (lda in halves): config 5 with fp16 block buffers.
+template <bool POOL, bool OUT16 = false, bool IN16 = false>
 __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restrict__ A, long lda,
                                                           const float* __restrict__ W, float* __restrict__ out, long ldc,
                                                           long M, int N, int K, const float* __restrict__ scale,
@@ -92,7 +103,7 @@ __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restric
             const int kc = k < K ? k : 0;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                va[p] = ld4(A + src[p] + kc);
+                va[p] = lda4<IN16>(A, src[p] + kc);
                 const int n = n0 + r0 + 32 * p;
                 vb[p] = ld4(W + (long)(n < N ? n : N - 1) * K + kc);
             }
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restric
                 float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float4 v = ld4(A + src[p] + ((q >> 1) * (long)S_in + (q & 1)) * lda + kc);
+                    float4 v = lda4<IN16>(A, src[p] + ((q >> 1) * (long)S_in + (q & 1)) * lda + kc);
                     if (has_act) {
                         v.x = act1(v.x, sc4.x, sh4.x); v.y = act1(v.y, sc4.y, sh4.y);
                         v.z = act1(v.z, sc4.z, sh4.z); v.w = act1(v.w, sc4.w, sh4.w);
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restric
                 }
                 va[p] = make_float4(0.25f * s.x, 0.25f * s.y, 0.25f * s.z, 0.25f * s.w);
             } else {
-                float4 v = ld4(A + src[p] + kc);
+                float4 v = lda4<IN16>(A, src[p] + kc);
                 if (has_act) {
                     v.x = act1(v.x, sc4.x, sh4.x); v.y = act1(v.y, sc4.y, sh4.y);
                     v.z = act1(v.z, sc4.z, sh4.z); v.w = act1(v.w, sc4.w, sh4.w);
@@ -179,11 +190,13 @@ __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restric
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int col = n0 + 64 * wn + 32 * nt + i;
-                const float osc = col < N ? oscale[col] : 0.f, osh = col < N ? oshift[col] : 0.f;
+                const bool oact = oscale != nullptr;      // no consumer activation (transitions): plain rounding
+                const float osc = (oact && col < N) ? oscale[col] : 1.f, osh = (oact && col < N) ? oshift[col] : 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    Os[((r & 3) + 8 * (r >> 2) + 4 * h) * LDO + 32 * nt + i] =
-                        (_Float16)fmaxf(fmaf(acc[mt][nt][r], osc, osh), 0.f);
+                for (int r = 0; r < 16; ++r) {
+                    const float v = fmaf(acc[mt][nt][r], osc, osh);
+                    Os[((r & 3) + 8 * (r >> 2) + 4 * h) * LDO + 32 * nt + i] = (_Float16)(oact ? fmaxf(v, 0.f) : v);
+                }
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {                  // 32 rows x 8 pieces of 16 B
@@ -344,5 +357,29 @@ GNX_EXPORT int gnx_conv1x1_bnrelu_f16_act16(const float* A, long lda, const floa
     dim3 grid(gnx_cdiv(M, 128), gnx_cdiv(N, 128));
     conv1x1_f16_kernel<false, true><<<grid, 256, 0, stream>>>(A, lda, W, reinterpret_cast<float*>(out16), ldc16, M, N, K,
                                                               scale, shift, 0, out_scale, out_shift);
+    return gnx_launch_status();
+}
+
+// Config 5 with fp16 block buffers: A16 [M][K] halves (lda16), out16 [M][N] halves (ldc16).  out_scale / out_shift may both be
+// NULL (transition: no consumer activation at the store); pool as gnx_conv1x1_bnrelu.
+GNX_EXPORT int gnx_conv1x1_bnrelu_f16_h(const void* A16, long lda16, const float* W, void* out16, long ldc16, long M, int N,
+                                        int K, const float* scale, const float* shift, const float* out_scale,
+                                        const float* out_shift, int pool, int S_in, hipStream_t stream) {
+    if (!A16 || !W || !out16 || M < 0 || N <= 0 || K <= 0 || lda16 < K || ldc16 < N || (!scale) != (!shift) ||
+        (!out_scale) != (!out_shift) || (pool && S_in < 2))
+        return GNX_ERR_BAD_ARG;
+    if (!(al16h(W) && al16h(out16) && (reinterpret_cast<uintptr_t>(A16) & 7) == 0 && lda16 % 4 == 0 && K % 4 == 0 &&
+          N % 8 == 0 && ldc16 % 8 == 0 && (!scale || (al16h(scale) && al16h(shift))) && (!pool || S_in % 2 == 0)))
+        return GNX_ERR_UNSUPPORTED;
+    if (M == 0) return GNX_OK;
+    dim3 grid(gnx_cdiv(M, 128), gnx_cdiv(N, 128));
+    const float* A = reinterpret_cast<const float*>(A16);
+    float* out = reinterpret_cast<float*>(out16);
+    if (pool)
+        conv1x1_f16_kernel<true, true, true><<<grid, 256, 0, stream>>>(A, lda16, W, out, ldc16, M, N, K, scale, shift, S_in,
+                                                                       out_scale, out_shift);
+    else
+        conv1x1_f16_kernel<false, true, true><<<grid, 256, 0, stream>>>(A, lda16, W, out, ldc16, M, N, K, scale, shift, 0,
+                                                                        out_scale, out_shift);
     return gnx_launch_status();
 }

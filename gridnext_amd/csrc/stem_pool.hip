@@ -194,7 +194,8 @@ constexpr int SP_LDT = 72;         // floats per position of the activated tile 
                                    // two lane halves of an accumulator store (positions p and p + 4) hit disjoint banks
 // WO = width of the conv0 map: 64 (128-px patches: tiles of 2 rows, one pooled row each, one carried row) or 128
 // (256-px patches: tiles of 1 row; a pooled row is emitted on every odd conv row from the two carried rows and the new one).
-template <int WO>
+// H16: the pooled output is stored as fp16 ([rows][ldo halves]): config 5 with fp16 block buffers.
+template <int WO, bool H16 = false>
 __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              float* __restrict__ out, long ldo, int H, int Wd, int O,
                                                              const float* __restrict__ scale,
@@ -207,6 +208,15 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __rest
     constexpr int NIT = (WO / 2) * 16 / 256;              // pooling items per thread: (pooled x, 4 channels)
     constexpr int KT = CIN * KH * 8, LDB = KT + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    auto store4 = [](float* o, long off, const float4& v) {     // 4 channels of a pooled position at element offset off
+        if constexpr (H16) {
+            typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+            const half4 hv = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+            *reinterpret_cast<half4*>(reinterpret_cast<_Float16*>(o) + off) = hv;
+        } else {
+            *reinterpret_cast<float4*>(o + off) = v;
+        }
+    };
     float* Bs = lds;                          // [64][LDB] weights, kx zero-padded to 8
     float* Ps = lds + 64 * LDB;               // [CIN][PH][PW]
     float* Ts = Ps + CIN * PH * PW;           // [128 positions][SP_LDT] activated conv tile
@@ -332,15 +342,14 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __rest
                                                   fmaxf(fmaxf(cv.z, m0.z), m1.z), fmaxf(fmaxf(cv.w, m0.w), m1.w));
                     carry[q] = m1;
                     if (4 * c4 < O)
-                        *reinterpret_cast<float4*>(out + ((img * (Ho2 / 2) + tt) * (long)(WO / 2) + px) * ldo + 4 * c4) = o4;
+                        store4(out, ((img * (Ho2 / 2) + tt) * (long)(WO / 2) + px) * ldo + 4 * c4, o4);
                 } else {                                  // one row per tile: emit pooled row (tt-1)/2 on odd rows
                     if (tt & 1) {
                         const float4 c2 = carry2[q], c1 = carry[q];
                         const float4 o4 = make_float4(fmaxf(fmaxf(c2.x, c1.x), m0.x), fmaxf(fmaxf(c2.y, c1.y), m0.y),
                                                       fmaxf(fmaxf(c2.z, c1.z), m0.z), fmaxf(fmaxf(c2.w, c1.w), m0.w));
                         if (4 * c4 < O)
-                            *reinterpret_cast<float4*>(out + ((img * (Ho2 / 2) + (tt >> 1)) * (long)(WO / 2) + px) * ldo +
-                                                       4 * c4) = o4;
+                            store4(out, ((img * (Ho2 / 2) + (tt >> 1)) * (long)(WO / 2) + px) * ldo + 4 * c4, o4);
                     }
                     carry2[q] = carry[q];
                     carry[q] = m0;
@@ -415,6 +424,7 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_vec4_kernel(const float* _
 
 // ------------------------------------------------------------------------------------------------ BN+ReLU+global average pool
 // out[img][c] = mean over the S2 positions of relu(x*scale+shift)
+template <bool IN16 = false>
 __global__ __launch_bounds__(256) void bnrelu_avgpool_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out,
                                                              long ldo, int C, int S2, const float* __restrict__ scale,
                                                              const float* __restrict__ shift) {
@@ -425,7 +435,11 @@ __global__ __launch_bounds__(256) void bnrelu_avgpool_kernel(const float* __rest
     float acc = 0.f;
     if (c < C) {
         const float sc = scale[c], sh = shift[c];
-        for (int r = rl; r < S2; r += 4) acc += fmaxf(fmaf(in[(img * S2 + r) * ldi + c], sc, sh), 0.f);
+        for (int r = rl; r < S2; r += 4) {
+            const long off = (img * S2 + r) * ldi + c;
+            const float v = IN16 ? (float)reinterpret_cast<const _Float16*>(in)[off] : in[off];
+            acc += fmaxf(fmaf(v, sc, sh), 0.f);
+        }
     }
     red[rl][cl] = acc;
     __syncthreads();
@@ -469,12 +483,13 @@ GNX_EXPORT int gnx_conv_stem(const float* x, const float* w, float* out, long ld
 // maxpool3x3s2p1(relu(scale * conv7x7s2p3(x) + shift)) without the intermediate map.  Supported geometry: Cin = 3, the
 // conv output is 64 or 128 wide and even-high (128- / 256-px patches), O <= 64 and O % 4 == 0; anything else returns
 // GNX_ERR_UNSUPPORTED and the caller runs gnx_conv_stem + gnx_bnrelu_maxpool.
-GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool(const float* x, const float* w, float* out, long ldo, long imgs, int Cin,
-                                            int H, int W, int O, int KH, int KW, int stride, int pad, const float* scale,
-                                            const float* shift, hipStream_t stream) {
+template <bool H16>
+static int stem_pool_launch(const float* x, const float* w, float* out, long ldo, long imgs, int Cin, int H, int W, int O,
+                            int KH, int KW, int stride, int pad, const float* scale, const float* shift, hipStream_t stream) {
     if (!x || !w || !out || !scale || !shift || imgs < 0 || Cin <= 0 || O <= 0 || H <= 0 || W <= 0 || ldo < O)
         return GNX_ERR_BAD_ARG;
-    if (Cin != 3 || KH != 7 || KW != 7 || stride != 2 || pad != 3 || O > 64 || O % 4 != 0 || ldo % 4 != 0 || !al16(out))
+    if (Cin != 3 || KH != 7 || KW != 7 || stride != 2 || pad != 3 || O > 64 || O % 4 != 0 || ldo % 4 != 0 ||
+        (reinterpret_cast<uintptr_t>(out) & (H16 ? 7 : 15)) != 0)
         return GNX_ERR_UNSUPPORTED;
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
     if ((Wo != 64 && Wo != 128) || W != 2 * Wo || Ho % 2 != 0 || Ho <= 0 || !al16(x))
@@ -486,23 +501,35 @@ GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool(const float* x, const float* w, floa
     if (Wo == 64) {
         static bool conf = false;
         if (!conf) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel<64>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel<64, H16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
                 return GNX_ERR_LAUNCH;
             conf = true;
         }
-        conv_stem_pool_kernel<64><<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale, shift, imgs);
+        conv_stem_pool_kernel<64, H16><<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale, shift, imgs);
     } else {
         static bool conf = false;
         if (!conf) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel<128>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel<128, H16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
                 return GNX_ERR_LAUNCH;
             conf = true;
         }
-        conv_stem_pool_kernel<128><<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale, shift, imgs);
+        conv_stem_pool_kernel<128, H16><<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale, shift, imgs);
     }
     return gnx_launch_status();
+}
+GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool(const float* x, const float* w, float* out, long ldo, long imgs, int Cin,
+                                            int H, int W, int O, int KH, int KW, int stride, int pad, const float* scale,
+                                            const float* shift, hipStream_t stream) {
+    return stem_pool_launch<false>(x, w, out, ldo, imgs, Cin, H, W, O, KH, KW, stride, pad, scale, shift, stream);
+}
+// the same with the pooled map stored as fp16 [rows][ldo halves] (config 5 with fp16 block buffers)
+GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool_h16(const float* x, const float* w, void* out16, long ldo, long imgs, int Cin,
+                                                int H, int W, int O, int KH, int KW, int stride, int pad,
+                                                const float* scale, const float* shift, hipStream_t stream) {
+    return stem_pool_launch<true>(x, w, reinterpret_cast<float*>(out16), ldo, imgs, Cin, H, W, O, KH, KW, stride, pad, scale,
+                                  shift, stream);
 }
 
 // in [imgs*Hi*Wi][C] (ldi) -> out [imgs*Ho*Wo][C] (ldo): max over 3x3 s2 p1 windows of relu(in*scale+shift)
@@ -533,6 +560,17 @@ GNX_EXPORT int gnx_bnrelu_avgpool(const float* in, long ldi, float* out, long ld
     if (imgs == 0) return GNX_OK;
     if (imgs > 2147483647L) return GNX_ERR_UNSUPPORTED;
     dim3 grid((unsigned)imgs, gnx_cdiv(C, 64));
-    bnrelu_avgpool_kernel<<<grid, 256, 0, stream>>>(in, ldi, out, ldo, C, S2, scale, shift);
+    bnrelu_avgpool_kernel<false><<<grid, 256, 0, stream>>>(in, ldi, out, ldo, C, S2, scale, shift);
+    return gnx_launch_status();
+}
+// the same reading fp16 activations [rows][ldi halves] (config 5 with fp16 block buffers)
+GNX_EXPORT int gnx_bnrelu_avgpool_h16(const void* in16, long ldi, float* out, long ldo, long imgs, int C, int S2,
+                                      const float* scale, const float* shift, hipStream_t stream) {
+    if (!in16 || !out || !scale || !shift || imgs < 0 || C <= 0 || S2 <= 0 || ldi < C || ldo < C) return GNX_ERR_BAD_ARG;
+    if (imgs == 0) return GNX_OK;
+    if (imgs > 2147483647L) return GNX_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)imgs, gnx_cdiv(C, 64));
+    bnrelu_avgpool_kernel<true><<<grid, 256, 0, stream>>>(reinterpret_cast<const float*>(in16), ldi, out, ldo, C, S2, scale,
+                                                          shift);
     return gnx_launch_status();
 }

@@ -62,6 +62,7 @@ class DenseNet(nn.Module):
         self.mfma = 'f32'           # 'f16': fp16 matrix-core operands in the eval forward (BASELINE config 5)
         self.winograd = True        # eval forward: conv2 as Winograd F(2,3) along x where the shape allows (fp32 path;
                                     # same arithmetic type, 1.5x fewer matrix operations, rounding-level differences)
+        self.f16_buffers = True     # mfma = 'f16' only: the block buffers themselves in fp16 where the shapes allow
         self.l3_blocking = False    # option: run each dense block over Infinity-Cache-sized sub-ranges of spots
                                     # (measured r01: slower - 15x more, smaller launches; kept for experiments)
         self.l3_budget = 160 * 1024 * 1024
@@ -270,10 +271,37 @@ class DenseNet(nn.Module):
         hs, sizes = self._geometry(P)
         chunk = self._auto_chunk(P, N)
         mid = self.bn_size * self.growth_rate
+        if sfx and self.atonce is None and chunk >= 8:
+            # fp16 path: chunks of whole 128-row tiles whose element offsets fit 32 bits (what its DMA kernels index with)
+            lim = min((2 ** 31 - 1) // (sz * sz * max(mid, blk[3])) for blk, sz in zip(self._blocks, sizes))
+            chunk = max(8, min(chunk, lim) // 8 * 8)
         conv0 = self.features.conv0
         c0 = conv0.out_channels
+        def sub_range(bi, n):
+            # L3 blocking: run a block's whole layer chain over a sub-range of spots whose buffers fit the
+            # 256 MiB Infinity Cache (so the 2*L re-reads of the block buffer are served on-die), but never so
+            # few spots that a launch has fewer than ~512 workgroups.
+            _, _, _, c_total = self._blocks[bi]
+            s = sizes[bi]
+            per_spot = s * s * (c_total + mid) + (hs * hs * c0 if (bi == 0 and hs is not None) else 0)
+            fit = max(1, self.l3_budget // (4 * per_spot))
+            fill = -(-512 * 128 // (s * s))
+            sub = n if not self.l3_blocking else max(1, min(n, max(fit, fill)))
+            if sub >= 8:
+                sub -= sub % 8                              # whole 128-row tiles down to the 4 x 4 maps (16 rows per spot)
+            return sub
+
+        # config 5 with fp16 BLOCK BUFFERS: the concatenated features live in HBM as fp16 (as under the reference's autocast),
+        # every kernel of the chain reads / writes halves.  Taken when every launch of the call has a shape those kernels
+        # take (decided here, for the whole call: the buffers cannot change type half-way).
+        use_h = bool(sfx) and self.f16_buffers and not self.small_inputs and P in (128, 256) and c0 % 4 == 0 and \
+            self.growth_rate == 32 and mid % 128 == 0 and N % 8 == 0 and chunk % 8 == 0 and \
+            all(s in (4, 8, 16, 32, 64) for s in sizes) and \
+            all(sub_range(bi, min(chunk, N)) * sizes[bi] ** 2 * max(mid, self._blocks[bi][3]) < 2 ** 31
+                for bi in range(len(sizes)))
+        self._used_f16_buffers = use_h                          # introspection (tests, bench)
         # workspace for one chunk
-        bufs = [torch.empty((chunk * s * s, c_total), device=dev, dtype=F32)
+        bufs = [torch.empty((chunk * s * s, c_total), device=dev, dtype=torch.float16 if use_h else F32)
                 for (_, _, _, c_total), s in zip(self._blocks, sizes)]
         bott = torch.empty((chunk * sizes[0] * sizes[0], mid), device=dev, dtype=F32)
         bott16 = bott.view(torch.float16)                       # the same memory as [rows][2 mid] halves (fp16 path)
@@ -286,15 +314,7 @@ class DenseNet(nn.Module):
             xs = x[s0:s0 + n]
             for bi, ((c_in, layers, trans, c_total), s) in enumerate(zip(self._blocks, sizes)):
                 buf = bufs[bi]
-                # L3 blocking: run a block's whole layer chain over a sub-range of spots whose buffers fit the
-                # 256 MiB Infinity Cache (so the 2*L re-reads of the block buffer are served on-die), but never so
-                # few spots that a launch has fewer than ~512 workgroups.
-                per_spot = s * s * (c_total + mid) + (hs * hs * c0 if (bi == 0 and hs is not None) else 0)
-                fit = max(1, self.l3_budget // (4 * per_spot))
-                fill = -(-512 * 128 // (s * s))
-                sub = n if not self.l3_blocking else max(1, min(n, max(fit, fill)))
-                if sub >= 8:
-                    sub -= sub % 8                          # whole 128-row tiles down to the 4 x 4 maps (16 rows per spot)
+                sub = sub_range(bi, n)
                 for u0 in range(0, n, sub):
                     nu = min(sub, n - u0)
                     rows = buf[u0 * s * s:(u0 + nu) * s * s]
@@ -304,6 +324,10 @@ class DenseNet(nn.Module):
                         if self.small_inputs:
                             L.call('gnx_conv_stem', L.ptr(xu), L.ptr(w0), L.ptr(rows), c_total, nu, 3, P, P, c0,
                                    3, 3, 1, 1, st)
+                        elif use_h:
+                            sc, sh = fold[self.features.norm0]
+                            L.call('gnx_conv_stem_bnrelu_maxpool_h16', L.ptr(xu), L.ptr(w0), L.ptr(rows, torch.float16), c_total,
+                                   nu, 3, P, P, c0, 7, 7, 2, 3, L.ptr(sc), L.ptr(sh), st)
                         else:
                             sc, sh = fold[self.features.norm0]
                             # conv0 -> norm0 -> relu0 -> pool0 in one kernel where the geometry allows (128-px
@@ -324,7 +348,15 @@ class DenseNet(nn.Module):
                         sc1, sh1 = fold[layer.norm1]
                         sc2, sh2 = fold[layer.norm2]
                         t0 = self._probe_begin()
-                        if sfx and self._f16_dma_ok(M, s, mid, c_total):
+                        if use_h:
+                            L.call('gnx_conv1x1_bnrelu_f16_h', L.ptr(rows, torch.float16), c_total,
+                                   L.ptr(layer.conv1.weight), L.ptr(bott16, torch.float16), mid, M, mid, cin, L.ptr(sc1),
+                                   L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), 0, 0, st)
+                            t1 = self._probe_mark('conv1x1', t0)
+                            L.call('gnx_conv3x3_f16_dma_h', L.ptr(bott16, torch.float16), mid,
+                                   L.ptr(w2h[layer], torch.float16), rows.data_ptr() + 2 * cin, c_total, M,
+                                   self.growth_rate, mid, s, st)
+                        elif sfx and self._f16_dma_ok(M, s, mid, c_total):
                             # fp16 bottleneck: conv1 stores it activated and rounded, conv2 streams it by DMA.  The choice
                             # depends on the map size and channel counts only (128 | M holds for every whole spot)
                             L.call('gnx_conv1x1_bnrelu_f16_act16', L.ptr(rows), c_total, L.ptr(layer.conv1.weight),
@@ -365,13 +397,23 @@ class DenseNet(nn.Module):
                         sct, sht = fold[trans.norm]
                         # transitions are HBM-bound (4x the input bytes of their output): the fp32 wave-specialised
                         # kernel serves both matrix precisions
-                        L.call('gnx_conv1x1_bnrelu', L.ptr(rows), c_total, L.ptr(trans.conv.weight),
-                               L.ptr(nxt[u0 * so * so:]), nxt.shape[1], nu * so * so, trans.conv.out_channels,
-                               c_total, L.ptr(sct), L.ptr(sht), 1, s, st)
+                        if use_h:
+                            L.call('gnx_conv1x1_bnrelu_f16_h', L.ptr(rows, torch.float16), c_total,
+                                   L.ptr(trans.conv.weight), L.ptr(nxt[u0 * so * so:], torch.float16), nxt.shape[1],
+                                   nu * so * so, trans.conv.out_channels, c_total, L.ptr(sct), L.ptr(sht), None, None, 1, s,
+                                   st)
+                        else:
+                            L.call('gnx_conv1x1_bnrelu', L.ptr(rows), c_total, L.ptr(trans.conv.weight),
+                                   L.ptr(nxt[u0 * so * so:]), nxt.shape[1], nu * so * so, trans.conv.out_channels,
+                                   c_total, L.ptr(sct), L.ptr(sht), 1, s, st)
             scf, shf = fold[self.features.norm_final]
             s_last = sizes[-1]
-            L.call('gnx_bnrelu_avgpool', L.ptr(bufs[-1]), bufs[-1].shape[1], L.ptr(feats[s0:]), self.num_features,
-                   n, self.num_features, s_last * s_last, L.ptr(scf), L.ptr(shf), st)
+            if use_h:
+                L.call('gnx_bnrelu_avgpool_h16', L.ptr(bufs[-1], torch.float16), bufs[-1].shape[1], L.ptr(feats[s0:]),
+                       self.num_features, n, self.num_features, s_last * s_last, L.ptr(scf), L.ptr(shf), st)
+            else:
+                L.call('gnx_bnrelu_avgpool', L.ptr(bufs[-1]), bufs[-1].shape[1], L.ptr(feats[s0:]), self.num_features,
+                       n, self.num_features, s_last * s_last, L.ptr(scf), L.ptr(shf), st)
         if not self.classify:
             return feats
         return GF.linear(feats, self.classifier.weight.detach(), self.classifier.bias.detach())

@@ -152,6 +152,19 @@ int gnx_conv1x1_bnrelu_f16_act16(const float* A, long lda, const float* W, void*
                                  gnx_stream_t stream);
 int gnx_conv3x3_f16_dma(const void* A16, long lda16, const void* Wr16, float* out, long ldc, long M, int N, int K, int S,
                         gnx_stream_t stream);
+/* Config 5 with fp16 BLOCK BUFFERS (the concatenated features themselves live in HBM as fp16, as they do under the
+ * reference's autocast): the stem, conv1 (and the transitions: pool = 1, out_scale = out_shift = NULL), conv2 and the final
+ * pool reading / writing [rows][ld halves]; arithmetic as the entry points above. */
+int gnx_conv_stem_bnrelu_maxpool_h16(const float* x, const float* w, void* out16, long ldo, long imgs, int Cin, int H, int W,
+                                     int O, int KH, int KW, int stride, int pad, const float* scale, const float* shift,
+                                     gnx_stream_t stream);
+int gnx_conv1x1_bnrelu_f16_h(const void* A16, long lda16, const float* W, void* out16, long ldc16, long M, int N, int K,
+                             const float* scale, const float* shift, const float* out_scale, const float* out_shift,
+                             int pool, int S_in, gnx_stream_t stream);
+int gnx_conv3x3_f16_dma_h(const void* A16, long lda16, const void* Wr16, void* out16, long ldc16, long M, int N, int K, int S,
+                          gnx_stream_t stream);
+int gnx_bnrelu_avgpool_h16(const void* in16, long ldi, float* out, long ldo, long imgs, int C, int S2, const float* scale,
+                           const float* shift, gnx_stream_t stream);
 
 /* ---- DenseNet-BC backward (the gradients torch.autograd derives for gridnext/densenet.py) -----------------------------
  * Data gradients reuse gnx_conv1x1_bnrelu / gnx_conv3x3_bnrelu with weights transformed by gnx_transpose_weight

@@ -436,6 +436,74 @@ def test_conv3x3_f16_dma(L, n, S):
                    L.stream()) == L.ERR_UNSUPPORTED
 
 
+def test_fp16_block_buffer_kernels(L):
+    """Config 5 with fp16 block buffers: the *_h / *_h16 entry points read and write fp16 matrices and are otherwise the
+    fp32-buffer kernels - checked against those on the same (fp16-representable) values."""
+    H = torch.float16
+    g = torch.Generator().manual_seed(5)
+    st = L.stream()
+    # stem: fp16 pooled map == the fp32 one rounded
+    n, O = 5, 64
+    x = torch.rand(n, 3, 128, 128, generator=g).to(DEV)
+    W0 = (torch.randn(O, 3, 7, 7, generator=g) * 0.1).to(DEV)
+    sc0, sh0 = (torch.rand(O, generator=g) + 0.5).to(DEV), (torch.randn(O, generator=g) * 0.2).to(DEV)
+    o32 = torch.empty(n * 1024, 96, device=DEV)
+    o16 = torch.full((n * 1024, 96), 7.0, device=DEV, dtype=H)
+    L.call('gnx_conv_stem_bnrelu_maxpool', L.ptr(x), L.ptr(W0), L.ptr(o32), 96, n, 3, 128, 128, O, 7, 7, 2, 3, L.ptr(sc0),
+           L.ptr(sh0), st)
+    L.call('gnx_conv_stem_bnrelu_maxpool_h16', L.ptr(x), L.ptr(W0), L.ptr(o16, H), 96, n, 3, 128, 128, O, 7, 7, 2, 3,
+           L.ptr(sc0), L.ptr(sh0), st)
+    assert torch.equal(o16[:, :O], o32[:, :O].half()) and float(o16[:, O:].float().min()) == 7.0
+    # conv1 on fp16 activations == the fp32-input kernel on the same values
+    M, K, N, ct = 2048, 96, 128, 160
+    A16 = torch.randn(M, ct, generator=g).half().to(DEV)
+    A32 = A16.float()
+    W = (torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    sc, sh = (torch.rand(K, generator=g) + 0.5).to(DEV), (torch.randn(K, generator=g) * 0.5).to(DEV)
+    osc, osh = (torch.rand(N, generator=g) + 0.5).to(DEV), (torch.randn(N, generator=g) * 0.5).to(DEV)
+    b1 = torch.empty(M, N, device=DEV, dtype=H)
+    b2 = torch.empty(M, N, device=DEV, dtype=H)
+    L.call('gnx_conv1x1_bnrelu_f16_act16', L.ptr(A32), ct, L.ptr(W), L.ptr(b1, H), N, M, N, K, L.ptr(sc), L.ptr(sh), L.ptr(osc),
+           L.ptr(osh), st)
+    L.call('gnx_conv1x1_bnrelu_f16_h', L.ptr(A16, H), ct, L.ptr(W), L.ptr(b2, H), N, M, N, K, L.ptr(sc), L.ptr(sh), L.ptr(osc),
+           L.ptr(osh), 0, 0, st)
+    assert torch.equal(b1, b2)
+    # transition (pool, no consumer activation) against torch on the same fp16 values
+    nI, S, Kt, Nt = 3, 8, 64, 40
+    xt = torch.randn(nI, Kt, S, S, generator=g).half()
+    Wt = torch.randn(Nt, Kt, generator=g) * 0.1
+    sct, sht = torch.rand(Kt, generator=g) + 0.5, torch.randn(Kt, generator=g) * 0.5
+    act = torch.relu(xt.float() * sct.view(1, -1, 1, 1) + sht.view(1, -1, 1, 1))
+    ref = F.conv2d(F.avg_pool2d(act, 2, 2).half().double(), Wt.half().double().view(Nt, Kt, 1, 1))
+    At = xt.permute(0, 2, 3, 1).reshape(-1, Kt).contiguous().to(DEV)
+    So = S // 2
+    ot = torch.empty(nI * So * So, Nt, device=DEV, dtype=H)
+    Wtd, sctd, shtd = Wt.to(DEV), sct.to(DEV), sht.to(DEV)
+    L.call('gnx_conv1x1_bnrelu_f16_h', L.ptr(At, H), Kt, L.ptr(Wtd), L.ptr(ot, H), Nt, nI * So * So, Nt, Kt, L.ptr(sctd),
+           L.ptr(shtd), None, None, 1, S, st)
+    close(ot.reshape(nI, So, So, Nt).permute(0, 3, 1, 2).double(), ref, rtol=2e-3)
+    # conv2 with an fp16 output == the fp32-output kernel rounded
+    S2, n2 = 8, 4
+    a16 = torch.relu(torch.randn(n2 * S2 * S2, 128, generator=g)).half().to(DEV)
+    Wc = (torch.randn(32, 128, 3, 3, generator=g) * 0.05).to(DEV)
+    Wr = torch.empty(9, 32, 128, device=DEV)
+    L.call('gnx_repack_conv3x3', L.ptr(Wc), L.ptr(Wr), 32, 128, st)
+    Wr16 = Wr.half()
+    c32 = torch.empty(n2 * S2 * S2, 40, device=DEV)
+    c16 = torch.full((n2 * S2 * S2, 40), 7.0, device=DEV, dtype=H)
+    L.call('gnx_conv3x3_f16_dma', L.ptr(a16, H), 128, L.ptr(Wr16, H), L.ptr(c32), 40, n2 * S2 * S2, 32, 128, S2, st)
+    L.call('gnx_conv3x3_f16_dma_h', L.ptr(a16, H), 128, L.ptr(Wr16, H), L.ptr(c16, H), 40, n2 * S2 * S2, 32, 128, S2, st)
+    assert torch.equal(c16[:, :32], c32[:, :32].half()) and float(c16[:, 32:].float().min()) == 7.0
+    # final pool reading fp16
+    f16 = torch.randn(6 * 16, 200, generator=g).half().to(DEV)
+    scf, shf = (torch.rand(200, generator=g) + 0.5).to(DEV), (torch.randn(200, generator=g) * 0.3).to(DEV)
+    p32, p16 = torch.empty(6, 200, device=DEV), torch.empty(6, 200, device=DEV)
+    f32 = f16.float()
+    L.call('gnx_bnrelu_avgpool', L.ptr(f32), 200, L.ptr(p32), 200, 6, 200, 16, L.ptr(scf), L.ptr(shf), st)
+    L.call('gnx_bnrelu_avgpool_h16', L.ptr(f16, H), 200, L.ptr(p16), 200, 6, 200, 16, L.ptr(scf), L.ptr(shf), st)
+    assert torch.equal(p32, p16)
+
+
 @pytest.mark.parametrize("n,O,P", [(3, 64, 128), (300, 64, 128), (2, 32, 128), (3, 64, 256), (270, 64, 256), (2, 32, 256)])
 def test_stem_fused_with_norm0_relu0_pool0(L, n, O, P):
     """conv0 -> norm0 -> relu0 -> pool0 in one kernel (128- and 256-px geometry) vs torch; other geometries must say

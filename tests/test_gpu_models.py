@@ -428,6 +428,40 @@ def test_fp16_mfma_conv_path_config5():
     assert agree >= 0.95, agree
 
 
+def test_fp16_block_buffers_config5_128px():
+    """Config 5 with the block buffers themselves in fp16 (taken at 128 / 256 px for whole multiples of 8 spots): DenseNet-121
+    at 128 px against the fp32 HIP path and the fp16 path with fp32 buffers; tolerances as test_fp16_mfma_conv_path_config5
+    (two roundings to fp16 per feature instead of one)."""
+    import gridnext_amd as ga
+    from oracle import densenet as odn
+    cfg = odn.DenseNetCfg(num_classes=8, **odn.DENSENET121)
+    sd = odn.closed_form_state(cfg)
+    m = ga.DenseNet(num_classes=8, **odn.DENSENET121)
+    m.load_state_dict(sd)
+    m.to(DEV).eval()
+    x = torch.rand(24, 3, 128, 128, generator=torch.Generator().manual_seed(7)).to(DEV)
+    with torch.no_grad():
+        out32 = m(x).cpu()
+        m.mfma = 'f16'
+        m.f16_buffers = False
+        out16 = m(x).cpu()
+        assert not m._used_f16_buffers
+        m.f16_buffers = True
+        out16h = m(x).cpu()
+        assert m._used_f16_buffers
+        out16h_odd = m(x[:23]).cpu()                              # 23 spots: not whole tiles -> fp32 buffers
+        assert not m._used_f16_buffers
+    scale = out32.abs().max().item()
+    e16 = (out16 - out32).abs().max().item() / scale
+    e16h = (out16h - out32).abs().max().item() / scale
+    print("fp16 path vs fp32: fp32 buffers %.2e, fp16 buffers %.2e" % (e16, e16h))
+    assert e16 < 2e-2 and e16h < 3e-2 and e16h > 1e-6
+    assert (out16h_odd - out16[:23]).abs().max().item() / scale < 1e-3     # other kernels for ragged tiles: rounding only
+    top = out32.topk(2, dim=1).values
+    decided = (top[:, 0] - top[:, 1]) > 5e-2
+    assert (out16h.argmax(1)[decided] == out32.argmax(1)[decided]).float().mean().item() >= 0.95
+
+
 def test_full_size_multimodal_array_config4():
     """BASELINE config 4 at full size: one synthetic 78x64 array of 128-px patches + 2000-gene counts through
     GridNetHexMM (DenseNet-121 + count MLP + hex g).  Too large to rerun on the CPU in a test, so: a random sample of
