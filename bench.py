@@ -280,7 +280,7 @@ def main():
             # config 5's kernels multiply 16x faster than they can be fed: they are priced against HBM (algorithmic bytes
             # per launch / launch time); the fp32-FLOP figure stays in `matrix_tflops` for reference
             h16 = bool(getattr(f_img, '_used_f16_buffers', False))     # block buffers in fp16: every operand is 2 B
-            for kind, name in (('conv1x1', 'conv1x1_f16_kernel<IN16, OUT16>' if h16 else 'conv1x1_f16_kernel'),
+            for kind, name in (('conv1x1', 'conv1x1_h16_kernel' if h16 else 'conv1x1_f16_kernel'),
                                ('conv3x3', 'conv3x3_dma_kernel<H16, O16>' if h16 else 'conv3x3_dma_kernel<H16> / conv3x3_f16_kernel')):
                 kk = kern[kind]
                 if h16:

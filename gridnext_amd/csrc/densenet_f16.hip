@@ -223,6 +223,112 @@ __global__ __launch_bounds__(256) void conv1x1_f16_kernel(const float* __restric
         }
 }
 
+// ---- conv1 on fp16 block buffers (dense layers of config 5): A16 [M][K] halves, W16 [N][K] halves (the weight rounded once),
+// out16 = fp16(relu(osc * y + osh)).  128 x 128 tile, K chunks of 64: a thread moves 16 B (8 halves) per row piece, two
+// workgroup barriers per 64 channels instead of per 32, chunk k+1's loads in flight while chunk k is activated, staged and
+// multiplied.  LDS rows of 72 halves (9 sixteen-byte slots: conflict-free ds_read_b128).
+constexpr int LDH2 = 72;
+__global__ __launch_bounds__(256) void conv1x1_h16_kernel(const _Float16* __restrict__ A, long lda,
+                                                          const _Float16* __restrict__ W, _Float16* __restrict__ out,
+                                                          long ldc, long M, int N, int K,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ oscale,
+                                                          const float* __restrict__ oshift) {
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * 128 * LDH2];
+    _Float16* const As = smem;
+    _Float16* const Bs = smem + 128 * LDH2;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, i = lane & 31;
+    const int kq = t & 7, r0 = t >> 3;                     // this thread's 8 k of a chunk, first of its 4 rows
+    const long m0 = (long)blockIdx.x * 128;
+    const int n0 = blockIdx.y * 128;
+    long srcA[4], srcW[4];
+    bool rok[4], nok[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const long row = m0 + r0 + 32 * p;
+        rok[p] = row < M;
+        srcA[p] = (rok[p] ? row : 0) * lda;
+        const int n = n0 + r0 + 32 * p;
+        nok[p] = n < N;
+        srcW[p] = (long)(nok[p] ? n : 0) * K;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int nkt = (K + 63) / 64;
+    half8 va[4], vb[4];
+    auto fetch = [&](int kt) {
+        const int k = kt * 64 + 8 * kq;
+        const int kc = k < K ? k : 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            va[p] = ldh8(A + srcA[p] + kc);
+            vb[p] = ldh8(W + srcW[p] + kc);
+        }
+    };
+    fetch(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k = kt * 64 + 8 * kq;
+        const bool kok = k < K;                            // 8 | K: the whole piece is in or out
+        const int kc = kok ? k : 0;
+        const float4 sc0 = ld4(scale + kc), sc1 = ld4(scale + kc + 4), sh0 = ld4(shift + kc), sh1 = ld4(shift + kc + 4);
+        const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+        const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+        __syncthreads();                                   // the previous chunk's fragment reads are done
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            half8 a, w = vb[p];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = (_Float16)act1((float)va[p][j], sc[j], sh[j]);
+            if (!(rok[p] && kok)) a = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (!(nok[p] && kok)) w = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            *reinterpret_cast<half8*>(&As[(r0 + 32 * p) * LDH2 + 8 * kq]) = a;
+            *reinterpret_cast<half8*>(&Bs[(r0 + 32 * p) * LDH2 + 8 * kq]) = w;
+        }
+        __syncthreads();
+        fetch(kt + 1 < nkt ? kt + 1 : kt);                 // branch-free; the last one is a harmless re-read
+        asm volatile("" ::: "memory");                     // keep the prefetch in front of the multiply
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const half8 a0 = ldh8(&As[(64 * wm + i) * LDH2 + 16 * s + 8 * h]);
+            const half8 a1 = ldh8(&As[(64 * wm + 32 + i) * LDH2 + 16 * s + 8 * h]);
+            const half8 b0 = ldh8(&Bs[(64 * wn + i) * LDH2 + 16 * s + 8 * h]);
+            const half8 b1 = ldh8(&Bs[(64 * wn + 32 + i) * LDH2 + 16 * s + 8 * h]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // activated, rounded, turned through the LDS: 16-B stores (see conv1x1_f16_kernel<.., OUT16>)
+    _Float16* const Os = smem + wave * 32 * LDH2;
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = n0 + 64 * wn + 32 * nt + i;
+            const float osc = col < N ? oscale[col] : 0.f, osh = col < N ? oshift[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Os[((r & 3) + 8 * (r >> 2) + 4 * h) * LDH2 + 32 * nt + i] = (_Float16)fmaxf(fmaf(acc[mt][nt][r], osc, osh), 0.f);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int piece = lane + 64 * p, rr = piece >> 3, c8 = piece & 7;
+            const long row = m0 + 64 * wm + 32 * mt + rr;
+            const int col = n0 + 64 * wn + 8 * c8;
+            if (row < M && col < N)
+                *reinterpret_cast<half8*>(out + row * ldc + col) = *reinterpret_cast<const half8*>(&Os[rr * LDH2 + 8 * c8]);
+        }
+    }
+}
+
 // ---- conv3x3 (pad 1): same contiguous-strip scheme as the fp32 kernel, fp16 LDS image
 __global__ __launch_bounds__(256) void conv3x3_f16_kernel(const float* __restrict__ A, long lda,
                                                           const float* __restrict__ Wr, float* __restrict__ out, long ldc,
@@ -381,5 +487,24 @@ GNX_EXPORT int gnx_conv1x1_bnrelu_f16_h(const void* A16, long lda16, const float
     else
         conv1x1_f16_kernel<false, true, true><<<grid, 256, 0, stream>>>(A, lda16, W, out, ldc16, M, N, K, scale, shift, 0,
                                                                         out_scale, out_shift);
+    return gnx_launch_status();
+}
+
+// Dense-layer conv1 of config 5 on fp16 block buffers with fp16 weights (W16 = the weight rounded once, [N][K] halves):
+// gnx_conv1x1_bnrelu_f16_h (pool = 0, with consumer activation) in chunks of 64 channels and 16-B loads.  32 | K, 8 | N.
+GNX_EXPORT int gnx_conv1x1_bnrelu_h16(const void* A16, long lda16, const void* W16, void* out16, long ldc16, long M, int N,
+                                      int K, const float* scale, const float* shift, const float* out_scale,
+                                      const float* out_shift, hipStream_t stream) {
+    if (!A16 || !W16 || !out16 || !scale || !shift || !out_scale || !out_shift || M < 0 || N <= 0 || K <= 0 || lda16 < K ||
+        ldc16 < N)
+        return GNX_ERR_BAD_ARG;
+    if (!(al16h(A16) && al16h(W16) && al16h(out16) && al16h(scale) && al16h(shift) && lda16 % 8 == 0 && K % 8 == 0 &&
+          N % 8 == 0 && ldc16 % 8 == 0))
+        return GNX_ERR_UNSUPPORTED;
+    if (M == 0) return GNX_OK;
+    dim3 grid(gnx_cdiv(M, 128), gnx_cdiv(N, 128));
+    conv1x1_h16_kernel<<<grid, 256, 0, stream>>>(reinterpret_cast<const _Float16*>(A16), lda16,
+                                                 reinterpret_cast<const _Float16*>(W16), reinterpret_cast<_Float16*>(out16),
+                                                 ldc16, M, N, K, scale, shift, out_scale, out_shift);
     return gnx_launch_status();
 }

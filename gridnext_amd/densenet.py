@@ -173,6 +173,18 @@ class DenseNet(nn.Module):
         self._cache['w2h'] = (w2, table)
         return table
 
+    def _conv1_f16(self):
+        """{layer: conv1 weight [mid][cin] rounded to fp16} (config 5 on fp16 block buffers), refreshed with the weights."""
+        layers = [l for _, ls, _, _ in self._blocks for l in ls]
+        key = tuple(l.conv1.weight._version for l in layers) + (str(layers[0].conv1.weight.device),)
+        hit = self._cache.get('w1h')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        table = {l: l.conv1.weight.detach().reshape(l.conv1.weight.shape[0], -1).to(torch.float16).contiguous()
+                 for l in layers}
+        self._cache['w1h'] = (key, table)
+        return table
+
     def _f16_dma_ok(self, M, s, mid, c_total):
         """Shapes gnx_conv3x3_f16_dma takes (conv3x3.hip): growth 32, 128 | mid, power-of-two maps 4..64, whole 128-row
         tiles, 32-bit element offsets."""
@@ -300,6 +312,7 @@ class DenseNet(nn.Module):
             all(sub_range(bi, min(chunk, N)) * sizes[bi] ** 2 * max(mid, self._blocks[bi][3]) < 2 ** 31
                 for bi in range(len(sizes)))
         self._used_f16_buffers = use_h                          # introspection (tests, bench)
+        w1h = self._conv1_f16() if use_h else None
         # workspace for one chunk
         bufs = [torch.empty((chunk * s * s, c_total), device=dev, dtype=torch.float16 if use_h else F32)
                 for (_, _, _, c_total), s in zip(self._blocks, sizes)]
@@ -349,9 +362,9 @@ class DenseNet(nn.Module):
                         sc2, sh2 = fold[layer.norm2]
                         t0 = self._probe_begin()
                         if use_h:
-                            L.call('gnx_conv1x1_bnrelu_f16_h', L.ptr(rows, torch.float16), c_total,
-                                   L.ptr(layer.conv1.weight), L.ptr(bott16, torch.float16), mid, M, mid, cin, L.ptr(sc1),
-                                   L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), 0, 0, st)
+                            L.call('gnx_conv1x1_bnrelu_h16', L.ptr(rows, torch.float16), c_total,
+                                   L.ptr(w1h[layer], torch.float16), L.ptr(bott16, torch.float16), mid, M, mid, cin,
+                                   L.ptr(sc1), L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), st)
                             t1 = self._probe_mark('conv1x1', t0)
                             L.call('gnx_conv3x3_f16_dma_h', L.ptr(bott16, torch.float16), mid,
                                    L.ptr(w2h[layer], torch.float16), rows.data_ptr() + 2 * cin, c_total, M,

@@ -161,6 +161,11 @@ int gnx_conv_stem_bnrelu_maxpool_h16(const float* x, const float* w, void* out16
 int gnx_conv1x1_bnrelu_f16_h(const void* A16, long lda16, const float* W, void* out16, long ldc16, long M, int N, int K,
                              const float* scale, const float* shift, const float* out_scale, const float* out_shift,
                              int pool, int S_in, gnx_stream_t stream);
+/* gnx_conv1x1_bnrelu_h16: the dense-layer case of gnx_conv1x1_bnrelu_f16_h (pool = 0, consumer activation) with the weight
+ * rounded to fp16 once (W16 [N][K] halves): chunks of 64 channels, 16-B loads. */
+int gnx_conv1x1_bnrelu_h16(const void* A16, long lda16, const void* W16, void* out16, long ldc16, long M, int N, int K,
+                           const float* scale, const float* shift, const float* out_scale, const float* out_shift,
+                           gnx_stream_t stream);
 int gnx_conv3x3_f16_dma_h(const void* A16, long lda16, const void* Wr16, void* out16, long ldc16, long M, int N, int K, int S,
                           gnx_stream_t stream);
 int gnx_bnrelu_avgpool_h16(const void* in16, long ldi, float* out, long ldo, long imgs, int C, int S2, const float* scale,

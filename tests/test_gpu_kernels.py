@@ -468,6 +468,11 @@ def test_fp16_block_buffer_kernels(L):
     L.call('gnx_conv1x1_bnrelu_f16_h', L.ptr(A16, H), ct, L.ptr(W), L.ptr(b2, H), N, M, N, K, L.ptr(sc), L.ptr(sh), L.ptr(osc),
            L.ptr(osh), 0, 0, st)
     assert torch.equal(b1, b2)
+    b3 = torch.full((M, N + 8), 7.0, device=DEV, dtype=H)
+    W16 = W.half()
+    L.call('gnx_conv1x1_bnrelu_h16', L.ptr(A16, H), ct, L.ptr(W16, H), L.ptr(b3, H), N + 8, M, N, K, L.ptr(sc), L.ptr(sh),
+           L.ptr(osc), L.ptr(osh), st)                             # the 64-channel-chunk form with fp16 weights: same bits
+    assert torch.equal(b3[:, :N], b2) and float(b3[:, N:].float().min()) == 7.0
     # transition (pool, no consumer activation) against torch on the same fp16 values
     nI, S, Kt, Nt = 3, 8, 64, 40
     xt = torch.randn(nI, Kt, S, S, generator=g).half()
