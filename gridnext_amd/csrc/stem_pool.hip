@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256) void conv_stem_patch_kernel(const float* __res
 // 2t+1, pooled row t = max over conv rows {2t-1, 2t, 2t+1} and columns {2px-1, 2px, 2px+1}.  Row 2t-1 is the previous
 // tile's second row: every thread owns the same (px, 4 channels) items in every tile, so that carry lives in registers.
 // relu >= 0, so "outside the map" contributes 0 exactly as in gnx_bnrelu_maxpool.
-constexpr int SP_LDT = 72;         // floats per position of the activated tile in LDS: 4 * 72 = 32 (mod 64) banks, so the
-                                   // two lane halves of an accumulator store (positions p and p + 4) hit disjoint banks
+constexpr int SP_LDT = 40;         // floats per position of the activated 32-channel half tile in LDS: 4 * 40 = 32 (mod 64)
+                                   // banks, so the two lane halves of an accumulator store (positions p, p + 4) hit disjoint banks
 // WO = width of the conv0 map: 64 (128-px patches: tiles of 2 rows, one pooled row each, one carried row) or 128
 // (256-px patches: tiles of 1 row; a pooled row is emitted on every odd conv row from the two carried rows and the new one).
 // H16: the pooled output is stored as fp16 ([rows][ldo halves]): config 5 with fp16 block buffers.
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __rest
     constexpr int PH = STRIDE * (RT - 1) + KH, PW = ((WO - 1) * STRIDE + 8 + 1 + 1) & ~1;      // input patch per channel
     constexpr int F4R = WO * STRIDE / 4;                  // 16-B pieces per input row (row width 2 WO)
     constexpr int NPC = CIN * PH * F4R, NPRE = (NPC + 255) / 256;       // patch pieces, per thread
-    constexpr int NIT = (WO / 2) * 16 / 256;              // pooling items per thread: (pooled x, 4 channels)
+    constexpr int NIT = (WO / 2) * 8 / 256;               // pooling items per thread and pass: (pooled x, 4 of 32 channels)
     constexpr int KT = CIN * KH * 8, LDB = KT + 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     auto store4 = [](float* o, long off, const float4& v) {     // 4 channels of a pooled position at element offset off
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __rest
     const float* pb = Bs + i * LDB + 4 * h;
     const float sc0 = i < O ? scale[i] : 0.f, sh0 = i < O ? shift[i] : 0.f;
     const float sc1 = 32 + i < O ? scale[32 + i] : 0.f, sh1 = 32 + i < O ? shift[32 + i] : 0.f;
-    const int c4 = t & 15, pxa = t >> 4;                  // pooling items of this thread: (pxa + 16 q, c4)
+    const int c4 = t & 7, pxa = t >> 3;                   // pooling items of this thread: (pxa + 32 q, c4) per pass
     const int Ho2 = (H + 2 * PAD - KH) / STRIDE + 1;      // conv rows (even), pooled rows Ho2 / 2
     const int ntt = Ho2 / RT;                             // tiles per image
 
@@ -266,9 +266,10 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __rest
     fetch_patch(blockIdx.x, 0);
 
     for (long img = blockIdx.x; img < imgs; img += gridDim.x) {
-        float4 carry[NIT], carry2[NIT];                   // horizontal maxima of the last (and, WO = 128, second-last) row
+        float4 carry[2][NIT], carry2[2][NIT];             // horizontal maxima of the last (and, WO = 128, second-last) row
 #pragma unroll
-        for (int q = 0; q < NIT; ++q) carry[q] = carry2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < NIT; ++q)
+            carry[0][q] = carry[1][q] = carry2[0][q] = carry2[1][q] = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int tt = 0; tt < ntt; ++tt) {
             __syncthreads();                              // previous tile's fragment and Ts reads are done
             stash_patch();
@@ -312,47 +313,52 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __rest
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             }
-            // norm0 + relu0 on the accumulators, tile to LDS (lane = channel, register = position)
+            // norm0 + relu0 on the accumulators, tile to LDS (lane = channel, register = position) and pool0 - in two
+            // passes of 32 channels (acc0, then acc1), so that the activated tile takes 20 KB instead of 37 and TWO
+            // workgroups fit a CU: one's patch stash, pooling and barriers then hide behind the other's MFMAs
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-                Ts[rr * SP_LDT + i] = fmaxf(fmaf(acc0[r], sc0, sh0), 0.f);
-                Ts[rr * SP_LDT + 32 + i] = fmaxf(fmaf(acc1[r], sc1, sh1), 0.f);
-            }
-            __syncthreads();
-            // pool0
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1) __syncthreads();           // pass 0's pooling reads are done
 #pragma unroll
-            for (int q = 0; q < NIT; ++q) {
-                const int px = pxa + 16 * q;
-                float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;            // horizontal maxima of the tile's rows
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int ox = 2 * px + dx;
-                    if (ox < 0) continue;                                        // ox <= WO - 1 always
-                    const float4 v0 = ld4(&Ts[ox * SP_LDT + 4 * c4]);
-                    m0 = make_float4(fmaxf(m0.x, v0.x), fmaxf(m0.y, v0.y), fmaxf(m0.z, v0.z), fmaxf(m0.w, v0.w));
-                    if (RT == 2) {
-                        const float4 v1 = ld4(&Ts[(WO + ox) * SP_LDT + 4 * c4]);
-                        m1 = make_float4(fmaxf(m1.x, v1.x), fmaxf(m1.y, v1.y), fmaxf(m1.z, v1.z), fmaxf(m1.w, v1.w));
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    Ts[rr * SP_LDT + i] = pass == 0 ? fmaxf(fmaf(acc0[r], sc0, sh0), 0.f) : fmaxf(fmaf(acc1[r], sc1, sh1), 0.f);
                 }
-                if (RT == 2) {                            // rows 2tt, 2tt+1 + the carried row 2tt-1 -> pooled row tt
-                    const float4 cv = carry[q];
-                    const float4 o4 = make_float4(fmaxf(fmaxf(cv.x, m0.x), m1.x), fmaxf(fmaxf(cv.y, m0.y), m1.y),
-                                                  fmaxf(fmaxf(cv.z, m0.z), m1.z), fmaxf(fmaxf(cv.w, m0.w), m1.w));
-                    carry[q] = m1;
-                    if (4 * c4 < O)
-                        store4(out, ((img * (Ho2 / 2) + tt) * (long)(WO / 2) + px) * ldo + 4 * c4, o4);
-                } else {                                  // one row per tile: emit pooled row (tt-1)/2 on odd rows
-                    if (tt & 1) {
-                        const float4 c2 = carry2[q], c1 = carry[q];
-                        const float4 o4 = make_float4(fmaxf(fmaxf(c2.x, c1.x), m0.x), fmaxf(fmaxf(c2.y, c1.y), m0.y),
-                                                      fmaxf(fmaxf(c2.z, c1.z), m0.z), fmaxf(fmaxf(c2.w, c1.w), m0.w));
-                        if (4 * c4 < O)
-                            store4(out, ((img * (Ho2 / 2) + (tt >> 1)) * (long)(WO / 2) + px) * ldo + 4 * c4, o4);
+                __syncthreads();
+                const int ch = 32 * pass + 4 * c4;        // first of this item's 4 output channels
+#pragma unroll
+                for (int q = 0; q < NIT; ++q) {
+                    const int px = pxa + 32 * q;
+                    float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;        // horizontal maxima of the tile's rows
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int ox = 2 * px + dx;
+                        if (ox < 0) continue;                                    // ox <= WO - 1 always
+                        const float4 v0 = ld4(&Ts[ox * SP_LDT + 4 * c4]);
+                        m0 = make_float4(fmaxf(m0.x, v0.x), fmaxf(m0.y, v0.y), fmaxf(m0.z, v0.z), fmaxf(m0.w, v0.w));
+                        if (RT == 2) {
+                            const float4 v1 = ld4(&Ts[(WO + ox) * SP_LDT + 4 * c4]);
+                            m1 = make_float4(fmaxf(m1.x, v1.x), fmaxf(m1.y, v1.y), fmaxf(m1.z, v1.z), fmaxf(m1.w, v1.w));
+                        }
                     }
-                    carry2[q] = carry[q];
-                    carry[q] = m0;
+                    if (RT == 2) {                        // rows 2tt, 2tt+1 + the carried row 2tt-1 -> pooled row tt
+                        const float4 cv = carry[pass][q];
+                        const float4 o4 = make_float4(fmaxf(fmaxf(cv.x, m0.x), m1.x), fmaxf(fmaxf(cv.y, m0.y), m1.y),
+                                                      fmaxf(fmaxf(cv.z, m0.z), m1.z), fmaxf(fmaxf(cv.w, m0.w), m1.w));
+                        carry[pass][q] = m1;
+                        if (ch < O)
+                            store4(out, ((img * (Ho2 / 2) + tt) * (long)(WO / 2) + px) * ldo + ch, o4);
+                    } else {                              // one row per tile: emit pooled row (tt-1)/2 on odd rows
+                        if (tt & 1) {
+                            const float4 c2 = carry2[pass][q], c1 = carry[pass][q];
+                            const float4 o4 = make_float4(fmaxf(fmaxf(c2.x, c1.x), m0.x), fmaxf(fmaxf(c2.y, c1.y), m0.y),
+                                                          fmaxf(fmaxf(c2.z, c1.z), m0.z), fmaxf(fmaxf(c2.w, c1.w), m0.w));
+                            if (ch < O)
+                                store4(out, ((img * (Ho2 / 2) + (tt >> 1)) * (long)(WO / 2) + px) * ldo + ch, o4);
+                        }
+                        carry2[pass][q] = carry[pass][q];
+                        carry[pass][q] = m0;
+                    }
                 }
             }
         }
@@ -497,7 +503,8 @@ static int stem_pool_launch(const float* x, const float* w, float* out, long ldo
     if (imgs == 0) return GNX_OK;
     const int RT = 128 / Wo, PH = 2 * (RT - 1) + 7, PW = ((Wo - 1) * 2 + 8 + 2) & ~1;
     const size_t lds_bytes = ((size_t)64 * (3 * 7 * 8 + 4) + (size_t)3 * PH * PW + (size_t)128 * SP_LDT) * sizeof(float);
-    const int grid = (int)(imgs < 256 ? imgs : 256);
+    const int per_cu = lds_bytes <= 80 * 1024 ? 2 : 1;     // 128-px geometry: 77 KB, two workgroups per CU
+    const int grid = (int)(imgs < 256 * per_cu ? imgs : 256 * per_cu);
     if (Wo == 64) {
         static bool conf = false;
         if (!conf) {
