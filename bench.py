@@ -35,7 +35,7 @@ DENSENET121 = dict(growth_rate=32, block_config=(6, 12, 24, 16), num_init_featur
                    small_inputs=False)
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E
-PMC_TRAFFIC_FILE = 'r01k_pmc_traffic.json'
+PMC_TRAFFIC_FILE = 'r01l_pmc_traffic.json'
 
 
 def conv3x3_flops_per_spot(patch):
