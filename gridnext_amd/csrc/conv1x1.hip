@@ -300,7 +300,8 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
     // workgroup instead of four more 1-KB loads per producer wave and chunk.
     float* sS = reinterpret_cast<float*>(lds + 4 * OPB);
     if (ACT) {
-        for (int k = t; k < K; k += 64 * (4 + NP)) { sS[k] = scale[k]; sS[K + k] = shift[k]; }
+        const float ps = POOL ? 0.25f : 1.f;               // pool-first transition: relu(s x + t) / 4 = relu((s/4) x + t/4)
+        for (int k = t; k < K; k += 64 * (4 + NP)) { sS[k] = ps * scale[k]; sS[K + k] = ps * shift[k]; }
         __syncthreads();
     }
 
@@ -333,19 +334,25 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
                 const int oy = rem / So, ox = rem - oy * So;
                 return ((long)img * S_in + 2 * oy) * S_in + 2 * ox;
             };
-            auto loadp = [&]() {
+            // Per-TILE state of the loads (resources, the lane's two source-row offsets): the integer divisions of srcrow()
+            // cost ~60 VALU instructions, which the producers - VALU-starved beside the MFMA waves - paid on every chunk.
+            __amdgpu_buffer_rsrc_t rA, rW;
+            int vo0 = 0, vo1 = 0;
+            auto settile = [&]() {
                 const int tm = ptile / tilesN, tn = ptile - tm * tilesN;
                 const long base = srcrow(tm * 128);
                 long left = (rows_in - base) * lda - (lda - K);                 // floats behind the resource base
                 const long span = (long)(4 * 128 + 2 * S_in + 4) * lda;
                 if (left > span) left = span;
-                const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float*>(A + base * lda), 0, (int)(left * 4), 0x00020000);
-                const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
+                rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + base * lda), 0, (int)(left * 4), 0x00020000);
+                rW = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<float*>(W + (long)tn * 128 * K), 0, (N - tn * 128 < 128 ? N - tn * 128 : 128) * K * 4,
                     0x00020000);          // rows past N read as 0 (buffer bounds check): ragged last column tile
-                const int vo0 = (int)(srcrow(tm * 128 + 32 * pw + lr) - base) * lda * 4 + lc * 16;
-                const int vo1 = (int)(srcrow(tm * 128 + 32 * pw + lr + 16) - base) * lda * 4 + lc * 16;
+                vo0 = (int)(srcrow(tm * 128 + 32 * pw + lr) - base) * lda * 4 + lc * 16;
+                vo1 = (int)(srcrow(tm * 128 + 32 * pw + lr + 16) - base) * lda * 4 + lc * 16;
+            };
+            settile();
+            auto loadp = [&]() {
                 const int kb = pkt << 7;
                 pk0 = pkt << 5;
 #pragma unroll
@@ -359,8 +366,12 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
                 pwv[1] = bld(rW, voW0, kb + 64);
                 pwv[2] = bld(rW, voW1, kb);
                 pwv[3] = bld(rW, voW1, kb + 64);
-                if (++pkt == nk) { pkt = 0; ptile = tile_of(++pround); }
-                if (ptile >= T) ptile = bx;
+                if (++pkt == nk) {
+                    pkt = 0;
+                    ptile = tile_of(++pround);
+                    if (ptile >= T) ptile = bx;
+                    settile();
+                }
             };
             auto stashp = [&](int buf) {
                 char* d = st + buf * 2 * OPB;
@@ -374,15 +385,17 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                    // the LDS copy of scale / shift carries the pool's 1/4 (exact: a power of two), so the mean is the sum
+                    float4 sum = pa[4 * q];
+                    if (ACT) sum = act4(sum, sc[q & 1], sh[q & 1]);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 1; u < 4; ++u) {
                         float4 v = pa[4 * q + u];
                         if (ACT) v = act4(v, sc[q & 1], sh[q & 1]);
                         sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
                     }
-                    *reinterpret_cast<float4*>(d + (q >> 1) * 2048 + (q & 1) * 1024) =
-                        make_float4(0.25f * sum.x, 0.25f * sum.y, 0.25f * sum.z, 0.25f * sum.w);
+                    if (!ACT) sum = make_float4(0.25f * sum.x, 0.25f * sum.y, 0.25f * sum.z, 0.25f * sum.w);
+                    *reinterpret_cast<float4*>(d + (q >> 1) * 2048 + (q & 1) * 1024) = sum;
                     *reinterpret_cast<float4*>(d + OPB + (q >> 1) * 2048 + (q & 1) * 1024) = pwv[q];
                 }
             };
