@@ -554,8 +554,11 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
         auto store = [&](f32x16& acc, int mt, int nt) {
             const int col = tn * 128 + 64 * wn + 32 * nt + i;
             if (col - i >= N) return;                      // 32 | N: whole fragments in or out
-            if (oscale) {
-                const float osc = oscale[col], osh = oshift[col];
+            if (oscale) {                                  // (buffer loads: see the stores below)
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(oscale), 0, N * 4, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(oshift), 0, N * 4, 0x00020000);
+                const float osc = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, col * 4, 0, 0));
+                const float osh = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rt, col * 4, 0, 0));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = fmaxf(fmaf(acc[r], osc, osh), 0.f);
             }
