@@ -8,23 +8,30 @@ the 2000-gene count grid, concat, 5-layer hex corrector g, foreground-masked CE,
 the count MLP, whose parameters still require grad - the reference's GridNetHexMM quirk), gradient
 all-reduce over ranks, Adam step on the corrector.  Inputs are resident in HBM before the timed region.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          # self-launching: N > 1 spawns one worker process per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # torchrun: every process is a worker (RANK/WORLD_SIZE set)
 
-Rank 0 prints ONE JSON line (contract in the task description) with `roofline` for the dominant kernel
-(the 1x1 or the 3x3 conv of the dense layers, whichever took more of the step; FLOP-weighted over its 58
-launches per step, timed with HIP events on the
-launch stream inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N=1).
+The launching parent never touches the GPU (it does not even import torch): it starts N fresh children with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, waits, and exits non-zero if any of them failed.
+
+Rank 0 prints ONE JSON line (contract in the task description) with
+  * `roofline`      the dominant kernel (the 1x1 or the 3x3 conv of the dense layers, whichever took more of the step;
+                    FLOP-weighted over its 58 launches per step, timed with HIP events on the launch stream inside the
+                    timed region);
+  * `cpu_baseline`  the CPU oracle on a bounded sample (rank 0, N = 1 only): 1 warm-up + 2 timed steps on a 26x16
+                    sub-grid, physical cores, CPU model string, the SAME weights as the GPU leg;
+  * `ce_vs_ref`     BASELINE.json's "CE vs ref": the masked CE of that sub-grid through the HIP path and through the
+                    oracle, same weights and inputs (|dCE| <= 1e-4 asserted for f32), argmax agreement on decided spots;
+  * `series`        the second series of SURVEY 8d on the same box: `train_f` = both classifiers trained through f_opt
+                    (DenseNet forward + backward), with its own roofline object.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
-import torch.nn as nn
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -35,12 +42,18 @@ DENSENET121 = dict(growth_rate=32, block_config=(6, 12, 24, 16), num_init_featur
                    small_inputs=False)
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E
-PMC_TRAFFIC_FILE = 'r01l_pmc_traffic.json'
+PMC_TRAFFIC_FILES = ('r02_pmc_traffic.json', 'r01l_pmc_traffic.json')   # newest first
+SUB_H, SUB_W = 26, 16               # the sub-grid of the CPU leg (416 spots)
+
+
+# ------------------------------------------------------------------------------------------ algorithmic work per spot
+def _first_map(patch):
+    return ((patch + 6 - 7) // 2 + 1 + 2 - 3) // 2 + 1
 
 
 def conv3x3_flops_per_spot(patch):
     """Algorithmic FLOPs of all dense-layer 3x3 convs per spot (2*K*N MAC-flops per output position)."""
-    s = ((patch + 6 - 7) // 2 + 1 + 2 - 3) // 2 + 1
+    s = _first_map(patch)
     total = 0
     for n_layers in DENSENET121['block_config']:
         total += n_layers * s * s * 2 * (9 * 128) * 32
@@ -51,7 +64,7 @@ def conv3x3_flops_per_spot(patch):
 def conv3x3_executed_flops_per_spot(patch):
     """Matrix FLOPs the conv2 launches actually execute: power-of-two maps of 8 x 8 and up run Winograd F(2,3) along x -
     12 instead of 18 multiply-accumulate "taps" per output pair, i.e. 2/3 of the direct count."""
-    s = ((patch + 6 - 7) // 2 + 1 + 2 - 3) // 2 + 1
+    s = _first_map(patch)
     total = 0
     for n_layers in DENSENET121['block_config']:
         f = n_layers * s * s * 2 * (9 * 128) * 32
@@ -62,7 +75,7 @@ def conv3x3_executed_flops_per_spot(patch):
 
 def conv3x3_bytes_per_spot(patch):
     """Algorithmic HBM bytes of those launches per spot: the 128-channel bottleneck in, 32 new channels out."""
-    s = ((patch + 6 - 7) // 2 + 1 + 2 - 3) // 2 + 1
+    s = _first_map(patch)
     total = 0
     for n_layers in DENSENET121['block_config']:
         total += n_layers * s * s * 4 * (128 + 32)
@@ -71,7 +84,7 @@ def conv3x3_bytes_per_spot(patch):
 
 
 def _conv1x1_layers(patch):
-    s = ((patch + 6 - 7) // 2 + 1 + 2 - 3) // 2 + 1
+    s = _first_map(patch)
     c = DENSENET121['num_init_features']
     for n_layers in DENSENET121['block_config']:
         for l in range(n_layers):
@@ -90,7 +103,49 @@ def conv1x1_bytes_per_spot(patch):
     return sum(s * s * 4 * (k + 128) for s, k in _conv1x1_layers(patch))
 
 
+def dgrad1x1_bytes_per_spot(patch):
+    """conv1 data gradient fused with norm1/relu1's adjoint: the 128-wide bottleneck gradient in, then three passes over
+    [M][cin] (layer input for mask and x_hat, block gradient read, block gradient written back)."""
+    return sum(s * s * 4 * (128 + 3 * k) for s, k in _conv1x1_layers(patch))
+
+
+# kind -> (kernel name, FLOPs per spot, algorithmic bytes per spot)           (backward kinds: the f-trained series)
+KINDS = {
+    'conv1x1': ('conv1x1_ws_kernel', conv1x1_flops_per_spot, conv1x1_bytes_per_spot),
+    'conv3x3': ('conv3x3_dma_kernel', conv3x3_flops_per_spot, conv3x3_bytes_per_spot),
+    'wgrad3x3': ('wgrad 3x3 (gnx_wgrad_bnrelu, taps = 9: slab kernel + fixed-order reduce)', conv3x3_flops_per_spot,
+                 conv3x3_bytes_per_spot),
+    'wgrad1x1': ('wgrad 1x1 (gnx_wgrad_bnrelu, taps = 1: slab kernel + fixed-order reduce)', conv1x1_flops_per_spot,
+                 conv1x1_bytes_per_spot),
+    'dgrad3x3': ('conv3x3_dma_kernel, data-gradient shape (K = 32, N = 128)', conv3x3_flops_per_spot,
+                 conv3x3_bytes_per_spot),
+    'dgrad1x1_bn1': ('conv1x1_ws_kernel<..., dgrad + norm1/relu1 adjoint>', conv1x1_flops_per_spot,
+                     dgrad1x1_bytes_per_spot),
+}
+
+
+def kernel_table(probe, patch, steps):
+    """{kind: roofline dict} from the (kind, start_event, end_event) records of `steps` timed steps."""
+    kern = {}
+    for kind in sorted({k for k, _, _ in probe}):
+        if kind not in KINDS:
+            continue
+        name, flops_per_spot, bytes_per_spot = KINDS[kind]
+        ms = sum(s.elapsed_time(e) for k, s, e in probe if k == kind)
+        n_launch = sum(1 for k, _, _ in probe if k == kind)
+        flops = flops_per_spot(patch) * H * W * steps
+        achieved = flops / (ms * 1e-3) / 1e12
+        kern[kind] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
+                      "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                      "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
+                      "flops_per_launch_avg": flops / max(n_launch, 1),
+                      "algorithmic_bytes_per_launch_avg": bytes_per_spot(patch) * H * W * steps / max(n_launch, 1),
+                      "ms_per_step": ms / steps}
+    return kern
+
+
 def build_model(device, patch=128):
+    import torch
     import gridnext_amd as ga
     from gridnext_amd.synthetic import count_mlp
     torch.manual_seed(0)
@@ -99,72 +154,161 @@ def build_model(device, patch=128):
     return ga.GridNetHexMM(f_img, f_cnt, (3, patch, patch), (GENES,), (H, W), CLASSES).to(device)
 
 
-def cpu_baseline(patch, seed=0):
-    """The CPU oracle (oracle/, kind 'port') on a bounded sample of the same step: a 26x16 = 416-spot
-    sub-grid, same model family, same loss/backward/optimizer work, host cores of this box."""
-    from oracle import densenet as odn, gridnet as ogn, masked_ce as oce
+# ------------------------------------------------------------------------------------------ CPU leg + CE vs reference
+def _host_cpu():
+    """(physical cores this process may use, CPU model string)."""
+    model, cores = 'unknown', set()
+    try:
+        phys = core = None
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.startswith('model name') and model == 'unknown':
+                    model = line.split(':', 1)[1].strip()
+                elif line.startswith('physical id'):
+                    phys = line.split(':', 1)[1].strip()
+                elif line.startswith('core id'):
+                    core = line.split(':', 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    n_phys = len(cores) or (os.cpu_count() or 1)
+    try:
+        n_phys = min(n_phys, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    return max(1, n_phys), model
+
+
+def cpu_leg(model, patch, mfma, device, timed_steps=2):
+    """The CPU oracle (oracle/, kind 'port') and the HIP path on the SAME bounded sample and the SAME weights: a 26x16
+    = 416-spot sub-grid of synthetic array 0, tutorial mode.  Returns (cpu_baseline, ce_vs_ref).
+    The HIP side runs first (forward + masked CE), on copies of the trainable parts so the benchmark model is untouched;
+    the oracle then does 1 warm-up + `timed_steps` timed training steps (forward, CE, backward, Adam on the corrector)."""
+    import copy
+    import torch
+    import gridnext_amd as ga
+    from gridnext_amd import functional as GF
     from gridnext_amd.synthetic import count_mlp
-    hs, ws = 26, 16
-    torch.manual_seed(seed)
-    f_img = odn.DenseNet(num_classes=CLASSES, **{k: v for k, v in DENSENET121.items()})
-    g = ogn.GridNetHexMM(f_img, count_mlp(GENES, CLASSES), (3, patch, patch), (GENES,), (hs, ws), CLASSES)
+    from oracle import densenet as odn, gridnet as ogn, masked_ce as oce
+
+    cores, cpu_model = _host_cpu()
+    torch.set_num_threads(cores)
+    gen = torch.Generator().manual_seed(12345)
+    x_img = torch.rand((1, SUB_H, SUB_W, 3, patch, patch), generator=gen)
+    x_cnt = torch.randint(0, 10, (1, GENES, SUB_H, SUB_W), generator=gen).float()
+    y = torch.randint(0, CLASSES + 1, (1, SUB_H, SUB_W), generator=gen)
+    x_img *= (y > 0).float().view(1, SUB_H, SUB_W, 1, 1, 1)
+    x_cnt *= (y > 0).float().view(1, 1, SUB_H, SUB_W)
+
+    # ---- HIP path on the sub-grid: the benchmark model's own image f (frozen: shared), copies of count f and corrector
+    sub = ga.GridNetHexMM(model.image_classifier, copy.deepcopy(model.count_classifier), (3, patch, patch), (GENES,),
+                          (SUB_H, SUB_W), CLASSES).to(device)
+    sub.corrector.load_state_dict(model.corrector.state_dict())
+    sub.train()
+    sub.patch_classifier.eval()
+    state = {k: v.detach().cpu().clone() for k, v in sub.state_dict().items()}
+    with torch.no_grad():
+        logits = sub.forward_nhwc([x_img.to(device), x_cnt.to(device)])
+        loss_hip, stats, preds = GF.masked_cross_entropy(logits.reshape(-1, CLASSES), y.to(device), 1)
+    torch.cuda.synchronize()
+    loss_hip, preds_hip = float(loss_hip.item()), preds.cpu()
+    del sub
+
+    # ---- oracle with the same weights
+    f_img = odn.DenseNet(num_classes=CLASSES, **DENSENET121)
+    f_img.load_named_state({k[len('image_classifier.'):]: v for k, v in state.items()
+                            if k.startswith('image_classifier.')})
+    f_cnt = count_mlp(GENES, CLASSES)
+    f_cnt.load_state_dict({k[len('count_classifier.'):]: v for k, v in state.items()
+                           if k.startswith('count_classifier.')})
+    g = ogn.GridNetHexMM(f_img, f_cnt, (3, patch, patch), (GENES,), (SUB_H, SUB_W), CLASSES)
+    g.corrector.load_state_dict({k[len('corrector.'):]: v for k, v in state.items() if k.startswith('corrector.')})
     for p in g.patch_classifier.parameters():
         p.requires_grad = False
     opt = torch.optim.Adam(g.corrector.parameters(), lr=1e-3)
-    gen = torch.Generator().manual_seed(seed)
-    x_img = torch.rand((1, hs, ws, 3, patch, patch), generator=gen)
-    x_cnt = torch.randint(0, 10, (1, GENES, hs, ws), generator=gen).float()
-    y = torch.randint(0, CLASSES + 1, (1, hs, ws), generator=gen)
     g.train()
     g.patch_classifier.eval()
+
+    def step():
+        out = g([x_img, x_cnt])
+        loss, _, _ = oce.masked_ce(out, y, 1)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        return out.detach(), float(loss.item())
+
     t0 = time.time()
-    out = g([x_img, x_cnt])
-    loss, _, _ = oce.masked_ce(out, y, 1)
-    loss.backward()
-    opt.step()
-    opt.zero_grad()
-    dt = time.time() - t0
-    n = hs * ws
-    return {"value": n / dt, "unit": "spots/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 step on a %dx%d sub-grid (%d spots of %d px, 2000 genes), %.1f s" % (hs, ws, n, patch, dt)}
+    out_ref, loss_ref = step()                                   # warm-up step; its forward is the CE comparison
+    warm = time.time() - t0
+    t0 = time.time()
+    for _ in range(timed_steps):
+        step()
+    dt = (time.time() - t0) / timed_steps
+    n = SUB_H * SUB_W
+
+    rows = out_ref.permute(0, 2, 3, 1).reshape(-1, CLASSES)
+    fg = y.reshape(-1) > 0
+    top = rows.topk(2, dim=1).values
+    decided = fg & ((top[:, 0] - top[:, 1]) > 1e-3)
+    agree = int((preds_hip[decided] == rows.argmax(1)[decided]).sum())
+    ce = {"hip": loss_hip, "oracle": loss_ref, "abs_diff": abs(loss_hip - loss_ref),
+          "argmax_agree": agree, "argmax_compared": int(decided.sum()),
+          "near_ties": int((fg & ~decided).sum()), "foreground_spots": int(fg.sum()),
+          "sample": "%dx%d sub-grid (%d spots of %d px, %d genes), same state_dict and inputs on both sides; "
+                    "forward + masked CE in tutorial mode (image f eval, count f and g train-mode BN)"
+                    % (SUB_H, SUB_W, n, patch, GENES),
+          "dtype": mfma, "gate": "abs_diff <= 1e-4 (f32)" if mfma == 'f32' else "reported only (fp16 operands)"}
+    base = {"value": n / dt, "unit": "spots/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
+            "sample": "1 warm-up (%.1f s) + %d timed training steps (%.1f s each) on a %dx%d sub-grid (%d spots of %d px, "
+                      "%d genes), torch CPU threads = physical cores" % (warm, timed_steps, dt, SUB_H, SUB_W, n, patch, GENES)}
+    return base, ce
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--patch', type=int, default=128)
-    ap.add_argument('--arrays', type=int, default=2, help='distinct synthetic arrays resident per GPU')
-    ap.add_argument('--train-f', action='store_true',
-                    help='second series (SURVEY 8d): both classifiers trained through f_opt, DenseNet backward included')
-    ap.add_argument('--mfma', default='f32', choices=['f32', 'f16'],
-                    help="matrix-core operand type of the DenseNet convs; 'f16' = BASELINE config 5's fp16 MFMA path "
-                         "(fp32 accumulate; NOT the headline, reported as dtype f16)")
-    ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-kernel-timing', action='store_true')
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------ tape size (f trained)
+def tape_bytes(patch, spots):
+    """HBM the f-trained step holds at its peak, in bytes: the raw tensors of the tape (stem map, block buffers, one
+    bottleneck per layer) plus the backward's block-gradient buffers and scratch.  No recompute."""
+    hs = (patch + 6 - 7) // 2 + 1
+    s = _first_map(patch)
+    c = DENSENET121['num_init_features']
+    total = hs * hs * c                                      # conv0 map
+    biggest = 0
+    for n_layers in DENSENET121['block_config']:
+        c_total = c + n_layers * DENSENET121['growth_rate']
+        block = s * s * c_total
+        total += block + n_layers * s * s * 128              # block buffer + every layer's bottleneck
+        biggest = max(biggest, 2 * block + 2 * s * s * 128)  # its gradient, tC scratch, tA, tB
+        c = c_total // 2
+        s //= 2
+    return 4 * spots * (total + biggest + 3 * patch * patch)
 
+
+# ------------------------------------------------------------------------------------------ one worker = one GPU
+def worker_main(args):
+    import torch
+    import torch.nn as nn
     from gridnext_amd import distributed as gdist
     from gridnext_amd import training as gtrain
     from gridnext_amd.synthetic import visium_array
     rank, world, device = gdist.init_from_env(args.backend)
     assert torch.cuda.is_available(), "bench.py measures the HIP path; no HIP device visible"
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+
+    if args.train_f:
+        free, _ = torch.cuda.mem_get_info(device)
+        need = tape_bytes(args.patch, H * W) + args.arrays * 4 * H * W * (3 * args.patch ** 2 + GENES)
+        if need > free:
+            raise SystemExit("bench.py --train-f --patch %d: the f-trained step keeps ~%.0f GB of activations on the tape "
+                             "(no recompute), %.0f GB of HBM are free. Use --patch 128, or fewer resident --arrays."
+                             % (args.patch, need / 1e9, free / 1e9))
 
     model = build_model(device, args.patch)
     gdist.broadcast_module(model)
     optimizer = torch.optim.Adam(model.corrector.parameters(), lr=1e-3)
-    f_opt = None
-    if args.train_f:
-        f_opt = torch.optim.Adam(list(model.image_classifier.parameters()) +
-                                 list(model.count_classifier.parameters()), lr=1e-4)
-    else:
-        for p in model.patch_classifier.parameters():           # Tutorial_multimodal.ipynb cell 27
-            p.requires_grad = False
     criterion = nn.CrossEntropyLoss()
-    stepped = gdist.optimizer_params(optimizer, f_opt)
 
     # synthetic arrays, resident in HBM (different per rank: weak scaling, 1 array per GPU per step)
     arrays = []
@@ -189,41 +333,75 @@ def main():
         for m, mo in zip(bns, moms):
             m.momentum = mo
         f_img.eval()
-    model.train()
-    model.patch_classifier.eval()
 
-    def step(i):
-        inputs, labels = arrays[i % len(arrays)]
-        loss, correct, n_fg = gtrain._grid_loss(model, inputs, labels, criterion, 1, True)
-        loss.backward()
-        gdist.allreduce_gradients(stepped)
-        optimizer.step()
-        optimizer.zero_grad()
-        if f_opt is not None:
-            f_opt.step()
-            f_opt.zero_grad()
-        return loss
+    def run_series(train_f, steps, warmup, probe_on):
+        """`warmup` untimed + `steps` timed steps; returns (seconds for the timed steps - max over ranks -, last loss,
+        probe records)."""
+        f_opt = None
+        params = list(model.image_classifier.parameters()) + list(model.count_classifier.parameters())
+        if train_f:
+            for p in params:
+                p.requires_grad = True
+            f_opt = torch.optim.Adam(params, lr=1e-4)
+        else:
+            for p in model.patch_classifier.parameters():           # Tutorial_multimodal.ipynb cell 27
+                p.requires_grad = False
+        stepped = gdist.optimizer_params(optimizer, f_opt)
+        model.train()
+        model.patch_classifier.eval()
 
-    for i in range(args.warmup):
-        step(i)
-    if not args.no_kernel_timing:
-        f_img._probe = []                                       # (kind, start_event, end_event) per timed launch
-    if gdist.is_active():
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        last = step(args.warmup + i)
-    torch.cuda.synchronize()
-    if gdist.is_active():
-        torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
-    if gdist.is_active():
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        def step(i):
+            inputs, labels = arrays[i % len(arrays)]
+            loss, correct, n_fg = gtrain._grid_loss(model, inputs, labels, criterion, 1, True)
+            loss.backward()
+            gdist.allreduce_gradients(stepped)
+            optimizer.step()
+            optimizer.zero_grad()
+            if f_opt is not None:
+                f_opt.step()
+                f_opt.zero_grad()
+            return loss
+
+        f_img._probe = None
+        for i in range(warmup):
+            step(i)
+        if probe_on:
+            f_img._probe = []                                       # (kind, start_event, end_event) per timed launch
+        if gdist.is_active():
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            last = step(warmup + i)
+        torch.cuda.synchronize()
+        if gdist.is_active():
+            torch.distributed.barrier()
+        elapsed = time.perf_counter() - t0
+        if gdist.is_active():
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        probe, f_img._probe = f_img._probe, None
+        return elapsed, float(last.item()), probe
+
+    # ---- CE vs reference + CPU baseline (rank 0, N = 1 only), BEFORE any optimizer step: initial weights on both sides
+    cpu_base = ce = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_base, ce = cpu_leg(model, args.patch, args.mfma, device)
+        if args.mfma == 'f32':
+            assert ce["abs_diff"] <= 1e-4, "CE of the HIP path differs from the CPU oracle by %.3e (> 1e-4)" % ce["abs_diff"]
+
+    elapsed, last_loss, probe = run_series(args.train_f, args.steps, args.warmup, not args.no_kernel_timing)
 
     spots = H * W * world * args.steps
+    names = [None] * world
+    mine = "rank %d: %s (cuda:%d)" % (rank, torch.cuda.get_device_name(device), device.index)
+    if gdist.is_active():
+        torch.distributed.all_gather_object(names, mine)
+    else:
+        names = [mine]
+    mode = ("f AND g trained (f_opt; DenseNet forward+backward, eval-mode BN as training.py:126)" if args.train_f
+            else "f frozen/eval (tutorial mode)")
     result = {
         "metric": "spots/sec training throughput (multimodal f+g)",
         "value": spots / elapsed, "unit": "spots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -231,51 +409,41 @@ def main():
         "vs_baseline": None, "dtype": args.mfma, "data": "synthetic",
         "config": {"workload": "C4: multimodal f(DenseNet-121 @%dpx + count-MLP 2000 genes) + hex g on 78x64 Visium "
                                "grids, 1 array (4992 spots) per GPU per step, %s, "
-                               "g trained with Adam, masked CE" % (args.patch, "f AND g trained (f_opt; DenseNet "
-                               "forward+backward, eval-mode BN as training.py:126)" if args.train_f else
-                               "f frozen/eval (tutorial mode)"),
+                               "g trained with Adam, masked CE" % (args.patch, mode),
                    "arrays_per_gpu_per_step": 1, "spots_per_array": H * W, "parallelism": "dp%d" % world,
-                   "final_loss": float(last.item())},
+                   "final_loss": last_loss},
+        "rccl_ranks": world, "backend": (torch.distributed.get_backend() if gdist.is_active() else "none (1 process)"),
+        "devices": names,
     }
-    probe = getattr(f_img, '_probe', None)
     if probe:
-        # the two matrix kernels of the dense layers, each timed per launch with HIP events on the launch stream inside
-        # the timed region; the roofline object describes whichever took more of the step
-        kern = {}
-        for kind, flops_per_spot, bytes_per_spot, name in (
-                ('conv1x1', conv1x1_flops_per_spot, conv1x1_bytes_per_spot, 'conv1x1_ws_kernel'),
-                ('conv3x3', conv3x3_flops_per_spot, conv3x3_bytes_per_spot, 'conv3x3_dma_kernel')):
-            ms = sum(s.elapsed_time(e) for k, s, e in probe if k == kind)
-            n_launch = sum(1 for k, _, _ in probe if k == kind)
-            flops = flops_per_spot(args.patch) * H * W * args.steps
-            achieved = flops / (ms * 1e-3) / 1e12
-            kern[kind] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
-                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
-                          "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
-                          "flops_per_launch_avg": flops / max(n_launch, 1),
-                          "algorithmic_bytes_per_launch_avg": bytes_per_spot(args.patch) * H * W * args.steps
-                          / max(n_launch, 1), "ms_per_step": ms / args.steps}
+        kern = kernel_table(probe, args.patch, args.steps)
         # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in separate
         # runs, KiB units, FETCH doubled for 16-B/lane loads as MI355X_MICROARCH.md prescribes): tools/pmc_traffic.py,
         # profiles/README.md
-        tfile = os.path.join(ROOT, 'profiles', PMC_TRAFFIC_FILE)
-        if os.path.exists(tfile) and args.patch == 128 and args.mfma == 'f32':
+        tfile = next((os.path.join(ROOT, 'profiles', f) for f in PMC_TRAFFIC_FILES
+                      if os.path.exists(os.path.join(ROOT, 'profiles', f))), None)
+        if tfile and args.patch == 128 and args.mfma == 'f32' and not args.train_f:
             with open(tfile) as fh:
                 tr = json.load(fh)
             for kind in kern:
                 if kind in tr:
                     kern[kind]["traffic"] = tr[kind]["hbm_bytes_per_launch"]
-                    kern[kind]["traffic_source"] = "profiles/%s (PMC, separate passes)" % PMC_TRAFFIC_FILE
-        if getattr(f_img, 'winograd', False) and args.mfma == 'f32':
-            # `achieved` above counts direct-convolution FLOPs (the algorithmic figure of SURVEY 8d); the Winograd launches
-            # execute fewer: report the executed rate next to it
+                    kern[kind]["traffic_source"] = "profiles/%s (PMC, separate passes)" % os.path.basename(tfile)
+        if getattr(f_img, 'winograd', False) and args.mfma == 'f32' and not args.train_f:
+            # The Winograd launches execute 2/3 of the direct-convolution multiply-adds: `achieved` / `frac` are the
+            # EXECUTED matrix FLOPs against the matrix peak (a fraction of peak must be work the pipe did); the
+            # direct-convolution credit (the algorithmic figure of SURVEY 8d) is kept under `direct_conv_*`.
             k3 = kern['conv3x3']
             ex = conv3x3_executed_flops_per_spot(args.patch) * H * W * args.steps
             k3["kernel"] = "conv3x3_wino_kernel (S >= 8) + conv3x3_dma_kernel (S = 4)"
-            k3["algorithm"] = ("Winograd F(2,3) along x for maps of 8 x 8 and up: 2/3 of the direct multiply-adds; `achieved` and "
-                               "`frac` count direct-convolution FLOPs, `executed_*` the matrix FLOPs actually issued")
-            k3["executed_achieved"] = ex / (k3["ms_per_step"] * args.steps * 1e-3) / 1e12
-            k3["executed_frac"] = k3["executed_achieved"] / PEAK_F32_MATRIX_TFLOPS
+            k3["algorithm"] = ("Winograd F(2,3) along x for maps of 8 x 8 and up: 2/3 of the direct multiply-adds. "
+                               "`achieved`/`frac` = executed matrix FLOPs; `direct_conv_*` = the same time credited with "
+                               "direct-convolution FLOPs (can exceed the peak, not a fraction of it)")
+            k3["direct_conv_tflops"] = k3["achieved"]
+            k3["direct_conv_flops_per_launch_avg"] = k3["flops_per_launch_avg"]
+            k3["achieved"] = ex / (k3["ms_per_step"] * args.steps * 1e-3) / 1e12
+            k3["frac"] = k3["achieved"] / PEAK_F32_MATRIX_TFLOPS
+            k3["flops_per_launch_avg"] = ex / max(k3["launches"], 1)
         if args.mfma == 'f16':
             # config 5's kernels multiply 16x faster than they can be fed: they are priced against HBM (algorithmic bytes
             # per launch / launch time); the fp32-FLOP figure stays in `matrix_tflops` for reference
@@ -289,17 +457,106 @@ def main():
                 gbs = kk["algorithmic_bytes_per_launch_avg"] / (kk["avg_launch_ms"] * 1e-3) / 1e9
                 kk.update({"bound": "hbm", "kernel": name, "matrix_tflops": kk["achieved"], "achieved": gbs,
                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS})
-        dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
-        other = [k for k in kern if k != dom][0]
-        result["roofline"] = dict(kern[dom])
-        result["roofline"]["second_kernel"] = kern[other]
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.patch)
+        order = sorted(kern, key=lambda k: -kern[k]["ms_per_step"])
+        result["roofline"] = dict(kern[order[0]])
+        if len(order) > 1:
+            result["roofline"]["second_kernel"] = kern[order[1]]
+        if len(order) > 2:
+            result["roofline"]["other_kernels"] = {k: {f: kern[k][f] for f in ("kernel", "achieved", "frac", "ms_per_step",
+                                                                                "launches")} for k in order[2:]}
+    if ce is not None:
+        result["ce_vs_ref"] = ce
+    if cpu_base is not None:
+        result["cpu_baseline"] = cpu_base
+
+    # ---- second series of SURVEY 8d in the same run: f trained (DenseNet forward + backward)
+    if not args.train_f and not args.no_series and args.mfma == 'f32' and args.patch == 128:
+        free, _ = torch.cuda.mem_get_info(device)
+        if tape_bytes(args.patch, H * W) < free:
+            el, loss_tf, probe_tf = run_series(True, args.series_steps, 1, not args.no_kernel_timing)
+            ser = {"value": H * W * world * args.series_steps / el, "unit": "spots/s",
+                   "ms_per_step": 1e3 * el / args.series_steps, "steps": args.series_steps, "warmup": 1,
+                   "workload": "the same step with both classifiers trained through f_opt (Adam, lr 1e-4): DenseNet-121 "
+                               "forward with tape + full backward, eval-mode BN (training.py:126)",
+                   "final_loss": loss_tf}
+            if probe_tf:
+                kt = kernel_table(probe_tf, args.patch, args.series_steps)
+                order = sorted(kt, key=lambda k: -kt[k]["ms_per_step"])
+                ser["roofline"] = dict(kt[order[0]])
+                ser["roofline"]["other_kernels"] = {k: {f: kt[k][f] for f in ("kernel", "achieved", "frac", "ms_per_step",
+                                                                               "launches")} for k in order[1:]}
+            result["series"] = {"train_f": ser}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if gdist.is_active():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------ launcher (no GPU, no torch)
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(n, argv):
+    """Start `n` worker processes (one per GPU) and wait for them.  This process never initialises the GPU: it imports
+    neither torch nor the package; children are fresh interpreters (never exec'd over a process that touched the card)."""
+    port = os.environ.get('MASTER_PORT') or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), '--worker'] + argv, env=env))
+    failed = 0
+    pending = dict(enumerate(procs))
+    while pending:
+        for r, p in list(pending.items()):
+            rc = p.poll()
+            if rc is None:
+                continue
+            del pending[r]
+            if rc != 0:
+                failed = failed or rc
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, rc))
+                for q in pending.values():           # exact PIDs of our own children, never a pattern
+                    q.terminate()
+        time.sleep(0.2)
+    return failed
+
+
+def parse(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--patch', type=int, default=128)
+    ap.add_argument('--arrays', type=int, default=2, help='distinct synthetic arrays resident per GPU')
+    ap.add_argument('--train-f', action='store_true',
+                    help='headline line = the second series (SURVEY 8d): both classifiers trained through f_opt')
+    ap.add_argument('--mfma', default='f32', choices=['f32', 'f16'],
+                    help="matrix-core operand type of the DenseNet convs; 'f16' = BASELINE config 5's fp16 MFMA path "
+                         "(fp32 accumulate; NOT the headline, reported as dtype f16)")
+    ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-series', action='store_true', help='skip the f-trained series appended to the default run')
+    ap.add_argument('--series-steps', type=int, default=3)
+    ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    under_launcher = args.worker or 'RANK' in os.environ or int(os.environ.get('WORLD_SIZE', '1')) > 1
+    if args.gpus > 1 and not under_launcher:
+        sys.exit(launch(args.gpus, argv))
+    worker_main(args)
 
 
 if __name__ == '__main__':

@@ -108,8 +108,27 @@ class DenseNet(nn.Module):
             elif 'classifier' in name and 'bias' in name:
                 param.data.fill_(0)
         self._cache = {}
+        self._cache_epoch = 0       # part of every cache key; bumped by invalidate_cache()
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_cache())
 
     # ------------------------------------------------------------------ cached, derived device tensors
+    def invalidate_cache(self):
+        """Drop the derived device tensors of the eval forward (folded BN scale/shift, repacked / Winograd / fp16 conv
+        weights).  They are keyed on each source tensor's (`_version`, `data_ptr()`), which catches optimizer steps and
+        `.to()`; writes that bump neither - kernels updating running statistics through raw pointers, `p.data` writes,
+        collectives into `.data` - must call this.  Called by the training forward, `load_state_dict`, `_apply`
+        (`.to()`, `.float()`, ...) and `distributed.broadcast_module`."""
+        self._cache = {}
+        self._cache_epoch += 1
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_cache()
+        return out
+
+    def _key(self, tensors):
+        return (self._cache_epoch,) + tuple(v for t in tensors for v in (t._version, t.data_ptr()))
+
     def _bn_modules(self):
         mods = []
         if not self.small_inputs:
@@ -125,8 +144,7 @@ class DenseNet(nn.Module):
     def _folded_eval(self):
         """{bn module: (scale, shift)} for running-stat BN; refreshed when any BN tensor changed."""
         mods = self._bn_modules()
-        key = tuple(t._version for m in mods for t in (m.weight, m.bias, m.running_mean, m.running_var)) + \
-            (str(mods[0].weight.device),)
+        key = self._key([t for m in mods for t in (m.weight, m.bias, m.running_mean, m.running_var)])
         hit = self._cache.get('fold')
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -148,7 +166,7 @@ class DenseNet(nn.Module):
     def _repacked_conv2(self):
         """{layer: conv2 weight as [tap][growth][mid]} refreshed when a conv2 weight changed."""
         layers = [l for _, ls, _, _ in self._blocks for l in ls]
-        key = tuple(l.conv2.weight._version for l in layers) + (str(layers[0].conv2.weight.device),)
+        key = self._key([l.conv2.weight for l in layers])
         hit = self._cache.get('w2')
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -176,7 +194,7 @@ class DenseNet(nn.Module):
     def _conv1_f16(self):
         """{layer: conv1 weight [mid][cin] rounded to fp16} (config 5 on fp16 block buffers), refreshed with the weights."""
         layers = [l for _, ls, _, _ in self._blocks for l in ls]
-        key = tuple(l.conv1.weight._version for l in layers) + (str(layers[0].conv1.weight.device),)
+        key = self._key([l.conv1.weight for l in layers])
         hit = self._cache.get('w1h')
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -194,7 +212,7 @@ class DenseNet(nn.Module):
     def _winograd_conv2(self):
         """{layer: conv2 weight as Winograd F(2,3)-along-x factors [3][4][growth][mid]} refreshed with the weights."""
         layers = [l for _, ls, _, _ in self._blocks for l in ls]
-        key = tuple(l.conv2.weight._version for l in layers) + (str(layers[0].conv2.weight.device),)
+        key = self._key([l.conv2.weight for l in layers])
         hit = self._cache.get('w2u')
         if hit is not None and hit[0] == key:
             return hit[1]

@@ -46,10 +46,18 @@ def _bn(model_bn, X_ptr, ld, M, training, dev, st):
 
 
 def gammas_nonzero(model):
-    """True when no norm2 weight of the network is exactly zero: one device reduction and one host read per forward (the
-    activated-bottleneck form of the training forward cannot recover x_hat where gamma == 0)."""
-    w = torch.cat([l.norm2.weight.detach().reshape(-1) for _, ls, _, _ in model._blocks for l in ls])
-    return bool((w != 0).all().item())
+    """True when no norm2 weight of the network is exactly zero (the activated-bottleneck form of the training forward
+    cannot recover x_hat where gamma == 0).  One device reduction and one host read per change of those weights: the
+    answer is cached with the model's other derived tensors, keyed on the weights' versions."""
+    ws = [l.norm2.weight for _, ls, _, _ in model._blocks for l in ls]
+    key = model._key(ws)
+    hit = model._cache.get('g2nz')
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    w = torch.cat([t.detach().reshape(-1) for t in ws])
+    ok = bool((w != 0).all().item())
+    model._cache['g2nz'] = (key, ok)
+    return ok
 
 
 class _DenseNetFn(Function):
@@ -101,15 +109,19 @@ class _DenseNetFn(Function):
                 activated = act_ok
                 if activated:
                     s2 = _bn(layer.norm2, None, mid, M, False, dev, st)
+                    t0 = model._probe_begin()
                     L.call('gnx_conv1x1_bnrelu_act', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid, M,
                            mid, cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s2[0]), L.ptr(s2[1]), st)
+                    model._probe_mark('conv1x1', t0)
                     # the direct form, not Winograd: a rounding-level change of a pre-activation that sits exactly at 0
                     # flips a ReLU mask of the next layer and with it a visible part of a gradient (measured on the
                     # closed-form test net: 1 % of one norm1.bias gradient); the frozen eval forward has no such cliff
                     w2 = torch.empty((9, g, mid), device=dev, dtype=F32)
                     L.call('gnx_repack_conv3x3', L.ptr(w2c), L.ptr(w2), g, mid, st)
+                    t0 = model._probe_begin()
                     L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2), _cols(buf, cin), c_total, M, g, mid, s,
                            None, None, st)
+                    model._probe_mark('conv3x3', t0)
                 else:
                     L.call('gnx_conv1x1_bnrelu', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid, M, mid,
                            cin, L.ptr(s1[0]), L.ptr(s1[1]), 0, 0, st)
@@ -137,6 +149,10 @@ class _DenseNetFn(Function):
         L.call('gnx_bnrelu_avgpool', L.ptr(bufs[-1]), bufs[-1].shape[1], L.ptr(feats), c_last, N, c_last,
                s_last * s_last, L.ptr(sf[0]), L.ptr(sf[1]), st)
         tape.feats = feats
+        # backward re-reads the live conv / classifier weights: remember which values this forward used
+        tape.versions = [(p, p._version, p.data_ptr()) for p in params]
+        if training:
+            model.invalidate_cache()      # running statistics were updated through raw pointers (no _version bump)
         ctx.tape, ctx.model = tape, model
         ctx.x_needs_grad = x.requires_grad
         if not model.classify:
@@ -150,6 +166,14 @@ class _DenseNetFn(Function):
     @staticmethod
     def backward(ctx, dout):
         model, tape = ctx.model, ctx.tape
+        if tape is None:
+            raise RuntimeError("gridnext_amd.DenseNet: the tape of this forward was already consumed (a second backward / "
+                               "retain_graph=True is not supported: run the forward again)")
+        for p, ver, addr in tape.versions:
+            if p._version != ver or p.data_ptr() != addr:
+                raise RuntimeError("gridnext_amd.DenseNet: a parameter was modified between forward and backward "
+                                   "(optimizer.step() or load_state_dict before loss.backward()); its gradient would be "
+                                   "computed from the new value")
         if ctx.x_needs_grad:
             raise NotImplementedError("gradient with respect to the input patches is not part of the GridNext path")
         dout = dout.contiguous()
@@ -182,8 +206,10 @@ class _DenseNetFn(Function):
             dw = new_like(w)
             ws = torch.empty(L.query('gnx_wgrad_workspace', M, Nn, K, taps), device=dev, dtype=F32)
             sc, sh = (L.ptr(stats[0]), L.ptr(stats[1])) if stats is not None else (None, None)
+            t0 = model._probe_begin()
             L.call('gnx_wgrad_bnrelu', dy_ptr, lddy, x_ptr, ldx, sc, sh, L.ptr(dw), L.ptr(ws), M, Nn, K, S, taps, pool, 0,
                    st)
+            model._probe_mark('wgrad3x3' if taps == 9 else ('wgrad_trans' if pool else 'wgrad1x1'), t0)
 
         # ---- classifier
         c_last = model.num_features
@@ -236,10 +262,13 @@ class _DenseNetFn(Function):
                 wgrad(layer.conv2.weight, dy2, c_total, L.ptr(bott), mid, None if activated else s2, M, g, mid, s, 9, 0)
                 wb = torch.empty((9, mid, g), device=dev, dtype=F32)
                 L.call('gnx_repack_conv3x3_bwd', L.ptr(layer.conv2.weight.detach().contiguous()), L.ptr(wb), g, mid, st)
+                t0 = model._probe_begin()
                 L.call('gnx_conv3x3_bnrelu', dy2, c_total, L.ptr(wb), L.ptr(tA), mid, M, mid, g, s, None, None, st)
+                t0 = model._probe_mark('dgrad3x3', t0)
                 # norm2 + relu2
                 bn_bwd(layer.norm2, s2, L.ptr(tA), mid, L.ptr(bott), mid, L.ptr(tB), mid, M, mid, 0,
                        relu=2 if activated else 1)
+                model._probe_mark('bn2_bwd', t0)
                 # conv1
                 wgrad(layer.conv1.weight, L.ptr(tB), mid, L.ptr(buf), c_total, s1, M, mid, cin, s, 1, 0)
                 w1t = torch.empty((cin, mid), device=dev, dtype=F32)
@@ -252,11 +281,14 @@ class _DenseNetFn(Function):
                     dg = new_like(bn1.weight) if want(bn1.weight) else None
                     db = new_like(bn1.bias) if want(bn1.bias) else None
                     ws = torch.empty(L.query('gnx_conv1x1_dgrad_bn_workspace', M, cin), device=dev, dtype=F32)
+                    t0 = model._probe_begin()
                     rc = L.query('gnx_conv1x1_dgrad_bnrelu_bwd', L.ptr(tB), mid, L.ptr(w1t), L.ptr(buf), c_total,
                                  L.ptr(dbuf), c_total, M, cin, mid, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s1[2]), L.ptr(s1[3]),
                                  L.ptr(dg), L.ptr(db), 0, L.ptr(ws), st)
                     if rc not in (0, L.ERR_UNSUPPORTED):
                         raise RuntimeError("gnx_conv1x1_dgrad_bnrelu_bwd failed (%d)" % rc)
+                    if rc == 0:
+                        model._probe_mark('dgrad1x1_bn1', t0)
                 if rc == L.ERR_UNSUPPORTED:
                     L.call('gnx_conv1x1_bnrelu', L.ptr(tB), mid, L.ptr(w1t), L.ptr(tC), c_total, M, cin, mid, None, None,
                            0, 0, st)

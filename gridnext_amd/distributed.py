@@ -18,8 +18,13 @@ import torch.distributed as dist
 from torch.utils.data import Sampler
 
 
+def _forced():
+    """GNX_DP_FORCE=1: run the collectives even in a 1-rank group (rehearsing the RCCL path on a one-GPU box)."""
+    return os.environ.get('GNX_DP_FORCE') == '1'
+
+
 def is_active():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _forced())
 
 
 def rank():
@@ -41,8 +46,11 @@ def init_from_env(backend=None):
     device = torch.device('cuda:%d' % local) if use_gpu else torch.device('cpu')
     if use_gpu:
         torch.cuda.set_device(device)
-    if ws > 1 and not dist.is_initialized():
+    if (ws > 1 or _forced()) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group(backend or ('nccl' if use_gpu else 'gloo'))
     return rank(), world_size(), device
 
@@ -103,8 +111,26 @@ def broadcast_module(module, src=0):
     """Make every rank start from rank `src`'s parameters and buffers."""
     if not is_active():
         return
+    # one collective per dtype (a DenseNet-121 has 727 state tensors), then copy_ under no_grad: copy_ bumps each tensor's
+    # version counter, which - together with invalidate_cache() - keeps derived-weight caches from going stale on ranks
+    # that ran a forward before the broadcast
+    seen, by_dtype = set(), {}
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src)
+        if id(t) not in seen:
+            seen.add(id(t))
+            by_dtype.setdefault(t.dtype, []).append(t)
+    with torch.no_grad():
+        for dtype, tensors in by_dtype.items():
+            flat = torch.cat([t.detach().reshape(-1) for t in tensors])
+            dist.broadcast(flat, src)
+            off = 0
+            for t in tensors:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
+    for m in module.modules():
+        if hasattr(m, 'invalidate_cache'):
+            m.invalidate_cache()
 
 
 class ShardedSampler(Sampler):

@@ -74,8 +74,18 @@ class GridNet(nn.Module):
         n = count_grid.shape[0] * count_grid.shape[2] if count_grid is not None else spots.shape[0]
         lim = self.atonce_patch_limit
         if isinstance(f, DenseNet):
-            f.atonce = lim                         # chunking happens inside the HIP forward
-            return f(spots)
+            on_tape = f.training or (torch.is_grad_enabled() and any(p.requires_grad for p in f.parameters()))
+            if not on_tape:
+                keep, f.atonce = f.atonce, lim     # chunking happens inside the HIP eval forward
+                try:
+                    return f(spots)
+                finally:
+                    f.atonce = keep                # the user's own setting is not ours to change
+            if lim is None or lim >= n:
+                return f(spots)
+            # gradient / train-mode path: one tape per chunk of `atonce_patch_limit` spots, as the reference's checkpointed
+            # chunks (:88-104) - in train mode BatchNorm batch statistics are per chunk there too.  Nothing is recomputed.
+            return torch.cat([f(spots.narrow(0, s0, min(lim, n - s0))) for s0 in range(0, n, lim)], 0)
         if lim is None or lim >= n:
             return _spot_rows(f, spots, count_grid)
         if spots is None:

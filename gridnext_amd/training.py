@@ -47,8 +47,10 @@ class _PhaseMeter:
         self.loss = 0.0            # python float (host path) or 0-dim float64 tensor (device path)
         self.correct = 0
         self.counted = 0
+        self.items = 0             # dataset items this rank actually saw (wrap-around duplicates of a sharded sampler included)
 
     def add(self, loss, batch_size, correct, counted):
+        self.items += batch_size
         if torch.is_tensor(loss):
             loss = loss.detach().double()
         self.loss = self.loss + loss * batch_size
@@ -56,8 +58,14 @@ class _PhaseMeter:
         self.counted = self.counted + counted
 
     def totals(self):
-        vals = [float(v) for v in (self.loss, self.correct, self.counted)]      # the only host sync of a phase
+        vals = [float(v) for v in (self.loss, self.correct, self.counted, self.items)]   # the only host sync of a phase
         return gdist.allreduce_sums(vals, self.device)
+
+    def n_items(self, dataset_len, items_seen):
+        """The divisor of the epoch loss: len(dataset) as in the reference (training.py:73, :178); data-parallel, the number
+        of items the ranks actually processed - a ShardedSampler pads the tail so every rank gets the same count, and those
+        duplicates are in the loss sum."""
+        return int(items_seen) if gdist.is_active() else dataset_len
 
 
 class _BestKeeper:
@@ -133,8 +141,8 @@ def train_spotwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
                         gdist.allreduce_gradients(gdist.optimizer_params(optimizer))
                         optimizer.step()
                 meter.add(loss if outputs.is_cuda else loss.item(), batch_size, correct, batch_size)
-            loss_sum, n_right, _ = meter.totals()
-            n_items = len(dataloaders[phase].dataset)
+            loss_sum, n_right, _, seen = meter.totals()
+            n_items = meter.n_items(len(dataloaders[phase].dataset), seen)
             epoch_loss, epoch_acc = loss_sum / n_items, n_right / n_items
             _report(phase, epoch_loss, epoch_acc)
             if phase == 'val':
@@ -206,8 +214,8 @@ def train_gridwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
                                 f_opt.step()
                                 f_opt.zero_grad()
                 meter.add(loss if labels.is_cuda else loss.item(), batch_size, correct, n_fg)
-            loss_sum, n_right, n_fg_total = meter.totals()
-            epoch_loss = loss_sum / len(dataloaders[phase].dataset)
+            loss_sum, n_right, n_fg_total, seen = meter.totals()
+            epoch_loss = loss_sum / meter.n_items(len(dataloaders[phase].dataset), seen)
             epoch_acc = n_right / n_fg_total if n_fg_total else float('nan')
             _report(phase, epoch_loss, epoch_acc)
             if phase == 'val':

@@ -66,6 +66,27 @@ def _worker(rank, world, port, out_dir):
     ds = TensorDataset(torch.arange(7))
     mine = list(gdist.ShardedSampler(ds))
     assert len(mine) == 4 and mine == list(range(7))[rank::2] + ([0] if rank == 1 else [])
+    # broadcast_module: rank 0's values everywhere, version counters bumped, derived-weight caches dropped (a rank that ran
+    # a forward before the broadcast must not keep folded / repacked weights of its own initialisation)
+    import gridnext_amd as ga
+    torch.manual_seed(100 + rank)
+    dn = ga.DenseNet(growth_rate=4, block_config=(2,), num_init_features=8, bn_size=2, num_classes=3, small_inputs=True)
+    dn._cache['fold'] = ('stale',)
+    w = dn.features.conv0.weight
+    v0, e0 = w._version, dn._cache_epoch
+    gdist.broadcast_module(dn)
+    assert dn._cache == {} and dn._cache_epoch > e0 and w._version > v0
+    ref = [torch.zeros_like(w) for _ in range(world)]
+    torch.distributed.all_gather(ref, w.detach())
+    assert torch.equal(ref[0], ref[1])
+    assert dn.features.denseblock1.denselayer1.norm1.num_batches_tracked.dtype == torch.int64
+    # epoch statistics with a padded tail: 3 items over 2 ranks -> 4 items processed, the divisor follows
+    from gridnext_amd.training import _PhaseMeter
+    meter = _PhaseMeter(dev)
+    for _ in gdist.ShardedSampler(TensorDataset(torch.arange(3))):
+        meter.add(2.0, 1, 1, 1)
+    loss_sum, _, _, seen = meter.totals()
+    assert seen == 4 and loss_sum / meter.n_items(3, seen) == 2.0
     # the loop
     m, x, y = _make_problem()
     gdist.broadcast_module(m)

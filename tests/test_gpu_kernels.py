@@ -454,6 +454,19 @@ def test_fp16_block_buffer_kernels(L):
     L.call('gnx_conv_stem_bnrelu_maxpool_h16', L.ptr(x), L.ptr(W0), L.ptr(o16, H), 96, n, 3, 128, 128, O, 7, 7, 2, 3,
            L.ptr(sc0), L.ptr(sh0), st)
     assert torch.equal(o16[:, :O], o32[:, :O].half()) and float(o16[:, O:].float().min()) == 7.0
+    # the same at config 5's real patch size: 256 px (conv map 128 wide, pooled map 64 x 64)
+    n2 = 3
+    x2 = torch.rand(n2, 3, 256, 256, generator=g).to(DEV)
+    p32 = torch.empty(n2 * 4096, 96, device=DEV)
+    p16 = torch.full((n2 * 4096, 96), 7.0, device=DEV, dtype=H)
+    L.call('gnx_conv_stem_bnrelu_maxpool', L.ptr(x2), L.ptr(W0), L.ptr(p32), 96, n2, 3, 256, 256, O, 7, 7, 2, 3, L.ptr(sc0),
+           L.ptr(sh0), st)
+    L.call('gnx_conv_stem_bnrelu_maxpool_h16', L.ptr(x2), L.ptr(W0), L.ptr(p16, H), 96, n2, 3, 256, 256, O, 7, 7, 2, 3,
+           L.ptr(sc0), L.ptr(sh0), st)
+    assert torch.equal(p16[:, :O], p32[:, :O].half()) and float(p16[:, O:].float().min()) == 7.0
+    ref2 = torch.nn.functional.max_pool2d(torch.relu(torch.nn.functional.conv2d(x2.cpu(), W0.cpu(), stride=2, padding=3)
+                                                     * sc0.cpu().view(1, -1, 1, 1) + sh0.cpu().view(1, -1, 1, 1)), 3, 2, 1)
+    close(p32[:, :O].reshape(n2, 64, 64, O).permute(0, 3, 1, 2), ref2, rtol=2e-4)
     # conv1 on fp16 activations == the fp32-input kernel on the same values
     M, K, N, ct = 2048, 96, 128, 160
     A16 = torch.randn(M, ct, generator=g).half().to(DEV)

@@ -265,3 +265,56 @@ def test_patch_datasets_contract(tmp_path):
         ox, oy = pseudo_hex_to_oddr(cx, cy)
         want = torch.from_numpy(pixels[(a, cstr)]).permute(2, 0, 1).float() / 255
         assert torch.equal(grid[oy, ox], want)
+
+
+def test_densenet_derived_weight_cache_is_invalidated_by_every_kind_of_write():
+    """the eval forward's derived tensors (folded BN, repacked conv weights) are keyed on (_version, data_ptr)
+    of their sources plus a model epoch; writes that bump no version counter must go through invalidate_cache()."""
+    import gridnext_amd as ga
+    m = ga.DenseNet(growth_rate=4, block_config=(2, 2), num_init_features=8, bn_size=2, num_classes=5, small_inputs=False)
+    bn = m.features.norm0
+    srcs = [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    k0 = m._key(srcs)
+    with torch.no_grad():
+        bn.weight.mul_(2.0)                                   # in-place op: version counter
+    k1 = m._key(srcs)
+    assert k1 != k0
+    bn.running_mean.data.fill_(3.0)                           # .data write: no version bump ...
+    assert m._key(srcs) == k1
+    m._cache['fold'] = ('stale',)
+    m.invalidate_cache()                                      # ... which is what invalidate_cache() is for
+    assert m._cache == {} and m._key(srcs) != k1
+    k2 = m._key(srcs)
+    m._cache['fold'] = ('stale',)
+    m.load_state_dict(m.state_dict())                         # load_state_dict hook
+    assert m._cache == {} and m._key(srcs) != k2
+    m._cache['fold'] = ('stale',)
+    m.double()                                                # _apply (.to / .float / .double / .cuda)
+    assert m._cache == {}
+
+
+def test_grid_forward_does_not_change_the_users_densenet_chunk_setting():
+    """GridNet used to leave `f.atonce = atonce_patch_limit` behind on the user's DenseNet."""
+    import inspect
+    import gridnext_amd.gridnet_models as gm
+    src = inspect.getsource(gm.GridNet._f_rows)
+    assert 'finally' in src and 'f.atonce = keep' in src
+
+
+def test_bench_launcher_parent_stays_off_the_gpu_and_reports_failed_ranks():
+    """`python bench.py --gpus N` starts N fresh worker processes; the parent imports neither torch nor the package, and a
+    failing rank (here: every rank, there is no HIP device in this container) makes it exit non-zero instead of hanging."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.argv=['bench.py']; import bench; "
+            "assert 'torch' not in sys.modules and 'gridnext_amd' not in sys.modules; "
+            "a = bench.parse(['--gpus', '4', '--steps', '3']); assert a.gpus == 4 and not a.worker; print('ok')")
+    out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr
+    if torch.cuda.is_available():
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                          '--no-cpu-baseline'], cwd=ROOT, capture_output=True, text=True, timeout=280, env=env)
+    assert out.returncode != 0
+    assert 'exited with code' in out.stderr
