@@ -23,7 +23,9 @@ Rank 0 prints ONE JSON line (contract in the task description) with
                     sub-grid, physical cores, CPU model string, the SAME weights as the GPU leg;
   * `ce_vs_ref`     BASELINE.json's "CE vs ref": the masked CE of that sub-grid through the HIP path and through the
                     oracle, same weights and inputs (|dCE| <= 1e-4 asserted for f32), argmax agreement on decided spots;
-  * `series`        the second series of SURVEY 8d on the same box: `train_f` = both classifiers trained through f_opt
+  * `series`        further series on the same box: `from_host` = the same step fed from pageable host memory (uint8
+                    patches, DataLoader, pinned double-buffered H2D prefetcher; PCIe inside the timed region - never the
+                    headline `value`); `train_f` = the second series of SURVEY 8d, both classifiers trained through f_opt
                     (DenseNet forward + backward), with its own roofline object.
 """
 import argparse
@@ -140,6 +142,7 @@ def kernel_table(probe, patch, steps):
                       "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
                       "flops_per_launch_avg": flops / max(n_launch, 1),
                       "algorithmic_bytes_per_launch_avg": bytes_per_spot(patch) * H * W * steps / max(n_launch, 1),
+                      "algorithmic_gbs": bytes_per_spot(patch) * H * W * steps / (ms * 1e-3) / 1e9,
                       "ms_per_step": ms / steps}
     return kern
 
@@ -284,6 +287,77 @@ def tape_bytes(patch, spots):
         c = c_total // 2
         s //= 2
     return 4 * spots * (total + biggest + 3 * patch * patch)
+
+
+# ------------------------------------------------------------------------------------------ feed from host memory
+def from_host_series(args, model, optimizer, criterion, device, rank, world):
+    """The same tutorial-mode step fed the way `train_gridwise` is fed in real use: a Dataset of arrays living in pageable
+    host memory (uint8 patches: 245 MB per 128-px array; float counts; labels) -> DataLoader(batch_size=1) ->
+    prefetch.DevicePrefetcher (pinned staging ring, non_blocking H2D on a side stream one batch ahead, event-ordered) ->
+    the step.  ToTensor's / 255 runs inside the stem kernel."""
+    import torch
+    from torch.utils.data import DataLoader, Dataset
+    from gridnext_amd import distributed as gdist
+    from gridnext_amd import prefetch
+    from gridnext_amd import training as gtrain
+    steps, warmup = args.steps, max(args.warmup, 2)
+    host = []
+    for a in range(args.arrays):
+        gen = torch.Generator().manual_seed(5000 + 1000 * rank + a)
+        y = torch.randint(0, CLASSES + 1, (H, W), generator=gen)
+        x8 = torch.randint(0, 256, (H, W, 3, args.patch, args.patch), generator=gen, dtype=torch.uint8)
+        x8 *= (y > 0).to(torch.uint8).view(H, W, 1, 1, 1)
+        xc = torch.randint(0, 10, (GENES, H, W), generator=gen).float() * (y > 0).float().unsqueeze(0)
+        host.append(((x8, xc), y))
+
+    class Arrays(Dataset):
+        def __len__(self):
+            return steps + warmup
+
+        def __getitem__(self, i):
+            return host[i % len(host)]
+
+    for p in model.patch_classifier.parameters():
+        p.requires_grad = False
+    stepped = gdist.optimizer_params(optimizer)
+    model.train()
+    model.patch_classifier.eval()
+    pf = prefetch.DevicePrefetcher(DataLoader(Arrays(), batch_size=1), device)
+    it = iter(pf)
+
+    def step():
+        inputs, labels = next(it)
+        loss, _, _ = gtrain._grid_loss(model, inputs, labels, criterion, 1, True)
+        loss.backward()
+        gdist.allreduce_gradients(stepped)
+        optimizer.step()
+        optimizer.zero_grad()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    if gdist.is_active():
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    if gdist.is_active():
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if gdist.is_active():
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    for _ in it:                                                  # exhaust (nothing left) so the producer thread ends
+        pass
+    return {"value": H * W * world * steps / elapsed, "unit": "spots/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+            "warmup": warmup, "final_loss": float(last.item()),
+            "h2d_bytes_per_step": pf.bytes_moved // (steps + warmup),
+            "workload": "the headline step fed from pageable host memory: Dataset -> DataLoader(batch_size=1) -> pinned "
+                        "double-buffered H2D prefetcher (side stream, one batch ahead); uint8 patches (ToTensor fused into the "
+                        "stem kernel), float32 counts, int64 labels; timed region includes collate, staging and PCIe"}
 
 
 # ------------------------------------------------------------------------------------------ one worker = one GPU
@@ -469,6 +543,11 @@ def worker_main(args):
     if cpu_base is not None:
         result["cpu_baseline"] = cpu_base
 
+    # ---- the real loop feed: arrays in pageable HOST memory, uint8 patches, through a DataLoader and the
+    #      pinned double-buffered prefetcher the training loops use; the timed region includes collate, staging and PCIe
+    if (args.from_host or not args.no_series) and not args.train_f:
+        result.setdefault("series", {})["from_host"] = from_host_series(args, model, optimizer, criterion, device, rank, world)
+
     # ---- second series of SURVEY 8d in the same run: f trained (DenseNet forward + backward)
     if not args.train_f and not args.no_series and args.mfma == 'f32' and args.patch == 128:
         free, _ = torch.cuda.mem_get_info(device)
@@ -485,7 +564,7 @@ def worker_main(args):
                 ser["roofline"] = dict(kt[order[0]])
                 ser["roofline"]["other_kernels"] = {k: {f: kt[k][f] for f in ("kernel", "achieved", "frac", "ms_per_step",
                                                                                "launches")} for k in order[1:]}
-            result["series"] = {"train_f": ser}
+            result.setdefault("series", {})["train_f"] = ser
     if rank == 0:
         print(json.dumps(result), flush=True)
     if gdist.is_active():
@@ -544,7 +623,9 @@ def parse(argv):
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--no-series', action='store_true', help='skip the f-trained series appended to the default run')
+    ap.add_argument('--no-series', action='store_true', help='skip the extra series appended to the default run')
+    ap.add_argument('--from-host', action='store_true',
+                    help='(with --no-series) still run the fed-from-host-memory series: uint8 patches through the prefetcher')
     ap.add_argument('--series-steps', type=int, default=3)
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args(argv)

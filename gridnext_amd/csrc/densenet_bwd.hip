@@ -429,6 +429,24 @@ __global__ void avgpool2_bwd_kernel(const float* __restrict__ dP, long ldp, floa
 
 // adjoint of out = maxpool3x3s2p1(relu(in*scale+shift)) with respect to the ACTIVATED input:
 // dAct[pos][c] = sum over the (<=4) windows containing pos of dOut[window] * [act(pos) is that window's maximum and > 0]
+// Ties: torch's max_pool2d sends a window's gradient to ONE element, the first maximal one in its row-major scan of the
+// window (`val > maxval` while scanning); constant regions - white slide background, all-zero background spots whose
+// conv0 map is the constant relu(shift) - tie everywhere, so "every element equal to the maximum" is not the same function.
+// pool_first_max: no element of window (oy, ox) that the scan visits before (y, x) has the value a (= the window's maximum).
+__device__ __forceinline__ bool pool_first_max(const float* __restrict__ in, long ldi, long img, int Hi, int Wi, int oy,
+                                               int ox, int y, int x, int c, float sc, float sh, float a) {
+    const int y0 = 2 * oy - 1 < 0 ? 0 : 2 * oy - 1;
+    const int x0 = 2 * ox - 1 < 0 ? 0 : 2 * ox - 1, x1 = 2 * ox + 1 >= Wi ? Wi - 1 : 2 * ox + 1;
+    for (int iy = y0; iy <= y; ++iy) {
+        const int xe = iy == y ? x - 1 : x1;
+        for (int ix = x0; ix <= xe; ++ix) {
+            const long r = (img * Hi + iy) * (long)Wi + ix;
+            if (fmaxf(fmaf(in[r * ldi + c], sc, sh), 0.f) == a) return false;
+        }
+    }
+    return true;
+}
+
 __global__ void maxpool_bwd_kernel(const float* __restrict__ in, long ldi, const float* __restrict__ pooled, long ldp,
                                    const float* __restrict__ dOut, long lddo, float* __restrict__ dAct, long lda,
                                    long Min, int C, int Hi, int Wi, int Ho, int Wo, const float* __restrict__ scale,
@@ -449,7 +467,8 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ in, long ldi, const
                 for (int ox = (x) / 2; ox <= (x + 1) / 2; ++ox) {
                     if (ox < 0 || ox >= Wo) continue;
                     const long o = (img * Ho + oy) * Wo + ox;
-                    if (pooled[o * ldp + c] == a) g += dOut[o * lddo + c];
+                    if (pooled[o * ldp + c] == a && pool_first_max(in, ldi, img, Hi, Wi, oy, ox, y, x, c, scale[c], shift[c], a))
+                        g += dOut[o * lddo + c];
                 }
             }
         }
@@ -506,10 +525,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_vec4_kernel(const float* __re
                 const long o = (img * Ho + oy) * Wo + ox;
                 const float4 p = *reinterpret_cast<const float4*>(pooled + o * ldp + c);
                 const float4 d = *reinterpret_cast<const float4*>(dOut + o * lddo + c);
-                if (a0 > 0.f && p.x == a0) g.x += d.x;
-                if (a1 > 0.f && p.y == a1) g.y += d.y;
-                if (a2 > 0.f && p.z == a2) g.z += d.z;
-                if (a3 > 0.f && p.w == a3) g.w += d.w;
+                if (a0 > 0.f && p.x == a0 && pool_first_max(in, ldi, img, Hi, Wi, oy, ox, y, x, c, sc.x, sh.x, a0)) g.x += d.x;
+                if (a1 > 0.f && p.y == a1 && pool_first_max(in, ldi, img, Hi, Wi, oy, ox, y, x, c + 1, sc.y, sh.y, a1)) g.y += d.y;
+                if (a2 > 0.f && p.z == a2 && pool_first_max(in, ldi, img, Hi, Wi, oy, ox, y, x, c + 2, sc.z, sh.z, a2)) g.z += d.z;
+                if (a3 > 0.f && p.w == a3 && pool_first_max(in, ldi, img, Hi, Wi, oy, ox, y, x, c + 3, sc.w, sh.w, a3)) g.w += d.w;
             }
         }
         *reinterpret_cast<float4*>(dAct + r * lda + c) = g;

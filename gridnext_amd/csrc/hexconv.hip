@@ -16,6 +16,11 @@
 //   tap a of kernel0      : (dp, dq) = (0, a-1)
 //   tap (a,b) of kernel1  : (dp, dq) = (2b-1, (p even ? -1 : 0) + a)
 // Roofline: HBM/latency bound (7*I*O MAC per position on a 4992-position grid); see DESIGN.md.
+//
+// Channel counts: any I, O >= 1.  One launch handles up to 64 x 64 (forward, data gradient) or 32 x 32 (weight gradient)
+// channels - the corrector's own shapes (f_dim <= 64 -> 32 -> n_classes) are single launches; wider layers (many classes,
+// classify=False feature inputs) are tiled over channel chunks by the entry points, the later input chunks accumulating
+// onto the earlier ones' result.
 #include "common.h"
 
 namespace {
@@ -61,31 +66,34 @@ __device__ __forceinline__ float load_w(const float* k0, const float* k1, int I,
 constexpr int POS_PER_BLOCK = 16;      // 312 workgroups on a 78 x 64 grid (64 per block left 178 CUs idle: 38 us per launch)
 
 // y[pos][o] = bias[o] + sum_t sum_i W_t[o][i] * x[nbr_t(pos)][i]
+// One (input chunk, output chunk) pair of channels: I, O are the chunk's sizes, i0 / o0 its first channels, IF / OF the
+// layer's full channel counts (= the row strides of x, y and of the parameter tensors).
 __global__ __launch_bounds__(256) void hexconv_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ k0, const float* __restrict__ k1,
-    const float* __restrict__ bias, float* __restrict__ y, HexGeom g, int I, int O, int opad) {
+    const float* __restrict__ bias, float* __restrict__ y, HexGeom g, int I, int O, int opad,
+    int IF, int OF, int i0, int o0) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [7][I][O]
     for (int idx = threadIdx.x; idx < 7 * I * O; idx += blockDim.x) {
         const int o = idx % O, i = (idx / O) % I, t = idx / (O * I);
-        wl[idx] = load_w(k0, k1, I, t, o, i);
+        wl[idx] = load_w(k0, k1, IF, t, o0 + o, i0 + i);
     }
     __syncthreads();
     const int o = threadIdx.x % opad, pl0 = threadIdx.x / opad, pstep = blockDim.x / opad;
     const int npos = g.B * g.H * g.W;
     const int base = blockIdx.x * POS_PER_BLOCK;
     if (o >= O) return;
-    const bool vec = (I & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    const float bo = bias ? bias[o] : 0.f;
+    const bool vec = ((I | IF | i0) & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const float bo = bias ? bias[o0 + o] : 0.f;
     for (int pl = pl0; pl < POS_PER_BLOCK; pl += pstep) {
         const int pos = base + pl;
         if (pos >= npos) break;
         const int xx = pos % g.W, yy = (pos / g.W) % g.H, b = pos / (g.W * g.H);
-        float acc = bo;
+        float acc = i0 == 0 ? bo : y[(size_t)pos * OF + o0 + o];      // later input chunks continue the sum
 #pragma unroll
         for (int t = 0; t < 7; ++t) {
             const int n = g.nbr(b, yy, xx, t);
             if (n < 0) continue;
-            const float* xr = x + (size_t)n * I;
+            const float* xr = x + (size_t)n * IF + i0;
             const float* wr = wl + t * I * O + o;
             if (vec) {                                      // 16-B loads of the neighbour's row, same order of the adds
                 for (int i = 0; i < I; i += 4) {
@@ -99,35 +107,35 @@ __global__ __launch_bounds__(256) void hexconv_fwd_kernel(
                 for (int i = 0; i < I; ++i) acc = fmaf(wr[i * O], xr[i], acc);
             }
         }
-        y[(size_t)pos * O + o] = acc;
+        y[(size_t)pos * OF + o0 + o] = acc;
     }
 }
 
 // dx[pos][i] = sum_t sum_o W_t[o][i] * dy[src_t(pos)][o]
 __global__ __launch_bounds__(256) void hexconv_bwd_data_kernel(
     const float* __restrict__ dy, const float* __restrict__ k0, const float* __restrict__ k1,
-    float* __restrict__ dx, HexGeom g, int I, int O, int ipad) {
+    float* __restrict__ dx, HexGeom g, int I, int O, int ipad, int IF, int OF, int i0, int o0) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [7][O][I]
     for (int idx = threadIdx.x; idx < 7 * I * O; idx += blockDim.x) {
         const int i = idx % I, o = (idx / I) % O, t = idx / (O * I);
-        wl[idx] = load_w(k0, k1, I, t, o, i);
+        wl[idx] = load_w(k0, k1, IF, t, o0 + o, i0 + i);
     }
     __syncthreads();
     const int i = threadIdx.x % ipad, pl0 = threadIdx.x / ipad, pstep = blockDim.x / ipad;
     const int npos = g.B * g.H * g.W;
     const int base = blockIdx.x * POS_PER_BLOCK;
     if (i >= I) return;
-    const bool vec = (O & 3) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+    const bool vec = ((O | OF | o0) & 3) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
     for (int pl = pl0; pl < POS_PER_BLOCK; pl += pstep) {
         const int pos = base + pl;
         if (pos >= npos) break;
         const int xx = pos % g.W, yy = (pos / g.W) % g.H, b = pos / (g.W * g.H);
-        float acc = 0.f;
+        float acc = o0 == 0 ? 0.f : dx[(size_t)pos * IF + i0 + i];    // later output chunks continue the sum
 #pragma unroll
         for (int t = 0; t < 7; ++t) {
             const int s = g.src(b, yy, xx, t);
             if (s < 0) continue;
-            const float* dr = dy + (size_t)s * O;
+            const float* dr = dy + (size_t)s * OF + o0;
             const float* wr = wl + t * I * O + i;
             if (vec) {
                 for (int o = 0; o < O; o += 4) {
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(256) void hexconv_bwd_data_kernel(
                 for (int o = 0; o < O; ++o) acc = fmaf(wr[o * I], dr[o], acc);
             }
         }
-        dx[(size_t)pos * I + i] = acc;
+        dx[(size_t)pos * IF + i0 + i] = acc;
     }
 }
 
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(256) void hexconv_bwd_data_kernel(
 constexpr int WG_CHUNK = 16;       // positions staged per LDS pass
 __global__ __launch_bounds__(256) void hexconv_bwd_weight_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
-    HexGeom g, int I, int O, int pos_per_block) {
+    HexGeom g, int I, int O, int pos_per_block, int IF, int OF, int i0, int o0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dys = lds;                          // [WG_CHUNK][O]
     float* xs = lds + WG_CHUNK * O;            // [WG_CHUNK][7][I]
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256) void hexconv_bwd_weight_kernel(
         __syncthreads();
         for (int idx = threadIdx.x; idx < cnt * O; idx += blockDim.x) {
             const int pos = base + c0 + idx / O;
-            dys[idx] = pos < npos ? dy[(size_t)pos * O + idx % O] : 0.f;
+            dys[idx] = pos < npos ? dy[(size_t)pos * OF + o0 + idx % O] : 0.f;
         }
         // neighbour rows once per (position, tap) - not once per staged element - then row copies
         if (threadIdx.x < cnt * 7) {
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256) void hexconv_bwd_weight_kernel(
         for (int idx = threadIdx.x; idx < cnt * 7 * I; idx += blockDim.x) {
             const int q = idx / I, i = idx - q * I;           // q = pl * 7 + t
             const int n = nbrs[q];
-            xs[idx] = n >= 0 ? x[(size_t)n * I + i] : 0.f;
+            xs[idx] = n >= 0 ? x[(size_t)n * IF + i0 + i] : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(256) void hexconv_bwd_weight_kernel(
 // fixed-order sum of the partial slabs, scattered into hexagdly's parameter layouts (accumulating or not)
 __global__ void hexconv_reduce_weight_kernel(const float* __restrict__ partial, int nblk, int I, int O,
                                              float* __restrict__ dk0, float* __restrict__ dk1,
-                                             float* __restrict__ dbias, int accumulate) {
+                                             float* __restrict__ dbias, int accumulate, int IF, int i0, int o0) {
     const int nout = 7 * O * I + O;
     const int out = blockIdx.x * blockDim.x + threadIdx.x;
     if (out >= nout) return;
@@ -230,39 +238,49 @@ __global__ void hexconv_reduce_weight_kernel(const float* __restrict__ partial, 
     float* dst;
     if (out < 7 * O * I) {
         const int i = out % I, o = (out / I) % O, t = out / (O * I);
-        dst = t < 3 ? dk0 + (o * I + i) * 3 + t : dk1 + (o * I + i) * 4 + (t - 3);
+        const int oi = (o0 + o) * IF + i0 + i;
+        dst = t < 3 ? dk0 + oi * 3 + t : dk1 + oi * 4 + (t - 3);
     } else {
-        if (!dbias) return;
-        dst = dbias + (out - 7 * O * I);
+        if (!dbias || i0 != 0) return;                  // the bias gradient comes from the first input chunk's launches
+        dst = dbias + o0 + (out - 7 * O * I);
     }
     *dst = accumulate ? *dst + s : s;
 }
 
 int pow2_at_least(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+constexpr int HEX_CHUNK = 64;      // channels per launch, forward and data gradient (7 * 64 * 64 weights = 112 KB of LDS)
+constexpr int HEX_WCHUNK = 32;     // channels per launch, weight gradient (MAXACC accumulators per thread)
+
 }  // namespace
 
 GNX_EXPORT int gnx_hexconv_fwd(const float* x, const float* kernel0, const float* kernel1, const float* bias,
                                float* y, int B, int H, int W, int I, int O, int mode, hipStream_t stream) {
-    if (!x || !kernel0 || !kernel1 || !y || B < 0 || H <= 0 || W <= 0 || I <= 0 || O <= 0 || I > 64 || O > 64)
-        return GNX_ERR_BAD_ARG;
+    if (!x || !kernel0 || !kernel1 || !y || B < 0 || H <= 0 || W <= 0 || I <= 0 || O <= 0) return GNX_ERR_BAD_ARG;
     const long npos = (long)B * H * W;
     if (npos == 0) return GNX_OK;
     HexGeom g{B, H, W, mode};
-    hexconv_fwd_kernel<<<gnx_cdiv(npos, POS_PER_BLOCK), 256, 7 * I * O * sizeof(float), stream>>>(
-        x, kernel0, kernel1, bias, y, g, I, O, pow2_at_least(O));
+    for (int o0 = 0; o0 < O; o0 += HEX_CHUNK)
+        for (int i0 = 0; i0 < I; i0 += HEX_CHUNK) {         // input chunks in order: chunk k continues chunk k-1's sums
+            const int oc = O - o0 < HEX_CHUNK ? O - o0 : HEX_CHUNK, ic = I - i0 < HEX_CHUNK ? I - i0 : HEX_CHUNK;
+            hexconv_fwd_kernel<<<gnx_cdiv(npos, POS_PER_BLOCK), 256, 7 * ic * oc * sizeof(float), stream>>>(
+                x, kernel0, kernel1, bias, y, g, ic, oc, pow2_at_least(oc), I, O, i0, o0);
+        }
     return gnx_launch_status();
 }
 
 GNX_EXPORT int gnx_hexconv_bwd_data(const float* dy, const float* kernel0, const float* kernel1, float* dx,
                                     int B, int H, int W, int I, int O, int mode, hipStream_t stream) {
-    if (!dy || !kernel0 || !kernel1 || !dx || B < 0 || H <= 0 || W <= 0 || I <= 0 || O <= 0 || I > 64 || O > 64)
-        return GNX_ERR_BAD_ARG;
+    if (!dy || !kernel0 || !kernel1 || !dx || B < 0 || H <= 0 || W <= 0 || I <= 0 || O <= 0) return GNX_ERR_BAD_ARG;
     const long npos = (long)B * H * W;
     if (npos == 0) return GNX_OK;
     HexGeom g{B, H, W, mode};
-    hexconv_bwd_data_kernel<<<gnx_cdiv(npos, POS_PER_BLOCK), 256, 7 * I * O * sizeof(float), stream>>>(
-        dy, kernel0, kernel1, dx, g, I, O, pow2_at_least(I));
+    for (int i0 = 0; i0 < I; i0 += HEX_CHUNK)
+        for (int o0 = 0; o0 < O; o0 += HEX_CHUNK) {
+            const int oc = O - o0 < HEX_CHUNK ? O - o0 : HEX_CHUNK, ic = I - i0 < HEX_CHUNK ? I - i0 : HEX_CHUNK;
+            hexconv_bwd_data_kernel<<<gnx_cdiv(npos, POS_PER_BLOCK), 256, 7 * ic * oc * sizeof(float), stream>>>(
+                dy, kernel0, kernel1, dx, g, ic, oc, pow2_at_least(ic), I, O, i0, o0);
+        }
     return gnx_launch_status();
 }
 
@@ -279,25 +297,30 @@ static int hex_ppb(long npos) {
 // workspace floats needed by gnx_hexconv_bwd_weight
 GNX_EXPORT long gnx_hexconv_bwd_weight_workspace(int B, int H, int W, int I, int O) {
     const long npos = (long)B * H * W;
-    return (long)gnx_cdiv(npos, hex_ppb(npos)) * (7L * O * I + O);
+    const long ic = I < HEX_WCHUNK ? I : HEX_WCHUNK, oc = O < HEX_WCHUNK ? O : HEX_WCHUNK;     // one chunk pair at a time
+    return (long)gnx_cdiv(npos, hex_ppb(npos)) * (7L * oc * ic + oc);
 }
 
 GNX_EXPORT int gnx_hexconv_bwd_weight(const float* x, const float* dy, float* dkernel0, float* dkernel1,
                                       float* dbias, float* workspace, int B, int H, int W, int I, int O,
                                       int mode, int accumulate, hipStream_t stream) {
-    if (!x || !dy || !dkernel0 || !dkernel1 || !workspace || I <= 0 || O <= 0 || I > 32 || O > 32 ||
-        H <= 0 || W <= 0 || B < 0)
+    if (!x || !dy || !dkernel0 || !dkernel1 || !workspace || I <= 0 || O <= 0 || H <= 0 || W <= 0 || B < 0)
         return GNX_ERR_BAD_ARG;
     const long npos = (long)B * H * W;
     const int ppb = hex_ppb(npos);
     const int nblk = gnx_cdiv(npos, ppb);
-    const int nout = 7 * O * I + O;
     HexGeom g{B, H, W, mode};
-    if (nblk > 0) {
-        const size_t lds = (size_t)(WG_CHUNK * O + WG_CHUNK * 7 * I) * sizeof(float);
-        hexconv_bwd_weight_kernel<<<nblk, 256, lds, stream>>>(x, dy, workspace, g, I, O, ppb);
-    }
-    hexconv_reduce_weight_kernel<<<gnx_cdiv(nout, 256), 256, 0, stream>>>(workspace, nblk, I, O, dkernel0,
-                                                                          dkernel1, dbias, accumulate);
+    // one (input chunk, output chunk) pair after the other on the stream, each through the same workspace
+    for (int o0 = 0; o0 < O; o0 += HEX_WCHUNK)
+        for (int i0 = 0; i0 < I; i0 += HEX_WCHUNK) {
+            const int oc = O - o0 < HEX_WCHUNK ? O - o0 : HEX_WCHUNK, ic = I - i0 < HEX_WCHUNK ? I - i0 : HEX_WCHUNK;
+            const int nout = 7 * oc * ic + oc;
+            if (nblk > 0) {
+                const size_t lds = (size_t)(WG_CHUNK * oc + WG_CHUNK * 7 * ic) * sizeof(float);
+                hexconv_bwd_weight_kernel<<<nblk, 256, lds, stream>>>(x, dy, workspace, g, ic, oc, ppb, I, O, i0, o0);
+            }
+            hexconv_reduce_weight_kernel<<<gnx_cdiv(nout, 256), 256, 0, stream>>>(workspace, nblk, ic, oc, dkernel0, dkernel1,
+                                                                                  dbias, accumulate, I, i0, o0);
+        }
     return gnx_launch_status();
 }

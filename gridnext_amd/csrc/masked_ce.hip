@@ -10,12 +10,10 @@
 // (training.py:61-62: every row counts, labels 0..C-1).
 //   stats     = {n_fg, n_correct} (argmax = first maximal index, as torch.max)
 // No dynamic shapes, no host sync: n_fg stays on the device.  Fixed-order two-stage reduction (deterministic).
-// HBM-bound: (4*C + 8) B per spot forward.
+// HBM-bound: (4*C + 8) B per spot forward.  Any C >= 1 (one thread walks a row's C logits; the path's C is 5..20).
 #include "common.h"
 
 namespace {
-
-constexpr int MAXC = 64;
 
 __global__ __launch_bounds__(256) void masked_ce_fwd_kernel(const float* __restrict__ z, long ld,
                                                             const long long* __restrict__ labels, long M, int C,
@@ -129,7 +127,7 @@ GNX_EXPORT long gnx_masked_ce_workspace(long M) { return 3L * gnx_cdiv(M, 256); 
 GNX_EXPORT int gnx_masked_ce_fwd(const float* logits, long ld, const long long* labels, long M, int C,
                                  int label_base, float accum_iters, float* loss, long long* stats, long long* preds,
                                  double* workspace, hipStream_t stream) {
-    if (!logits || !labels || !loss || !stats || !workspace || M <= 0 || C <= 0 || C > MAXC || ld < C)
+    if (!logits || !labels || !loss || !stats || !workspace || M <= 0 || C <= 0 || ld < C)
         return GNX_ERR_BAD_ARG;
     const int nblk = gnx_cdiv(M, 256);
     masked_ce_fwd_kernel<<<nblk, 256, 0, stream>>>(logits, ld, labels, M, C, label_base, workspace, preds);
@@ -140,7 +138,7 @@ GNX_EXPORT int gnx_masked_ce_fwd(const float* logits, long ld, const long long* 
 GNX_EXPORT int gnx_masked_ce_bwd(const float* logits, long ld, const long long* labels, long M, int C,
                                  int label_base, const long long* stats, const float* dloss, float accum_iters, float* dlogits,
                                  long lddz, hipStream_t stream) {
-    if (!logits || !labels || !stats || !dlogits || M <= 0 || C <= 0 || C > MAXC || ld < C || lddz < C)
+    if (!logits || !labels || !stats || !dlogits || M <= 0 || C <= 0 || ld < C || lddz < C)
         return GNX_ERR_BAD_ARG;
     masked_ce_bwd_kernel<<<gnx_cdiv(M, 256), 256, 0, stream>>>(logits, ld, labels, M, C, label_base, stats, dloss,
                                                                  accum_iters, dlogits, lddz);
@@ -150,7 +148,7 @@ GNX_EXPORT int gnx_masked_ce_bwd(const float* logits, long ld, const long long* 
 // Row softmax + argmax of channels-last logits (all_fgd_predictions, gridnext/utils.py:36-47)
 GNX_EXPORT int gnx_softmax_rows(const float* logits, long ld, long M, int C, float* probs, long ldp, long long* preds,
                                 hipStream_t stream) {
-    if (!logits || !probs || M <= 0 || C <= 0 || C > MAXC || ld < C || ldp < C) return GNX_ERR_BAD_ARG;
+    if (!logits || !probs || M <= 0 || C <= 0 || ld < C || ldp < C) return GNX_ERR_BAD_ARG;
     softmax_rows_kernel<<<gnx_cdiv(M, 256), 256, 0, stream>>>(logits, ld, M, C, probs, ldp, preds);
     return gnx_launch_status();
 }

@@ -4,6 +4,50 @@
 
 namespace {
 
+// ------------------------------------------------------------------------------------------------ uint8 patches
+// The reference turns 8-bit patch files into floats on the HOST (torchvision ToTensor: u8 / 255, image_datasets.py:102-105,
+// optionally Normalize: (v - mean) / std) and ships 4 bytes per pixel over PCIe and through HBM.  Here patches stay uint8
+// up to the stem kernel's operand load.  Bit-for-bit the same floats: u / 255 as one reciprocal multiply plus one
+// Newton step on fused multiply-adds, which is the correctly rounded quotient for every u in 0..255 (checked exhaustively
+// against torch's division, tests/test_gpu_kernels.py; the bare multiply is off by one ulp for 126 of the 256 values);
+// Normalize's division the same way with 1 / std.  nrm = {mean[3], std[3], 1/std[3]} or NULL.
+__device__ __forceinline__ float u8_unit(float u) {
+    constexpr float R255 = 1.0f / 255.0f;
+    const float q = u * R255;
+    const float e = fmaf(-255.0f, q, u);
+    return fmaf(e, R255, q);
+}
+__device__ __forceinline__ float u8_pixel(float u, bool norm, float mean, float sd, float rsd) {
+    float v = u8_unit(u);
+    if (norm) {
+        const float t = v - mean;
+        const float q = t * rsd;
+        const float e = fmaf(-sd, q, t);
+        v = fmaf(e, rsd, q);
+    }
+    return v;
+}
+// 4 consecutive pixels of one channel plane: a dword of bytes -> 4 floats
+__device__ __forceinline__ float4 u8x4_pixels(uint32_t wv, bool norm, float mean, float sd, float rsd) {
+    return make_float4(u8_pixel((float)(wv & 0xffu), norm, mean, sd, rsd),
+                       u8_pixel((float)((wv >> 8) & 0xffu), norm, mean, sd, rsd),
+                       u8_pixel((float)((wv >> 16) & 0xffu), norm, mean, sd, rsd),
+                       u8_pixel((float)(wv >> 24), norm, mean, sd, rsd));
+}
+
+// out[img][c][y][x] (float) = ToTensor (+ Normalize) of x8[img][c][y][x]: 4 pixels per thread (HW % 4 == 0)
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* __restrict__ x8, float* __restrict__ out, long n4,
+                                                        long hw4, int C, const float* __restrict__ nrm) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const int c = (int)((i / hw4) % C);
+        const bool norm = nrm != nullptr && c < 3;
+        const float mean = norm ? nrm[c] : 0.f, sd = norm ? nrm[3 + c] : 1.f, rsd = norm ? nrm[6 + c] : 1.f;
+        const uint32_t wv = reinterpret_cast<const uint32_t*>(x8)[i];
+        reinterpret_cast<float4*>(out)[i] = u8x4_pixels(wv, norm, mean, sd, rsd);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ stem conv (NCHW in, NHWC out)
 // out[(img,oy,ox)][o] = sum_{c,ky,kx} x[img][c][oy*st+ky-pad][ox*st+kx-pad] * w[o][c][ky][kx]
 // im2col is built in LDS one input channel at a time: K-chunk = KH x 8 (kx padded to 8 with zero weights).
@@ -195,11 +239,16 @@ constexpr int SP_LDT = 40;         // floats per position of the activated 32-ch
 // WO = width of the conv0 map: 64 (128-px patches: tiles of 2 rows, one pooled row each, one carried row) or 128
 // (256-px patches: tiles of 1 row; a pooled row is emitted on every odd conv row from the two carried rows and the new one).
 // H16: the pooled output is stored as fp16 ([rows][ldo halves]): config 5 with fp16 block buffers.
-template <int WO, bool H16 = false>
-__global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// U8: the patches are uint8 [imgs][3][H][W]; ToTensor (+ Normalize, nrm != NULL) happens between the load and the LDS
+// stash (a quarter of the input bytes: 245 MB instead of 981 MB per 128-px array).
+template <int WO, bool H16 = false, bool U8 = false>
+__global__ __launch_bounds__(256) void conv_stem_pool_kernel(const void* __restrict__ xv, const float* __restrict__ w,
                                                              float* __restrict__ out, long ldo, int H, int Wd, int O,
                                                              const float* __restrict__ scale,
-                                                             const float* __restrict__ shift, long imgs) {
+                                                             const float* __restrict__ shift, long imgs,
+                                                             const float* __restrict__ nrm) {
+    const float* __restrict__ x = reinterpret_cast<const float*>(xv);
+    const uint8_t* __restrict__ x8 = reinterpret_cast<const uint8_t*>(xv);
     constexpr int CIN = 3, KH = 7, KW = 7, STRIDE = 2, PAD = 3;
     constexpr int RT = 128 / WO;                          // conv rows per tile
     constexpr int PH = STRIDE * (RT - 1) + KH, PW = ((WO - 1) * STRIDE + 8 + 1 + 1) & ~1;      // input patch per channel
@@ -240,7 +289,10 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __rest
 
     // Patch staging: CIN * PH input rows of 2 WO floats as 16-B pieces, fetched one tile AHEAD into registers while the
     // current tile multiplies.
-    float4 pre[NPRE];
+    float4 pre[U8 ? 1 : NPRE];
+    uint32_t pre8[U8 ? NPRE : 1];             // U8: a piece is the same 4 pixels, as one dword of bytes
+    bool in8[U8 ? NPRE : 1];                  // ... and whether it lies inside the image (outside stays 0.0f, not "pixel 0":
+                                              // the conv pads the NORMALISED input with zeros)
     auto fetch_patch = [&](long img, int tt) {
         const int iy0 = RT * tt * STRIDE - PAD;
 #pragma unroll
@@ -248,8 +300,16 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __rest
             const int j = t + 256 * q;
             const int f4 = j % F4R, py = (j / F4R) % PH, c = (j / F4R) / PH;
             const int iy = iy0 + py;
-            pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < NPC && iy >= 0 && iy < H) pre[q] = ld4(x + ((img * CIN + c) * H + iy) * (long)Wd + 4 * f4);
+            const bool inside = j < NPC && iy >= 0 && iy < H;
+            if constexpr (U8) {
+                pre8[q] = 0u;
+                in8[q] = inside;
+                if (inside)
+                    pre8[q] = *reinterpret_cast<const uint32_t*>(x8 + ((img * CIN + c) * H + iy) * (long)Wd + 4 * f4);
+            } else {
+                pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (inside) pre[q] = ld4(x + ((img * CIN + c) * H + iy) * (long)Wd + 4 * f4);
+            }
         }
     };
     auto stash_patch = [&]() {
@@ -258,7 +318,16 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const float* __rest
             const int j = t + 256 * q;
             if (j < NPC) {
                 float* d = Ps + (j / F4R) * PW + PAD + 4 * (j % F4R);        // patch column = ix + PAD
-                d[0] = pre[q].x; d[1] = pre[q].y; d[2] = pre[q].z; d[3] = pre[q].w;
+                if constexpr (U8) {
+                    const int c = (j / F4R) / PH;
+                    const bool norm = nrm != nullptr;
+                    const float4 v = in8[q] ? u8x4_pixels(pre8[q], norm, norm ? nrm[c] : 0.f, norm ? nrm[3 + c] : 1.f,
+                                                          norm ? nrm[6 + c] : 1.f)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                } else {
+                    d[0] = pre[q].x; d[1] = pre[q].y; d[2] = pre[q].z; d[3] = pre[q].w;
+                }
             }
         }
     };
@@ -489,17 +558,19 @@ GNX_EXPORT int gnx_conv_stem(const float* x, const float* w, float* out, long ld
 // maxpool3x3s2p1(relu(scale * conv7x7s2p3(x) + shift)) without the intermediate map.  Supported geometry: Cin = 3, the
 // conv output is 64 or 128 wide and even-high (128- / 256-px patches), O <= 64 and O % 4 == 0; anything else returns
 // GNX_ERR_UNSUPPORTED and the caller runs gnx_conv_stem + gnx_bnrelu_maxpool.
-template <bool H16>
-static int stem_pool_launch(const float* x, const float* w, float* out, long ldo, long imgs, int Cin, int H, int W, int O,
-                            int KH, int KW, int stride, int pad, const float* scale, const float* shift, hipStream_t stream) {
+template <bool H16, bool U8 = false>
+static int stem_pool_launch(const void* x, const float* w, float* out, long ldo, long imgs, int Cin, int H, int W, int O,
+                            int KH, int KW, int stride, int pad, const float* scale, const float* shift, hipStream_t stream,
+                            const float* nrm = nullptr) {
     if (!x || !w || !out || !scale || !shift || imgs < 0 || Cin <= 0 || O <= 0 || H <= 0 || W <= 0 || ldo < O)
         return GNX_ERR_BAD_ARG;
     if (Cin != 3 || KH != 7 || KW != 7 || stride != 2 || pad != 3 || O > 64 || O % 4 != 0 || ldo % 4 != 0 ||
         (reinterpret_cast<uintptr_t>(out) & (H16 ? 7 : 15)) != 0)
         return GNX_ERR_UNSUPPORTED;
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-    if ((Wo != 64 && Wo != 128) || W != 2 * Wo || Ho % 2 != 0 || Ho <= 0 || !al16(x))
-        return GNX_ERR_UNSUPPORTED;                        // 16-B row pieces, whole 128-position tiles
+    if ((Wo != 64 && Wo != 128) || W != 2 * Wo || Ho % 2 != 0 || Ho <= 0 ||
+        (reinterpret_cast<uintptr_t>(x) & (U8 ? 3 : 15)) != 0)
+        return GNX_ERR_UNSUPPORTED;                        // 16-B (u8: 4-B) row pieces, whole 128-position tiles
     if (imgs == 0) return GNX_OK;
     const int RT = 128 / Wo, PH = 2 * (RT - 1) + 7, PW = ((Wo - 1) * 2 + 8 + 2) & ~1;
     const size_t lds_bytes = ((size_t)64 * (3 * 7 * 8 + 4) + (size_t)3 * PH * PW + (size_t)128 * SP_LDT) * sizeof(float);
@@ -508,21 +579,21 @@ static int stem_pool_launch(const float* x, const float* w, float* out, long ldo
     if (Wo == 64) {
         static bool conf = false;
         if (!conf) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel<64, H16>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel<64, H16, U8>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
                 return GNX_ERR_LAUNCH;
             conf = true;
         }
-        conv_stem_pool_kernel<64, H16><<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale, shift, imgs);
+        conv_stem_pool_kernel<64, H16, U8><<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale, shift, imgs, nrm);
     } else {
         static bool conf = false;
         if (!conf) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel<128, H16>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel<128, H16, U8>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
                 return GNX_ERR_LAUNCH;
             conf = true;
         }
-        conv_stem_pool_kernel<128, H16><<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale, shift, imgs);
+        conv_stem_pool_kernel<128, H16, U8><<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale, shift, imgs, nrm);
     }
     return gnx_launch_status();
 }
@@ -537,6 +608,35 @@ GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool_h16(const float* x, const float* w, 
                                                 const float* scale, const float* shift, hipStream_t stream) {
     return stem_pool_launch<true>(x, w, reinterpret_cast<float*>(out16), ldo, imgs, Cin, H, W, O, KH, KW, stride, pad, scale,
                                   shift, stream);
+}
+
+// The fused stem on uint8 patches x8 [imgs][3][H][W] (image_datasets.py:102-105 does ToTensor on the host):
+// ToTensor (u8 / 255) and, with norm != NULL, Normalize ((v - mean[c]) / std[c]; norm = {mean[3], std[3], 1/std[3]} on the
+// device) are applied between the load and the LDS stash - bit-for-bit the floats the float entry point would be given.
+// out_f16 != 0: the pooled map is stored as fp16 (config 5's fp16 block buffers).  Geometry as gnx_conv_stem_bnrelu_maxpool.
+GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool_u8(const uint8_t* x8, const float* w, void* out, long ldo, long imgs, int Cin,
+                                               int H, int W, int O, int KH, int KW, int stride, int pad, const float* scale,
+                                               const float* shift, const float* norm, int out_f16, hipStream_t stream) {
+    if (out_f16)
+        return stem_pool_launch<true, true>(x8, w, reinterpret_cast<float*>(out), ldo, imgs, Cin, H, W, O, KH, KW, stride, pad,
+                                            scale, shift, stream, norm);
+    return stem_pool_launch<false, true>(x8, w, reinterpret_cast<float*>(out), ldo, imgs, Cin, H, W, O, KH, KW, stride, pad,
+                                         scale, shift, stream, norm);
+}
+
+// ToTensor (+ Normalize) as its own pass: x8 [imgs][C][H][W] uint8 -> out float, the same floats as above.  For the paths
+// that need float patches in HBM (training forward: conv0's weight gradient re-reads them; geometries the fused stem does
+// not take).  H * W % 4 == 0, 4-B aligned input, 16-B aligned output; norm as above (C must be 3 with it) or NULL.
+GNX_EXPORT int gnx_u8_to_f32(const uint8_t* x8, float* out, long imgs, int C, int H, int W, const float* norm,
+                             hipStream_t stream) {
+    if (!x8 || !out || imgs < 0 || C <= 0 || H <= 0 || W <= 0 || (norm && C != 3)) return GNX_ERR_BAD_ARG;
+    const long hw = (long)H * W;
+    if (hw % 4 != 0 || (reinterpret_cast<uintptr_t>(x8) & 3) != 0 || !al16(out)) return GNX_ERR_UNSUPPORTED;
+    const long n4 = imgs * C * hw / 4;
+    if (n4 == 0) return GNX_OK;
+    const long blocks = (n4 + 255) / 256;
+    u8_to_f32_kernel<<<(int)(blocks < 256 * 16 ? blocks : 256 * 16), 256, 0, stream>>>(x8, out, n4, hw / 4, C, norm);
+    return gnx_launch_status();
 }
 
 // in [imgs*Hi*Wi][C] (ldi) -> out [imgs*Ho*Wo][C] (ldo): max over 3x3 s2 p1 windows of relu(in*scale+shift)

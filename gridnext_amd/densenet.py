@@ -54,8 +54,7 @@ class DenseNet(nn.Module):
                  num_classes=10, small_inputs=True, efficient=False, classify=True):
         super().__init__()
         assert 0 < compression <= 1, 'compression of densenet should be between 0 and 1'
-        if drop_rate and drop_rate > 0:
-            raise NotImplementedError("dropout inside dense layers (drop_rate>0) is not used on the GridNext path")
+        self.drop_rate = float(drop_rate or 0)      # dropout after conv2 (:42-43): identity outside training mode
         self.growth_rate, self.block_config = growth_rate, tuple(block_config)
         self.bn_size, self.small_inputs, self.classify = bn_size, small_inputs, classify
         self.atonce = None          # spots per chunk in eval mode (None = auto)
@@ -63,6 +62,9 @@ class DenseNet(nn.Module):
         self.winograd = True        # eval forward: conv2 as Winograd F(2,3) along x where the shape allows (fp32 path;
                                     # same arithmetic type, 1.5x fewer matrix operations, rounding-level differences)
         self.f16_buffers = True     # mfma = 'f16' only: the block buffers themselves in fp16 where the shapes allow
+        self.input_norm = None      # (mean[3], std[3]) of a torchvision Normalize to apply to UINT8 input patches after the
+                                    # u8 / 255 of ToTensor (fused into the stem's operand load); float inputs are taken as
+                                    # already transformed by the dataset, as in the reference
         self.l3_blocking = False    # option: run each dense block over Infinity-Cache-sized sub-ranges of spots
                                     # (measured r01: slower - 15x more, smaller launches; kept for experiments)
         self.l3_budget = 160 * 1024 * 1024
@@ -227,6 +229,34 @@ class DenseNet(nn.Module):
         self._cache['w2u'] = (key, table)
         return table
 
+    def _norm_vector(self, dev):
+        """Device floats {mean[3], std[3], 1/std[3]} for the uint8 entry points, or None (ToTensor only)."""
+        if self.input_norm is None:
+            return None
+        mean, std = self.input_norm
+        key = (tuple(float(v) for v in mean), tuple(float(v) for v in std), str(dev), self._cache_epoch)
+        hit = self._cache.get('nrm')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        m = torch.tensor(key[0], dtype=F32)
+        sd = torch.tensor(key[1], dtype=F32)
+        assert m.numel() == 3 and sd.numel() == 3, "input_norm = (mean[3], std[3])"
+        v = torch.cat([m, sd, 1.0 / sd]).to(dev)              # 1 / std: one correctly rounded fp32 division
+        self._cache['nrm'] = (key, v)
+        return v
+
+    def _float_patches(self, x):
+        """ToTensor (+ Normalize) of uint8 patches (N, 3, P, P) as its own pass -> float32, the floats torch would produce
+        (gnx_u8_to_f32); float input passes through."""
+        if x.dtype != torch.uint8:
+            return x.contiguous().float()
+        x = x.contiguous()
+        out = torch.empty(x.shape, device=x.device, dtype=F32)
+        if x.numel():
+            L.call('gnx_u8_to_f32', x.data_ptr(), L.ptr(out), x.shape[0], x.shape[1], x.shape[2], x.shape[3],
+                   L.ptr(self._norm_vector(x.device)), L.stream())
+        return out
+
     def _geometry(self, P):
         if self.small_inputs:
             hs, s = None, P
@@ -272,6 +302,43 @@ class DenseNet(nn.Module):
         self._probe.append((kind, start, ev))
         return ev
 
+    # ------------------------------------------------------------------ stem of the eval forward
+    def _stem_eval(self, xu, rows, c_total, P, hs, use_h, fold, w0, stem_out, chunk, st):
+        """conv0 (-> norm0 -> relu0 -> pool0) of `xu` (float or uint8 patches) into the first block buffer `rows`.
+        Returns the conv0-map scratch buffer (allocated on first need by the two-kernel path)."""
+        nu = xu.shape[0]
+        dev = xu.device
+        c0 = self.features.conv0.out_channels
+        if self.small_inputs:
+            xu = self._float_patches(xu)
+            L.call('gnx_conv_stem', L.ptr(xu), L.ptr(w0), L.ptr(rows), c_total, nu, 3, P, P, c0, 3, 3, 1, 1, st)
+            return stem_out
+        sc, sh = fold[self.features.norm0]
+        # conv0 -> norm0 -> relu0 -> pool0 in one kernel where the geometry allows (128- / 256-px patches): the conv0 map
+        # (5.2 GB per 128-px array) then never touches HBM.  uint8 patches: ToTensor (+ Normalize) inside that kernel too.
+        if xu.dtype == torch.uint8:
+            rc = L.query('gnx_conv_stem_bnrelu_maxpool_u8', xu.data_ptr(), L.ptr(w0), rows.data_ptr(), c_total, nu, 3, P, P,
+                         c0, 7, 7, 2, 3, L.ptr(sc), L.ptr(sh), L.ptr(self._norm_vector(dev)), 1 if use_h else 0, st)
+            if rc == 0:
+                return stem_out
+            if rc != L.ERR_UNSUPPORTED:
+                raise RuntimeError("gnx_conv_stem_bnrelu_maxpool_u8 failed (%d)" % rc)
+            xu = self._float_patches(xu)                      # other geometries: convert, then the float stems
+        if use_h:
+            L.call('gnx_conv_stem_bnrelu_maxpool_h16', L.ptr(xu), L.ptr(w0), L.ptr(rows, torch.float16), c_total, nu, 3, P, P,
+                   c0, 7, 7, 2, 3, L.ptr(sc), L.ptr(sh), st)
+            return stem_out
+        rc = L.query('gnx_conv_stem_bnrelu_maxpool', L.ptr(xu), L.ptr(w0), L.ptr(rows), c_total, nu, 3, P, P, c0, 7, 7, 2, 3,
+                     L.ptr(sc), L.ptr(sh), st)
+        if rc == L.ERR_UNSUPPORTED:
+            if stem_out is None:
+                stem_out = torch.empty((chunk * hs * hs, c0), device=dev, dtype=F32)
+            L.call('gnx_conv_stem', L.ptr(xu), L.ptr(w0), L.ptr(stem_out), c0, nu, 3, P, P, c0, 7, 7, 2, 3, st)
+            L.call('gnx_bnrelu_maxpool', L.ptr(stem_out), c0, L.ptr(rows), c_total, nu, c0, hs, hs, L.ptr(sc), L.ptr(sh), st)
+        elif rc != 0:
+            raise RuntimeError("gnx_conv_stem_bnrelu_maxpool failed (%d)" % rc)
+        return stem_out
+
     # ------------------------------------------------------------------ forward
     def forward(self, x):
         if not x.is_cuda:
@@ -279,7 +346,15 @@ class DenseNet(nn.Module):
                                "there is no CPU fallback" % x.device)
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3]:
             raise ValueError("expected square RGB patches (N, 3, P, P), got %s" % (tuple(x.shape),))
+        if x.dtype not in (torch.uint8, torch.float32):
+            x = x.float()
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if self.training and self.drop_rate > 0:
+            # F.dropout(new_features, p, training=self.training) (:42-43) is the identity in eval mode - which is how every
+            # grid-level use runs f (training.py:126) - so a network built with drop_rate > 0 loads and runs frozen or
+            # fine-tuned under train_gridwise.  Training-mode dropout (train_spotwise on such a network) is not built.
+            raise NotImplementedError("gridnext_amd.DenseNet: train-mode dropout (drop_rate=%g with model.train()) is not "
+                                      "implemented; eval mode - where dropout is the identity - works" % self.drop_rate)
         if self.training or needs_grad:
             from .densenet_train import densenet_autograd       # training / gradient path
             return densenet_autograd(self, x)
@@ -287,7 +362,8 @@ class DenseNet(nn.Module):
 
     @torch.no_grad()
     def _forward_eval(self, x):
-        x = x.contiguous().float()
+        # uint8 patches stay uint8 up to the stem kernel's operand load (a quarter of the bytes over PCIe and out of HBM)
+        x = x.contiguous() if x.dtype == torch.uint8 else x.contiguous().float()
         N, _, P, _ = x.shape
         dev = x.device
         st = L.stream()
@@ -351,29 +427,7 @@ class DenseNet(nn.Module):
                     rows = buf[u0 * s * s:(u0 + nu) * s * s]
                     M = nu * s * s
                     if bi == 0:
-                        xu = xs[u0:u0 + nu]
-                        if self.small_inputs:
-                            L.call('gnx_conv_stem', L.ptr(xu), L.ptr(w0), L.ptr(rows), c_total, nu, 3, P, P, c0,
-                                   3, 3, 1, 1, st)
-                        elif use_h:
-                            sc, sh = fold[self.features.norm0]
-                            L.call('gnx_conv_stem_bnrelu_maxpool_h16', L.ptr(xu), L.ptr(w0), L.ptr(rows, torch.float16), c_total,
-                                   nu, 3, P, P, c0, 7, 7, 2, 3, L.ptr(sc), L.ptr(sh), st)
-                        else:
-                            sc, sh = fold[self.features.norm0]
-                            # conv0 -> norm0 -> relu0 -> pool0 in one kernel where the geometry allows (128-px
-                            # patches): the conv0 map (5.2 GB per array) then never touches HBM
-                            rc = L.query('gnx_conv_stem_bnrelu_maxpool', L.ptr(xu), L.ptr(w0), L.ptr(rows), c_total, nu,
-                                         3, P, P, c0, 7, 7, 2, 3, L.ptr(sc), L.ptr(sh), st)
-                            if rc == L.ERR_UNSUPPORTED:
-                                if stem_out is None:
-                                    stem_out = torch.empty((chunk * hs * hs, c0), device=dev, dtype=F32)
-                                L.call('gnx_conv_stem', L.ptr(xu), L.ptr(w0), L.ptr(stem_out), c0, nu, 3, P, P, c0,
-                                       7, 7, 2, 3, st)
-                                L.call('gnx_bnrelu_maxpool', L.ptr(stem_out), c0, L.ptr(rows), c_total, nu, c0, hs, hs,
-                                       L.ptr(sc), L.ptr(sh), st)
-                            elif rc != 0:
-                                raise RuntimeError("gnx_conv_stem_bnrelu_maxpool failed (%d)" % rc)
+                        stem_out = self._stem_eval(xs[u0:u0 + nu], rows, c_total, P, hs, use_h, fold, w0, stem_out, chunk, st)
                     for li, layer in enumerate(layers):
                         cin = c_in + li * self.growth_rate
                         sc1, sh1 = fold[layer.norm1]

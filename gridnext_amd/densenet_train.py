@@ -63,7 +63,7 @@ def gammas_nonzero(model):
 class _DenseNetFn(Function):
     @staticmethod
     def forward(ctx, model, x, *params):
-        x = x.contiguous().float()
+        x = model._float_patches(x)       # uint8 patches: ToTensor (+ Normalize) as one pass (conv0's wgrad re-reads floats)
         N, _, P, _ = x.shape
         dev = x.device
         st = L.stream()

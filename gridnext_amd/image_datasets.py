@@ -32,6 +32,17 @@ def to_tensor(img):
     return t.float().div(255) if t.dtype == torch.uint8 else t.float()
 
 
+def to_tensor_u8(img):
+    """PIL image -> uint8 CHW, NOT divided: the / 255 of ToTensor then happens on the device, inside the stem kernel
+    (`gridnext_amd.DenseNet` takes uint8 patches; a quarter of the bytes over PCIe and out of HBM)."""
+    arr = np.array(img)
+    if arr.ndim == 2:
+        arr = arr[:, :, None]
+    if arr.dtype != np.uint8:
+        raise TypeError("raw_uint8 needs 8-bit images (got %s)" % arr.dtype)
+    return torch.from_numpy(np.ascontiguousarray(arr)).permute(2, 0, 1).contiguous()
+
+
 def _spot_labels(annot_file, position_file, Visium, afile_delim, class_names):
     if Visium:
         coords, strs = read_annotfile(annot_file, position_file=position_file, Visium=True, afile_delim=afile_delim)
@@ -42,8 +53,9 @@ def _spot_labels(annot_file, position_file, Visium, afile_delim, class_names):
 
 class PatchDataset(Dataset):
     def __init__(self, img_files, annot_files=None, position_files=None, Visium=True,
-                 img_transforms=None, afile_delim=',', img_ext='jpg', verbose=False):
+                 img_transforms=None, afile_delim=',', img_ext='jpg', verbose=False, raw_uint8=False):
         super().__init__()
+        self.raw_uint8 = raw_uint8            # addition: yield uint8 patches (ToTensor's / 255 is fused into the stem kernel)
         _check_files(img_files, annot_files, position_files, Visium, 'img_files')
         names = None
         if Visium and annot_files is not None:
@@ -67,7 +79,7 @@ class PatchDataset(Dataset):
         else:
             for imdir in img_files:
                 self.imgpath_mapping += glob.glob(os.path.join(imdir, '*.' + img_ext))
-        self.preprocess = to_tensor if img_transforms is None else img_transforms
+        self.preprocess = (to_tensor_u8 if raw_uint8 else to_tensor) if img_transforms is None else img_transforms
         if annot_files is not None and verbose:
             print('%d image patches without annotation' % skipped)
 
@@ -77,20 +89,21 @@ class PatchDataset(Dataset):
     def __getitem__(self, idx):
         img = self.preprocess(Image.open(self.imgpath_mapping[idx]))
         label = torch.tensor(self.annotations[idx]).long() if len(self.annotations) > 0 else torch.empty(0)
-        return img.float(), label
+        return (img if self.raw_uint8 else img.float()), label
 
 
 class PatchGridDataset(Dataset):
     def __init__(self, img_files, annot_files=None, position_files=None, Visium=True,
-                 img_transforms=None, afile_delim=',', img_ext='jpg', h_st=78, w_st=64):
+                 img_transforms=None, afile_delim=',', img_ext='jpg', h_st=78, w_st=64, raw_uint8=False):
         super().__init__()
+        self.raw_uint8 = raw_uint8            # addition: yield a uint8 patch grid (245 MB instead of 981 MB at 128 px)
         _check_files(img_files, annot_files, position_files, Visium, 'img_files')
         if Visium and annot_files is not None:
             self.classes = _label_names(annot_files, position_files, ',')
         self.img_files, self.annot_files, self.position_files = img_files, annot_files, position_files
         self.h_st, self.w_st, self.Visium = h_st, w_st, Visium
         self.afile_delim, self.img_ext = afile_delim, img_ext
-        self.preprocess = to_tensor if img_transforms is None else img_transforms
+        self.preprocess = (to_tensor_u8 if raw_uint8 else to_tensor) if img_transforms is None else img_transforms
 
     def __len__(self):
         return len(self.img_files)
@@ -110,11 +123,12 @@ class PatchGridDataset(Dataset):
             ax, ay = int(hit.group(1)), int(hit.group(2))
             patch = self.preprocess(Image.open(os.path.join(self.img_files[idx], fname)))
             if grid is None:
-                grid = torch.zeros((self.h_st, self.w_st) + tuple(patch.shape))
+                grid = torch.zeros((self.h_st, self.w_st) + tuple(patch.shape),
+                                   dtype=torch.uint8 if self.raw_uint8 else torch.float32)
             x, y = pseudo_hex_to_oddr(ax, ay) if self.Visium else (ax, ay)
             if lookup is not None:
                 cstr = '%d_%d' % (ax, ay)
                 if cstr in lookup:
                     labels[y, x] = int(lookup[cstr]) + 1            # 0 is reserved for background
             grid[y, x] = patch
-        return grid.float(), labels.long()
+        return (grid if self.raw_uint8 else grid.float()), labels.long()

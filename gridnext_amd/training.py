@@ -12,6 +12,9 @@ What differs underneath (MI355X-first):
   * on a HIP device with a plain `nn.CrossEntropyLoss()` the permute -> mask-gather -> CE -> argmax chain is ONE
     fused kernel pair on channels-last logits (no dynamic shapes, no host sync per batch); epoch statistics are
     accumulated on the device and read back once per phase;
+  * batches are fed by `prefetch.DevicePrefetcher`: pinned staging buffers, `non_blocking` host -> device copies on a
+    side stream one batch ahead, event-ordered (the reference's blocking `.to(device)` of pageable memory, :47-51,
+    :135-139, sits inside every step); uint8 patches are converted inside the stem kernel;
   * when torch.distributed is initialised with world_size > 1 the loop is data-parallel: gradients of the
     optimised parameters are all-reduced (RCCL over xGMI) before every optimizer step, epoch statistics are
     summed over ranks, rank 0 writes checkpoints.  Shard the arrays with `distributed.ShardedSampler`.
@@ -26,6 +29,7 @@ import torch.nn as nn
 
 from . import distributed as gdist
 from . import functional as GF
+from . import prefetch
 
 
 def _plain_ce(criterion):
@@ -118,6 +122,7 @@ def train_spotwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
             loader = dataloaders[phase]
             if hasattr(getattr(loader, 'sampler', None), 'set_epoch'):
                 loader.sampler.set_epoch(epoch)
+            loader = prefetch.wrap(loader, device)         # pinned, double-buffered H2D one batch ahead (no-op on the CPU)
             if display:
                 from tqdm import tqdm
                 loader = tqdm(loader)
@@ -199,6 +204,7 @@ def train_gridwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
             loader = dataloaders[phase]
             if hasattr(getattr(loader, 'sampler', None), 'set_epoch'):
                 loader.sampler.set_epoch(epoch)
+            loader = prefetch.wrap(loader, device)         # pinned, double-buffered H2D one batch ahead (no-op on the CPU)
             for batch_ind, (inputs, labels) in enumerate(loader):
                 batch_size = labels.size(0)
                 inputs, labels = _to_device(inputs, device), labels.to(device)

@@ -29,7 +29,9 @@ typedef void* gnx_stream_t; /* hipStream_t */
  * gridnext/gridnet_models.py:130-147.  x/y/dx/dy: [B][H][W][C] channels-last.  kernel0 [O][I][3][1],
  * kernel1 [O][I][2][2], bias [O] (hexagdly's parameter shapes).  mode 0: hexagdly addressing (odd columns
  * shifted down, gridnext/hexagdly_tools.py:68); mode 1: Visium odd-right grid, i.e. the
- * rot90/flip -> conv -> flip/rot90 sandwich of gridnet_models.py:178-185 without moving data. */
+ * rot90/flip -> conv -> flip/rot90 sandwich of gridnet_models.py:178-185 without moving data.
+ * Any I, O >= 1: up to 64 x 64 channels (weight gradient: 32 x 32) are one launch, wider layers are tiled over
+ * channel chunks inside the call. */
 int gnx_hexconv_fwd(const float* x, const float* kernel0, const float* kernel1, const float* bias, float* y,
                     int B, int H, int W, int I, int O, int mode, gnx_stream_t stream);
 int gnx_hexconv_bwd_data(const float* dy, const float* kernel0, const float* kernel1, float* dx,
@@ -158,6 +160,18 @@ int gnx_conv3x3_f16_dma(const void* A16, long lda16, const void* Wr16, float* ou
 int gnx_conv_stem_bnrelu_maxpool_h16(const float* x, const float* w, void* out16, long ldo, long imgs, int Cin, int H, int W,
                                      int O, int KH, int KW, int stride, int pad, const float* scale, const float* shift,
                                      gnx_stream_t stream);
+/* ---- uint8 patches (SURVEY 8f-2 input pipeline) -------------------------------------------------------------------
+ * The reference converts 8-bit patch files to floats on the host (torchvision ToTensor, gridnext/image_datasets.py:102-105,
+ * :185; optionally Normalize) and moves 4 bytes per pixel host -> device (training.py:135-139).  Here patches stay uint8
+ * [imgs][3][H][W] until the stem kernel's operand load: u8 / 255 and, with norm != NULL, (v - mean[c]) / std[c] - bit for bit
+ * the floats torch produces.  norm: device floats {mean[3], std[3], 1/std[3]}.  gnx_conv_stem_bnrelu_maxpool_u8 = the fused
+ * stem (same geometries; out_f16: pooled map stored as fp16); gnx_u8_to_f32 = the conversion alone (H*W % 4 == 0), for the
+ * training forward (conv0's weight gradient re-reads float patches) and other geometries. */
+int gnx_conv_stem_bnrelu_maxpool_u8(const unsigned char* x8, const float* w, void* out, long ldo, long imgs, int Cin, int H,
+                                    int W, int O, int KH, int KW, int stride, int pad, const float* scale,
+                                    const float* shift, const float* norm, int out_f16, gnx_stream_t stream);
+int gnx_u8_to_f32(const unsigned char* x8, float* out, long imgs, int C, int H, int W, const float* norm,
+                  gnx_stream_t stream);
 int gnx_conv1x1_bnrelu_f16_h(const void* A16, long lda16, const float* W, void* out16, long ldc16, long M, int N, int K,
                              const float* scale, const float* shift, const float* out_scale, const float* out_shift,
                              int pool, int S_in, gnx_stream_t stream);

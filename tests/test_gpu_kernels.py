@@ -39,7 +39,11 @@ def L():
 # ----------------------------------------------------------------------------------------------- hex conv
 @pytest.mark.parametrize("B,H,W,I,O,oddr", [(2, 7, 6, 5, 9, True), (1, 78, 64, 16, 32, True),
                                              (2, 9, 8, 32, 7, False), (1, 5, 4, 14, 32, True),
-                                             (3, 1, 1, 3, 4, True), (1, 2, 3, 32, 32, False)])
+                                             (3, 1, 1, 3, 4, True), (1, 2, 3, 32, 32, False),
+                                             # wider than one launch takes (64 x 64 forward / 32 x 32 weight gradient):
+                                             # tiled over channel chunks - many classes, classify=False feature inputs
+                                             (1, 9, 7, 40, 32, True), (2, 6, 5, 64, 64, True), (1, 7, 6, 150, 70, True),
+                                             (1, 5, 6, 33, 130, False)])
 def test_hexconv_fwd_bwd(GF, B, H, W, I, O, oddr):
     from oracle import hexconv as ohex
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + I)
@@ -109,6 +113,26 @@ def test_bn_relu_fwd_bwd(GF, M, C, relu, training):
 
 
 # ----------------------------------------------------------------------------------------------- masked CE
+@pytest.mark.parametrize("C", [1, 17, 64, 65, 300])
+def test_masked_ce_any_class_count(GF, C):
+    """The fused CE / softmax take any number of classes (r1 refused C > 64): against torch's own CE on the CPU."""
+    g = torch.Generator().manual_seed(C)
+    M = 777
+    z = torch.randn(M, C, generator=g) * 3
+    lab = torch.randint(0, C + 1, (M,), generator=g)                    # 0 = background
+    zr = z.clone().requires_grad_(True)
+    keep = lab > 0
+    ref = nn.functional.cross_entropy(zr[keep], lab[keep] - 1) / 2
+    ref.backward()
+    zd = z.to(DEV).requires_grad_(True)
+    loss, stats, preds = GF.masked_cross_entropy(zd, lab.to(DEV), 2)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5
+    close(zd.grad, zr.grad, rtol=1e-4, atol=1e-9)
+    assert int(stats[0]) == int(keep.sum())
+    assert torch.equal(preds.cpu(), z.argmax(1))
+
+
 def test_masked_ce_reference_maps(GF):
     g = load_golden('masked_ce_maynard')
     z = torch.from_numpy(g['logits'])                      # (7, 78, 64)
@@ -595,3 +619,83 @@ def test_stem_conv_and_pools(L, n, P, O, KH, stride, pad):
     L.call('gnx_bnrelu_avgpool', L.ptr(out), O, L.ptr(gap), O, n, O, Ho * Ho, L.ptr(scd), L.ptr(shd),
            L.stream())
     close(gap, act.mean((2, 3)), rtol=1e-4)
+
+
+# ----------------------------------------------------------------------------------------------- round 2 additions
+@pytest.mark.parametrize("C,Hi", [(8, 12), (64, 32), (6, 9)])
+def test_maxpool_backward_routes_ties_like_torch(L, C, Hi):
+    """pool0's adjoint on maps with TIES (piecewise-constant conv0 maps: white slide background, all-zero background spots):
+    torch sends a window's gradient to the first maximal element of its row-major scan, not to every maximal one.
+    Found by the C2-shape gradient test (closed-form images, norm0.weight off by 8x its magnitude)."""
+    g = torch.Generator().manual_seed(C + Hi)
+    n = 3
+    # a conv0 map that is constant on 3x2 blocks plus a few random cells, channels-last rows
+    coarse = torch.randint(-2, 4, (n, C, (Hi + 2) // 3, (Hi + 1) // 2), generator=g).float()
+    raw = coarse.repeat_interleave(3, 2).repeat_interleave(2, 3)[:, :, :Hi, :Hi].contiguous()
+    raw[:, :, 1::5, 2::7] += torch.rand(raw[:, :, 1::5, 2::7].shape, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    xr = raw.clone().requires_grad_(True)
+    act = torch.relu(xr * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    act.retain_grad()
+    mp = F.max_pool2d(act, 3, 2, 1)
+    Ho = mp.shape[2]
+    dout = torch.randn(mp.shape, generator=g)
+    mp.backward(dout)
+    rows = raw.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV)
+    scd, shd = sc.to(DEV), sh.to(DEV)
+    pooled = torch.empty((n * Ho * Ho, C), device=DEV)
+    L.call('gnx_bnrelu_maxpool', L.ptr(rows), C, L.ptr(pooled), C, n, C, Hi, Hi, L.ptr(scd), L.ptr(shd), L.stream())
+    assert torch.equal(pooled.reshape(n, Ho, Ho, C).permute(0, 3, 1, 2).cpu(), mp.detach())
+    dO = dout.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV)
+    dAct = torch.empty((n * Hi * Hi, C), device=DEV)
+    L.call('gnx_maxpool_bwd', L.ptr(rows), C, L.ptr(pooled), C, L.ptr(dO), C, L.ptr(dAct), C, n, C, Hi, Hi, L.ptr(scd),
+           L.ptr(shd), L.stream())
+    # torch's d/d(act) includes elements at exactly 0 (a window of zeros): the ReLU mask removes them either way
+    want = (act.grad * (act.detach() > 0)).permute(0, 2, 3, 1).reshape(-1, C)
+    close(dAct, want, rtol=1e-6, atol=1e-7, what='dAct with ties')
+
+
+def test_uint8_patches_equal_float_patches_bit_for_bit(L):
+    """patches kept as uint8 up to the stem's operand load.  ToTensor's u8 / 255 (and Normalize's (v - m) / s)
+    inside the kernels must be the floats torch computes on the host: all 256 byte values x 3 channels through
+    gnx_u8_to_f32, then the fused u8 stem against the fused float stem on the torch-converted patches - bit for bit."""
+    st = L.stream()
+    # every byte value in every channel
+    x8 = torch.arange(256, dtype=torch.uint8).repeat(3, 4).reshape(1, 3, 4, 256).contiguous()
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    nrm = torch.cat([mean, std, 1.0 / std]).to(DEV)
+    out = torch.empty((1, 3, 4, 256), device=DEV)
+    L.call('gnx_u8_to_f32', x8.to(DEV).data_ptr(), L.ptr(out), 1, 3, 4, 256, None, st)
+    assert torch.equal(out.cpu(), x8.float().div(255))                          # torchvision ToTensor
+    L.call('gnx_u8_to_f32', x8.to(DEV).data_ptr(), L.ptr(out), 1, 3, 4, 256, L.ptr(nrm), st)
+    want = x8.float().div(255).sub(mean.view(1, 3, 1, 1)).div(std.view(1, 3, 1, 1))    # + Normalize
+    assert torch.equal(out.cpu(), want)
+    g = torch.Generator().manual_seed(8)
+    O = 64
+    W0 = (torch.randn(O, 3, 7, 7, generator=g) * 0.1).to(DEV)
+    sc0, sh0 = (torch.rand(O, generator=g) + 0.5).to(DEV), (torch.randn(O, generator=g) * 0.2).to(DEV)
+    for P, n in ((128, 5), (256, 3)):
+        u8 = torch.randint(0, 256, (n, 3, P, P), generator=g, dtype=torch.uint8)
+        u8[0] = 255                                                             # a saturated patch
+        u8[-1, :, : P // 2] = 0                                                 # and a half-empty one
+        S = P // 4
+        for norm in (None, nrm):
+            xf = u8.float().div(255)
+            if norm is not None:
+                xf = xf.sub(mean.view(1, 3, 1, 1)).div(std.view(1, 3, 1, 1))
+            o_f = torch.empty(n * S * S, 96, device=DEV)
+            o_u = torch.full((n * S * S, 96), 7.0, device=DEV)
+            L.call('gnx_conv_stem_bnrelu_maxpool', L.ptr(xf.to(DEV)), L.ptr(W0), L.ptr(o_f), 96, n, 3, P, P, O, 7, 7, 2, 3,
+                   L.ptr(sc0), L.ptr(sh0), st)
+            L.call('gnx_conv_stem_bnrelu_maxpool_u8', u8.to(DEV).data_ptr(), L.ptr(W0), o_u.data_ptr(), 96, n, 3, P, P, O,
+                   7, 7, 2, 3, L.ptr(sc0), L.ptr(sh0), L.ptr(norm), 0, st)
+            assert torch.equal(o_u[:, :O], o_f[:, :O]) and float(o_u[:, O:].min()) == 7.0
+            o_h = torch.empty(n * S * S, 96, device=DEV, dtype=torch.float16)
+            L.call('gnx_conv_stem_bnrelu_maxpool_u8', u8.to(DEV).data_ptr(), L.ptr(W0), o_h.data_ptr(), 96, n, 3, P, P, O,
+                   7, 7, 2, 3, L.ptr(sc0), L.ptr(sh0), L.ptr(norm), 1, st)
+            assert torch.equal(o_h[:, :O], o_f[:, :O].half())
+    # geometry the fused stem does not take -> UNSUPPORTED (the caller converts and takes the float stems)
+    u8 = torch.zeros((1, 3, 64, 64), dtype=torch.uint8, device=DEV)
+    o = torch.empty(256, 64, device=DEV)
+    assert L.query('gnx_conv_stem_bnrelu_maxpool_u8', u8.data_ptr(), L.ptr(W0), o.data_ptr(), 64, 1, 3, 64, 64, O, 7, 7, 2, 3,
+                   L.ptr(sc0), L.ptr(sh0), None, 0, st) == L.ERR_UNSUPPORTED

@@ -619,3 +619,171 @@ def test_fp16_mfma_conv_path_config5_at_256px(buffers):
     assert 1e-6 < err16 < 3e-2, err16
     assert d_ce16 < 2e-2
     assert agree >= 0.95, agree
+
+
+def test_dropout_network_runs_in_eval_mode_and_refuses_train_mode():
+    """densenet.py:42-43: dropout after conv2 is the identity unless the module is in training mode.  A network built with
+    drop_rate > 0 therefore loads reference weights and runs frozen or fine-tuned under train_gridwise (f is always in eval
+    mode there, training.py:126); train-mode dropout is the documented refusal."""
+    import gridnext_amd as ga
+    from gridnext_amd import functional as GF
+    g = load_golden('densenet_tiny_large')
+    m = ga.DenseNet(drop_rate=0.2, **TINY_LARGE)
+    m.load_state_dict(sub(g, 'sd'))
+    m.to(DEV).eval()
+    x = torch.from_numpy(g['x']).to(DEV)
+    with torch.no_grad():
+        close(m(x), g['eval_out'], rtol=2e-4, what='eval_out with drop_rate')
+    out = m(x)                                                    # eval-mode gradient path (train_gridwise + f_opt)
+    loss, _, _ = GF.masked_cross_entropy(out, torch.from_numpy(g['labels']).to(DEV), 1, label_base=0)
+    loss.backward()
+    ref = sub(g, 'evalgrad')
+    close(m.classifier.weight.grad, ref['classifier.weight'], rtol=2e-3, atol=2e-6, what='grad')
+    m.train()
+    with pytest.raises(NotImplementedError, match='dropout'):
+        m(x)
+
+
+def test_checkpoint_round_trip_through_the_hip_modules(tmp_path):
+    """train_gridwise on the HIP modules writes `outfile` (model state_dict) and `<stem>.opt`
+    ({'g_opt', 'f_opt'} when f_opt is given, training.py:187-195) with the reference's key names and order - including the
+    image network stored twice (`patch_classifier.*` and `image_classifier.*`) - and the files load back into a fresh HIP
+    model AND into the reference-keyed oracle model, giving the same forward."""
+    import gridnext_amd as ga
+    from gridnext_amd.synthetic import count_mlp
+    from oracle import densenet as odn, gridnet as ogn
+    g = load_golden('gridwise_hexmm_fopt')
+    G, H, W, P, C = 20, 6, 4, 32, 5
+
+    def fresh():
+        return ga.GridNetHexMM(ga.DenseNet(**TINY_LARGE), count_mlp(G, C), (3, P, P), (G,), (H, W), C)
+
+    m = fresh()
+    m.load_state_dict(sub(g, 'init'))
+    xi, xc, y = torch.from_numpy(g['x_img']), torch.from_numpy(g['x_cnt']), torch.from_numpy(g['y'])
+    data = [((xi[i], xc[i]), y[i]) for i in range(4)]
+    dl = {'train': DataLoader(data[:3], batch_size=1, shuffle=False), 'val': DataLoader(data[3:], batch_size=1, shuffle=False)}
+    opt = torch.optim.Adam(m.corrector.parameters(), lr=1e-3)
+    f_opt = torch.optim.Adam(list(m.image_classifier.parameters()) + list(m.count_classifier.parameters()), lr=1e-4)
+    out = str(tmp_path / 'g.pth')
+    (m, vh, th), _ = quiet(ga.train_gridwise, m, dl, nn.CrossEntropyLoss(), opt, num_epochs=2, outfile=out, f_opt=f_opt,
+                           accum_iters=2)
+    saved = torch.load(out, map_location='cpu')
+    ref_keys = [k[5:] for k in g if k.startswith('init/')]
+    assert list(saved.keys()) == ref_keys                          # the reference's names, in the reference's order
+    dup = [k for k in ref_keys if k.startswith('patch_classifier.')]
+    assert dup and all(torch.equal(saved[k], saved['image_classifier.' + k[len('patch_classifier.'):]]) for k in dup)
+    opt_saved = torch.load(str(tmp_path / 'g.opt'), map_location='cpu')
+    assert set(opt_saved) == {'g_opt', 'f_opt'} and 'state' in opt_saved['g_opt'] and 'param_groups' in opt_saved['f_opt']
+    # the loop hands back the best-validation weights: those are what the file holds
+    for k, v in m.state_dict().items():
+        assert torch.equal(v.cpu(), saved[k]), k
+    # -> fresh HIP model
+    m2 = fresh()
+    m2.load_state_dict(saved)
+    m2.to(DEV).eval()
+    m.eval()
+    xin = [xi[:2].to(DEV), xc[:2].to(DEV)]
+    with torch.no_grad():
+        a, b = m(xin), m2(xin)
+    assert torch.equal(a, b)
+    # -> optimizer state resumes
+    opt2 = torch.optim.Adam(m2.corrector.parameters(), lr=1e-3)
+    opt2.load_state_dict(opt_saved['g_opt'])
+    assert len(opt2.state_dict()['state']) == len(opt_saved['g_opt']['state'])
+    # -> the reference-keyed oracle model (what a GridNext user's load_state_dict would do)
+    om = ogn.GridNetHexMM(odn.DenseNet(**TINY_LARGE), count_mlp(G, C), (3, P, P), (G,), (H, W), C)
+    om.corrector.load_state_dict({k[len('corrector.'):]: v for k, v in saved.items() if k.startswith('corrector.')})
+    om.count_classifier.load_state_dict({k[len('count_classifier.'):]: v for k, v in saved.items()
+                                         if k.startswith('count_classifier.')})
+    om.image_classifier.load_named_state({k[len('image_classifier.'):]: v for k, v in saved.items()
+                                          if k.startswith('image_classifier.')})
+    om.eval()
+    with torch.no_grad():
+        ref = om([xi[:2], xc[:2]])
+    close(a, ref, rtol=3e-4, what='HIP-written checkpoint in the oracle model')
+
+
+def test_uint8_patch_pipeline_equals_float_pipeline():
+    """SURVEY 8f-2 at model level: DenseNet-121 on uint8 patches (ToTensor fused into the stem) == the same network on the
+    host-converted float patches, bit for bit - eval forward at 128 px, fp16 path, an unfused geometry (64 px), the
+    training forward (separate conversion pass), and with a Normalize given as `input_norm`."""
+    import gridnext_amd as ga
+    from oracle import densenet as odn
+    cfg = odn.DenseNetCfg(num_classes=8, **odn.DENSENET121)
+    m = ga.DenseNet(num_classes=8, **odn.DENSENET121)
+    m.load_state_dict(odn.closed_form_state(cfg))
+    m.to(DEV).eval()
+    g = torch.Generator().manual_seed(21)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    for P, n in ((128, 8), (64, 5)):
+        u8 = torch.randint(0, 256, (n, 3, P, P), generator=g, dtype=torch.uint8)
+        for norm in (None, (mean, std)):
+            m.input_norm = norm
+            xf = u8.float().div(255)
+            if norm is not None:
+                xf = xf.sub(torch.tensor(mean).view(1, 3, 1, 1)).div(torch.tensor(std).view(1, 3, 1, 1))
+            with torch.no_grad():
+                a = m(xf.to(DEV))
+                b = m(u8.to(DEV))
+            assert torch.equal(a, b), (P, norm)
+    m.input_norm = None
+    u8 = torch.randint(0, 256, (8, 3, 128, 128), generator=g, dtype=torch.uint8)
+    with torch.no_grad():
+        m.mfma = 'f16'
+        a, b = m(u8.float().div(255).to(DEV)), m(u8.to(DEV))
+        assert m._used_f16_buffers and torch.equal(a, b)
+        m.mfma = 'f32'
+    m.train()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    ya = m(u8[:4].float().div(255).to(DEV))
+    ya.sum().backward()
+    ga_ = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    m.load_state_dict(sd0)
+    yb = m(u8[:4].to(DEV))
+    yb.sum().backward()
+    assert torch.equal(ya, yb)
+    for k, p in m.named_parameters():
+        assert torch.equal(p.grad, ga_[k]), k
+
+
+def test_prefetcher_feeds_the_grid_loop_from_host_memory():
+    """The pinned, double-buffered H2D feed (prefetch.py) under train_gridwise: arrays in pageable HOST memory with uint8
+    patches give exactly the history of the same arrays resident on the device as float patches."""
+    import gridnext_amd as ga
+    from gridnext_amd import prefetch
+    from gridnext_amd.synthetic import count_mlp
+    G, H, W, P, C = 20, 6, 4, 128, 5
+    gen = torch.Generator().manual_seed(3)
+    u8 = torch.randint(0, 256, (5, H, W, 3, P, P), generator=gen, dtype=torch.uint8)
+    xc = torch.randint(0, 10, (5, G, H, W), generator=gen).float()
+    y = torch.randint(0, C + 1, (5, H, W), generator=gen)
+    hist = []
+    for host in (False, True):
+        torch.manual_seed(0)
+        m = ga.GridNetHexMM(ga.DenseNet(num_classes=C, growth_rate=8, block_config=(2, 2, 2, 2), num_init_features=16, bn_size=2,
+                                        small_inputs=False), count_mlp(G, C), (3, P, P), (G,), (H, W), C)
+        for p in m.patch_classifier.parameters():
+            p.requires_grad = False
+        if host:
+            data = [((u8[i], xc[i]), y[i]) for i in range(5)]                          # pageable host memory, uint8
+        else:
+            data = [((u8[i].float().div(255).to(DEV), xc[i].to(DEV)), y[i].to(DEV)) for i in range(5)]
+        dl = {'train': DataLoader(data[:4], batch_size=1), 'val': DataLoader(data[4:], batch_size=1)}
+        opt = torch.optim.Adam(m.corrector.parameters(), lr=1e-3)
+        (m, vh, th), _ = quiet(ga.train_gridwise, m, dl, nn.CrossEntropyLoss(), opt, num_epochs=2)
+        hist.append((th, vh))
+    assert hist[0] == hist[1]
+    # the prefetcher itself: order, device placement, byte count, early exit
+    data = [((u8[i], xc[i]), y[i]) for i in range(5)]
+    pf = prefetch.DevicePrefetcher(DataLoader(data, batch_size=1), DEV)
+    seen = []
+    for (xi, xcnt), yy in pf:
+        assert xi.is_cuda and xi.dtype == torch.uint8 and xcnt.is_cuda and yy.is_cuda
+        seen.append(int(xi.sum().item()))
+    assert seen == [int(u8[i].sum()) for i in range(5)]
+    assert pf.bytes_moved == 5 * (u8[0].numel() + 4 * xc[0].numel() + 8 * y[0].numel())
+    for k, _ in enumerate(prefetch.DevicePrefetcher(DataLoader(data, batch_size=1), DEV)):
+        if k == 1:
+            break                                                                     # consumer leaves early: no hang

@@ -318,3 +318,118 @@ def test_bench_launcher_parent_stays_off_the_gpu_and_reports_failed_ranks():
                           '--no-cpu-baseline'], cwd=ROOT, capture_output=True, text=True, timeout=280, env=env)
     assert out.returncode != 0
     assert 'exited with code' in out.stderr
+
+
+def _splotch_tree(tmp_path, rng, H, W, G, P, ext='jpg'):
+    """One synthetic array in the formats MultiModal*Dataset read: count TSV (genes x 'x_y' spots), Splotch one-hot
+    annotation TSV (annotations x spots), one '<x>_<y>.jpg' per spot that has image data."""
+    from PIL import Image
+    spots = [(2 * x + (row % 2), row) for row in range(H) for x in range(W) if rng.rand() < 0.8]      # pseudo-hex (col, row)
+    names = ['%d_%d' % s for s in spots]
+    counts = rng.poisson(3.0, size=(G, len(spots)))
+    cfile = str(tmp_path / 'counts.tsv')
+    with open(cfile, 'w') as fh:
+        fh.write('\t'.join([''] + names) + '\n')
+        for gi in range(G):
+            fh.write('\t'.join(['G%d' % gi] + [str(v) for v in counts[gi]]) + '\n')
+    labels = {}
+    afile = str(tmp_path / 'annot.tsv')
+    annotated = [n for i, n in enumerate(names) if i % 4 != 3]
+    with open(afile, 'w') as fh:
+        fh.write('\t'.join([''] + annotated) + '\n')
+        for k in range(3):
+            row = []
+            for n in annotated:
+                labels.setdefault(n, int(rng.randint(0, 3)))
+                row.append('1' if labels[n] == k else '0')
+            fh.write('\t'.join(['AAR%d' % k] + row) + '\n')
+    imdir = tmp_path / 'patches'
+    imdir.mkdir()
+    pixels = {}
+    for i, n in enumerate(names):
+        if i % 5 == 0:
+            continue                                              # spot without image data
+        img = rng.randint(1, 256, size=(P, P, 3), dtype=np.uint8)
+        Image.fromarray(img).save(str(imdir / ('%s.%s' % (n, ext))), quality=95)
+        pixels[n] = np.array(Image.open(str(imdir / ('%s.%s' % (n, ext)))))      # what a JPEG decoder returns
+    return cfile, afile, str(imdir), names, counts, labels, pixels
+
+
+def test_multimodal_file_datasets_contract(tmp_path):
+    """MultiModalDataset / MultiModalGridDataset (reference multimodal_datasets.py:141-246, DEFUNCT there): constructor
+    signatures, skip rules and item tuples on a hand-built tree, JPEG patches through the ToTensor contract
+    (uint8 HWC -> float32 CHW / 255)."""
+    import inspect
+    from gridnext_amd import MultiModalDataset, MultiModalGridDataset
+    from gridnext_amd.utils import pseudo_hex_to_oddr
+    assert list(inspect.signature(MultiModalDataset.__init__).parameters)[1:8] == \
+        ['count_files', 'img_files', 'annot_files', 'select_genes', 'img_transforms', 'cfile_delim', 'afile_delim']
+    assert list(inspect.signature(MultiModalGridDataset.__init__).parameters)[1:11] == \
+        ['count_files', 'img_files', 'annot_files', 'select_genes', 'h_st', 'w_st', 'Visium', 'img_transforms',
+         'cfile_delim', 'afile_delim']
+    rng = np.random.RandomState(11)
+    H, W, G, P = 6, 5, 4, 8
+    cfile, afile, imdir, names, counts, labels, pixels = _splotch_tree(tmp_path, rng, H, W, G, P)
+    with pytest.raises(ValueError):
+        MultiModalDataset([cfile], [imdir, imdir], [afile])
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        ds = MultiModalDataset([cfile], [imdir], [afile])
+    usable = [n for n in names if n in labels and n in pixels]
+    assert len(ds) == len(usable) and 'no image data' in buf.getvalue()
+    for i in (0, len(ds) - 1):
+        cvec, img, y = ds[i]
+        n = usable[i]
+        assert torch.equal(cvec, torch.from_numpy(counts[:, names.index(n)].astype(np.float32)))
+        assert img.dtype == torch.float32 and img.shape == (3, P, P)
+        assert torch.equal(img, torch.from_numpy(pixels[n]).permute(2, 0, 1).float() / 255)          # ToTensor on a JPEG
+        assert int(y) == labels[n] and y.dtype == torch.int64
+    gd = MultiModalGridDataset([cfile], [imdir], [afile], h_st=H, w_st=W)
+    cg, pg, ag = gd[0]
+    assert cg.shape == (G, H, W) and pg.shape == (H, W, 3, P, P) and ag.shape == (H, W) and ag.dtype == torch.int64
+    want_fg = 0
+    for n in names:
+        x, y = pseudo_hex_to_oddr(*map(int, n.split('_')))
+        if n in labels and n in pixels:
+            want_fg += 1
+            assert int(ag[y, x]) == labels[n] + 1
+            assert torch.equal(cg[:, y, x], torch.from_numpy(counts[:, names.index(n)].astype(np.float32)))
+            assert torch.equal(pg[y, x], torch.from_numpy(pixels[n]).permute(2, 0, 1).float() / 255)
+        else:                                                     # no image or no annotation: background everywhere
+            assert int(ag[y, x]) == 0 and float(pg[y, x].abs().max()) == 0.0
+            if n not in pixels:
+                assert float(cg[:, y, x].abs().max()) == 0.0
+    assert int((ag > 0).sum()) == want_fg
+    (xi, xc), y2 = MultiModalGridDataset([cfile], [imdir], [afile], h_st=H, w_st=W, training_pairs=True)[0]
+    assert torch.equal(xi, pg) and torch.equal(xc, cg) and torch.equal(y2, ag)
+    batch = next(iter(DataLoader(MultiModalGridDataset([cfile], [imdir], [afile], h_st=H, w_st=W, training_pairs=True),
+                                 batch_size=1)))
+    assert isinstance(batch[0], list) and batch[0][0].shape == (1, H, W, 3, P, P)       # what train_gridwise tests for
+
+
+def test_patch_dataset_reads_jpeg_through_the_totensor_contract(tmp_path):
+    """image_datasets.py:102-105: the default transform is ToTensor - JPEG file -> decoder's uint8 HWC -> float CHW / 255."""
+    from PIL import Image
+    from gridnext_amd.image_datasets import PatchDataset
+    rng = np.random.RandomState(5)
+    d = tmp_path / 'arr'
+    d.mkdir()
+    img = rng.randint(0, 256, size=(16, 16, 3), dtype=np.uint8)
+    Image.fromarray(img).save(str(d / 'spot_3_4.jpg'), quality=90)
+    decoded = np.array(Image.open(str(d / 'spot_3_4.jpg')))
+    ds = PatchDataset([str(d)], annot_files=None, Visium=False)
+    x, _ = ds[0]
+    assert x.dtype == torch.float32 and torch.equal(x, torch.from_numpy(decoded).permute(2, 0, 1).float() / 255)
+
+
+def test_prefetcher_is_transparent_on_the_cpu_and_keeps_batch_structure():
+    """prefetch.DevicePrefetcher: on a CPU 'device' it is the loader itself; helper functions keep (list, tensor) nesting."""
+    from gridnext_amd import prefetch
+    data = [((torch.rand(2, 3), torch.rand(4)), torch.tensor(i)) for i in range(5)]
+    dl = DataLoader(data, batch_size=2)
+    assert prefetch.wrap(dl, torch.device('cpu')) is dl
+    got = list(prefetch.DevicePrefetcher(dl, 'cpu'))
+    assert len(got) == 3 and isinstance(got[0][0], list) and got[0][0][0].shape == (2, 2, 3)
+    flat = prefetch._tensors(got[0], [])
+    assert len(flat) == 3
+    doubled = prefetch._map(got[0], lambda t: t * 2)
+    assert isinstance(doubled[0], list) and torch.equal(doubled[1], got[0][1] * 2)
