@@ -13,6 +13,7 @@
 // MFMA operand maps for a weight gradient (reduction index = position m): A[i=n][kk=m] = dY[m][n],
 // B[kk=m][j=k] = act(X)[m'][k]; both are read from [position][channel] LDS images with conflict-free ds_read_b32.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -350,6 +351,312 @@ __global__ __launch_bounds__(256) void wgrad_pf_kernel(const float* __restrict__
                 const int n = n0 + 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (n < N) dst[(long)n * K + k] = acc[a][r];
             }
+        }
+    }
+}
+
+
+// ================================================================================================ round 2: transposed images
+// The kernels above read their MFMA operands one float at a time (ds_read_b32) from [position][channel] LDS images and, for
+// the 3x3, mask image borders with a v_cndmask per MFMA inside the matrix stream (r1: 0.59 / 0.52 of the fp32 matrix peak).
+// An operand of a weight-gradient MFMA is "my channel, two positions" (the reduction runs over positions), so four
+// consecutive MFMA steps of a lane want FOUR CONSECUTIVE POSITIONS of one channel: with the LDS images transposed to
+// [channel][position] that is one ds_read_b128.  Which two positions meet in one MFMA is free - lane half h takes positions
+// 8g + 4h + s in step s of group g - it only reorders the fp32 sum over positions.
+//   * staging: a thread loads a 4 position x 4 channel block (four coalesced 16-B loads; lanes of an 8-lane group walk
+//     8 position blocks of one channel quad, so every row segment a wave touches is a full 128-B line), applies the
+//     forward's BN+ReLU, and writes the four channel rows with ds_write_b128 (8 lanes = 128 contiguous bytes: conflict-free);
+//   * rows are padded to 4 * odd floats: the 16 lanes of a ds_read_b128 group hit 16 distinct bank quads (0 conflicts);
+//   * 1x1: a wave owns 64 n x 64 k (2 x 2 accumulators): 4 fragment reads per 16 MFMAs (r1: 20 ds_read_b32);
+//   * 3x3: dW[tap][n][k] = sum_m' dY[m' - dy S - dx][n] X[m'][k]: the SHIFT goes to the narrow operand (32 channels).  Three
+//     copies of the dY strip are staged, one per dx, with the horizontal border baked in (copy_dx[q] = dY[q - dx] where
+//     column(q) - dx lies inside the row, else 0); the vertical shift dy S is a multiple of 4 positions, i.e. an aligned
+//     offset into the same copy; a group of 8 positions lies in ONE image row (S >= 8), so "row y' has no neighbour above /
+//     below" is wave-uniform and is a scalar branch that SKIPS the 12 MFMAs of those taps (exact: they would add zeros).
+//     No select, no mask in the matrix stream; 10 fragment reads per 36 MFMAs (r1: 10 per 9 plus 9 v_cndmask).
+// Tiles are prefetched into registers one ahead (as wgrad_pf_kernel); two workgroups share a CU (<= 70 KB of LDS each),
+// so one's staging hides behind the other's MFMAs.  Slab layout and the fixed-order reduce are unchanged.
+constexpr int WT_PAD = 4;
+
+__device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 bufld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+
+// ---- 1x1: dW[n][k] = sum_m dY[m][n] act(X[m][k]).  A workgroup owns 128 n x 256 k (a wave 64 n x 128 k: 2 x 4 accumulators)
+// over its range of 32-position tiles: per tile it takes in 32 x (128 + 256) floats for 128 MFMAs per wave - 6 B per cycle
+// and CU at the full matrix rate, where a 128 x 128 workgroup needs 8 (the r1 kernel and a first 128 x 128 transposed form
+// both stalled at ~105 TFLOP/s on exactly that: ~10 B per cycle and CU is what the load path delivers).  The workgroups
+// of one position range (one per 256-wide k block) get block ids with equal residue mod 8 and consecutive quotients: same
+// XCD, launched together, so the dY tile they all read comes from HBM once.  grid (splits * k blocks, N / 128), 256 threads.
+constexpr int W1_TILE = 32, W1_P = W1_TILE + WT_PAD;          // 36 = 4 * 9
+__global__ __launch_bounds__(256, 2) void wgrad1_t_kernel(const float* __restrict__ dY, long lddy,
+                                                          const float* __restrict__ X, long ldx,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ slabs, long M, int N, int K, int nsplit,
+                                                          int kblocks, long tiles_per_split) {
+    __shared__ __attribute__((aligned(16))) float Yt[128 * W1_P];       // [n][position]
+    __shared__ __attribute__((aligned(16))) float Xt[256 * W1_P];       // [k][position]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    // block id -> (split, k block): id = 8 * slot + xcd, slot = group * kblocks + kb, split = 8 * group + xcd  (8 | nsplit)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int split = 8 * (slot / kblocks) + xcd, kb = slot % kblocks;
+    const int n0 = blockIdx.y * 128, kbase = kb * 256;
+    const int wn = wave >> 1, wk = wave & 1;
+    const bool has_act = scale != nullptr;
+    const long ntiles = (M + W1_TILE - 1) / W1_TILE;
+    const long tile0 = (long)split * tiles_per_split;
+    const long tile1 = min(tile0 + tiles_per_split, ntiles);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // staging roles: position block lane & 7 everywhere; X: channel quads 8 (wave + 4 j) + (lane >> 3), j = 0, 1;
+    // dY: channel quad 8 wave + (lane >> 3)
+    const int pb = lane & 7, ql = lane >> 3;
+    const int qy = 8 * wave + ql;
+    int qx[2];
+    bool kok[2];
+    float4 sc4[2], sh4[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        qx[j] = 8 * (wave + 4 * j) + ql;
+        kok[j] = kbase + 4 * qx[j] < K;                        // 4 | K: a quad is in or out as a whole
+        const int kld = kok[j] ? kbase + 4 * qx[j] : 0;
+        sc4[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+        sh4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_act) { sc4[j] = *reinterpret_cast<const float4*>(scale + kld); sh4[j] = *reinterpret_cast<const float4*>(shift + kld); }
+    }
+    float4 ry[4], rx[2][4];
+    auto fetch = [&](long tile) {
+        const long m0 = tile * W1_TILE;
+        const long left = M - m0;
+        const int rows = (int)(left < W1_TILE ? left : W1_TILE);
+        // one buffer resource per tile and operand: rows past M read as 0 (BUFFER loads: free beside MFMA waves)
+        const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(dY + m0 * lddy), 0, (int)(((long)(rows - 1) * lddy + N) * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(X + m0 * ldx), 0, (int)(((long)(rows - 1) * ldx + K) * 4), 0x00020000);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long row = 4 * pb + e;
+            ry[e] = bufld4(rY, (int)((row * lddy + n0 + 4 * qy) * 4), 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                rx[j][e] = bufld4(rX, (int)((row * ldx + (kok[j] ? kbase + 4 * qx[j] : 0)) * 4), 0);
+        }
+    };
+    auto stash = [&](long tile) {
+        const long m0 = tile * W1_TILE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float4 v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = rx[j][e];
+                if (has_act)
+                    v[e] = make_float4(act1(v[e].x, sc4[j].x, sh4[j].x), act1(v[e].y, sc4[j].y, sh4[j].y),
+                                       act1(v[e].z, sc4[j].z, sh4[j].z), act1(v[e].w, sc4[j].w, sh4[j].w));
+                if (!kok[j] || m0 + 4 * pb + e >= M) v[e] = make_float4(0.f, 0.f, 0.f, 0.f);   // act(0) != 0
+            }
+            float* dx = Xt + (4 * qx[j]) * W1_P + 4 * pb;
+            *reinterpret_cast<float4*>(dx) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+            *reinterpret_cast<float4*>(dx + W1_P) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+            *reinterpret_cast<float4*>(dx + 2 * W1_P) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
+            *reinterpret_cast<float4*>(dx + 3 * W1_P) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+        }
+        float* dy = Yt + (4 * qy) * W1_P + 4 * pb;
+        *reinterpret_cast<float4*>(dy) = make_float4(ry[0].x, ry[1].x, ry[2].x, ry[3].x);
+        *reinterpret_cast<float4*>(dy + W1_P) = make_float4(ry[0].y, ry[1].y, ry[2].y, ry[3].y);
+        *reinterpret_cast<float4*>(dy + 2 * W1_P) = make_float4(ry[0].z, ry[1].z, ry[2].z, ry[3].z);
+        *reinterpret_cast<float4*>(dy + 3 * W1_P) = make_float4(ry[0].w, ry[1].w, ry[2].w, ry[3].w);
+    };
+
+    const float* pa = Yt + (64 * wn + i) * W1_P + 4 * h;          // + 32 W1_P: the second n sub-tile
+    const float* pbk = Xt + (128 * wk + i) * W1_P + 4 * h;        // + 32 b W1_P: k sub-tile b
+    if (tile0 < tile1) fetch(tile0);
+    for (long tile = tile0; tile < tile1; ++tile) {
+        __syncthreads();                           // the previous tile's fragment reads are done
+        stash(tile);
+        __syncthreads();
+        fetch(tile + 1 < tile1 ? tile + 1 : tile); // branch-free; the last one is a harmless re-read
+        asm volatile("" ::: "memory");             // keep the prefetch in front of the multiply
+#pragma unroll
+        for (int g = 0; g < W1_TILE / 8; ++g) {
+            const float4 a0 = lds4(pa + 8 * g), a1 = lds4(pa + 32 * W1_P + 8 * g);
+            const float4 b0 = lds4(pbk + 8 * g), b1 = lds4(pbk + 32 * W1_P + 8 * g);
+            const float4 b2 = lds4(pbk + 64 * W1_P + 8 * g), b3 = lds4(pbk + 96 * W1_P + 8 * g);
+#define GNX_W1_STEP(c)                                                                        \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b0.c, acc[0][0], 0, 0, 0); \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b1.c, acc[0][1], 0, 0, 0); \
+            acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b2.c, acc[0][2], 0, 0, 0); \
+            acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b3.c, acc[0][3], 0, 0, 0); \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b0.c, acc[1][0], 0, 0, 0); \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b1.c, acc[1][1], 0, 0, 0); \
+            acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b2.c, acc[1][2], 0, 0, 0); \
+            acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b3.c, acc[1][3], 0, 0, 0);
+            GNX_W1_STEP(x) GNX_W1_STEP(y) GNX_W1_STEP(z) GNX_W1_STEP(w)
+#undef GNX_W1_STEP
+        }
+    }
+    // slab[split][n][k] (an empty split writes its zeros)
+    float* dst = slabs + (long)split * N * K;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int k = kbase + 128 * wk + 32 * b + i;
+        if (k >= K) continue;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + 64 * wn + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                dst[(long)n * K + k] = acc[a][b][r];
+            }
+    }
+}
+
+// ---- 3x3: dW[tap][n][k], N == 32, 128 | K, maps of S x S with S in {8, 16, 32};  grid (split, 1, K / 128), 256 threads
+constexpr int W9_TILE = 32, W9_PX = W9_TILE + WT_PAD;         // 36 = 4 * 9
+template <int S>
+__global__ __launch_bounds__(256, 2) void wgrad9_t_kernel(const float* __restrict__ dY, long lddy,
+                                                          const float* __restrict__ X, long ldx,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ slabs, long M, int K, long tiles_per_split) {
+    constexpr int NPOS = W9_TILE + 2 * S;         // dY strip: positions m0 - S .. m0 + 32 + S - 1
+    constexpr int P2 = NPOS + 8 + WT_PAD;         // + 8 zero columns; 108 / 76 / 60 = 4 * odd
+    constexpr int NB = NPOS / 4;                  // position blocks of the strip: 24 / 16 / 12
+    __shared__ __attribute__((aligned(16))) float Xt[128 * W9_PX];       // [k][position]
+    __shared__ __attribute__((aligned(16))) float Yc[3 * 32 * P2];       // [dx + 1][n][strip position]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    const int kbase = blockIdx.z * 128;
+    const bool has_act = scale != nullptr;
+    const long ntiles = M / W9_TILE;
+    const long tile0 = (long)blockIdx.x * tiles_per_split;
+    const long tile1 = min(tile0 + tiles_per_split, ntiles);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    // staging roles.  X: position block lane & 7, channel quad 8 wave + (lane >> 3).  dY: the first NB * 8 threads, block
+    // t % NB of quad t / NB, positions 4 pbY - 1 .. 4 pbY + 4 of the strip (one to each side for the dx = +-1 copies)
+    const int pbX = lane & 7, qX = 8 * wave + (lane >> 3);
+    const int kX = kbase + 4 * qX;
+    float4 scX = make_float4(1.f, 1.f, 1.f, 1.f), shX = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (has_act) { scX = *reinterpret_cast<const float4*>(scale + kX); shX = *reinterpret_cast<const float4*>(shift + kX); }
+    const bool doY = t < NB * 8;
+    const int pbY = t % NB, qY = doY ? t / NB : 0;
+    float4 rx[4], ry[6];
+    auto fetch = [&](long tile) {
+        const long m0 = tile * W9_TILE;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rx[e] = *reinterpret_cast<const float4*>(X + (m0 + 4 * pbX + e) * ldx + kX);
+        if (doY) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                long p = m0 - S + 4 * pbY + e - 1;
+                p = p < 0 ? 0 : (p < M ? p : M - 1);          // clamped: rows outside [0, M) are zeroed at the stash
+                ry[e] = *reinterpret_cast<const float4*>(dY + p * lddy + 4 * qY);
+            }
+        }
+    };
+    auto stash = [&](long tile) {
+        const long m0 = tile * W9_TILE;
+        {
+            float4 v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = rx[e];
+                if (has_act)
+                    v[e] = make_float4(act1(v[e].x, scX.x, shX.x), act1(v[e].y, scX.y, shX.y), act1(v[e].z, scX.z, shX.z),
+                                       act1(v[e].w, scX.w, shX.w));
+            }
+            float* d = Xt + (4 * qX) * W9_PX + 4 * pbX;
+            *reinterpret_cast<float4*>(d) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+            *reinterpret_cast<float4*>(d + W9_PX) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+            *reinterpret_cast<float4*>(d + 2 * W9_PX) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
+            *reinterpret_cast<float4*>(d + 3 * W9_PX) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+        }
+        if (doY) {
+            float4 v[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                const long p = m0 - S + 4 * pbY + e - 1;
+                v[e] = (p >= 0 && p < M) ? ry[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            // column of strip position 4 pbY + e (S | m0 - S + 4 pbY's row start: S is a power of two, 4 | S)
+            const int x0 = (int)((m0 + 4 * pbY) & (S - 1));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {                     // copy c holds dY[q - dx], dx = c - 1
+                float4 w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int xs = x0 + e - (c - 1);          // source column: must stay inside the row
+                    w[e] = (xs >= 0 && xs < S) ? v[e + 1 - (c - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                float* d = Yc + (c * 32 + 4 * qY) * P2 + 4 * pbY;
+                *reinterpret_cast<float4*>(d) = make_float4(w[0].x, w[1].x, w[2].x, w[3].x);
+                *reinterpret_cast<float4*>(d + P2) = make_float4(w[0].y, w[1].y, w[2].y, w[3].y);
+                *reinterpret_cast<float4*>(d + 2 * P2) = make_float4(w[0].z, w[1].z, w[2].z, w[3].z);
+                *reinterpret_cast<float4*>(d + 3 * P2) = make_float4(w[0].w, w[1].w, w[2].w, w[3].w);
+            }
+        }
+    };
+
+    for (int idx = t; idx < 3 * 32 * 8; idx += 256) Yc[(idx >> 3) * P2 + NPOS + (idx & 7)] = 0.f;       // the zero columns
+    const float* pbx = Xt + (32 * wave + i) * W9_PX + 4 * h;
+    const float* pay = Yc + i * P2 + 4 * h;                   // + strip position (tile position 0 with dy = 0: S)
+    if (tile0 < tile1) fetch(tile0);
+    for (long tile = tile0; tile < tile1; ++tile) {
+        __syncthreads();
+        stash(tile);
+        __syncthreads();
+        fetch(tile + 1 < tile1 ? tile + 1 : tile);
+        asm volatile("" ::: "memory");
+        // A group of 8 positions lies in one image row (S >= 8).  In the top row the taps with dy = +1 have no source row, in
+        // the bottom row those with dy = -1: their fragment reads are pointed at 8 zero columns kept at the end of every
+        // strip row (a scalar select on the read offset - no branch, no select on the data, nothing in the matrix stream
+        // depends on it; the 12 MFMAs then add exact zeros: 2 / (3 S) of the work).  A branch around those MFMAs instead
+        // kept the compiler from hoisting the next group's reads over the current MFMAs: 97 vs 128 TFLOP/s at S = 16.
+        const long m0 = tile * W9_TILE;
+#pragma unroll
+        for (int g = 0; g < W9_TILE / 8; ++g) {
+            const int yrow = (int)(((m0 + 8 * g) / S) & (S - 1));     // image row of these 8 positions: wave-uniform
+            const float4 b = lds4(pbx + 8 * g);
+#pragma unroll
+            for (int dyi = 0; dyi < 3; ++dyi) {               // dy = dyi - 1: needs 0 <= yrow - dy < S
+                const bool none = (dyi == 2 && yrow == 0) || (dyi == 0 && yrow == S - 1);
+                const int j0 = none ? NPOS : S + 8 * g - (dyi - 1) * S;
+                const float* base = pay + j0;
+                const float4 am = lds4(base), a0 = lds4(base + 32 * P2), ap = lds4(base + 64 * P2);   // dx = -1, 0, +1
+                f32x16& cm = acc[3 * dyi], &c0 = acc[3 * dyi + 1], &cp = acc[3 * dyi + 2];
+#define GNX_W9_STEP(c)                                                           \
+                cm = __builtin_amdgcn_mfma_f32_32x32x2f32(am.c, b.c, cm, 0, 0, 0); \
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b.c, c0, 0, 0, 0); \
+                cp = __builtin_amdgcn_mfma_f32_32x32x2f32(ap.c, b.c, cp, 0, 0, 0);
+                GNX_W9_STEP(x) GNX_W9_STEP(y) GNX_W9_STEP(z) GNX_W9_STEP(w)
+#undef GNX_W9_STEP
+            }
+        }
+    }
+    const int k = kbase + 32 * wave + i;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        float* dst = slabs + ((long)blockIdx.x * 9 + tap) * 32 * K;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = (r & 3) + 8 * (r >> 2) + 4 * h;
+            dst[(long)n * K + k] = acc[tap][r];
         }
     }
 }
@@ -713,6 +1020,33 @@ GNX_EXPORT int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long
     const int nsplit = wgrad_splits(M, N, K);
     const long ntiles = (M + WG_BM - 1) / WG_BM;
     const long tps = (ntiles + nsplit - 1) / nsplit;
+    // round 2: transposed-image kernels for the dense layers' own shapes (GNX_WGRAD_R1 keeps the r1 kernels: A/B timing)
+    static const bool r1_kernels = getenv("GNX_WGRAD_R1") != nullptr;
+    const bool aligned = al16b(X) && al16b(dY) && ldx % 4 == 0 && lddy % 4 == 0 && (!scale || (al16b(scale) && al16b(shift)));
+    if (!r1_kernels && aligned && !pool) {
+        const long total = (long)taps * N * K;
+        // 128 < K: the 128 x 256 workgroup (K <= 128 would leave half of it multiplying zeros: the r1 kernel keeps those)
+        if (taps == 1 && K % 4 == 0 && K > 128 && N % 128 == 0 && nsplit % 8 == 0 &&
+            64L * (lddy > ldx ? lddy : ldx) < (1L << 28)) {
+            const long nt1 = (M + W1_TILE - 1) / W1_TILE;
+            const int kblocks = gnx_cdiv(K, 256);
+            dim3 grid1(nsplit * kblocks, N / 128);
+            wgrad1_t_kernel<<<grid1, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, N, K, nsplit, kblocks,
+                                                       (nt1 + nsplit - 1) / nsplit);
+            wgrad_reduce_kernel<<<gnx_cdiv(total, 256), 256, 0, stream>>>(workspace, nsplit, 1, N, K, dW, accumulate);
+            return gnx_launch_status();
+        }
+        if (taps == 9 && N == 32 && K % 128 == 0 && (S == 8 || S == 16 || S == 32) && M % W9_TILE == 0) {
+            const long nt9 = M / W9_TILE;
+            dim3 grid9(nsplit, 1, K / 128);
+            const long tps9 = (nt9 + nsplit - 1) / nsplit;
+            if (S == 32) wgrad9_t_kernel<32><<<grid9, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, K, tps9);
+            else if (S == 16) wgrad9_t_kernel<16><<<grid9, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, K, tps9);
+            else wgrad9_t_kernel<8><<<grid9, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, K, tps9);
+            wgrad_reduce_kernel<<<gnx_cdiv(total, 256), 256, 0, stream>>>(workspace, nsplit, 9, N, K, dW, accumulate);
+            return gnx_launch_status();
+        }
+    }
     const int halo = taps == 9 ? S + 1 : 0;
     const int nt = taps == 9 ? 1 : 4;
     const size_t lds_bytes = ((size_t)WG_BM * 32 * nt + (size_t)(WG_BM + 2 * halo) * LDX + WG_BM) * sizeof(float);

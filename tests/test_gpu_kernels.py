@@ -645,7 +645,7 @@ def test_maxpool_backward_routes_ties_like_torch(L, C, Hi):
     scd, shd = sc.to(DEV), sh.to(DEV)
     pooled = torch.empty((n * Ho * Ho, C), device=DEV)
     L.call('gnx_bnrelu_maxpool', L.ptr(rows), C, L.ptr(pooled), C, n, C, Hi, Hi, L.ptr(scd), L.ptr(shd), L.stream())
-    assert torch.equal(pooled.reshape(n, Ho, Ho, C).permute(0, 3, 1, 2).cpu(), mp.detach())
+    close(pooled.reshape(n, Ho, Ho, C).permute(0, 3, 1, 2), mp.detach(), rtol=1e-6, what='pooled')
     dO = dout.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(DEV)
     dAct = torch.empty((n * Hi * Hi, C), device=DEV)
     L.call('gnx_maxpool_bwd', L.ptr(rows), C, L.ptr(pooled), C, L.ptr(dO), C, L.ptr(dAct), C, n, C, Hi, Hi, L.ptr(scd),
@@ -699,3 +699,56 @@ def test_uint8_patches_equal_float_patches_bit_for_bit(L):
     o = torch.empty(256, 64, device=DEV)
     assert L.query('gnx_conv_stem_bnrelu_maxpool_u8', u8.data_ptr(), L.ptr(W0), o.data_ptr(), 64, 1, 3, 64, 64, O, 7, 7, 2, 3,
                    L.ptr(sc0), L.ptr(sh0), None, 0, st) == L.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("M,N,K,ldx,act", [(64 * 40, 128, 64, 96, True), (64 * 37 + 13, 128, 96, 256, True),
+                                           (5000, 128, 416, 512, True), (64 * 20, 256, 128, 128, False),
+                                           (300, 128, 992, 1024, True),
+                                           # enough tiles for a multiple-of-8 split count: the round-2 128 x 256 kernel
+                                           (64 * 300 + 13, 128, 416, 512, True), (40000, 256, 224, 256, True),
+                                           (20000, 128, 992, 1024, True), (33000, 128, 160, 160, False)])
+def test_wgrad_1x1_transposed_image_kernel(L, M, N, K, ldx, act):
+    """gnx_wgrad_bnrelu(taps = 1) on the dense layers' shapes (the round-2 [channel][position] kernel: 128 | N, 4 | K) vs
+    fp64: dW[n][k] = sum_m dY[m][n] relu(scale[k] X[m][k] + shift[k]).  Ragged last tile, K not a multiple of the
+    workgroup's 128-column range, leading dimensions wider than the operands."""
+    g = torch.Generator().manual_seed(M + K)
+    X = torch.randn(M, ldx, generator=g)
+    dY = torch.randn(M, N + 32, generator=g)
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+    A = torch.relu(X[:, :K].double() * sc.double() + sh.double()) if act else X[:, :K].double()
+    ref = dY[:, :N].double().t() @ A
+    Xd, dYd, scd, shd = X.to(DEV), dY.to(DEV), sc.to(DEV), sh.to(DEV)
+    dW = torch.full((N, K), 7.0, device=DEV)
+    ws = torch.empty(L.query('gnx_wgrad_workspace', M, N, K, 1), device=DEV)
+    L.call('gnx_wgrad_bnrelu', L.ptr(dYd), N + 32, L.ptr(Xd), ldx, L.ptr(scd) if act else None, L.ptr(shd) if act else None,
+           L.ptr(dW), L.ptr(ws), M, N, K, 0, 1, 0, 0, L.stream())
+    close(dW, ref, rtol=2e-5, atol=1e-5, what='dW 1x1')
+    L.call('gnx_wgrad_bnrelu', L.ptr(dYd), N + 32, L.ptr(Xd), ldx, L.ptr(scd) if act else None, L.ptr(shd) if act else None,
+           L.ptr(dW), L.ptr(ws), M, N, K, 0, 1, 0, 1, L.stream())                    # accumulate
+    close(dW, 2 * ref, rtol=2e-5, atol=1e-5, what='dW 1x1 accumulated')
+
+
+@pytest.mark.parametrize("n,S,K,act", [(3, 32, 128, False), (5, 16, 128, True), (9, 8, 128, True), (4, 8, 256, False),
+                                       (2, 4, 128, True), (1, 32, 128, True)])
+def test_wgrad_3x3_transposed_image_kernel(L, n, S, K, act):
+    """gnx_wgrad_bnrelu(taps = 9) vs torch's conv2d weight gradient in fp64: maps of 8 / 16 / 32 (round-2 kernel: shifted
+    dY copies, border rows skipped by scalar branches) and 4 (the r1 kernel); several images per tile and tiles inside
+    an image, so that every border case of every tap is hit."""
+    g = torch.Generator().manual_seed(n * 100 + S)
+    N, M = 32, n * S * S
+    ld = 160
+    X = torch.randn(M, K, generator=g)
+    dYfull = torch.randn(M, ld, generator=g)
+    c0 = 64                                                    # the 32 gradient columns sit inside a wider block buffer
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+    A = torch.relu(X.double() * sc.double() + sh.double()) if act else X.double()
+    x4 = A.reshape(n, S, S, K).permute(0, 3, 1, 2).contiguous().requires_grad_(False)
+    w = torch.zeros(N, K, 3, 3, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x4, w, padding=1)
+    y.backward(dYfull[:, c0:c0 + N].double().reshape(n, S, S, N).permute(0, 3, 1, 2).contiguous())
+    Xd, dYd, scd, shd = X.to(DEV), dYfull.to(DEV), sc.to(DEV), sh.to(DEV)
+    dW = torch.full((N, K, 3, 3), 7.0, device=DEV)
+    ws = torch.empty(L.query('gnx_wgrad_workspace', M, N, K, 9), device=DEV)
+    L.call('gnx_wgrad_bnrelu', dYd.data_ptr() + 4 * c0, ld, L.ptr(Xd), K, L.ptr(scd) if act else None,
+           L.ptr(shd) if act else None, L.ptr(dW), L.ptr(ws), M, N, K, S, 9, 0, 0, L.stream())
+    close(dW, w.grad, rtol=2e-5, atol=1e-5, what='dW 3x3')

@@ -89,6 +89,36 @@ def main():
             fl = 2.0 * M * 1152 * 32
             print("conv3x3 S=%2d M=%8d  %8.3f ms  %6.1f TFLOP/s (direct-conv FLOPs)" % (S, M, ms, fl / ms / 1e9))
             del A, out
+    if args.only in ('', 'wgrad1'):
+        # weight gradient of conv1 (taps = 1): dW[128][K] = dY^T act(X); GNX_WGRAD_R1=1 selects the round-1 kernels
+        for S, K, ct in shapes:
+            M = n * S * S
+            X = torch.randn(M, ct, device=DEV)
+            dY = torch.randn(M, 128, device=DEV)
+            sc, sh = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
+            dW = torch.empty(128, K, device=DEV)
+            ws = torch.empty(L.query('gnx_wgrad_workspace', M, 128, K, 1), device=DEV)
+            ms = timeit(lambda: L.call('gnx_wgrad_bnrelu', L.ptr(dY), 128, L.ptr(X), ct, L.ptr(sc), L.ptr(sh), L.ptr(dW),
+                                       L.ptr(ws), M, 128, K, 0, 1, 0, 0, st), args.reps)
+            fl = 2.0 * M * K * 128
+            print("wgrad1x1 S=%2d K=%4d M=%8d  %8.3f ms  %6.1f TFLOP/s  %5.2f TB/s" %
+                  (S, K, M, ms, fl / ms / 1e9, 4.0 * M * (K + 128) / ms / 1e9))
+            del X, dY, ws
+    if args.only in ('', 'wgrad9'):
+        for S in (32, 16, 8, 4):
+            M = n * S * S
+            X = torch.randn(M, 128, device=DEV)
+            ct = 256
+            dY = torch.randn(M, ct, device=DEV)
+            dW = torch.empty(32, 128, 3, 3, device=DEV)
+            sc, sh = torch.rand(128, device=DEV) + 0.5, torch.randn(128, device=DEV) * 0.1
+            scp, shp = (None, None) if args.noact else (L.ptr(sc), L.ptr(sh))
+            ws = torch.empty(L.query('gnx_wgrad_workspace', M, 32, 128, 9), device=DEV)
+            ms = timeit(lambda: L.call('gnx_wgrad_bnrelu', dY.data_ptr() + 4 * 64, ct, L.ptr(X), 128, scp, shp, L.ptr(dW),
+                                       L.ptr(ws), M, 32, 128, S, 9, 0, 0, st), args.reps)
+            fl = 2.0 * M * 1152 * 32
+            print("wgrad3x3 S=%2d M=%8d  %8.3f ms  %6.1f TFLOP/s" % (S, M, ms, fl / ms / 1e9))
+            del X, dY, ws
     if args.only in ('', 'stem'):
         x = torch.rand(n, 3, 128, 128, device=DEV)
         w = torch.randn(64, 3, 7, 7, device=DEV) * 0.05
