@@ -842,6 +842,39 @@ __global__ __launch_bounds__(256) void maxpool_bwd_vec4_kernel(const float* __re
     }
 }
 
+// The adjoint by recorded window index (gnx_bnrelu_maxpool_argmax): element (y, x) receives window (oy, ox)'s gradient iff
+// that window's recorded maximum is this element.  No activation is recomputed, the conv0 map is not read (5.2 GB per
+// 128-px array), ties go where torch sends them.  4 channels per thread.
+__global__ __launch_bounds__(256) void maxpool_bwd_argmax_kernel(const unsigned char* __restrict__ amax,
+                                                                 const float* __restrict__ dOut, long lddo,
+                                                                 float* __restrict__ dAct, long lda, long Min, int C4,
+                                                                 int Hi, int Wi, int Ho, int Wo) {
+    const long total = Min * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / C4;
+        const int c = 4 * (int)(idx - r * C4);
+        const long img = r / ((long)Hi * Wi);
+        const int rem = (int)(r - img * Hi * Wi);
+        const int y = rem / Wi, x = rem - y * Wi;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oy = y / 2; oy <= (y + 1) / 2; ++oy) {
+            if (oy >= Ho) continue;
+            for (int ox = x / 2; ox <= (x + 1) / 2; ++ox) {
+                if (ox >= Wo) continue;
+                const long o = (img * Ho + oy) * Wo + ox;
+                const unsigned li = 3 * (y - 2 * oy + 1) + (x - 2 * ox + 1);
+                const unsigned am = *reinterpret_cast<const unsigned*>(amax + o * (4L * C4) + c);
+                const float4 d = *reinterpret_cast<const float4*>(dOut + o * lddo + c);
+                if ((am & 0xffu) == li) g.x += d.x;
+                if (((am >> 8) & 0xffu) == li) g.y += d.y;
+                if (((am >> 16) & 0xffu) == li) g.z += d.z;
+                if ((am >> 24) == li) g.w += d.w;
+            }
+        }
+        *reinterpret_cast<float4*>(dAct + r * lda + c) = g;
+    }
+}
+
 // ---- stem conv weight gradient: dW[o][c][ky][kx] = sum_{img,oy,ox} dS[(img,oy,ox)][o] * x[img][c][oy*st+ky-pad][ox*st+kx-pad]
 // Workgroup = 8x16 output tile; the input patch is staged like the forward; wave w reduces positions 32w..32w+31 of the
 // tile into 2 (o-tiles) x CIN x 2 (k-tiles of 32 over ky*8+kx) accumulators and the four waves write separate slabs.
@@ -1001,11 +1034,24 @@ int wgrad_splits(long M, int N, int K) {
     return (int)s;
 }
 
+// position splits of the round-2 1x1 kernel: a multiple of 8 (its block ids encode the XCD), about 512 workgroups in all
+// (two per CU) over its ceil(K / 256) k blocks, never more than there are 32-position tiles; 0 = the shape is not its own
+int wgrad1_t_splits(long M, int N, int K) {
+    if (K % 4 != 0 || K <= 128 || N % 128 != 0) return 0;
+    const long nt = (M + W1_TILE - 1) / W1_TILE;
+    long s = 512 / ((long)gnx_cdiv(K, 256) * (N / 128));
+    if (s > nt) s = nt;
+    s &= ~7L;
+    return (int)s;
+}
+
 }  // namespace
 
 // floats of slab workspace for gnx_wgrad_bnrelu
 GNX_EXPORT long gnx_wgrad_workspace(long M, int N, int K, int taps) {
-    return (long)wgrad_splits(M, N, K) * taps * N * K;
+    long s = wgrad_splits(M, N, K);
+    if (taps == 1 && wgrad1_t_splits(M, N, K) > s) s = wgrad1_t_splits(M, N, K);
+    return s * taps * N * K;
 }
 
 // dW[n][k][tap] (= torch [N][K][kh][kw], taps = 1 or 9) of out = conv(act(X)) given dY = d out.
@@ -1026,14 +1072,14 @@ GNX_EXPORT int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long
     if (!r1_kernels && aligned && !pool) {
         const long total = (long)taps * N * K;
         // 128 < K: the 128 x 256 workgroup (K <= 128 would leave half of it multiplying zeros: the r1 kernel keeps those)
-        if (taps == 1 && K % 4 == 0 && K > 128 && N % 128 == 0 && nsplit % 8 == 0 &&
-            64L * (lddy > ldx ? lddy : ldx) < (1L << 28)) {
+        const int ns1 = taps == 1 ? wgrad1_t_splits(M, N, K) : 0;
+        if (ns1 > 0 && 64L * (lddy > ldx ? lddy : ldx) < (1L << 28)) {
             const long nt1 = (M + W1_TILE - 1) / W1_TILE;
             const int kblocks = gnx_cdiv(K, 256);
-            dim3 grid1(nsplit * kblocks, N / 128);
-            wgrad1_t_kernel<<<grid1, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, N, K, nsplit, kblocks,
-                                                       (nt1 + nsplit - 1) / nsplit);
-            wgrad_reduce_kernel<<<gnx_cdiv(total, 256), 256, 0, stream>>>(workspace, nsplit, 1, N, K, dW, accumulate);
+            dim3 grid1(ns1 * kblocks, N / 128);
+            wgrad1_t_kernel<<<grid1, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, N, K, ns1, kblocks,
+                                                       (nt1 + ns1 - 1) / ns1);
+            wgrad_reduce_kernel<<<gnx_cdiv(total, 256), 256, 0, stream>>>(workspace, ns1, 1, N, K, dW, accumulate);
             return gnx_launch_status();
         }
         if (taps == 9 && N == 32 && K % 128 == 0 && (S == 8 || S == 16 || S == 32) && M % W9_TILE == 0) {
@@ -1142,6 +1188,20 @@ GNX_EXPORT int gnx_maxpool_bwd(const float* in, long ldi, const float* pooled, l
     }
     maxpool_bwd_kernel<<<ew_grid(imgs * Hi * Wi * C), 256, 0, stream>>>(in, ldi, pooled, ldp, dOut, lddo, dAct, lda,
                                                                        imgs * Hi * Wi, C, Hi, Wi, Ho, Wo, scale, shift);
+    return gnx_launch_status();
+}
+
+// dAct [imgs*Hi*Wi][C] (lda) from the window indices recorded by gnx_bnrelu_maxpool_argmax and dOut [imgs*Ho*Wo][C] (lddo).
+// The gradient is with respect to the ACTIVATED map (the ReLU mask is applied by the BN adjoint that follows).  4 | C.
+GNX_EXPORT int gnx_maxpool_bwd_argmax(const unsigned char* argmax, const float* dOut, long lddo, float* dAct, long lda,
+                                      long imgs, int C, int Hi, int Wi, hipStream_t stream) {
+    if (!argmax || !dOut || !dAct || imgs <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || lddo < C || lda < C) return GNX_ERR_BAD_ARG;
+    if (C % 4 != 0 || lddo % 4 != 0 || lda % 4 != 0 || !al16b(dOut) || !al16b(dAct) ||
+        (reinterpret_cast<uintptr_t>(argmax) & 3) != 0)
+        return GNX_ERR_UNSUPPORTED;
+    const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+    maxpool_bwd_argmax_kernel<<<ew_grid(imgs * Hi * Wi * (C / 4)), 256, 0, stream>>>(argmax, dOut, lddo, dAct, lda,
+                                                                                    imgs * Hi * Wi, C / 4, Hi, Wi, Ho, Wo);
     return gnx_launch_status();
 }
 

@@ -435,10 +435,15 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const void* __restr
 }
 
 // ------------------------------------------------------------------------------------------------ BN+ReLU+maxpool 3x3 s2 p1
+// IDX: also store, per pooled element, WHICH window element is the maximum (0..8, row-major in the 3 x 3 window; the first
+// maximal one of the scan, as torch's max_pool2d picks it): the backward then routes gradients by index - no value
+// comparison, no re-read of the conv0 map, ties resolved exactly as the reference does.
+template <bool IDX>
 __global__ __launch_bounds__(256) void bnrelu_maxpool_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out,
                                                              long ldo, long Mout, int C, int Hi, int Wi, int Ho, int Wo,
                                                              const float* __restrict__ scale,
-                                                             const float* __restrict__ shift) {
+                                                             const float* __restrict__ shift,
+                                                             unsigned char* __restrict__ amax) {
     const long total = Mout * C;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long row = idx / C;
@@ -447,7 +452,8 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_kernel(const float* __rest
         const int rem = (int)(row - img * Ho * Wo);
         const int oy = rem / Wo, ox = rem - oy * Wo;
         const float sc = scale[c], sh = shift[c];
-        float m = 0.f;     // relu output is >= 0 and the window always holds a valid tap
+        float m = IDX ? -1.f : 0.f;     // relu output is >= 0 and the window always holds a valid tap
+        int am = 0;
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy) {
             const int iy = 2 * oy + dy;
@@ -456,19 +462,24 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_kernel(const float* __rest
             for (int dx = -1; dx <= 1; ++dx) {
                 const int ix = 2 * ox + dx;
                 if (ix < 0 || ix >= Wi) continue;
-                m = fmaxf(m, fmaf(in[((img * Hi + iy) * Wi + ix) * ldi + c], sc, sh));
+                const float v = fmaxf(fmaf(in[((img * Hi + iy) * Wi + ix) * ldi + c], sc, sh), 0.f);
+                if (IDX) { if (v > m) { m = v; am = 3 * (dy + 1) + dx + 1; } }
+                else m = fmaxf(m, v);
             }
         }
         out[row * ldo + c] = m;
+        if (IDX) amax[row * C + c] = (unsigned char)am;
     }
 }
 
 // same, 4 channels per thread with 16-B accesses (C % 4 == 0, aligned pointers / leading dimensions)
+template <bool IDX>
 __global__ __launch_bounds__(256) void bnrelu_maxpool_vec4_kernel(const float* __restrict__ in, long ldi,
                                                                   float* __restrict__ out, long ldo, long Mout, int C4,
                                                                   int Hi, int Wi, int Ho, int Wo,
                                                                   const float* __restrict__ scale,
-                                                                  const float* __restrict__ shift) {
+                                                                  const float* __restrict__ shift,
+                                                                  unsigned char* __restrict__ amax) {
     const long total = Mout * C4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long row = idx / C4;
@@ -477,7 +488,9 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_vec4_kernel(const float* _
         const int rem = (int)(row - img * Ho * Wo);
         const int oy = rem / Wo, ox = rem - oy * Wo;
         const float4 sc = ld4(scale + c), sh = ld4(shift + c);
-        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float m0 = IDX ? -1.f : 0.f;
+        float4 m = make_float4(m0, m0, m0, m0);
+        unsigned am = 0;                                      // four window indices, one per byte
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy) {
             const int iy = 2 * oy + dy;
@@ -487,13 +500,21 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_vec4_kernel(const float* _
                 const int ix = 2 * ox + dx;
                 if (ix < 0 || ix >= Wi) continue;
                 const float4 v = ld4(in + ((img * Hi + iy) * Wi + ix) * ldi + c);
-                m.x = fmaxf(m.x, fmaf(v.x, sc.x, sh.x));
-                m.y = fmaxf(m.y, fmaf(v.y, sc.y, sh.y));
-                m.z = fmaxf(m.z, fmaf(v.z, sc.z, sh.z));
-                m.w = fmaxf(m.w, fmaf(v.w, sc.w, sh.w));
+                const float a0 = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), a1 = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+                const float a2 = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f), a3 = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+                if (IDX) {
+                    const unsigned li = 3 * (dy + 1) + dx + 1;
+                    if (a0 > m.x) { m.x = a0; am = (am & 0xffffff00u) | li; }
+                    if (a1 > m.y) { m.y = a1; am = (am & 0xffff00ffu) | (li << 8); }
+                    if (a2 > m.z) { m.z = a2; am = (am & 0xff00ffffu) | (li << 16); }
+                    if (a3 > m.w) { m.w = a3; am = (am & 0x00ffffffu) | (li << 24); }
+                } else {
+                    m.x = fmaxf(m.x, a0); m.y = fmaxf(m.y, a1); m.z = fmaxf(m.z, a2); m.w = fmaxf(m.w, a3);
+                }
             }
         }
         *reinterpret_cast<float4*>(out + row * ldo + c) = m;
+        if (IDX) *reinterpret_cast<unsigned*>(amax + row * (4L * C4) + c) = am;
     }
 }
 
@@ -640,24 +661,44 @@ GNX_EXPORT int gnx_u8_to_f32(const uint8_t* x8, float* out, long imgs, int C, in
 }
 
 // in [imgs*Hi*Wi][C] (ldi) -> out [imgs*Ho*Wo][C] (ldo): max over 3x3 s2 p1 windows of relu(in*scale+shift)
-GNX_EXPORT int gnx_bnrelu_maxpool(const float* in, long ldi, float* out, long ldo, long imgs, int C, int Hi, int Wi,
-                                  const float* scale, const float* shift, hipStream_t stream) {
+static int bnrelu_maxpool_launch(const float* in, long ldi, float* out, long ldo, unsigned char* amax, long imgs, int C,
+                                 int Hi, int Wi, const float* scale, const float* shift, hipStream_t stream) {
     if (!in || !out || !scale || !shift || imgs < 0 || C <= 0 || Hi <= 0 || Wi <= 0 || ldi < C || ldo < C)
         return GNX_ERR_BAD_ARG;
     const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
     const long Mout = imgs * Ho * Wo;
     if (Mout == 0) return GNX_OK;
-    if (C % 4 == 0 && ldi % 4 == 0 && ldo % 4 == 0 && al16(in) && al16(out) && al16(scale) && al16(shift)) {
+    if (C % 4 == 0 && ldi % 4 == 0 && ldo % 4 == 0 && al16(in) && al16(out) && al16(scale) && al16(shift) &&
+        (reinterpret_cast<uintptr_t>(amax) & 3) == 0) {
         long blocks = (Mout * (C / 4) + 255) / 256;
         if (blocks > 16384) blocks = 16384;
-        bnrelu_maxpool_vec4_kernel<<<(int)blocks, 256, 0, stream>>>(in, ldi, out, ldo, Mout, C / 4, Hi, Wi, Ho, Wo,
-                                                                     scale, shift);
+        if (amax)
+            bnrelu_maxpool_vec4_kernel<true><<<(int)blocks, 256, 0, stream>>>(in, ldi, out, ldo, Mout, C / 4, Hi, Wi, Ho, Wo,
+                                                                               scale, shift, amax);
+        else
+            bnrelu_maxpool_vec4_kernel<false><<<(int)blocks, 256, 0, stream>>>(in, ldi, out, ldo, Mout, C / 4, Hi, Wi, Ho, Wo,
+                                                                                scale, shift, nullptr);
         return gnx_launch_status();
     }
     long blocks = (Mout * C + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    bnrelu_maxpool_kernel<<<(int)blocks, 256, 0, stream>>>(in, ldi, out, ldo, Mout, C, Hi, Wi, Ho, Wo, scale, shift);
+    if (amax)
+        bnrelu_maxpool_kernel<true><<<(int)blocks, 256, 0, stream>>>(in, ldi, out, ldo, Mout, C, Hi, Wi, Ho, Wo, scale, shift, amax);
+    else
+        bnrelu_maxpool_kernel<false><<<(int)blocks, 256, 0, stream>>>(in, ldi, out, ldo, Mout, C, Hi, Wi, Ho, Wo, scale, shift,
+                                                                      nullptr);
     return gnx_launch_status();
+}
+GNX_EXPORT int gnx_bnrelu_maxpool(const float* in, long ldi, float* out, long ldo, long imgs, int C, int Hi, int Wi,
+                                  const float* scale, const float* shift, hipStream_t stream) {
+    return bnrelu_maxpool_launch(in, ldi, out, ldo, nullptr, imgs, C, Hi, Wi, scale, shift, stream);
+}
+// The same, also recording which window element (0..8, row-major in the 3 x 3 window; the first maximal one, as torch's
+// max_pool2d) gave each pooled value: argmax [imgs*Ho*Wo][C] bytes, consumed by gnx_maxpool_bwd_argmax.
+GNX_EXPORT int gnx_bnrelu_maxpool_argmax(const float* in, long ldi, float* out, long ldo, unsigned char* argmax, long imgs,
+                                         int C, int Hi, int Wi, const float* scale, const float* shift, hipStream_t stream) {
+    if (!argmax) return GNX_ERR_BAD_ARG;
+    return bnrelu_maxpool_launch(in, ldi, out, ldo, argmax, imgs, C, Hi, Wi, scale, shift, stream);
 }
 
 // in [imgs*S2][C] (ldi) -> out [imgs][C] (ldo): mean over positions of relu(in*scale+shift)

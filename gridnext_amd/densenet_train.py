@@ -87,8 +87,17 @@ class _DenseNetFn(Function):
             stem_out = torch.empty((N * hs * hs, c0), device=dev, dtype=F32)
             L.call('gnx_conv_stem', L.ptr(x), L.ptr(w0), L.ptr(stem_out), c0, N, 3, P, P, c0, 7, 7, 2, 3, st)
             s0 = _bn(model.features.norm0, L.ptr(stem_out), c0, N * hs * hs, training, dev, st)
-            L.call('gnx_bnrelu_maxpool', L.ptr(stem_out), c0, L.ptr(bufs[0]), ld1, N, c0, hs, hs, L.ptr(s0[0]),
-                   L.ptr(s0[1]), st)
+            # pool0 records WHICH window element won (one byte per pooled element): its adjoint then routes by index, ties
+            # exactly as torch's max_pool2d and without re-reading the conv0 map
+            hp = (hs + 2 - 3) // 2 + 1
+            tape.pool_idx = None
+            if c0 % 4 == 0:
+                tape.pool_idx = torch.empty((N * hp * hp, c0), device=dev, dtype=torch.uint8)
+                L.call('gnx_bnrelu_maxpool_argmax', L.ptr(stem_out), c0, L.ptr(bufs[0]), ld1, tape.pool_idx.data_ptr(), N, c0,
+                       hs, hs, L.ptr(s0[0]), L.ptr(s0[1]), st)
+            else:
+                L.call('gnx_bnrelu_maxpool', L.ptr(stem_out), c0, L.ptr(bufs[0]), ld1, N, c0, hs, hs, L.ptr(s0[0]),
+                       L.ptr(s0[1]), st)
             tape.stem_out, tape.stats0 = stem_out, s0
         tape.layers = []          # per block: list of (bott, stats1, stats2, bottleneck stored activated?)
         act_ok = (not training) and gammas_nonzero(model)
@@ -336,8 +345,12 @@ class _DenseNetFn(Function):
             if need:
                 s0 = tape.stats0
                 dAct = torch.empty((M0, c0), device=dev, dtype=F32)
-                L.call('gnx_maxpool_bwd', L.ptr(tape.stem_out), c0, L.ptr(bufs[0]), c_total1, L.ptr(dbufs[0]), c_total1,
-                       L.ptr(dAct), c0, N, c0, hs, hs, L.ptr(s0[0]), L.ptr(s0[1]), st)
+                if tape.pool_idx is not None:
+                    L.call('gnx_maxpool_bwd_argmax', tape.pool_idx.data_ptr(), L.ptr(dbufs[0]), c_total1, L.ptr(dAct), c0,
+                           N, c0, hs, hs, st)
+                else:
+                    L.call('gnx_maxpool_bwd', L.ptr(tape.stem_out), c0, L.ptr(bufs[0]), c_total1, L.ptr(dbufs[0]), c_total1,
+                           L.ptr(dAct), c0, N, c0, hs, hs, L.ptr(s0[0]), L.ptr(s0[1]), st)
                 dS = torch.empty((M0, c0), device=dev, dtype=F32)
                 bn_bwd(model.features.norm0, s0, L.ptr(dAct), c0, L.ptr(tape.stem_out), c0, L.ptr(dS), c0, M0, c0, 0)
                 if want(conv0.weight):

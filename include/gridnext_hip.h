@@ -203,6 +203,15 @@ int gnx_avgpool2_bwd(const float* dP, long ldp, float* dA, long lda, long imgs, 
 int gnx_maxpool_bwd(const float* in, long ldi, const float* pooled, long ldp, const float* dOut, long lddo, float* dAct,
                     long lda, long imgs, int C, int Hi, int Wi, const float* scale, const float* shift,
                     gnx_stream_t stream);
+/* Pooling by recorded index (the training forward): gnx_bnrelu_maxpool_argmax = gnx_bnrelu_maxpool that also stores, per
+ * pooled element, which of its 3x3 window elements (0..8, row-major) is the maximum - the FIRST maximal one of the scan, as
+ * torch's max_pool2d (densenet.py:110) picks it; gnx_maxpool_bwd_argmax routes d(pooled) back by that index: no value
+ * comparison, no re-read of the conv0 map, ties (constant regions: white background, empty spots) go where torch sends
+ * them.  argmax: [imgs*Ho*Wo][C] bytes; 4 | C for the backward. */
+int gnx_bnrelu_maxpool_argmax(const float* in, long ldi, float* out, long ldo, unsigned char* argmax, long imgs, int C,
+                              int Hi, int Wi, const float* scale, const float* shift, gnx_stream_t stream);
+int gnx_maxpool_bwd_argmax(const unsigned char* argmax, const float* dOut, long lddo, float* dAct, long lda, long imgs,
+                           int C, int Hi, int Wi, gnx_stream_t stream);
 long gnx_conv0_wgrad_workspace(long imgs, int H, int W, int O, int KH, int KW, int stride, int pad); /* floats */
 int gnx_conv0_wgrad(const float* x, const float* dS, long ldd, float* dW, float* workspace, long imgs, int H, int W,
                     int O, int KH, int KW, int stride, int pad, int accumulate, gnx_stream_t stream);

@@ -653,6 +653,17 @@ def test_maxpool_backward_routes_ties_like_torch(L, C, Hi):
     # torch's d/d(act) includes elements at exactly 0 (a window of zeros): the ReLU mask removes them either way
     want = (act.grad * (act.detach() > 0)).permute(0, 2, 3, 1).reshape(-1, C)
     close(dAct, want, rtol=1e-6, atol=1e-7, what='dAct with ties')
+    # the training path's form: the forward records the winning window element, the adjoint routes by index - this is
+    # torch's d/d(act) itself, zeros included (the BN adjoint that follows applies the ReLU mask)
+    pooled2 = torch.empty_like(pooled)
+    amax = torch.full((n * Ho * Ho, C), 99, device=DEV, dtype=torch.uint8)
+    L.call('gnx_bnrelu_maxpool_argmax', L.ptr(rows), C, L.ptr(pooled2), C, amax.data_ptr(), n, C, Hi, Hi, L.ptr(scd), L.ptr(shd),
+           L.stream())
+    assert torch.equal(pooled2, pooled) and int(amax.max()) <= 8
+    if C % 4 == 0:
+        dAct2 = torch.empty_like(dAct)
+        L.call('gnx_maxpool_bwd_argmax', amax.data_ptr(), L.ptr(dO), C, L.ptr(dAct2), C, n, C, Hi, Hi, L.stream())
+        close(dAct2, act.grad.permute(0, 2, 3, 1).reshape(-1, C), rtol=1e-6, atol=1e-7, what='dAct by index')
 
 
 def test_uint8_patches_equal_float_patches_bit_for_bit(L):

@@ -6,12 +6,12 @@
 tag=${1:-rXX}
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+B="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-series"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_stats -o r --output-format csv -- $B > $R/gpurun_out/${tag}_stats.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_fetch -o r --output-format csv -- $B --no-kernel-timing > $R/gpurun_out/${tag}_fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_write -o r --output-format csv -- $B --no-kernel-timing > $R/gpurun_out/${tag}_write.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA -d $R/gpurun_out/${tag}_mfma -o r --output-format csv -- $B --no-kernel-timing > $R/gpurun_out/${tag}_mfma.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_trainf -o r --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --train-f --no-kernel-timing > $R/gpurun_out/${tag}_trainf.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_trainf -o r --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --train-f --no-series --no-kernel-timing > $R/gpurun_out/${tag}_trainf.log 2>&1 || exit 1
 cd $R
 python3 tools/pmc_traffic.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write > gpurun_out/${tag}_pmc_traffic.json
 echo done
