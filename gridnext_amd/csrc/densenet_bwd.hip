@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void wgrad1_t_kernel(const float* __restric
     }
 }
 
-// ---- 3x3: dW[tap][n][k], N == 32, 128 | K, maps of S x S with S in {8, 16, 32};  grid (split, 1, K / 128), 256 threads
+// ---- 3x3: dW[tap][n][k], N == 32, 128 | K, maps of S x S with S in {4, 8, 16, 32};  grid (split, 1, K / 128), 256 threads
 constexpr int W9_TILE = 32, W9_PX = W9_TILE + WT_PAD;         // 36 = 4 * 9
 template <int S>
 __global__ __launch_bounds__(256, 2) void wgrad9_t_kernel(const float* __restrict__ dY, long lddy,
@@ -631,7 +631,8 @@ __global__ __launch_bounds__(256, 2) void wgrad9_t_kernel(const float* __restric
         const long m0 = tile * W9_TILE;
 #pragma unroll
         for (int g = 0; g < W9_TILE / 8; ++g) {
-            const int yrow = (int)(((m0 + 8 * g) / S) & (S - 1));     // image row of these 8 positions: wave-uniform
+            // image row of this lane half's 4 positions (S >= 8: the same for both halves, i.e. wave-uniform)
+            const int yrow = (int)(((m0 + 8 * g + (S < 8 ? 4 * h : 0)) / S) & (S - 1));
             const float4 b = lds4(pbx + 8 * g);
 #pragma unroll
             for (int dyi = 0; dyi < 3; ++dyi) {               // dy = dyi - 1: needs 0 <= yrow - dy < S
@@ -1082,13 +1083,14 @@ GNX_EXPORT int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long
             wgrad_reduce_kernel<<<gnx_cdiv(total, 256), 256, 0, stream>>>(workspace, ns1, 1, N, K, dW, accumulate);
             return gnx_launch_status();
         }
-        if (taps == 9 && N == 32 && K % 128 == 0 && (S == 8 || S == 16 || S == 32) && M % W9_TILE == 0) {
+        if (taps == 9 && N == 32 && K % 128 == 0 && (S == 4 || S == 8 || S == 16 || S == 32) && M % W9_TILE == 0) {
             const long nt9 = M / W9_TILE;
             dim3 grid9(nsplit, 1, K / 128);
             const long tps9 = (nt9 + nsplit - 1) / nsplit;
             if (S == 32) wgrad9_t_kernel<32><<<grid9, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, K, tps9);
             else if (S == 16) wgrad9_t_kernel<16><<<grid9, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, K, tps9);
-            else wgrad9_t_kernel<8><<<grid9, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, K, tps9);
+            else if (S == 8) wgrad9_t_kernel<8><<<grid9, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, K, tps9);
+            else wgrad9_t_kernel<4><<<grid9, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, K, tps9);
             wgrad_reduce_kernel<<<gnx_cdiv(total, 256), 256, 0, stream>>>(workspace, nsplit, 9, N, K, dW, accumulate);
             return gnx_launch_status();
         }

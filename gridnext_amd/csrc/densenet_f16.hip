@@ -10,6 +10,7 @@
 // This first version keeps the fp32 kernels' tiling (K chunks of 32); with the matrix phase 16x shorter it is bound
 // by staging, not by the matrix cores - restructuring (whole-K tiles, fp16 activations in HBM) is future work.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -329,6 +330,120 @@ __global__ __launch_bounds__(256) void conv1x1_h16_kernel(const _Float16* __rest
     }
 }
 
+
+// ---- the same with 256-row tiles (round 2).  The kernel above moves, per 128-row tile and 64-channel chunk, 16 KB of
+// activations AND 16 KB of weights from L2 into the CU: twice the activation bytes, and L2 -> CU is what bounded it (3.3 TB/s
+// of activation traffic = 6.6 TB/s ~ 11 B per cycle and CU, the rate the load path delivers).  With 256 rows per workgroup a
+// weight chunk serves twice the rows (1.5x the activation bytes).  4 waves, each 128 rows x 64 columns (4 x 2 accumulators):
+// 6 fragment reads per 8 MFMAs.  55 KB of LDS: two workgroups per CU.
+__global__ __launch_bounds__(256, 2) void conv1x1_h16_m256_kernel(const _Float16* __restrict__ A, long lda,
+                                                                  const _Float16* __restrict__ W, _Float16* __restrict__ out,
+                                                                  long ldc, long M, int N, int K,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift,
+                                                                  const float* __restrict__ oscale,
+                                                                  const float* __restrict__ oshift) {
+    __shared__ __attribute__((aligned(16))) _Float16 smem[(256 + 128) * LDH2];
+    _Float16* const As = smem;
+    _Float16* const Bs = smem + 256 * LDH2;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, i = lane & 31;
+    const int kq = t & 7, r0 = t >> 3;                     // this thread's 8 k of a chunk, first of its 8 (A) / 4 (W) rows
+    const long m0 = (long)blockIdx.x * 256;
+    const int n0 = blockIdx.y * 128;
+    long srcA[8], srcW[4];
+    bool rok[8], nok[4];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const long row = m0 + r0 + 32 * p;
+        rok[p] = row < M;
+        srcA[p] = (rok[p] ? row : 0) * lda;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int n = n0 + r0 + 32 * p;
+        nok[p] = n < N;
+        srcW[p] = (long)(nok[p] ? n : 0) * K;
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int nkt = (K + 63) / 64;
+    half8 va[8], vb[4];
+    auto fetch = [&](int kt) {
+        const int k = kt * 64 + 8 * kq;
+        const int kc = k < K ? k : 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) va[p] = ldh8(A + srcA[p] + kc);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) vb[p] = ldh8(W + srcW[p] + kc);
+    };
+    fetch(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int k = kt * 64 + 8 * kq;
+        const bool kok = k < K;                            // 8 | K: the whole piece is in or out
+        const int kc = kok ? k : 0;
+        const float4 sc0 = ld4(scale + kc), sc1 = ld4(scale + kc + 4), sh0 = ld4(shift + kc), sh1 = ld4(shift + kc + 4);
+        const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+        const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+        __syncthreads();                                   // the previous chunk's fragment reads are done
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            half8 a;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = (_Float16)act1((float)va[p][j], sc[j], sh[j]);
+            if (!(rok[p] && kok)) a = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            *reinterpret_cast<half8*>(&As[(r0 + 32 * p) * LDH2 + 8 * kq]) = a;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            half8 w = vb[p];
+            if (!(nok[p] && kok)) w = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            *reinterpret_cast<half8*>(&Bs[(r0 + 32 * p) * LDH2 + 8 * kq]) = w;
+        }
+        __syncthreads();
+        fetch(kt + 1 < nkt ? kt + 1 : kt);                 // branch-free; the last one is a harmless re-read
+        asm volatile("" ::: "memory");                     // keep the prefetch in front of the multiply
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const half8 b0 = ldh8(&Bs[(64 * wn + i) * LDH2 + 16 * s + 8 * h]);
+            const half8 b1 = ldh8(&Bs[(64 * wn + 32 + i) * LDH2 + 16 * s + 8 * h]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const half8 af = ldh8(&As[(128 * wm + 32 * a + i) * LDH2 + 16 * s + 8 * h]);
+                acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b0, acc[a][0], 0, 0, 0);
+                acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b1, acc[a][1], 0, 0, 0);
+            }
+        }
+    }
+    // activated, rounded, turned through the LDS: 16-B stores
+    _Float16* const Os = smem + wave * 32 * LDH2;
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = n0 + 64 * wn + 32 * nt + i;
+            const float osc = col < N ? oscale[col] : 0.f, osh = col < N ? oshift[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Os[((r & 3) + 8 * (r >> 2) + 4 * h) * LDH2 + 32 * nt + i] = (_Float16)fmaxf(fmaf(acc[mt][nt][r], osc, osh), 0.f);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int piece = lane + 64 * p, rr = piece >> 3, c8 = piece & 7;
+            const long row = m0 + 128 * wm + 32 * mt + rr;
+            const int col = n0 + 64 * wn + 8 * c8;
+            if (row < M && col < N)
+                *reinterpret_cast<half8*>(out + row * ldc + col) = *reinterpret_cast<const half8*>(&Os[rr * LDH2 + 8 * c8]);
+        }
+    }
+}
+
 // ---- conv3x3 (pad 1): same contiguous-strip scheme as the fp32 kernel, fp16 LDS image
 __global__ __launch_bounds__(256) void conv3x3_f16_kernel(const float* __restrict__ A, long lda,
                                                           const float* __restrict__ Wr, float* __restrict__ out, long ldc,
@@ -502,6 +617,16 @@ GNX_EXPORT int gnx_conv1x1_bnrelu_h16(const void* A16, long lda16, const void* W
           N % 8 == 0 && ldc16 % 8 == 0))
         return GNX_ERR_UNSUPPORTED;
     if (M == 0) return GNX_OK;
+    // 256-row tiles (a weight chunk staged per 256 rows instead of 128) once they still fill the chip twice over
+    static const bool m128_only = getenv("GNX_H16_M128") != nullptr;
+    if (!m128_only && M >= 256L * 512 && K >= 192) {       // (measured: +3..6 % from K = 224 up, -4 % at K = 128)
+        dim3 grid(gnx_cdiv(M, 256), gnx_cdiv(N, 128));
+        conv1x1_h16_m256_kernel<<<grid, 256, 0, stream>>>(reinterpret_cast<const _Float16*>(A16), lda16,
+                                                          reinterpret_cast<const _Float16*>(W16),
+                                                          reinterpret_cast<_Float16*>(out16), ldc16, M, N, K, scale, shift,
+                                                          out_scale, out_shift);
+        return gnx_launch_status();
+    }
     dim3 grid(gnx_cdiv(M, 128), gnx_cdiv(N, 128));
     conv1x1_h16_kernel<<<grid, 256, 0, stream>>>(reinterpret_cast<const _Float16*>(A16), lda16,
                                                  reinterpret_cast<const _Float16*>(W16), reinterpret_cast<_Float16*>(out16),

@@ -9,7 +9,8 @@
 // /root/reference/notebooks/Tutorial_visium_count.ipynb cell 12 / Tutorial_multimodal.ipynb cell 23.
 //
 // Exact fp32: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate; bitwise an fmaf chain).  64x64 output tile
-// per 256-thread workgroup (4 waves, one 32x32 MFMA tile each), K step 16, LDS image [k][m] so every
+// per 256-thread workgroup (4 waves, one 32x32 MFMA tile each), K step 64 (r1: 16 - two workgroup barriers per 8 MFMAs
+// of a wave, 43 TFLOP/s on the 2000 -> 500 layer; now per 32), LDS image [k][m] so every
 // fragment read is a conflict-free ds_read_b32 whatever the source layout; next K-tile is prefetched
 // into registers while the current one is multiplied.  Bound: fp32 matrix peak 157.3 TFLOP/s
 // (2*M*N*K FLOP) for the 2000->500 layer, HBM for the count stream (K-major A is read once).
@@ -17,9 +18,9 @@
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 16, LD = 68;
+constexpr int BM = 64, BN = 64, BK = 64, LD = 68, NSUB = BK / 16;      // a K tile = NSUB sub-tiles of 16
 
-struct TileRegs { float v[4]; };
+struct TileRegs { float v[NSUB][4]; };
 
 // source K-contiguous ([row][k]): thread -> (row = t>>2, k quad = t&3)
 // source row-contiguous ([k][row]): thread -> (k = t>>4, row quad = t&15)
@@ -28,23 +29,26 @@ __device__ __forceinline__ TileRegs load_tile(const float* __restrict__ src, lon
                                               long k0, long K, bool vec_ok) {
     TileRegs r;
     const int t = threadIdx.x;
-    if (!KMAJOR) {
-        const long row = row0 + (t >> 2), k = k0 + 4 * (t & 3);
-        if (row < nrows && vec_ok && k + 3 < K) {
-            const float4 q = *reinterpret_cast<const float4*>(src + row * ld + k);
-            r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w;
-        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r.v[j] = (row < nrows && k + j < K) ? src[row * ld + k + j] : 0.f;
-        }
-    } else {
-        const long k = k0 + (t >> 4), row = row0 + 4 * (t & 15);
-        if (k < K && vec_ok && row + 3 < nrows) {
-            const float4 q = *reinterpret_cast<const float4*>(src + k * ld + row);
-            r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w;
-        } else {
+    for (int u = 0; u < NSUB; ++u) {
+        if (!KMAJOR) {
+            const long row = row0 + (t >> 2), k = k0 + 16 * u + 4 * (t & 3);
+            if (row < nrows && vec_ok && k + 3 < K) {
+                const float4 q = *reinterpret_cast<const float4*>(src + row * ld + k);
+                r.v[u][0] = q.x; r.v[u][1] = q.y; r.v[u][2] = q.z; r.v[u][3] = q.w;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r.v[j] = (k < K && row + j < nrows) ? src[k * ld + row + j] : 0.f;
+                for (int j = 0; j < 4; ++j) r.v[u][j] = (row < nrows && k + j < K) ? src[row * ld + k + j] : 0.f;
+            }
+        } else {
+            const long k = k0 + 16 * u + (t >> 4), row = row0 + 4 * (t & 15);
+            if (k < K && vec_ok && row + 3 < nrows) {
+                const float4 q = *reinterpret_cast<const float4*>(src + k * ld + row);
+                r.v[u][0] = q.x; r.v[u][1] = q.y; r.v[u][2] = q.z; r.v[u][3] = q.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r.v[u][j] = (k < K && row + j < nrows) ? src[k * ld + row + j] : 0.f;
+            }
         }
     }
     return r;
@@ -53,13 +57,16 @@ __device__ __forceinline__ TileRegs load_tile(const float* __restrict__ src, lon
 template <bool KMAJOR>
 __device__ __forceinline__ void store_tile(float* __restrict__ lds, const TileRegs& r) {
     const int t = threadIdx.x;
-    if (!KMAJOR) {
-        const int row = t >> 2, kq = t & 3;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds[(4 * kq + j) * LD + row] = r.v[j];
-    } else {
-        const int k = t >> 4, rq = t & 15;
-        *reinterpret_cast<float4*>(lds + k * LD + 4 * rq) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    for (int u = 0; u < NSUB; ++u) {
+        if (!KMAJOR) {
+            const int row = t >> 2, kq = t & 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lds[(16 * u + 4 * kq + j) * LD + row] = r.v[u][j];
+        } else {
+            const int k = 16 * u + (t >> 4), rq = t & 15;
+            *reinterpret_cast<float4*>(lds + k * LD + 4 * rq) = make_float4(r.v[u][0], r.v[u][1], r.v[u][2], r.v[u][3]);
+        }
     }
 }
 

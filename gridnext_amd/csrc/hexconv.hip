@@ -153,67 +153,68 @@ __global__ __launch_bounds__(256) void hexconv_bwd_data_kernel(
     }
 }
 
-// partial[blk][t][o][i] = sum over the block's positions of dy[pos][o] * x[nbr_t(pos)][i];
-// partial[blk][7*O*I + o] = sum dy[pos][o]
-constexpr int WG_CHUNK = 16;       // positions staged per LDS pass
+// Weight gradient on the matrix cores (round 2; the r1 kernel ran 7 * I * O scalar dot products per workgroup out of LDS:
+// 45 us per layer, the largest item of a count-only step).  dW_t[o][i] = sum_pos dy[pos][o] * x[nbr_t(pos)][i] is, per tap,
+// a [O x positions] x [positions x I] product: a workgroup takes 64 positions, stages dy [64][32] and the seven neighbour
+// rows of each position [64][7][32] (channels past O / I and neighbours outside the grid as zeros), and each of its four
+// waves multiplies its 16 positions with v_mfma_f32_32x32x2_f32 - position pair (2p, 2p + 1) per instruction, seven taps
+// sharing the dy fragment - into seven 32 x 32 accumulators.  partial[(4 blk + wave)][t][o][i] and [7 O I + o] (= sum dy) are
+// the slabs the fixed-order reduce below sums: deterministic, no atomics.
+constexpr int HW_POS = 64;         // positions per workgroup (16 per wave)
 __global__ __launch_bounds__(256) void hexconv_bwd_weight_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
-    HexGeom g, int I, int O, int pos_per_block, int IF, int OF, int i0, int o0) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* dys = lds;                          // [WG_CHUNK][O]
-    float* xs = lds + WG_CHUNK * O;            // [WG_CHUNK][7][I]
-    __shared__ int nbrs[WG_CHUNK * 7];
-    const int nout = 7 * O * I + O;
+    HexGeom g, int I, int O, int IF, int OF, int i0, int o0) {
+    __shared__ __attribute__((aligned(16))) float dys[HW_POS * 32];            // [position][o]
+    __shared__ __attribute__((aligned(16))) float xs[HW_POS * 7 * 32];         // [position][tap][i]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
     const int npos = g.B * g.H * g.W;
-    const int base = blockIdx.x * pos_per_block;
-    constexpr int MAXACC = 32;                 // covers 7*64*64/1024... sized for I,O<=32 at 256 threads
-    float acc[MAXACC];
-#pragma unroll
-    for (int j = 0; j < MAXACC; ++j) acc[j] = 0.f;
-    for (int c0 = 0; c0 < pos_per_block; c0 += WG_CHUNK) {
-        const int cnt = pos_per_block - c0 < WG_CHUNK ? pos_per_block - c0 : WG_CHUNK;      // positions of this pass
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < cnt * O; idx += blockDim.x) {
-            const int pos = base + c0 + idx / O;
-            dys[idx] = pos < npos ? dy[(size_t)pos * OF + o0 + idx % O] : 0.f;
-        }
-        // neighbour rows once per (position, tap) - not once per staged element - then row copies
-        if (threadIdx.x < cnt * 7) {
-            const int t = threadIdx.x % 7, pl = threadIdx.x / 7;
-            const int pos = base + c0 + pl;
-            int n = -1;
-            if (pos < npos) {
-                const int xx = pos % g.W, yy = (pos / g.W) % g.H, b = pos / (g.W * g.H);
-                n = g.nbr(b, yy, xx, t);
-            }
-            nbrs[threadIdx.x] = n;
-        }
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < cnt * 7 * I; idx += blockDim.x) {
-            const int q = idx / I, i = idx - q * I;           // q = pl * 7 + t
-            const int n = nbrs[q];
-            xs[idx] = n >= 0 ? x[(size_t)n * IF + i0 + i] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < MAXACC; ++j) {
-            const int out = threadIdx.x + j * 256;
-            float a = acc[j];
-            if (out < 7 * O * I) {
-                const int i = out % I, o = (out / I) % O, t = out / (O * I);
-                for (int pl = 0; pl < cnt; ++pl) a = fmaf(dys[pl * O + o], xs[(pl * 7 + t) * I + i], a);
-            } else if (out < nout) {
-                const int o = out - 7 * O * I;
-                for (int pl = 0; pl < cnt; ++pl) a += dys[pl * O + o];
-            }
-            acc[j] = a;
-        }
+    const int base = blockIdx.x * HW_POS;
+    for (int idx = t; idx < HW_POS * 32; idx += 256) {
+        const int pl = idx >> 5, o = idx & 31;
+        const int pos = base + pl;
+        dys[idx] = (pos < npos && o < O) ? dy[(size_t)pos * OF + o0 + o] : 0.f;
     }
-#pragma unroll
-    for (int j = 0; j < MAXACC; ++j) {
-        const int out = threadIdx.x + j * 256;
-        if (out < nout) partial[(size_t)blockIdx.x * nout + out] = acc[j];
+    for (int idx = t; idx < HW_POS * 7 * 32; idx += 256) {
+        const int ch = idx & 31, q = idx >> 5;                 // q = position * 7 + tap
+        const int pl = q / 7, tap = q - 7 * pl;
+        const int pos = base + pl;
+        float v = 0.f;
+        if (pos < npos && ch < I) {
+            const int xx = pos % g.W, yy = (pos / g.W) % g.H, b = pos / (g.W * g.H);
+            const int n = g.nbr(b, yy, xx, tap);
+            if (n >= 0) v = x[(size_t)n * IF + i0 + ch];
+        }
+        xs[idx] = v;
     }
+    __syncthreads();
+    f32x16 acc[7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    float bsum = 0.f;
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) {                           // this wave's positions 16 wave + 2 pp + h
+        const int pl = 16 * wave + 2 * pp + h;
+        const float a = dys[pl * 32 + i];                      // A[o = i][kk = h]
+        bsum += a;
+#pragma unroll
+        for (int tap = 0; tap < 7; ++tap)                      // B[kk = h][ch = i]
+            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs[(pl * 7 + tap) * 32 + i], acc[tap], 0, 0, 0);
+    }
+    const int nout = 7 * O * I + O;
+    float* dst = partial + (size_t)(4 * blockIdx.x + wave) * nout;
+    if (i < I) {                                               // D[row = o][col = ch = i]
+#pragma unroll
+        for (int tap = 0; tap < 7; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (o < O) dst[(tap * O + o) * I + i] = acc[tap][r];
+            }
+    }
+    bsum += __shfl_xor(bsum, 32, 64);                          // the two position halves of output channel i
+    if (h == 0 && i < O) dst[7 * O * I + i] = bsum;
 }
 
 // fixed-order sum of the partial slabs, scattered into hexagdly's parameter layouts (accumulating or not)
@@ -250,7 +251,7 @@ __global__ void hexconv_reduce_weight_kernel(const float* __restrict__ partial, 
 int pow2_at_least(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 constexpr int HEX_CHUNK = 64;      // channels per launch, forward and data gradient (7 * 64 * 64 weights = 112 KB of LDS)
-constexpr int HEX_WCHUNK = 32;     // channels per launch, weight gradient (MAXACC accumulators per thread)
+constexpr int HEX_WCHUNK = 32;     // channels per launch, weight gradient (one 32 x 32 MFMA tile per tap)
 
 }  // namespace
 
@@ -284,21 +285,11 @@ GNX_EXPORT int gnx_hexconv_bwd_data(const float* dy, const float* kernel0, const
     return gnx_launch_status();
 }
 
-// positions per workgroup of the weight-gradient kernel: aim at ~1024 workgroups (one 78 x 64 array at 128 positions
-// per workgroup was 39 workgroups on a 256-CU chip, 240 us per layer), whole LDS passes, at most 128
-static int hex_ppb(long npos) {
-    long ppb = (npos + 1023) / 1024;
-    ppb = (ppb + WG_CHUNK - 1) / WG_CHUNK * WG_CHUNK;
-    if (ppb < WG_CHUNK) ppb = WG_CHUNK;
-    if (ppb > 128) ppb = 128;
-    return (int)ppb;
-}
-
 // workspace floats needed by gnx_hexconv_bwd_weight
 GNX_EXPORT long gnx_hexconv_bwd_weight_workspace(int B, int H, int W, int I, int O) {
     const long npos = (long)B * H * W;
     const long ic = I < HEX_WCHUNK ? I : HEX_WCHUNK, oc = O < HEX_WCHUNK ? O : HEX_WCHUNK;     // one chunk pair at a time
-    return (long)gnx_cdiv(npos, hex_ppb(npos)) * (7L * oc * ic + oc);
+    return 4L * gnx_cdiv(npos, HW_POS) * (7L * oc * ic + oc);                                // one slab per wave
 }
 
 GNX_EXPORT int gnx_hexconv_bwd_weight(const float* x, const float* dy, float* dkernel0, float* dkernel1,
@@ -307,19 +298,15 @@ GNX_EXPORT int gnx_hexconv_bwd_weight(const float* x, const float* dy, float* dk
     if (!x || !dy || !dkernel0 || !dkernel1 || !workspace || I <= 0 || O <= 0 || H <= 0 || W <= 0 || B < 0)
         return GNX_ERR_BAD_ARG;
     const long npos = (long)B * H * W;
-    const int ppb = hex_ppb(npos);
-    const int nblk = gnx_cdiv(npos, ppb);
+    const int nblk = gnx_cdiv(npos, HW_POS);
     HexGeom g{B, H, W, mode};
     // one (input chunk, output chunk) pair after the other on the stream, each through the same workspace
     for (int o0 = 0; o0 < O; o0 += HEX_WCHUNK)
         for (int i0 = 0; i0 < I; i0 += HEX_WCHUNK) {
             const int oc = O - o0 < HEX_WCHUNK ? O - o0 : HEX_WCHUNK, ic = I - i0 < HEX_WCHUNK ? I - i0 : HEX_WCHUNK;
             const int nout = 7 * oc * ic + oc;
-            if (nblk > 0) {
-                const size_t lds = (size_t)(WG_CHUNK * oc + WG_CHUNK * 7 * ic) * sizeof(float);
-                hexconv_bwd_weight_kernel<<<nblk, 256, lds, stream>>>(x, dy, workspace, g, ic, oc, ppb, I, O, i0, o0);
-            }
-            hexconv_reduce_weight_kernel<<<gnx_cdiv(nout, 256), 256, 0, stream>>>(workspace, nblk, ic, oc, dkernel0, dkernel1,
+            if (nblk > 0) hexconv_bwd_weight_kernel<<<nblk, 256, 0, stream>>>(x, dy, workspace, g, ic, oc, I, O, i0, o0);
+            hexconv_reduce_weight_kernel<<<gnx_cdiv(nout, 256), 256, 0, stream>>>(workspace, 4 * nblk, ic, oc, dkernel0, dkernel1,
                                                                                   dbias, accumulate, I, i0, o0);
         }
     return gnx_launch_status();

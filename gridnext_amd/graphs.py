@@ -1,0 +1,146 @@
+"""hipGraph replay of the grid loop's step (new; SURVEY 7 "HIP streams and graphs instead of a tracing compiler").
+
+A count-only f + g step (BASELINE config 3) is ~60 kernels of 5-20 us: launched one by one from Python the step is bound
+by the host (0.86 ms per array against ~0.5 ms of kernel time).  `GridStepGraph` captures, per (phase, input shapes), ONE
+step of `train_gridwise` - f over the grid, g, the fused masked CE and, in the train phase, the whole backward - into a
+hipGraph (through `torch.cuda.CUDAGraph`: the C-ABI kernels are launched on torch's current stream, which is the capture
+stream) and replays it for every later batch of that shape:
+
+  * the first `WARMUP` batches of a shape run eagerly (they size caches, fold BatchNorm constants, repack weights);
+  * batch tensors are copied into static input buffers (40 MB of counts: microseconds); outputs are static tensors;
+  * the captured backward writes fresh gradients into graph-owned tensors; after each replay they are handed to
+    `p.grad` by copy (`p.grad = g.clone()` or `p.grad += g`), so the reference's accumulation semantics (no zero_grad
+    before the first backward, `accum_iters`) hold and nothing aliases graph memory;
+  * optimizer steps, gradient all-reduce and epoch statistics stay outside the graph (eager, unchanged).
+
+Used only where it is safe AND pays: every parameter of the spot classifier(s) that takes gradients is a plain MLP or
+frozen - a DenseNet on the gradient path keeps host-side state per forward (tape checks, cache invalidation) and its
+steps are GPU-bound anyway.  `GNX_GRAPH=0` disables it, `GNX_GRAPH=1` forces it for every fused-path model.
+"""
+import os
+
+import torch
+
+WARMUP = 2          # eager batches per (phase, shapes) before capture
+MAX_GRAPHS = 6      # distinct (phase, shapes) captured per loop call; further shapes stay eager
+
+
+def _shapes(obj):
+    if torch.is_tensor(obj):
+        return (tuple(obj.shape), obj.dtype)
+    if isinstance(obj, (list, tuple)):
+        return tuple(_shapes(o) for o in obj)
+    return None
+
+
+def _static_like(obj):
+    if torch.is_tensor(obj):
+        return torch.empty_like(obj)
+    return [_static_like(o) for o in obj]
+
+
+def _copy_into(dst, src):
+    if torch.is_tensor(dst):
+        dst.copy_(src, non_blocking=True)
+    else:
+        for d, s in zip(dst, src):
+            _copy_into(d, s)
+
+
+def wanted(model, fused_ok, device):
+    """Graph the grid step of this model?"""
+    flag = os.environ.get('GNX_GRAPH', '')
+    if flag == '0' or not fused_ok or torch.device(device).type != 'cuda' or not hasattr(model, 'forward_nhwc'):
+        return False
+    if flag == '1':
+        return True
+    from .densenet import DenseNet
+    from . import functional as GF
+    fs = [getattr(model, n) for n in ('image_classifier', 'count_classifier') if hasattr(model, n)] or \
+        [model.patch_classifier]
+    for f in fs:
+        if isinstance(f, DenseNet):
+            if f.training or any(p.requires_grad for p in f.parameters()):
+                return False                                   # tape, version checks, cache invalidation: host-side state
+            return False                                       # frozen DenseNet: the step is GPU-bound, nothing to gain
+        if not GF.is_hip_sequential(f):
+            return False                                       # an arbitrary user module: do not guess
+    return True
+
+
+class GridStepGraph:
+    """One captured step for one (phase, shapes).  `step_fn(inputs, labels) -> (loss, correct, n_fg)` is the eager step
+    WITHOUT the backward; `train` adds `loss.backward()` to the capture."""
+
+    def __init__(self, step_fn, params, train):
+        self.step_fn, self.train = step_fn, train
+        self.params = [p for p in params if p.requires_grad] if train else []
+        self.graph = None
+        self.seen = 0
+
+    def ready(self):
+        return self.graph is not None
+
+    def capture(self, inputs, labels):
+        self.s_inputs, self.s_labels = _static_like(inputs), _static_like(labels)
+        _copy_into(self.s_inputs, inputs)
+        _copy_into(self.s_labels, labels)
+        keep = [p.grad for p in self.params]
+        for p in self.params:
+            p.grad = None                                      # the captured backward then CREATES its gradient tensors
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
+            with torch.set_grad_enabled(self.train):
+                loss, correct, n_fg = self.step_fn(self.s_inputs, self.s_labels)
+                if self.train:
+                    loss.backward()
+        self.outs = (loss.detach(), correct, n_fg)
+        self.s_grads = [p.grad for p in self.params]           # graph-owned; None where a parameter got no gradient
+        for p, g in zip(self.params, keep):
+            p.grad = g                                         # capture ran nothing: the caller's gradients are untouched
+
+    def replay(self, inputs, labels):
+        _copy_into(self.s_inputs, inputs)
+        _copy_into(self.s_labels, labels)
+        self.graph.replay()
+        if self.train:
+            fresh, acc_dst, acc_src = [], [], []
+            for p, g in zip(self.params, self.s_grads):
+                if g is None:
+                    continue
+                if p.grad is None:
+                    fresh.append((p, g))
+                else:
+                    acc_dst.append(p.grad)
+                    acc_src.append(g)
+            for p, g in fresh:
+                p.grad = g.clone()
+            if acc_dst:
+                torch._foreach_add_(acc_dst, acc_src)
+        loss, correct, n_fg = self.outs
+        return loss.clone(), (correct.clone() if torch.is_tensor(correct) else correct), \
+            (n_fg.clone() if torch.is_tensor(n_fg) else n_fg)
+
+
+class GridStepGraphs:
+    """The per-loop-call collection: `run(phase_is_train, inputs, labels, eager_fn)`."""
+
+    def __init__(self, step_fn, params):
+        self.step_fn, self.params = step_fn, list(params)
+        self.table = {}
+
+    def run(self, train, inputs, labels):
+        """(loss, correct, n_fg, did_backward): graph replay when one exists for this phase and these shapes, else None."""
+        key = (bool(train), _shapes(inputs), _shapes(labels))
+        st = self.table.get(key)
+        if st is None:
+            if len(self.table) >= MAX_GRAPHS:
+                return None
+            st = self.table[key] = GridStepGraph(self.step_fn, self.params, train)
+        if not st.ready():
+            st.seen += 1
+            if st.seen <= WARMUP:
+                return None                                    # eager warm-up batch
+            st.capture(inputs, labels)
+        return st.replay(inputs, labels)

@@ -29,6 +29,7 @@ import torch.nn as nn
 
 from . import distributed as gdist
 from . import functional as GF
+from . import graphs
 from . import prefetch
 
 
@@ -194,6 +195,12 @@ def train_gridwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
     model.to(device)
     fused_ok = _plain_ce(criterion)
     stepped = gdist.optimizer_params(optimizer, f_opt)
+    # launch-bound models (count-only f + g: ~60 kernels of 5-20 us per array): the step is captured once per phase and input
+    # shape into a hipGraph and replayed (graphs.py); optimizer, all-reduce and statistics stay eager
+    stepper = None
+    if graphs.wanted(model, fused_ok, device):
+        stepper = graphs.GridStepGraphs(lambda i, l: _grid_loss(model, i, l, criterion, accum_iters, fused_ok),
+                                        model.parameters())
 
     for epoch in range(num_epochs):
         _banner(epoch, num_epochs)
@@ -205,13 +212,20 @@ def train_gridwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
             if hasattr(getattr(loader, 'sampler', None), 'set_epoch'):
                 loader.sampler.set_epoch(epoch)
             loader = prefetch.wrap(loader, device)         # pinned, double-buffered H2D one batch ahead (no-op on the CPU)
+            loss = None
             for batch_ind, (inputs, labels) in enumerate(loader):
+                loss = correct = n_fg = None        # (drops the previous step's autograd graph before a capture)
                 batch_size = labels.size(0)
                 inputs, labels = _to_device(inputs, device), labels.to(device)
                 with torch.set_grad_enabled(phase == 'train'):
-                    loss, correct, n_fg = _grid_loss(model, inputs, labels, criterion, accum_iters, fused_ok)
+                    replayed = stepper.run(phase == 'train', inputs, labels) if stepper is not None else None
+                    if replayed is not None:
+                        loss, correct, n_fg = replayed              # forward, loss and (train) backward: one graph launch
+                    else:
+                        loss, correct, n_fg = _grid_loss(model, inputs, labels, criterion, accum_iters, fused_ok)
+                        if phase == 'train':
+                            loss.backward()
                     if phase == 'train':
-                        loss.backward()
                         if batch_ind % accum_iters == 0:
                             gdist.allreduce_gradients(stepped)
                             optimizer.step()

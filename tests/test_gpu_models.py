@@ -787,3 +787,43 @@ def test_prefetcher_feeds_the_grid_loop_from_host_memory():
     for k, _ in enumerate(prefetch.DevicePrefetcher(DataLoader(data, batch_size=1), DEV)):
         if k == 1:
             break                                                                     # consumer leaves early: no hang
+
+
+@pytest.mark.parametrize("accum,fopt", [(1, False), (3, False), (2, True)])
+def test_graph_replayed_grid_loop_equals_the_eager_loop(monkeypatch, accum, fopt):
+    """graphs.py: the count-only f + g step captured into a hipGraph (forward, fused CE, backward) and replayed must leave
+    EXACTLY the eager loop's histories and weights - with gradient accumulation (accum_iters, no zero_grad before the first
+    backward), a trainable MLP f through f_opt, shuffled arrays, and a validation phase (its own graph)."""
+    import gridnext_amd as ga
+    from gridnext_amd import graphs
+    from gridnext_amd.synthetic import count_mlp
+    G, H, W, C = 24, 8, 6, 5
+    gen = torch.Generator().manual_seed(41)
+    x = torch.randint(0, 10, (9, G, H, W), generator=gen).float().to(DEV)
+    y = torch.randint(0, C + 1, (9, H, W), generator=gen).to(DEV)
+    results = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('GNX_GRAPH', flag)
+        torch.manual_seed(7)
+        m = ga.GridNetHexOddr(count_mlp(G, C), (G,), (H, W), C, use_bn=True)
+        if not fopt:
+            for p in m.patch_classifier.parameters():
+                p.requires_grad = False
+        assert graphs.wanted(m.to(DEV), True, DEV) == (flag == '1')
+        dl = {'train': DataLoader(TensorDataset(x[:7], y[:7]), batch_size=1, shuffle=True,
+                                  generator=torch.Generator().manual_seed(3)),
+              'val': DataLoader(TensorDataset(x[7:], y[7:]), batch_size=1)}
+        opt = torch.optim.Adam(m.corrector.parameters(), lr=1e-3)
+        f_opt = torch.optim.Adam(m.patch_classifier.parameters(), lr=1e-4) if fopt else None
+        (m, vh, th), _ = quiet(ga.train_gridwise, m, dl, nn.CrossEntropyLoss(), opt, num_epochs=3, f_opt=f_opt,
+                               accum_iters=accum)
+        results.append((th, vh, {k: v.clone() for k, v in m.state_dict().items()}))
+    (th0, vh0, sd0), (th1, vh1, sd1) = results
+    assert th0 == th1 and vh0 == vh1
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+    monkeypatch.delenv('GNX_GRAPH')
+    m = ga.GridNetHexOddr(count_mlp(G, C), (G,), (H, W), C).to(DEV)
+    assert graphs.wanted(m, True, DEV)                            # default: on for MLP classifiers ...
+    mm = ga.GridNetHexMM(ga.DenseNet(**TINY_LARGE), count_mlp(G, C), (3, 32, 32), (G,), (H, W), C).to(DEV)
+    assert not graphs.wanted(mm, True, DEV)                       # ... off when a DenseNet is part of the step

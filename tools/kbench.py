@@ -89,6 +89,21 @@ def main():
             fl = 2.0 * M * 1152 * 32
             print("conv3x3 S=%2d M=%8d  %8.3f ms  %6.1f TFLOP/s (direct-conv FLOPs)" % (S, M, ms, fl / ms / 1e9))
             del A, out
+    if args.only in ('', 'conv1x1h'):
+        # config 5: conv1 on fp16 block buffers (GNX_H16_M128=1 keeps the 128-row tiles)
+        H = torch.float16
+        for S, K, ct in shapes:
+            M = n * S * S
+            A = torch.randn(M, ct, device=DEV).to(H)
+            W = (torch.randn(128, K, device=DEV) * 0.05).to(H)
+            out = torch.empty(M, 128, device=DEV, dtype=H)
+            sc, sh = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
+            osc, osh = torch.rand(128, device=DEV) + 0.5, torch.randn(128, device=DEV) * 0.1
+            ms = timeit(lambda: L.call('gnx_conv1x1_bnrelu_h16', L.ptr(A, H), ct, L.ptr(W, H), L.ptr(out, H), 128, M, 128, K,
+                                       L.ptr(sc), L.ptr(sh), L.ptr(osc), L.ptr(osh), st), args.reps)
+            print("conv1x1_h16 S=%2d K=%4d M=%8d  %8.3f ms  %6.1f TFLOP/s  %5.2f TB/s (fp16 bytes)" %
+                  (S, K, M, ms, 2.0 * M * K * 128 / ms / 1e9, 2.0 * M * (K + 128) / ms / 1e9))
+            del A, out
     if args.only in ('', 'wgrad1'):
         # weight gradient of conv1 (taps = 1): dW[128][K] = dY^T act(X); GNX_WGRAD_R1=1 selects the round-1 kernels
         for S, K, ct in shapes:
