@@ -41,9 +41,11 @@ SIGNATURES = {
     'gnx_conv3x3_f16_dma': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _P]),
     'gnx_conv_stem_bnrelu_maxpool_h16': (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     'gnx_conv_stem_bnrelu_maxpool_u8': (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
+    'gnx_conv_stem_bnrelu_maxpool_f16mul': (_I, [_P, _I, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'gnx_u8_to_f32': (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
     'gnx_conv1x1_bnrelu_f16_h': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _P, _P, _I, _I, _P]),
     'gnx_conv1x1_bnrelu_h16': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _P, _P, _P]),
+    'gnx_bnrelu_avgpool2_h16': (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _P]),
     'gnx_conv3x3_f16_dma_h': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _P]),
     'gnx_bnrelu_avgpool_h16': (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _P]),
     'gnx_conv3x3_bnrelu': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P]),

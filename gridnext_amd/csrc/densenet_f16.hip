@@ -277,15 +277,18 @@ __global__ __launch_bounds__(256) void conv1x1_h16_kernel(const _Float16* __rest
         const int k = kt * 64 + 8 * kq;
         const bool kok = k < K;                            // 8 | K: the whole piece is in or out
         const int kc = kok ? k : 0;
-        const float4 sc0 = ld4(scale + kc), sc1 = ld4(scale + kc + 4), sh0 = ld4(shift + kc), sh1 = ld4(shift + kc + 4);
+        float4 sc0 = make_float4(1.f, 1.f, 1.f, 1.f), sc1 = sc0, sh0 = make_float4(0.f, 0.f, 0.f, 0.f), sh1 = sh0;
+        if (scale) { sc0 = ld4(scale + kc); sc1 = ld4(scale + kc + 4); sh0 = ld4(shift + kc); sh1 = ld4(shift + kc + 4); }
         const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
         const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
         __syncthreads();                                   // the previous chunk's fragment reads are done
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            half8 a, w = vb[p];
+            half8 a = va[p], w = vb[p];
+            if (scale) {                                   // (NULL: the operand is taken as it is - a pooled, activated input)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = (_Float16)act1((float)va[p][j], sc[j], sh[j]);
+                for (int j = 0; j < 8; ++j) a[j] = (_Float16)act1((float)va[p][j], sc[j], sh[j]);
+            }
             if (!(rok[p] && kok)) a = half8{0, 0, 0, 0, 0, 0, 0, 0};
             if (!(nok[p] && kok)) w = half8{0, 0, 0, 0, 0, 0, 0, 0};
             *reinterpret_cast<half8*>(&As[(r0 + 32 * p) * LDH2 + 8 * kq]) = a;
@@ -314,10 +317,13 @@ __global__ __launch_bounds__(256) void conv1x1_h16_kernel(const _Float16* __rest
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int col = n0 + 64 * wn + 32 * nt + i;
-            const float osc = col < N ? oscale[col] : 0.f, osh = col < N ? oshift[col] : 0.f;
+            const bool oact = oscale != nullptr;          // NULL (transitions): the product is stored as it is, rounded
+            const float osc = (oact && col < N) ? oscale[col] : 1.f, osh = (oact && col < N) ? oshift[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Os[((r & 3) + 8 * (r >> 2) + 4 * h) * LDH2 + 32 * nt + i] = (_Float16)fmaxf(fmaf(acc[mt][nt][r], osc, osh), 0.f);
+            for (int r = 0; r < 16; ++r) {
+                const float v = fmaf(acc[mt][nt][r], osc, osh);
+                Os[((r & 3) + 8 * (r >> 2) + 4 * h) * LDH2 + 32 * nt + i] = (_Float16)(oact ? fmaxf(v, 0.f) : v);
+            }
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -387,15 +393,18 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h16_m256_kernel(const _Float16
         const int k = kt * 64 + 8 * kq;
         const bool kok = k < K;                            // 8 | K: the whole piece is in or out
         const int kc = kok ? k : 0;
-        const float4 sc0 = ld4(scale + kc), sc1 = ld4(scale + kc + 4), sh0 = ld4(shift + kc), sh1 = ld4(shift + kc + 4);
+        float4 sc0 = make_float4(1.f, 1.f, 1.f, 1.f), sc1 = sc0, sh0 = make_float4(0.f, 0.f, 0.f, 0.f), sh1 = sh0;
+        if (scale) { sc0 = ld4(scale + kc); sc1 = ld4(scale + kc + 4); sh0 = ld4(shift + kc); sh1 = ld4(shift + kc + 4); }
         const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
         const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
         __syncthreads();                                   // the previous chunk's fragment reads are done
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            half8 a;
+            half8 a = va[p];
+            if (scale) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = (_Float16)act1((float)va[p][j], sc[j], sh[j]);
+                for (int j = 0; j < 8; ++j) a[j] = (_Float16)act1((float)va[p][j], sc[j], sh[j]);
+            }
             if (!(rok[p] && kok)) a = half8{0, 0, 0, 0, 0, 0, 0, 0};
             *reinterpret_cast<half8*>(&As[(r0 + 32 * p) * LDH2 + 8 * kq]) = a;
         }
@@ -428,10 +437,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h16_m256_kernel(const _Float16
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int col = n0 + 64 * wn + 32 * nt + i;
-            const float osc = col < N ? oscale[col] : 0.f, osh = col < N ? oshift[col] : 0.f;
+            const bool oact = oscale != nullptr;          // NULL (transitions): the product is stored as it is, rounded
+            const float osc = (oact && col < N) ? oscale[col] : 1.f, osh = (oact && col < N) ? oshift[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Os[((r & 3) + 8 * (r >> 2) + 4 * h) * LDH2 + 32 * nt + i] = (_Float16)fmaxf(fmaf(acc[mt][nt][r], osc, osh), 0.f);
+            for (int r = 0; r < 16; ++r) {
+                const float v = fmaf(acc[mt][nt][r], osc, osh);
+                Os[((r & 3) + 8 * (r >> 2) + 4 * h) * LDH2 + 32 * nt + i] = (_Float16)(oact ? fmaxf(v, 0.f) : v);
+            }
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -441,6 +453,44 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h16_m256_kernel(const _Float16
             if (row < M && col < N)
                 *reinterpret_cast<half8*>(out + row * ldc + col) = *reinterpret_cast<const half8*>(&Os[rr * LDH2 + 8 * c8]);
         }
+    }
+}
+
+// ---- transitions of config 5 on fp16 block buffers, pool-first in two steps (round 2).  The one-kernel form (the general
+// conv1x1_f16_kernel<POOL>) gathers the four source rows of every pooled row with 8-B loads, without prefetch, once per
+// 128-column tile of the output: 17.5 ms per 256-px array for the three transitions, ~1 TB/s.  Step 1 is this kernel:
+// P[img, oy, ox][c] = mean over the 2 x 2 window of relu(scale[c] x + shift[c]) (norm -> relu -> pool, densenet.py:50-54 with
+// the pool moved in front of the 1x1 conv: both are linear), 16-B loads and stores, fp32 arithmetic, one pass over the
+// block buffer.  Step 2 is conv1x1_h16_kernel on P with no prologue and no consumer activation (a quarter of the rows).
+__global__ __launch_bounds__(256) void bnrelu_avgpool2_h16_kernel(const _Float16* __restrict__ in, long ldi,
+                                                                  _Float16* __restrict__ out, long ldo, long Mout, int C8,
+                                                                  int S, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift) {
+    const long total = Mout * C8;
+    const int So = S >> 1;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long row = idx / C8;
+        const int c = 8 * (int)(idx - row * C8);
+        const long img = row / ((long)So * So);
+        const int rem = (int)(row - img * So * So);
+        const int oy = rem / So, ox = rem - oy * So;
+        const long src = ((img * S + 2 * oy) * S + 2 * ox) * ldi + c;
+        const float4 sc0 = ld4(scale + c), sc1 = ld4(scale + c + 4), sh0 = ld4(shift + c), sh1 = ld4(shift + c + 4);
+        const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+        const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+        half8 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ldh8(in + src + ((q >> 1) * (long)S + (q & 1)) * ldi);
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = act1((float)v[0][j], sc[j], sh[j]);                    // the four in the order of the one-kernel form
+            a += act1((float)v[1][j], sc[j], sh[j]);
+            a += act1((float)v[2][j], sc[j], sh[j]);
+            a += act1((float)v[3][j], sc[j], sh[j]);
+            o[j] = (_Float16)(0.25f * a);
+        }
+        *reinterpret_cast<half8*>(out + row * ldo + c) = o;
     }
 }
 
@@ -605,13 +655,34 @@ GNX_EXPORT int gnx_conv1x1_bnrelu_f16_h(const void* A16, long lda16, const float
     return gnx_launch_status();
 }
 
+// The 2 x 2 mean of the activated block buffer (step 1 of the two-step transition of config 5):
+// out16[img, oy, ox][c] = fp16(mean_{2x2} relu(scale[c] in16[img, 2oy + dy, 2ox + dx][c] + shift[c])).  8 | C, even S,
+// 16-B aligned rows.
+GNX_EXPORT int gnx_bnrelu_avgpool2_h16(const void* in16, long ldi, void* out16, long ldo, long imgs, int C, int S,
+                                       const float* scale, const float* shift, hipStream_t stream) {
+    if (!in16 || !out16 || !scale || !shift || imgs < 0 || C <= 0 || S < 2 || ldi < C || ldo < C) return GNX_ERR_BAD_ARG;
+    if (C % 8 != 0 || S % 2 != 0 || ldi % 8 != 0 || ldo % 8 != 0 || !al16h(in16) || !al16h(out16) || !al16h(scale) ||
+        !al16h(shift))
+        return GNX_ERR_UNSUPPORTED;
+    const long Mout = imgs * (S / 2) * (S / 2);
+    if (Mout == 0) return GNX_OK;
+    long blocks = (Mout * (C / 8) + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    bnrelu_avgpool2_h16_kernel<<<(int)blocks, 256, 0, stream>>>(reinterpret_cast<const _Float16*>(in16), ldi,
+                                                                reinterpret_cast<_Float16*>(out16), ldo, Mout, C / 8, S,
+                                                                scale, shift);
+    return gnx_launch_status();
+}
+
 // Dense-layer conv1 of config 5 on fp16 block buffers with fp16 weights (W16 = the weight rounded once, [N][K] halves):
-// gnx_conv1x1_bnrelu_f16_h (pool = 0, with consumer activation) in chunks of 64 channels and 16-B loads.  32 | K, 8 | N.
+// gnx_conv1x1_bnrelu_f16_h (pool = 0) in chunks of 64 channels and 16-B loads.  32 | K, 8 | N.  scale / shift NULL: no
+// prologue (the operand is used as it is); out_scale / out_shift NULL: no consumer activation at the store - together the
+// second step of a transition (gnx_bnrelu_avgpool2_h16 first).
 GNX_EXPORT int gnx_conv1x1_bnrelu_h16(const void* A16, long lda16, const void* W16, void* out16, long ldc16, long M, int N,
                                       int K, const float* scale, const float* shift, const float* out_scale,
                                       const float* out_shift, hipStream_t stream) {
-    if (!A16 || !W16 || !out16 || !scale || !shift || !out_scale || !out_shift || M < 0 || N <= 0 || K <= 0 || lda16 < K ||
-        ldc16 < N)
+    if (!A16 || !W16 || !out16 || (!scale) != (!shift) || (!out_scale) != (!out_shift) || M < 0 || N <= 0 || K <= 0 ||
+        lda16 < K || ldc16 < N)
         return GNX_ERR_BAD_ARG;
     if (!(al16h(A16) && al16h(W16) && al16h(out16) && al16h(scale) && al16h(shift) && lda16 % 8 == 0 && K % 8 == 0 &&
           N % 8 == 0 && ldc16 % 8 == 0))

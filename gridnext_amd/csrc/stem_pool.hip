@@ -434,6 +434,192 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const void* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ the same stem, fp16 MFMA
+// Config 5 (fp16 MFMA conv path): the kernel above multiplies in fp32 - 18 ms of a 112-ms array at 256 px, 15x the matrix
+// time of the fp16 form.  Here the patch and the weights are staged as halves and multiplied with v_mfma_f32_32x32x16_f16
+// (fp32 accumulate): k = 8 (c * 7 + ky) + kx, one instruction covers two (c, ky) groups - lane half h takes group 2 s + h,
+// its 8 consecutive kx are 8 consecutive halves of a patch row.  Those start at column 2 ox (4-B aligned only), so the A
+// fragment is four ds_read_b32 (conflict-free: consecutive lanes, consecutive dwords); the weights [64][176 + 8] halves are
+// 16-B aligned (ds_read_b128).  The 22nd group does not exist: its weights are zero and its A fragment re-reads group 20
+// (finite values).  Epilogue (norm0 + relu0 on the accumulators, pool0 through the LDS, fp16 store) as the fp32 kernel.
+// U8: uint8 patches (ToTensor / Normalize at the stash, as above).
+typedef _Float16 sp_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sp_half4 __attribute__((ext_vector_type(4)));
+template <int WO, bool U8>
+__global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __restrict__ xv, const float* __restrict__ w,
+                                                                 _Float16* __restrict__ out, long ldo, int H, int Wd, int O,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, long imgs,
+                                                                 const float* __restrict__ nrm) {
+    const float* __restrict__ x = reinterpret_cast<const float*>(xv);
+    const uint8_t* __restrict__ x8 = reinterpret_cast<const uint8_t*>(xv);
+    constexpr int CIN = 3, KH = 7, KW = 7, STRIDE = 2, PAD = 3;
+    constexpr int RT = 128 / WO;                          // conv rows per tile
+    constexpr int PH = STRIDE * (RT - 1) + KH, PW = ((WO - 1) * STRIDE + 8 + 1 + 1 + 7) & ~7;   // patch per channel (halves)
+    constexpr int F4R = WO * STRIDE / 4;                  // 4-pixel pieces per input row (row width 2 WO)
+    constexpr int NPC = CIN * PH * F4R, NPRE = (NPC + 255) / 256;
+    constexpr int NIT = (WO / 2) * 8 / 256;
+    constexpr int NG = CIN * KH, NSTEP = (NG + 1) / 2;    // 21 (c, ky) groups of 8 kx, two per MFMA
+    constexpr int LDBH = NSTEP * 16 + 8;                  // halves per weight row (184: 23 sixteen-byte slots)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    _Float16* Bs = reinterpret_cast<_Float16*>(lds);      // [64][LDBH]
+    _Float16* Ps = Bs + 64 * LDBH;                        // [CIN][PH][PW]
+    float* Ts = reinterpret_cast<float*>(Ps + CIN * PH * PW);       // [128 positions][SP_LDT] activated conv tile
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    for (int idx = t; idx < 64 * LDBH; idx += 256) {
+        const int n = idx / LDBH, rem = idx - n * LDBH;
+        const int kx = rem & 7, cky = rem >> 3;          // cky = c*KH + ky
+        float v = 0.f;
+        if (n < O && kx < KW && cky < NG) v = w[((long)n * CIN * KH + cky) * KW + kx];
+        Bs[idx] = (_Float16)v;
+    }
+    for (int idx = t; idx < CIN * PH * PW; idx += 256) Ps[idx] = (_Float16)0.f;     // the pad columns stay zero for good
+    const int trow = 32 * wave + i;                       // this lane's position in the RT x WO tile
+    const _Float16* pa = Ps + (STRIDE * (trow / WO)) * PW + STRIDE * (trow % WO);
+    const _Float16* pb = Bs + i * LDBH + 8 * h;
+    const float sc0 = i < O ? scale[i] : 0.f, sh0 = i < O ? shift[i] : 0.f;
+    const float sc1 = 32 + i < O ? scale[32 + i] : 0.f, sh1 = 32 + i < O ? shift[32 + i] : 0.f;
+    const int c4 = t & 7, pxa = t >> 3;
+    const int Ho2 = (H + 2 * PAD - KH) / STRIDE + 1;
+    const int ntt = Ho2 / RT;
+
+    float4 pre[U8 ? 1 : NPRE];
+    uint32_t pre8[U8 ? NPRE : 1];
+    bool in8[U8 ? NPRE : 1];
+    auto fetch_patch = [&](long img, int tt) {
+        const int iy0 = RT * tt * STRIDE - PAD;
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const int j = t + 256 * q;
+            const int f4 = j % F4R, py = (j / F4R) % PH, c = (j / F4R) / PH;
+            const int iy = iy0 + py;
+            const bool inside = j < NPC && iy >= 0 && iy < H;
+            if constexpr (U8) {
+                pre8[q] = 0u;
+                in8[q] = inside;
+                if (inside)
+                    pre8[q] = *reinterpret_cast<const uint32_t*>(x8 + ((img * CIN + c) * H + iy) * (long)Wd + 4 * f4);
+            } else {
+                pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (inside) pre[q] = ld4(x + ((img * CIN + c) * H + iy) * (long)Wd + 4 * f4);
+            }
+        }
+    };
+    auto stash_patch = [&]() {
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const int j = t + 256 * q;
+            if (j < NPC) {
+                _Float16* d = Ps + (j / F4R) * PW + PAD + 4 * (j % F4R);       // patch column = ix + PAD (odd: 3 + 4 f4)
+                float4 v;
+                if constexpr (U8) {
+                    const int c = (j / F4R) / PH;
+                    const bool norm = nrm != nullptr;
+                    v = in8[q] ? u8x4_pixels(pre8[q], norm, norm ? nrm[c] : 0.f, norm ? nrm[3 + c] : 1.f, norm ? nrm[6 + c] : 1.f)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    v = pre[q];
+                }
+                typedef _Float16 sp_half2 __attribute__((ext_vector_type(2)));
+                d[0] = (_Float16)v.x;                             // columns 3 + 4 f4 .. 6 + 4 f4: the middle pair is 4-B aligned
+                const sp_half2 mid = {(_Float16)v.y, (_Float16)v.z};
+                *reinterpret_cast<sp_half2*>(d + 1) = mid;
+                d[3] = (_Float16)v.w;
+            }
+        }
+    };
+    __syncthreads();                                      // Bs and the zeroed patch are in place
+    fetch_patch(blockIdx.x, 0);
+
+    for (long img = blockIdx.x; img < imgs; img += gridDim.x) {
+        float4 carry[2][NIT], carry2[2][NIT];
+#pragma unroll
+        for (int q = 0; q < NIT; ++q)
+            carry[0][q] = carry[1][q] = carry2[0][q] = carry2[1][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int tt = 0; tt < ntt; ++tt) {
+            __syncthreads();
+            stash_patch();
+            {
+                long nimg = img;
+                int nt2 = tt + 1;
+                if (nt2 == ntt) { nt2 = 0; nimg += gridDim.x; }
+                if (nimg >= imgs) nimg = blockIdx.x;
+                fetch_patch(nimg, nt2);
+            }
+            asm volatile("" ::: "memory");
+            __syncthreads();
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                // group 2 s + h: (c, ky) -> patch row; the missing 22nd group re-reads the 21st (its weights are zero)
+                const int g0 = 2 * s, g1 = 2 * s + 1 < NG ? 2 * s + 1 : NG - 1;
+                const int off0 = ((g0 / KH) * PH + (g0 % KH)) * PW, off1 = ((g1 / KH) * PH + (g1 % KH)) * PW;
+                // the 8 kx of position ox are patch columns 2 ox .. 2 ox + 7: four dwords at dword index ox of the row
+                const uint32_t* ap = reinterpret_cast<const uint32_t*>(pa + (h ? off1 : off0));
+                typedef unsigned u32x4a __attribute__((ext_vector_type(4)));
+                const u32x4a av = {ap[0], ap[1], ap[2], ap[3]};
+                const sp_half8 a = __builtin_bit_cast(sp_half8, av);
+                const sp_half8 b0 = *reinterpret_cast<const sp_half8*>(pb + 16 * s);
+                const sp_half8 b1 = *reinterpret_cast<const sp_half8*>(pb + 32 * LDBH + 16 * s);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b1, acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 1) __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    Ts[rr * SP_LDT + i] = pass == 0 ? fmaxf(fmaf(acc0[r], sc0, sh0), 0.f) : fmaxf(fmaf(acc1[r], sc1, sh1), 0.f);
+                }
+                __syncthreads();
+                const int ch = 32 * pass + 4 * c4;
+#pragma unroll
+                for (int q = 0; q < NIT; ++q) {
+                    const int px = pxa + 32 * q;
+                    float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int ox = 2 * px + dx;
+                        if (ox < 0) continue;
+                        const float4 v0 = ld4(&Ts[ox * SP_LDT + 4 * c4]);
+                        m0 = make_float4(fmaxf(m0.x, v0.x), fmaxf(m0.y, v0.y), fmaxf(m0.z, v0.z), fmaxf(m0.w, v0.w));
+                        if (RT == 2) {
+                            const float4 v1 = ld4(&Ts[(WO + ox) * SP_LDT + 4 * c4]);
+                            m1 = make_float4(fmaxf(m1.x, v1.x), fmaxf(m1.y, v1.y), fmaxf(m1.z, v1.z), fmaxf(m1.w, v1.w));
+                        }
+                    }
+                    float4 o4;
+                    bool emit;
+                    long orow;
+                    if (RT == 2) {
+                        const float4 cv = carry[pass][q];
+                        o4 = make_float4(fmaxf(fmaxf(cv.x, m0.x), m1.x), fmaxf(fmaxf(cv.y, m0.y), m1.y),
+                                         fmaxf(fmaxf(cv.z, m0.z), m1.z), fmaxf(fmaxf(cv.w, m0.w), m1.w));
+                        carry[pass][q] = m1;
+                        emit = true;
+                        orow = (img * (Ho2 / 2) + tt) * (long)(WO / 2) + px;
+                    } else {
+                        const float4 c2 = carry2[pass][q], c1 = carry[pass][q];
+                        o4 = make_float4(fmaxf(fmaxf(c2.x, c1.x), m0.x), fmaxf(fmaxf(c2.y, c1.y), m0.y),
+                                         fmaxf(fmaxf(c2.z, c1.z), m0.z), fmaxf(fmaxf(c2.w, c1.w), m0.w));
+                        emit = (tt & 1) != 0;
+                        orow = (img * (Ho2 / 2) + (tt >> 1)) * (long)(WO / 2) + px;
+                        carry2[pass][q] = carry[pass][q];
+                        carry[pass][q] = m0;
+                    }
+                    if (emit && ch < O) {
+                        const sp_half4 hv = {(_Float16)o4.x, (_Float16)o4.y, (_Float16)o4.z, (_Float16)o4.w};
+                        *reinterpret_cast<sp_half4*>(out + orow * ldo + ch) = hv;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ BN+ReLU+maxpool 3x3 s2 p1
 // IDX: also store, per pooled element, WHICH window element is the maximum (0..8, row-major in the 3 x 3 window; the first
 // maximal one of the scan, as torch's max_pool2d picks it): the backward then routes gradients by index - no value
@@ -629,6 +815,44 @@ GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool_h16(const float* x, const float* w, 
                                                 const float* scale, const float* shift, hipStream_t stream) {
     return stem_pool_launch<true>(x, w, reinterpret_cast<float*>(out16), ldo, imgs, Cin, H, W, O, KH, KW, stride, pad, scale,
                                   shift, stream);
+}
+
+// The fused stem with fp16 MATRIX OPERANDS (config 5's fp16 MFMA conv path: patch and weights rounded to fp16 as they are
+// staged, fp32 accumulate) storing the pooled map as fp16.  x: float patches, or uint8 patches when x_is_u8 (then norm as
+// for gnx_conv_stem_bnrelu_maxpool_u8).  Same geometries as gnx_conv_stem_bnrelu_maxpool; GNX_ERR_UNSUPPORTED otherwise.
+template <bool U8>
+static int stem_pool_f16_launch(const void* x, const float* w, void* out16, long ldo, long imgs, int Cin, int H, int W, int O,
+                                int KH, int KW, int stride, int pad, const float* scale, const float* shift,
+                                const float* nrm, hipStream_t stream) {
+    if (!x || !w || !out16 || !scale || !shift || imgs < 0 || Cin <= 0 || O <= 0 || H <= 0 || W <= 0 || ldo < O)
+        return GNX_ERR_BAD_ARG;
+    if (Cin != 3 || KH != 7 || KW != 7 || stride != 2 || pad != 3 || O > 64 || O % 4 != 0 || ldo % 4 != 0 ||
+        (reinterpret_cast<uintptr_t>(out16) & 7) != 0)
+        return GNX_ERR_UNSUPPORTED;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    if ((Wo != 64 && Wo != 128) || W != 2 * Wo || Ho % 2 != 0 || Ho <= 0 ||
+        (reinterpret_cast<uintptr_t>(x) & (U8 ? 3 : 15)) != 0)
+        return GNX_ERR_UNSUPPORTED;
+    if (imgs == 0) return GNX_OK;
+    const int RT = 128 / Wo, PH = 2 * (RT - 1) + 7, PW = ((Wo - 1) * 2 + 8 + 2 + 7) & ~7;
+    const size_t lds_bytes = ((size_t)64 * (11 * 16 + 8) + (size_t)3 * PH * PW) * 2 + (size_t)128 * SP_LDT * sizeof(float);
+    const int per_cu = lds_bytes <= 53 * 1024 ? 3 : 2;
+    const int grid = (int)(imgs < 256 * per_cu ? imgs : 256 * per_cu);
+    _Float16* o = reinterpret_cast<_Float16*>(out16);
+    if (Wo == 64)
+        conv_stem_pool_f16_kernel<64, U8><<<grid, 256, lds_bytes, stream>>>(x, w, o, ldo, H, W, O, scale, shift, imgs, nrm);
+    else
+        conv_stem_pool_f16_kernel<128, U8><<<grid, 256, lds_bytes, stream>>>(x, w, o, ldo, H, W, O, scale, shift, imgs, nrm);
+    return gnx_launch_status();
+}
+GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool_f16mul(const void* x, int x_is_u8, const float* w, void* out16, long ldo,
+                                                   long imgs, int Cin, int H, int W, int O, int KH, int KW, int stride,
+                                                   int pad, const float* scale, const float* shift, const float* norm,
+                                                   hipStream_t stream) {
+    if (x_is_u8)
+        return stem_pool_f16_launch<true>(x, w, out16, ldo, imgs, Cin, H, W, O, KH, KW, stride, pad, scale, shift, norm, stream);
+    if (norm) return GNX_ERR_BAD_ARG;                      // float patches are taken as already transformed
+    return stem_pool_f16_launch<false>(x, w, out16, ldo, imgs, Cin, H, W, O, KH, KW, stride, pad, scale, shift, nullptr, stream);
 }
 
 // The fused stem on uint8 patches x8 [imgs][3][H][W] (image_datasets.py:102-105 does ToTensor on the host):

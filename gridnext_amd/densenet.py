@@ -62,6 +62,7 @@ class DenseNet(nn.Module):
         self.winograd = True        # eval forward: conv2 as Winograd F(2,3) along x where the shape allows (fp32 path;
                                     # same arithmetic type, 1.5x fewer matrix operations, rounding-level differences)
         self.f16_buffers = True     # mfma = 'f16' only: the block buffers themselves in fp16 where the shapes allow
+        self.f16_stem = True        # ... and, with fp16 block buffers, conv0's matrix operands in fp16 too
         self.input_norm = None      # (mean[3], std[3]) of a torchvision Normalize to apply to UINT8 input patches after the
                                     # u8 / 255 of ToTensor (fused into the stem's operand load); float inputs are taken as
                                     # already transformed by the dataset, as in the reference
@@ -205,6 +206,17 @@ class DenseNet(nn.Module):
         self._cache['w1h'] = (key, table)
         return table
 
+    def _trans_f16(self):
+        """{transition: conv weight [c_out][c_in] rounded to fp16} (config 5's two-step transitions), refreshed with the weights."""
+        trs = [t for _, _, t, _ in self._blocks if t is not None]
+        key = self._key([t.conv.weight for t in trs])
+        hit = self._cache.get('wth')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        table = {t: t.conv.weight.detach().reshape(t.conv.weight.shape[0], -1).to(torch.float16).contiguous() for t in trs}
+        self._cache['wth'] = (key, table)
+        return table
+
     def _f16_dma_ok(self, M, s, mid, c_total):
         """Shapes gnx_conv3x3_f16_dma takes (conv3x3.hip): growth 32, 128 | mid, power-of-two maps 4..64, whole 128-row
         tiles, 32-bit element offsets."""
@@ -314,6 +326,16 @@ class DenseNet(nn.Module):
             L.call('gnx_conv_stem', L.ptr(xu), L.ptr(w0), L.ptr(rows), c_total, nu, 3, P, P, c0, 3, 3, 1, 1, st)
             return stem_out
         sc, sh = fold[self.features.norm0]
+        if use_h and self.f16_stem:
+            # config 5: the stem's matrix operands in fp16 too (float or uint8 patches)
+            u8 = xu.dtype == torch.uint8
+            rc = L.query('gnx_conv_stem_bnrelu_maxpool_f16mul', xu.data_ptr(), 1 if u8 else 0, L.ptr(w0), rows.data_ptr(),
+                         c_total, nu, 3, P, P, c0, 7, 7, 2, 3, L.ptr(sc), L.ptr(sh),
+                         L.ptr(self._norm_vector(dev)) if u8 else None, st)
+            if rc == 0:
+                return stem_out
+            if rc != L.ERR_UNSUPPORTED:
+                raise RuntimeError("gnx_conv_stem_bnrelu_maxpool_f16mul failed (%d)" % rc)
         # conv0 -> norm0 -> relu0 -> pool0 in one kernel where the geometry allows (128- / 256-px patches): the conv0 map
         # (5.2 GB per 128-px array) then never touches HBM.  uint8 patches: ToTensor (+ Normalize) inside that kernel too.
         if xu.dtype == torch.uint8:
@@ -482,7 +504,17 @@ class DenseNet(nn.Module):
                         sct, sht = fold[trans.norm]
                         # transitions are HBM-bound (4x the input bytes of their output): the fp32 wave-specialised
                         # kernel serves both matrix precisions
-                        if use_h:
+                        if use_h and c_total % 32 == 0:
+                            # two steps: norm -> relu -> 2x2 mean in one pass over the block buffer (16-B accesses), then the
+                            # 1x1 conv on the pooled rows without prologue or consumer activation
+                            pooled = torch.empty((nu * so * so, c_total), device=dev, dtype=torch.float16)
+                            L.call('gnx_bnrelu_avgpool2_h16', L.ptr(rows, torch.float16), c_total, L.ptr(pooled, torch.float16),
+                                   c_total, nu, c_total, s, L.ptr(sct), L.ptr(sht), st)
+                            L.call('gnx_conv1x1_bnrelu_h16', L.ptr(pooled, torch.float16), c_total,
+                                   L.ptr(self._trans_f16()[trans], torch.float16), L.ptr(nxt[u0 * so * so:], torch.float16),
+                                   nxt.shape[1], nu * so * so, trans.conv.out_channels, c_total, None, None, None, None, st)
+                            del pooled
+                        elif use_h:
                             L.call('gnx_conv1x1_bnrelu_f16_h', L.ptr(rows, torch.float16), c_total,
                                    L.ptr(trans.conv.weight), L.ptr(nxt[u0 * so * so:], torch.float16), nxt.shape[1],
                                    nu * so * so, trans.conv.out_channels, c_total, L.ptr(sct), L.ptr(sht), None, None, 1, s,

@@ -172,6 +172,12 @@ int gnx_conv_stem_bnrelu_maxpool_u8(const unsigned char* x8, const float* w, voi
                                     const float* shift, const float* norm, int out_f16, gnx_stream_t stream);
 int gnx_u8_to_f32(const unsigned char* x8, float* out, long imgs, int C, int H, int W, const float* norm,
                   gnx_stream_t stream);
+/* The fused stem with fp16 matrix operands (config 5: patch and weights rounded to fp16 at the LDS stash,
+ * v_mfma_f32_32x32x16_f16, fp32 accumulate), pooled map stored as fp16; x float patches, or uint8 when x_is_u8 (norm as
+ * above, else NULL). */
+int gnx_conv_stem_bnrelu_maxpool_f16mul(const void* x, int x_is_u8, const float* w, void* out16, long ldo, long imgs,
+                                        int Cin, int H, int W, int O, int KH, int KW, int stride, int pad,
+                                        const float* scale, const float* shift, const float* norm, gnx_stream_t stream);
 int gnx_conv1x1_bnrelu_f16_h(const void* A16, long lda16, const float* W, void* out16, long ldc16, long M, int N, int K,
                              const float* scale, const float* shift, const float* out_scale, const float* out_shift,
                              int pool, int S_in, gnx_stream_t stream);
@@ -180,6 +186,12 @@ int gnx_conv1x1_bnrelu_f16_h(const void* A16, long lda16, const float* W, void* 
 int gnx_conv1x1_bnrelu_h16(const void* A16, long lda16, const void* W16, void* out16, long ldc16, long M, int N, int K,
                            const float* scale, const float* shift, const float* out_scale, const float* out_shift,
                            gnx_stream_t stream);
+/* Transitions of config 5 in two steps (pool-first: norm -> relu -> 2x2 mean, then the 1x1 conv on a quarter of the rows,
+ * densenet.py:47-54): gnx_bnrelu_avgpool2_h16 writes the pooled, activated block buffer [imgs*(S/2)^2][C] halves;
+ * gnx_conv1x1_bnrelu_h16 with scale = shift = NULL (no prologue) and out_scale = out_shift = NULL (no consumer activation)
+ * multiplies it. */
+int gnx_bnrelu_avgpool2_h16(const void* in16, long ldi, void* out16, long ldo, long imgs, int C, int S, const float* scale,
+                            const float* shift, gnx_stream_t stream);
 int gnx_conv3x3_f16_dma_h(const void* A16, long lda16, const void* Wr16, void* out16, long ldc16, long M, int N, int K, int S,
                           gnx_stream_t stream);
 int gnx_bnrelu_avgpool_h16(const void* in16, long ldi, float* out, long ldo, long imgs, int C, int S2, const float* scale,

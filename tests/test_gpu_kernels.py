@@ -524,6 +524,17 @@ def test_fp16_block_buffer_kernels(L):
     L.call('gnx_conv1x1_bnrelu_f16_h', L.ptr(At, H), Kt, L.ptr(Wtd), L.ptr(ot, H), Nt, nI * So * So, Nt, Kt, L.ptr(sctd),
            L.ptr(shtd), None, None, 1, S, st)
     close(ot.reshape(nI, So, So, Nt).permute(0, 3, 1, 2).double(), ref, rtol=2e-3)
+    # the two-step transition (round 2): pooled activation as its own pass, then conv1x1_h16 without prologue / consumer
+    # activation - the same fp16 operands, the same k order: the one-kernel form's bits
+    Pt = torch.full((nI * So * So, Kt + 8), 7.0, device=DEV, dtype=H)
+    L.call('gnx_bnrelu_avgpool2_h16', L.ptr(At, H), Kt, L.ptr(Pt, H), Kt + 8, nI, Kt, S, L.ptr(sctd), L.ptr(shtd), st)
+    want_p = F.avg_pool2d(act, 2, 2).permute(0, 2, 3, 1).reshape(-1, Kt)
+    close(Pt[:, :Kt].float(), want_p, rtol=1e-3, atol=1e-3)
+    assert float(Pt[:, Kt:].float().min()) == 7.0
+    ot2 = torch.empty(nI * So * So, Nt, device=DEV, dtype=H)
+    L.call('gnx_conv1x1_bnrelu_h16', L.ptr(Pt, H), Kt + 8, L.ptr(Wtd.half(), H), L.ptr(ot2, H), Nt, nI * So * So, Nt, Kt, None,
+           None, None, None, st)
+    assert torch.equal(ot2, ot)
     # conv2 with an fp16 output == the fp32-output kernel rounded
     S2, n2 = 8, 4
     a16 = torch.relu(torch.randn(n2 * S2 * S2, 128, generator=g)).half().to(DEV)
@@ -696,7 +707,8 @@ def test_uint8_patches_equal_float_patches_bit_for_bit(L):
                 xf = xf.sub(mean.view(1, 3, 1, 1)).div(std.view(1, 3, 1, 1))
             o_f = torch.empty(n * S * S, 96, device=DEV)
             o_u = torch.full((n * S * S, 96), 7.0, device=DEV)
-            L.call('gnx_conv_stem_bnrelu_maxpool', L.ptr(xf.to(DEV)), L.ptr(W0), L.ptr(o_f), 96, n, 3, P, P, O, 7, 7, 2, 3,
+            xfd = xf.to(DEV)
+            L.call('gnx_conv_stem_bnrelu_maxpool', L.ptr(xfd), L.ptr(W0), L.ptr(o_f), 96, n, 3, P, P, O, 7, 7, 2, 3,
                    L.ptr(sc0), L.ptr(sh0), st)
             L.call('gnx_conv_stem_bnrelu_maxpool_u8', u8.to(DEV).data_ptr(), L.ptr(W0), o_u.data_ptr(), 96, n, 3, P, P, O,
                    7, 7, 2, 3, L.ptr(sc0), L.ptr(sh0), L.ptr(norm), 0, st)
@@ -763,3 +775,36 @@ def test_wgrad_3x3_transposed_image_kernel(L, n, S, K, act):
     L.call('gnx_wgrad_bnrelu', dYd.data_ptr() + 4 * c0, ld, L.ptr(Xd), K, L.ptr(scd) if act else None,
            L.ptr(shd) if act else None, L.ptr(dW), L.ptr(ws), M, N, K, S, 9, 0, 0, L.stream())
     close(dW, w.grad, rtol=2e-5, atol=1e-5, what='dW 3x3')
+
+
+@pytest.mark.parametrize("P,n", [(128, 5), (256, 3)])
+def test_stem_with_fp16_matrix_operands(L, P, n):
+    """Config 5's stem (gnx_conv_stem_bnrelu_maxpool_f16mul): patch and weights rounded to fp16 at the LDS stash, fp16 MFMA with
+    fp32 accumulation, fp16 pooled map - against torch on the SAME rounded operands (fp64 accumulate), from float patches and
+    from uint8 patches (with a Normalize)."""
+    H16 = torch.float16
+    g = torch.Generator().manual_seed(P)
+    O = 64
+    W0 = torch.randn(O, 3, 7, 7, generator=g) * 0.1
+    sc0, sh0 = torch.rand(O, generator=g) + 0.5, torch.randn(O, generator=g) * 0.2
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    nrm = torch.cat([mean, std, 1.0 / std]).to(DEV)
+    u8 = torch.randint(0, 256, (n, 3, P, P), generator=g, dtype=torch.uint8)
+    S = P // 4
+    for kind in ('float', 'u8', 'u8norm'):
+        if kind == 'float':
+            xf = torch.rand(n, 3, P, P, generator=g)
+            arg, is_u8, norm = xf.to(DEV), 0, None
+        else:
+            xf = u8.float().div(255)
+            if kind == 'u8norm':
+                xf = xf.sub(mean.view(1, 3, 1, 1)).div(std.view(1, 3, 1, 1))
+            arg, is_u8, norm = u8.to(DEV), 1, (nrm if kind == 'u8norm' else None)
+        conv = F.conv2d(xf.half().double(), W0.half().double(), stride=2, padding=3)
+        ref = F.max_pool2d(torch.relu(conv * sc0.double().view(1, -1, 1, 1) + sh0.double().view(1, -1, 1, 1)), 3, 2, 1)
+        out = torch.full((n * S * S, 96), 7.0, device=DEV, dtype=H16)
+        W0d, sc0d, sh0d = W0.to(DEV), sc0.to(DEV), sh0.to(DEV)               # (kept alive: the call takes raw pointers)
+        L.call('gnx_conv_stem_bnrelu_maxpool_f16mul', arg.data_ptr(), is_u8, L.ptr(W0d), out.data_ptr(), 96, n, 3, P, P, O,
+               7, 7, 2, 3, L.ptr(sc0d), L.ptr(sh0d), L.ptr(norm), L.stream())
+        close(out[:, :O].float().reshape(n, S, S, O).permute(0, 3, 1, 2), ref, rtol=2e-3, atol=2e-3, what=kind)
+        assert float(out[:, O:].float().min()) == 7.0
