@@ -367,6 +367,11 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
         } else {
             const int p = wave + NW * (slot - NSA);                            // weight group p / PPG = 2 tap + (n >> 4)
             if ((NPW % NW) && slot == NSA + NSW - 1 && p >= NPW) return;
+            // A tile of exactly two chunks (fp16 operands, 128 bottleneck channels: K = 64 float units) always puts chunk 0 in
+            // buffer 0 and chunk 1 in buffer 1: the weight images are the same bytes for every tile, so they are fetched with
+            // the workgroup's first two chunks only and stay RESIDENT.  (They were 74 of the 139 KB a 128-row tile moved
+            // through the LDS-DMA path, and that path - ~6.4 TB/s chip-wide - is what bounded the fp16 kernel.)
+            if (H16 && !NK1 && nk2 == 1 && nround > 0) return;
             const int grp = p / PPG, part = p % PPG;
             // weight rows [tap][N][K]: tap = grp >> 1, n = 32 * (column tile) + 16 * (grp & 1) + lane row
             dma16_buf(rW, voffW,

@@ -99,8 +99,9 @@ def main():
             out = torch.empty(M, 128, device=DEV, dtype=H)
             sc, sh = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
             osc, osh = torch.rand(128, device=DEV) + 0.5, torch.randn(128, device=DEV) * 0.1
+            scp, shp = (None, None) if args.noact else (L.ptr(sc), L.ptr(sh))
             ms = timeit(lambda: L.call('gnx_conv1x1_bnrelu_h16', L.ptr(A, H), ct, L.ptr(W, H), L.ptr(out, H), 128, M, 128, K,
-                                       L.ptr(sc), L.ptr(sh), L.ptr(osc), L.ptr(osh), st), args.reps)
+                                       scp, shp, L.ptr(osc), L.ptr(osh), st), args.reps)
             print("conv1x1_h16 S=%2d K=%4d M=%8d  %8.3f ms  %6.1f TFLOP/s  %5.2f TB/s (fp16 bytes)" %
                   (S, K, M, ms, 2.0 * M * K * 128 / ms / 1e9, 2.0 * M * (K + 128) / ms / 1e9))
             del A, out
