@@ -121,6 +121,9 @@ KINDS = {
                  conv1x1_bytes_per_spot),
     'dgrad3x3': ('conv3x3_dma_kernel, data-gradient shape (K = 32, N = 128)', conv3x3_flops_per_spot,
                  conv3x3_bytes_per_spot),
+    'dgrad3x3_bn2': ('conv3x3_dma_kernel<..., data-gradient shape + norm2/relu2 adjoint>', conv3x3_flops_per_spot,
+                     lambda patch: conv3x3_bytes_per_spot(patch) + sum(
+                         n_l * (_first_map(patch) >> b) ** 2 * 4 * 128 for b, n_l in enumerate(DENSENET121['block_config']))),
     'dgrad1x1_bn1': ('conv1x1_ws_kernel<..., dgrad + norm1/relu1 adjoint>', conv1x1_flops_per_spot,
                      dgrad1x1_bytes_per_spot),
 }

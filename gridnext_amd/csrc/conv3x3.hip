@@ -295,10 +295,21 @@ __global__ __launch_bounds__(256) void conv3x3_pipe_kernel(const float* __restri
 // in float units (K/2, lda/2), a 128-B LDS row holds 64 channels, and a fragment read (16 B = 8 consecutive k of a lane's
 // row; the two lane halves 16 k) feeds ONE v_mfma_f32_32x32x16_f16 where the fp32 form issues four 32x32x2.
 // O16: the output is fp16 too ([M][N] halves, ldc in halves): config 5 with fp16 block buffers.
-template <int S, int NW, int KC, bool NK1 = false, bool H16 = false, bool O16 = false>
+// BNADJ (round 2, with NK1 and N == 128: conv2's data gradient fused with norm2 -> relu2's adjoint in eval-statistics mode):
+// the column-tile store, instead of writing g = dL/d(conv2 input), reads the ACTIVATED bottleneck a[m][c] (bn.a), and writes
+//   out[m][c] = sc[c] g[m][c] where a > 0, else 0                                   (dL/d(conv1 output))
+// while the column sums sum_m g [a > 0] and sum_m g [a > 0] xhat, xhat = ((a - sh) / sc - mean) invstd, of everything the
+// workgroup processes stay in registers and leave as ONE slab per wave: bn.slab [gridDim.x * NW][2][N] (dbeta, dgamma).
+// The separate pass (read g, read a, write the result: 25 ms of a 289-ms step) disappears.
+struct C3BnAdj {
+    const float* a; int lda;
+    const float* sc; const float* sh; const float* mean; const float* inv;
+    float* slab;
+};
+template <int S, int NW, int KC, bool NK1 = false, bool H16 = false, bool O16 = false, bool BNADJ = false>
 __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __restrict__ A, int lda,
                                                               const float* __restrict__ Wr, float* __restrict__ out,
-                                                              int ldc, int M, int K, int N) {
+                                                              int ldc, int M, int K, int N, C3BnAdj bn = C3BnAdj()) {
     constexpr int BM = 32 * NW;
     constexpr int strip = BM + 2 * S + 2;
     constexpr int SR = (strip + 15) & ~15;                 // strip rows padded to whole groups of 16
@@ -398,6 +409,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
     const unsigned bB0 = lb + relB, bB1 = lb + BUFB + relB;
 
     bool stored = false;
+    float adj_b[4] = {0.f, 0.f, 0.f, 0.f}, adj_g[4] = {0.f, 0.f, 0.f, 0.f};      // BNADJ: this lane's column of column tile ct
     for (int round = 0, tile = tile_of(0); tile < T; tile = tile_of(++round)) {
         const int P = tile * BM + 32 * wave + i;
         const int rem = P % (S * S);
@@ -414,7 +426,34 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
-        auto store16 = [&](int col0) {
+        auto store16 = [&](int col0, auto ct_c) {
+            if constexpr (BNADJ) {
+                constexpr int ctc = decltype(ct_c)::value;
+                const int col = col0 + i;
+                const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (long)tile * BM * ldc, 0, BM * ldc * 4,
+                                                                                    0x00020000);
+                const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float*>(bn.a + (long)tile * BM * bn.lda), 0, BM * bn.lda * 4, 0x00020000);
+                const int vo = ((32 * wave + 4 * h) * ldc + col) * 4, va = ((32 * wave + 4 * h) * bn.lda + col) * 4;
+                float av[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    av[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, va, ((r & 3) + 8 * (r >> 2)) * bn.lda * 4, 0));
+                const float sc = bn.sc[col], sh = bn.sh[col], mu = bn.mean[col], is = bn.inv[col];
+                const float rsc = 1.f / sc;
+                float sb = adj_b[ctc], sg = adj_g[ctc];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {             // exactly 16 (buffer) stores
+                    const float d = av[r] > 0.f ? acc0[r] + acc1[r] : 0.f;
+                    sb += d;
+                    sg = fmaf(d, ((av[r] - sh) * rsc - mu) * is, sg);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc * d), ro, vo, ((r & 3) + 8 * (r >> 2)) * ldc * 4, 0);
+                }
+                adj_b[ctc] = sb;
+                adj_g[ctc] = sg;
+                stored = true;
+                return;
+            }
             if constexpr (O16) {
                 _Float16* o16 = reinterpret_cast<_Float16*>(out);
                 const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(o16 + (long)tile * BM * ldc, 0,
@@ -438,7 +477,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
                                                       ((r & 3) + 8 * (r >> 2)) * ldc * 4, 0);
             stored = true;
         };
-        auto do_chunk = [&](auto par_c, int ct) {
+        auto do_chunk = [&](auto par_c, int ct, auto ct_c) {
             constexpr int par = decltype(par_c)::value;
             if constexpr (NK1) {
 #pragma unroll
@@ -490,15 +529,56 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
                 if constexpr (step < STEPS - 1) { a = na; bq = nb; }
             });
             advance_next();
-            if constexpr (NK1) store16(32 * ct);
+            if constexpr (NK1) store16(32 * ct, ct_c);
         };
-        for (int c2 = 0; c2 < nk2; ++c2) {
-            do_chunk(std::integral_constant<int, 0>{}, 2 * c2);
-            do_chunk(std::integral_constant<int, 1>{}, 2 * c2 + 1);
+        if constexpr (BNADJ) {                             // N == 128: four column tiles, their sums in named registers
+            do_chunk(std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{});
+            do_chunk(std::integral_constant<int, 1>{}, 1, std::integral_constant<int, 1>{});
+            do_chunk(std::integral_constant<int, 0>{}, 2, std::integral_constant<int, 2>{});
+            do_chunk(std::integral_constant<int, 1>{}, 3, std::integral_constant<int, 3>{});
+        } else {
+            for (int c2 = 0; c2 < nk2; ++c2) {
+                do_chunk(std::integral_constant<int, 0>{}, 2 * c2, std::integral_constant<int, 0>{});
+                do_chunk(std::integral_constant<int, 1>{}, 2 * c2 + 1, std::integral_constant<int, 0>{});
+            }
         }
-        if constexpr (!NK1) store16(0);
+        if constexpr (!NK1) store16(0, std::integral_constant<int, 0>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (BNADJ) {
+        // one slab per wave: [2][N]; the two lane halves hold different rows of the same column
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const float sb = adj_b[ct] + __shfl_xor(adj_b[ct], 32), sg = adj_g[ct] + __shfl_xor(adj_g[ct], 32);
+            if (h == 0) {
+                float* sl = bn.slab + (long)(blockIdx.x * NW + wave) * 2 * N + 32 * ct + i;
+                sl[0] = sb;
+                sl[N] = sg;
+            }
+        }
+    }
+}
+
+// slab[nblk][2][C] -> dbeta[c] (+)= sum_b slab[b][0][c], dgamma[c] (+)= sum_b slab[b][1][c]; slabs added in index order, their
+// loads issued 16 at a time (deterministic)
+__global__ __launch_bounds__(256) void c3_adj_reduce_kernel(const float* __restrict__ slab, int nblk, int C,
+                                                            float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                            int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * C) return;
+    const int q = idx / C, c = idx - q * C;
+    float s0 = 0.f;
+    int b = 0;
+    for (; b + 16 <= nblk; b += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = slab[((long)(b + u) * 2 + q) * C + c];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s0 += v[u];
+    }
+    for (; b < nblk; ++b) s0 += slab[((long)b * 2 + q) * C + c];
+    float* dst = q == 0 ? dbeta : dgamma;
+    if (dst) dst[c] = accumulate ? dst[c] + s0 : s0;
 }
 
 // ------------------------------------------------------------------------------------------------ conv3x3, Winograd F(2,3) along x
@@ -775,6 +855,58 @@ GNX_EXPORT int gnx_conv3x3_winograd(const float* A, long lda, const float* Wu, f
 }
 
 // out[M][N] (ldc) = conv3x3_pad1(act(A[M = imgs*S*S][K] (lda))) with weights repacked to [tap][N][K]
+// floats of workspace for gnx_conv3x3_dgrad_bnrelu_bwd: one [2][N] slab per wave of at most 256 workgroups of 8 waves
+GNX_EXPORT long gnx_conv3x3_dgrad_bn_workspace(long M, int N) { return 256L * 8 * 2 * N; }
+
+// conv2's data gradient fused with norm2 -> relu2's adjoint (eval statistics, activated bottleneck: gnx_bn_relu_bwd(relu = 2)):
+//   dX[m][c] = scale[c] g[m][c] [A_act[m][c] > 0],   g = conv3x3(dY, Wb)[m][c]          (c < N = 128, dY has K = 32 channels)
+//   dbeta[c] (+)= sum_m g [a > 0],   dgamma[c] (+)= sum_m g [a > 0] ((a - shift) / scale - mean) invstd
+// == gnx_conv3x3_bnrelu(dY, Wb -> g) followed by gnx_bn_relu_bwd(g, A_act, relu = 2, training = 0), without the pass over
+// [M][128] in between.  Wb: gnx_repack_conv3x3_bwd's layout.  Shapes the LDS-DMA kernel takes in its data-gradient form with
+// N == 128 only; GNX_ERR_UNSUPPORTED otherwise (run the two calls).
+GNX_EXPORT int gnx_conv3x3_dgrad_bnrelu_bwd(const float* dY, long lddy, const float* Wb, const float* A_act, long lda,
+                                            float* dX, long lddx, long M, int N, int K, int S, const float* scale,
+                                            const float* shift, const float* mean, const float* invstd, float* dgamma,
+                                            float* dbeta, int accumulate, float* workspace, hipStream_t stream) {
+    if (!dY || !Wb || !A_act || !dX || !scale || !shift || !mean || !invstd || !workspace || M < 0 || N <= 0 || K <= 0 ||
+        S <= 0 || lddy < K || lda < N || lddx < N || (M % ((long)S * S)) != 0)
+        return GNX_ERR_BAD_ARG;
+    if (K != 32 || N != 128 || (M % C3_BM) != 0 || !al16(dY) || !al16(Wb) || lddy % 4 != 0 ||
+        M * (lddy > lddx ? (lddy > lda ? lddy : lda) : (lddx > lda ? lddx : lda)) >= (1L << 31) || getenv("GNX_NO_DMA") ||
+        getenv("GNX_NO_C3ADJ"))
+        return GNX_ERR_UNSUPPORTED;
+    if (M == 0) return GNX_OK;
+    C3BnAdj bn = {A_act, (int)lda, scale, shift, mean, invstd, workspace};
+    int nblk = 0;
+#define GNX_DMAA(SS)                                                                                              \
+    do {                                                                                                          \
+        if constexpr (SS <= 32) {                                                                                 \
+            if (M % 256 == 0 && M / 256 >= 1024) {                                                                \
+                nblk = 256 * 8;                                                                                   \
+                conv3x3_dma_kernel<SS, 8, 32, true, false, false, true><<<256, 512, 0, stream>>>(                 \
+                    dY, (int)lddy, Wb, dX, (int)lddx, (int)M, K, N, bn);                                          \
+                break;                                                                                            \
+            }                                                                                                     \
+        }                                                                                                         \
+        const long wgs = M / 128 > 256 ? 256 : M / 128;                                                           \
+        nblk = (int)wgs * 4;                                                                                      \
+        conv3x3_dma_kernel<SS, 4, 32, true, false, false, true><<<(int)wgs, 256, 0, stream>>>(                    \
+            dY, (int)lddy, Wb, dX, (int)lddx, (int)M, K, N, bn);                                                  \
+    } while (0)
+    switch (S) {
+        case 4: GNX_DMAA(4); break;
+        case 8: GNX_DMAA(8); break;
+        case 16: GNX_DMAA(16); break;
+        case 32: GNX_DMAA(32); break;
+        case 64: GNX_DMAA(64); break;
+        default: return GNX_ERR_UNSUPPORTED;
+    }
+#undef GNX_DMAA
+    if (dgamma || dbeta)
+        c3_adj_reduce_kernel<<<gnx_cdiv(2 * N, 256), 256, 0, stream>>>(workspace, nblk, N, dbeta, dgamma, accumulate);
+    return gnx_launch_status();
+}
+
 GNX_EXPORT int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, float* out, long ldc, long M, int N, int K,
                                   int S, const float* scale, const float* shift, hipStream_t stream) {
     if (!A || !Wr || !out || M < 0 || N <= 0 || K <= 0 || S <= 0 || lda < K || ldc < N || (!scale) != (!shift) ||

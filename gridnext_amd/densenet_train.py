@@ -271,13 +271,30 @@ class _DenseNetFn(Function):
                 wgrad(layer.conv2.weight, dy2, c_total, L.ptr(bott), mid, None if activated else s2, M, g, mid, s, 9, 0)
                 wb = torch.empty((9, mid, g), device=dev, dtype=F32)
                 L.call('gnx_repack_conv3x3_bwd', L.ptr(layer.conv2.weight.detach().contiguous()), L.ptr(wb), g, mid, st)
-                t0 = model._probe_begin()
-                L.call('gnx_conv3x3_bnrelu', dy2, c_total, L.ptr(wb), L.ptr(tA), mid, M, mid, g, s, None, None, st)
-                t0 = model._probe_mark('dgrad3x3', t0)
-                # norm2 + relu2
-                bn_bwd(layer.norm2, s2, L.ptr(tA), mid, L.ptr(bott), mid, L.ptr(tB), mid, M, mid, 0,
-                       relu=2 if activated else 1)
-                model._probe_mark('bn2_bwd', t0)
+                # conv2's data gradient and norm2 -> relu2's adjoint: ONE kernel where the bottleneck was stored activated
+                # (eval statistics) and the shape is the LDS-DMA kernel's; otherwise the product, then the adjoint pass
+                rc = L.ERR_UNSUPPORTED
+                if activated:
+                    bn2 = layer.norm2
+                    dg2 = new_like(bn2.weight) if want(bn2.weight) else None
+                    db2 = new_like(bn2.bias) if want(bn2.bias) else None
+                    ws2 = torch.empty(L.query('gnx_conv3x3_dgrad_bn_workspace', M, mid), device=dev, dtype=F32)
+                    t0 = model._probe_begin()
+                    rc = L.query('gnx_conv3x3_dgrad_bnrelu_bwd', dy2, c_total, L.ptr(wb), L.ptr(bott), mid, L.ptr(tB), mid, M,
+                                 mid, g, s, L.ptr(s2[0]), L.ptr(s2[1]), L.ptr(s2[2]), L.ptr(s2[3]), L.ptr(dg2), L.ptr(db2), 0,
+                                 L.ptr(ws2), st)
+                    if rc not in (0, L.ERR_UNSUPPORTED):
+                        raise RuntimeError("gnx_conv3x3_dgrad_bnrelu_bwd failed (%d)" % rc)
+                    if rc == 0:
+                        model._probe_mark('dgrad3x3_bn2', t0)
+                if rc == L.ERR_UNSUPPORTED:
+                    t0 = model._probe_begin()
+                    L.call('gnx_conv3x3_bnrelu', dy2, c_total, L.ptr(wb), L.ptr(tA), mid, M, mid, g, s, None, None, st)
+                    t0 = model._probe_mark('dgrad3x3', t0)
+                    # norm2 + relu2
+                    bn_bwd(layer.norm2, s2, L.ptr(tA), mid, L.ptr(bott), mid, L.ptr(tB), mid, M, mid, 0,
+                           relu=2 if activated else 1)
+                    model._probe_mark('bn2_bwd', t0)
                 # conv1
                 wgrad(layer.conv1.weight, L.ptr(tB), mid, L.ptr(buf), c_total, s1, M, mid, cin, s, 1, 0)
                 w1t = torch.empty((cin, mid), device=dev, dtype=F32)

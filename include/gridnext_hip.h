@@ -107,6 +107,14 @@ int gnx_conv1x1_dgrad_bnrelu_bwd(const float* dY, long lddy, const float* Wt, co
                                  long M, int N, int K, const float* scale, const float* shift, const float* mean,
                                  const float* invstd, float* dgamma, float* dbeta, int accumulate, float* workspace,
                                  gnx_stream_t stream);
+/* conv2's data gradient fused with norm2 -> relu2's adjoint (eval statistics; A_act = the ACTIVATED bottleneck the training
+ * forward stored): dX = scale * g * [A_act > 0] with g = conv3x3(dY, Wb), dbeta / dgamma from the same pass.  Replaces
+ * gnx_conv3x3_bnrelu(dY, Wb) + gnx_bn_relu_bwd(relu = 2) (torch.autograd through densenet.py:41).  N == 128, K == 32. */
+long gnx_conv3x3_dgrad_bn_workspace(long M, int N); /* floats */
+int gnx_conv3x3_dgrad_bnrelu_bwd(const float* dY, long lddy, const float* Wb, const float* A_act, long lda, float* dX,
+                                 long lddx, long M, int N, int K, int S, const float* scale, const float* shift,
+                                 const float* mean, const float* invstd, float* dgamma, float* dbeta, int accumulate,
+                                 float* workspace, gnx_stream_t stream);
 /* The same operation with norm1 folded into the operands (eval mode, weights frozen): relu(sc x + sh) = sc clamp(x) + sh,
  * clamp = max(., -sh/sc) for sc > 0, min for sc < 0.  gnx_conv1x1_fold_clamp makes Wf[N][K] = W sc, bounds[2][K] (private
  * order) and out_shift_f[N] = out_scale (W . sh) + out_shift once per weight / BN update; gnx_conv1x1_clamped_act then

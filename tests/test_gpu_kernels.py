@@ -808,3 +808,40 @@ def test_stem_with_fp16_matrix_operands(L, P, n):
                7, 7, 2, 3, L.ptr(sc0d), L.ptr(sh0d), L.ptr(norm), L.stream())
         close(out[:, :O].float().reshape(n, S, S, O).permute(0, 3, 1, 2), ref, rtol=2e-3, atol=2e-3, what=kind)
         assert float(out[:, O:].float().min()) == 7.0
+
+
+@pytest.mark.parametrize("n,S", [(8, 4), (6, 8), (4, 16), (2, 32), (64 * 4, 32)])
+def test_conv2_data_gradient_fused_with_norm2_adjoint(L, n, S):
+    """gnx_conv3x3_dgrad_bnrelu_bwd == gnx_conv3x3_bnrelu (data-gradient shape) followed by gnx_bn_relu_bwd(relu = 2) - dX to
+    rounding of the reciprocal (the fused kernel multiplies by 1 / scale), dgamma / dbeta to summation order."""
+    g = torch.Generator().manual_seed(S * 7 + n)
+    M, N, K, ld = n * S * S, 128, 32, 160
+    dYfull = torch.randn(M, ld, generator=g).to(DEV)
+    c0 = 96
+    W2 = (torch.randn(K, N, 3, 3, generator=g) * 0.05).to(DEV)               # conv2 weight [out = 32][in = 128][3][3]
+    wb = torch.empty(9, N, K, device=DEV)
+    L.call('gnx_repack_conv3x3_bwd', L.ptr(W2), L.ptr(wb), K, N, L.stream())
+    sc = (torch.rand(N, generator=g) + 0.5) * torch.where(torch.rand(N, generator=g) < 0.2, -1.0, 1.0)   # some negative gammas
+    sh, mu, inv = torch.randn(N, generator=g) * 0.3, torch.randn(N, generator=g) * 0.2, torch.rand(N, generator=g) + 0.5
+    x = torch.randn(M, N, generator=g)
+    a_act = torch.relu(x * sc + sh).to(DEV)                                   # the activated bottleneck the forward stored
+    scd, shd, mud, invd = sc.to(DEV), sh.to(DEV), mu.to(DEV), inv.to(DEV)
+    dyp = dYfull.data_ptr() + 4 * c0
+    # reference sequence
+    tA = torch.empty(M, N, device=DEV)
+    L.call('gnx_conv3x3_bnrelu', dyp, ld, L.ptr(wb), L.ptr(tA), N, M, N, K, S, None, None, L.stream())
+    tB = torch.empty(M, N, device=DEV)
+    dg, db = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    ws = torch.empty(L.query('gnx_bn_workspace', M, N), device=DEV)
+    L.call('gnx_bn_relu_bwd', L.ptr(tA), N, L.ptr(a_act), N, L.ptr(tB), N, M, N, L.ptr(scd), L.ptr(shd), L.ptr(mud), L.ptr(invd),
+           L.ptr(dg), L.ptr(db), 2, 0, 0, 0, L.ptr(ws), L.stream())
+    # fused
+    tB2 = torch.full((M, N), 7.0, device=DEV)
+    dg2, db2 = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    ws2 = torch.empty(L.query('gnx_conv3x3_dgrad_bn_workspace', M, N), device=DEV)
+    rc = L.query('gnx_conv3x3_dgrad_bnrelu_bwd', dyp, ld, L.ptr(wb), L.ptr(a_act), N, L.ptr(tB2), N, M, N, K, S, L.ptr(scd),
+                 L.ptr(shd), L.ptr(mud), L.ptr(invd), L.ptr(dg2), L.ptr(db2), 0, L.ptr(ws2), L.stream())
+    assert rc == 0
+    assert torch.equal(tB2, tB)
+    close(db2, db, rtol=2e-5, atol=1e-5, what='dbeta')
+    close(dg2, dg, rtol=2e-4, atol=1e-4, what='dgamma')
