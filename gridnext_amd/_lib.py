@@ -24,6 +24,8 @@ SIGNATURES = {
     'gnx_bn_fold_eval': (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
     'gnx_scale_shift_relu': (_I, [_P, _L, _P, _L, _L, _I, _P, _P, _I, _P]),
     'gnx_bn_relu_bwd': (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    'gnx_bnrelu_avgpool2': (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _P]),
+    'gnx_bn_relu_bwd_pooled': (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'gnx_colsum': (_I, [_P, _L, _L, _I, _P, _I, _P, _P]),
     'gnx_masked_ce_workspace': (_L, [_L]),
     'gnx_masked_ce_fwd': (_I, [_P, _L, _P, _L, _I, _I, _F, _P, _P, _P, _P, _P]),

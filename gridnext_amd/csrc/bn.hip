@@ -394,7 +394,11 @@ __global__ __launch_bounds__(256) void bn_bwd_eval_fused_kernel(const float* __r
                                                                 const float* __restrict__ shift,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, int relu,
-                                                                int dx_accumulate, float* __restrict__ partial) {
+                                                                int dx_accumulate, float* __restrict__ partial,
+                                                                int pool_S = 0) {
+    // pool_S > 0 (a transition's norm -> relu in front of its 2x2 average pool, densenet.py:50-54): dy is the gradient of the
+    // POOLED map [imgs * (pool_S/2)^2][C]; row r of x (position (y, x) of an S x S map) takes a quarter of its window's value -
+    // the unpooled gradient (a full-size pass: write 4x, read 4x) is never materialised.
     __shared__ float red[2][16][64];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;       // 16 channel-quads x 16 row lanes
     const int c = 4 * (blockIdx.y * 16 + cl);
@@ -406,7 +410,19 @@ __global__ __launch_bounds__(256) void bn_bwd_eval_fused_kernel(const float* __r
         const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, iss[4] = {is.x, is.y, is.z, is.w};
         for (long r = (long)blockIdx.x * 16 + rl; r < M; r += (long)gridDim.x * 16) {
             const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
-            const float4 dv = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+            long rd = r;
+            float dscale = 1.f;
+            if (pool_S > 0) {
+                const int S = pool_S, So = S >> 1;
+                const long img = r / ((long)S * S);
+                const int rem = (int)(r - img * S * S);
+                const int yy = rem / S, xx = rem - yy * S;
+                rd = (img * So + (yy >> 1)) * So + (xx >> 1);
+                dscale = ((yy >> 1) < So && (xx >> 1) < So) ? 0.25f : 0.f;         // (odd S: the last row / column is not pooled)
+                if (dscale == 0.f) rd = 0;
+            }
+            float4 dv = *reinterpret_cast<const float4*>(dy + rd * lddy + c);
+            if (pool_S > 0) dv = make_float4(dscale * dv.x, dscale * dv.y, dscale * dv.z, dscale * dv.w);
             const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
             float ds[4] = {dv.x, dv.y, dv.z, dv.w}, o[4];
 #pragma unroll
@@ -567,6 +583,71 @@ GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long 
 }
 
 // out[c] = sum_r x[r][c]  (bias gradient of a Linear layer); workspace: gnx_bn_workspace(M, C) floats
+// BN (eval statistics) -> ReLU adjoint reading the gradient of the 2x2-average-POOLED map (a transition, densenet.py:50-54):
+//   dX[m][c] = scale[c] * 0.25 dYp[pool(m)][c] * [scale x + shift > 0],  dbeta / dgamma from the same pass
+// == gnx_avgpool2_bwd followed by gnx_bn_relu_bwd(relu = 1, training = 0) without the full-size intermediate.
+// x / dX: [imgs*S*S][C]; dYp: [imgs*(S/2)^2][C].  4 | C, 16-B aligned operands; GNX_ERR_UNSUPPORTED otherwise.
+GNX_EXPORT int gnx_bn_relu_bwd_pooled(const float* dYp, long lddy, const float* x, long ldx, float* dx, long lddx, long imgs,
+                                      int S, int C, const float* scale, const float* shift, const float* save_mean,
+                                      const float* save_invstd, float* dgamma, float* dbeta, int accumulate,
+                                      float* workspace, hipStream_t stream) {
+    if (!dYp || !x || !dx || !scale || !shift || !save_mean || !save_invstd || !workspace || imgs <= 0 || S < 2 || C <= 0)
+        return GNX_ERR_BAD_ARG;
+    const long M = imgs * S * S;
+    const bool v4all = C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 &&
+                       ((reinterpret_cast<uintptr_t>(dYp) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
+                         reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
+                         reinterpret_cast<uintptr_t>(save_mean) | reinterpret_cast<uintptr_t>(save_invstd)) & 15) == 0;
+    if (!v4all) return GNX_ERR_UNSUPPORTED;
+    const int nblk = slab_count(M);
+    float* partial = workspace;
+    float* sums = workspace + (size_t)2 * nblk * C;
+    dim3 grid(nblk, gnx_cdiv(C, 64));
+    bn_bwd_eval_fused_kernel<<<grid, 256, 0, stream>>>(dYp, lddy, x, ldx, dx, lddx, M, C, scale, shift, save_mean, save_invstd, 1,
+                                                       0, partial, S);
+    bn_bwd_reduce_kernel<<<gnx_cdiv(C, 64), 256, 0, stream>>>(partial, nblk, C, sums, dgamma, dbeta, accumulate);
+    return gnx_launch_status();
+}
+
+// out[img, oy, ox][c] = mean over the 2x2 window of relu(scale[c] in[img, 2oy + dy, 2ox + dx][c] + shift[c]): the activated,
+// pooled input of a transition's 1x1 conv (pool-first), 16-B accesses - the operand of the transition's weight gradient.
+__global__ __launch_bounds__(256) void bnrelu_avgpool2_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out,
+                                                              long ldo, long Mout, int C4, int S,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift) {
+    const long total = Mout * C4;
+    const int So = S >> 1;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long row = idx / C4;
+        const int c = 4 * (int)(idx - row * C4);
+        const long img = row / ((long)So * So);
+        const int rem = (int)(row - img * So * So);
+        const int oy = rem / So, ox = rem - oy * So;
+        const long src = ((img * S + 2 * oy) * S + 2 * ox) * ldi + c;
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(in + src + ((q >> 1) * (long)S + (q & 1)) * ldi);
+            a.x += fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); a.y += fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+            a.z += fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); a.w += fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+        }
+        *reinterpret_cast<float4*>(out + row * ldo + c) = make_float4(0.25f * a.x, 0.25f * a.y, 0.25f * a.z, 0.25f * a.w);
+    }
+}
+GNX_EXPORT int gnx_bnrelu_avgpool2(const float* in, long ldi, float* out, long ldo, long imgs, int C, int S,
+                                   const float* scale, const float* shift, hipStream_t stream) {
+    if (!in || !out || !scale || !shift || imgs < 0 || C <= 0 || S < 2 || ldi < C || ldo < C) return GNX_ERR_BAD_ARG;
+    if (C % 4 != 0 || S % 2 != 0 || ldi % 4 != 0 || ldo % 4 != 0 ||
+        ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(scale) |
+          reinterpret_cast<uintptr_t>(shift)) & 15) != 0)
+        return GNX_ERR_UNSUPPORTED;
+    const long Mout = imgs * (S / 2) * (S / 2);
+    if (Mout == 0) return GNX_OK;
+    bnrelu_avgpool2_kernel<<<elementwise_grid(Mout * (C / 4)), 256, 0, stream>>>(in, ldi, out, ldo, Mout, C / 4, S, scale, shift);
+    return gnx_launch_status();
+}
+
 GNX_EXPORT int gnx_colsum(const float* x, long ld, long M, int C, float* out, int accumulate, float* workspace,
                           hipStream_t stream) {
     if (!x || !out || !workspace || M <= 0 || C <= 0 || ld < C) return GNX_ERR_BAD_ARG;

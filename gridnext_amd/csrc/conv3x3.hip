@@ -559,26 +559,38 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
     }
 }
 
-// slab[nblk][2][C] -> dbeta[c] (+)= sum_b slab[b][0][c], dgamma[c] (+)= sum_b slab[b][1][c]; slabs added in index order, their
-// loads issued 16 at a time (deterministic)
+// slab[nblk][2][C] -> dbeta[c] (+)= sum_b slab[b][0][c], dgamma[c] (+)= sum_b slab[b][1][c].  64 columns per workgroup, four
+// row lanes per column each summing a contiguous quarter of the slabs in index order (16 loads in flight), combined in a
+// fixed order: deterministic.
 __global__ __launch_bounds__(256) void c3_adj_reduce_kernel(const float* __restrict__ slab, int nblk, int C,
                                                             float* __restrict__ dbeta, float* __restrict__ dgamma,
                                                             int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 2 * C) return;
-    const int q = idx / C, c = idx - q * C;
+    __shared__ float part[4][64];
+    const int cl = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + cl;                  // over 2 C values: q = idx / C, c = idx % C
     float s0 = 0.f;
-    int b = 0;
-    for (; b + 16 <= nblk; b += 16) {
-        float v[16];
+    if (idx < 2 * C) {
+        const int q = idx / C, c = idx - q * C;
+        const int per = (nblk + 3) / 4;
+        int b = lane4 * per;
+        const int be = b + per < nblk ? b + per : nblk;
+        for (; b + 16 <= be; b += 16) {
+            float v[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = slab[((long)(b + u) * 2 + q) * C + c];
+            for (int u = 0; u < 16; ++u) v[u] = slab[((long)(b + u) * 2 + q) * C + c];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s0 += v[u];
+            for (int u = 0; u < 16; ++u) s0 += v[u];
+        }
+        for (; b < be; ++b) s0 += slab[((long)b * 2 + q) * C + c];
     }
-    for (; b < nblk; ++b) s0 += slab[((long)b * 2 + q) * C + c];
-    float* dst = q == 0 ? dbeta : dgamma;
-    if (dst) dst[c] = accumulate ? dst[c] + s0 : s0;
+    part[lane4][cl] = s0;
+    __syncthreads();
+    if (lane4 == 0 && idx < 2 * C) {
+        const int q = idx / C, c = idx - q * C;
+        const float tot = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+        float* dst = q == 0 ? dbeta : dgamma;
+        if (dst) dst[c] = accumulate ? dst[c] + tot : tot;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ conv3x3, Winograd F(2,3) along x
@@ -903,7 +915,7 @@ GNX_EXPORT int gnx_conv3x3_dgrad_bnrelu_bwd(const float* dY, long lddy, const fl
     }
 #undef GNX_DMAA
     if (dgamma || dbeta)
-        c3_adj_reduce_kernel<<<gnx_cdiv(2 * N, 256), 256, 0, stream>>>(workspace, nblk, N, dbeta, dgamma, accumulate);
+        c3_adj_reduce_kernel<<<gnx_cdiv(2 * N, 64), 256, 0, stream>>>(workspace, nblk, N, dbeta, dgamma, accumulate);
     return gnx_launch_status();
 }
 

@@ -328,21 +328,48 @@ class _DenseNetFn(Function):
                 Mp = N * ps * ps
                 stt = tape.trans[bi - 1]
                 c_out = p_trans.conv.out_channels
-                wgrad(p_trans.conv.weight, L.ptr(dbuf), c_total, L.ptr(bufs[bi - 1]), p_total, stt, M, c_out, p_total,
-                      ps, 1, 1)
+                # weight gradient: with eval statistics the pooled, activated input is built once (one 16-B pass) and the plain
+                # 1x1 weight-gradient kernel runs on a quarter of the rows; the in-kernel pooling form otherwise
+                rc = L.ERR_UNSUPPORTED
+                if want(p_trans.conv.weight) and not training:
+                    pooled = torch.empty((M, p_total), device=dev, dtype=F32)
+                    rc = L.query('gnx_bnrelu_avgpool2', L.ptr(bufs[bi - 1]), p_total, L.ptr(pooled), p_total, N, p_total, ps,
+                                 L.ptr(stt[0]), L.ptr(stt[1]), st)
+                    if rc == 0:
+                        wgrad(p_trans.conv.weight, L.ptr(dbuf), c_total, L.ptr(pooled), p_total, None, M, c_out, p_total, 0, 1, 0)
+                    elif rc != L.ERR_UNSUPPORTED:
+                        raise RuntimeError("gnx_bnrelu_avgpool2 failed (%d)" % rc)
+                    del pooled
+                if rc == L.ERR_UNSUPPORTED:
+                    wgrad(p_trans.conv.weight, L.ptr(dbuf), c_total, L.ptr(bufs[bi - 1]), p_total, stt, M, c_out, p_total,
+                          ps, 1, 1)
                 wt = torch.empty((p_total, c_out), device=dev, dtype=F32)
                 L.call('gnx_transpose_weight', L.ptr(p_trans.conv.weight.detach().contiguous()), L.ptr(wt), c_out,
                        p_total, st)
                 dPool = torch.empty((M, p_total), device=dev, dtype=F32)
                 L.call('gnx_conv1x1_bnrelu', L.ptr(dbuf), c_total, L.ptr(wt), L.ptr(dPool), p_total, M, p_total, c_out,
                        None, None, 0, 0, st)
-                dAct = torch.empty((Mp, p_total), device=dev, dtype=F32)
-                L.call('gnx_avgpool2_bwd', L.ptr(dPool), p_total, L.ptr(dAct), p_total, N, p_total, ps, st)
-                del dPool
                 dbufs[bi - 1] = torch.empty_like(bufs[bi - 1])
-                bn_bwd(p_trans.norm, stt, L.ptr(dAct), p_total, L.ptr(bufs[bi - 1]), p_total, L.ptr(dbufs[bi - 1]),
-                       p_total, Mp, p_total, 0)
-                del dAct
+                # norm -> relu adjoint straight from the POOLED gradient (eval statistics): the unpooled map - a full-size
+                # write and read - is never built
+                rc = L.ERR_UNSUPPORTED
+                if not training:
+                    bnp = p_trans.norm
+                    dgp = new_like(bnp.weight) if want(bnp.weight) else None
+                    dbp = new_like(bnp.bias) if want(bnp.bias) else None
+                    wsp = torch.empty(L.query('gnx_bn_workspace', Mp, p_total), device=dev, dtype=F32)
+                    rc = L.query('gnx_bn_relu_bwd_pooled', L.ptr(dPool), p_total, L.ptr(bufs[bi - 1]), p_total,
+                                 L.ptr(dbufs[bi - 1]), p_total, N, ps, p_total, L.ptr(stt[0]), L.ptr(stt[1]), L.ptr(stt[2]),
+                                 L.ptr(stt[3]), L.ptr(dgp), L.ptr(dbp), 0, L.ptr(wsp), st)
+                    if rc not in (0, L.ERR_UNSUPPORTED):
+                        raise RuntimeError("gnx_bn_relu_bwd_pooled failed (%d)" % rc)
+                if rc == L.ERR_UNSUPPORTED:
+                    dAct = torch.empty((Mp, p_total), device=dev, dtype=F32)
+                    L.call('gnx_avgpool2_bwd', L.ptr(dPool), p_total, L.ptr(dAct), p_total, N, p_total, ps, st)
+                    bn_bwd(p_trans.norm, stt, L.ptr(dAct), p_total, L.ptr(bufs[bi - 1]), p_total, L.ptr(dbufs[bi - 1]),
+                           p_total, Mp, p_total, 0)
+                    del dAct
+                del dPool
                 dbufs[bi] = None
                 bufs[bi] = None
 

@@ -61,6 +61,16 @@ int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long ldx, float*
                     const float* scale, const float* shift, const float* save_mean, const float* save_invstd,
                     float* dgamma, float* dbeta, int relu, int training, int accumulate, int dx_accumulate,
                     float* workspace, gnx_stream_t stream);
+/* Transitions (norm -> relu -> conv 1x1 -> avgpool 2x2, densenet.py:47-54, run pool-first): gnx_bnrelu_avgpool2 = the pooled,
+ * activated input [imgs*(S/2)^2][C] of the 1x1 conv (operand of its weight gradient); gnx_bn_relu_bwd_pooled = the adjoint
+ * of norm -> relu given the gradient of the POOLED map (== gnx_avgpool2_bwd + gnx_bn_relu_bwd(relu = 1, training = 0)
+ * without the full-size intermediate).  Eval statistics; 4 | C. */
+int gnx_bnrelu_avgpool2(const float* in, long ldi, float* out, long ldo, long imgs, int C, int S, const float* scale,
+                        const float* shift, gnx_stream_t stream);
+int gnx_bn_relu_bwd_pooled(const float* dYp, long lddy, const float* x, long ldx, float* dx, long lddx, long imgs, int S,
+                           int C, const float* scale, const float* shift, const float* save_mean,
+                           const float* save_invstd, float* dgamma, float* dbeta, int accumulate, float* workspace,
+                           gnx_stream_t stream);
 int gnx_colsum(const float* x, long ld, long M, int C, float* out, int accumulate, float* workspace,
                gnx_stream_t stream);
 

@@ -845,3 +845,37 @@ def test_conv2_data_gradient_fused_with_norm2_adjoint(L, n, S):
     assert torch.equal(tB2, tB)
     close(db2, db, rtol=2e-5, atol=1e-5, what='dbeta')
     close(dg2, dg, rtol=2e-4, atol=1e-4, what='dgamma')
+
+
+@pytest.mark.parametrize("n,S,C", [(3, 8, 64), (2, 32, 256), (5, 4, 1024), (2, 6, 40)])
+def test_transition_pooled_activation_and_pooled_adjoint(L, n, S, C):
+    """Transitions run pool-first.  gnx_bnrelu_avgpool2 (the pooled, activated input) vs torch; gnx_bn_relu_bwd_pooled (norm ->
+    relu adjoint straight from the pooled gradient) == gnx_avgpool2_bwd + gnx_bn_relu_bwd, bit for bit."""
+    g = torch.Generator().manual_seed(S + C)
+    ld = C + 8
+    x = torch.randn(n * S * S, ld, generator=g)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.4
+    mu, inv = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5
+    xd, scd, shd, mud, invd = x.to(DEV), sc.to(DEV), sh.to(DEV), mu.to(DEV), inv.to(DEV)
+    So = S // 2
+    act = torch.relu(x[:, :C] * sc + sh).reshape(n, S, S, C).permute(0, 3, 1, 2)
+    want = F.avg_pool2d(act, 2, 2).permute(0, 2, 3, 1).reshape(-1, C)
+    P = torch.full((n * So * So, C + 4), 7.0, device=DEV)
+    L.call('gnx_bnrelu_avgpool2', L.ptr(xd), ld, L.ptr(P), C + 4, n, C, S, L.ptr(scd), L.ptr(shd), L.stream())
+    close(P[:, :C], want, rtol=1e-6, atol=1e-6, what='pooled activation')
+    assert float(P[:, C:].min()) == 7.0
+    dYp = torch.randn(n * So * So, C, generator=g).to(DEV)
+    # reference: unpool, then the adjoint
+    dAct = torch.empty(n * S * S, C, device=DEV)
+    L.call('gnx_avgpool2_bwd', L.ptr(dYp), C, L.ptr(dAct), C, n, C, S, L.stream())
+    dx1 = torch.empty(n * S * S, ld, device=DEV)
+    dg1, db1 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ws = torch.empty(L.query('gnx_bn_workspace', n * S * S, C), device=DEV)
+    L.call('gnx_bn_relu_bwd', L.ptr(dAct), C, L.ptr(xd), ld, L.ptr(dx1), ld, n * S * S, C, L.ptr(scd), L.ptr(shd), L.ptr(mud),
+           L.ptr(invd), L.ptr(dg1), L.ptr(db1), 1, 0, 0, 0, L.ptr(ws), L.stream())
+    dx2 = torch.empty(n * S * S, ld, device=DEV)
+    dg2, db2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ws2 = torch.empty(L.query('gnx_bn_workspace', n * S * S, C), device=DEV)
+    L.call('gnx_bn_relu_bwd_pooled', L.ptr(dYp), C, L.ptr(xd), ld, L.ptr(dx2), ld, n, S, C, L.ptr(scd), L.ptr(shd), L.ptr(mud),
+           L.ptr(invd), L.ptr(dg2), L.ptr(db2), 0, L.ptr(ws2), L.stream())
+    assert torch.equal(dx2[:, :C], dx1[:, :C]) and torch.equal(dg2, dg1) and torch.equal(db2, db1)
