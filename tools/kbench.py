@@ -135,6 +135,18 @@ def main():
             fl = 2.0 * M * 1152 * 32
             print("wgrad3x3 S=%2d M=%8d  %8.3f ms  %6.1f TFLOP/s" % (S, M, ms, fl / ms / 1e9))
             del X, dY, ws
+    if args.only in ('', 'gemm'):
+        # the count MLP's first Linear on one array: C[4992][500] = A^T W^T, A = the (genes, spots) count grid read in place
+        M, N, K = 4992, 500, 2000
+        A = torch.randn(K, M, device=DEV)
+        W = torch.randn(N, K, device=DEV) * 0.05
+        Wt = W.t().contiguous()
+        bias = torch.randn(N, device=DEV)
+        C = torch.empty(M, N, device=DEV)
+        for bk, Bm, ldb in ((0, W, K), (1, Wt, N)):
+            ms = timeit(lambda: L.call('gnx_gemm_f32', L.ptr(A), M, 1, L.ptr(Bm), ldb, bk, L.ptr(bias), L.ptr(C), N, M, N, K, 0, st),
+                        args.reps)
+            print("gemm kmajor-A M=%d N=%d K=%d b_kmajor=%d  %8.3f ms  %6.1f TFLOP/s" % (M, N, K, bk, ms, 2.0 * M * N * K / ms / 1e9))
     if args.only in ('', 'stem'):
         x = torch.rand(n, 3, 128, 128, device=DEV)
         w = torch.randn(64, 3, 7, 7, device=DEV) * 0.05
