@@ -25,7 +25,8 @@ Rank 0 prints ONE JSON line (contract in the task description) with
                     oracle, same weights and inputs (|dCE| <= 1e-4 asserted for f32), argmax agreement on decided spots;
   * `series`        further series on the same box: `from_host` = the same step fed from pageable host memory (uint8
                     patches, DataLoader, pinned double-buffered H2D prefetcher; PCIe inside the timed region - never the
-                    headline `value`); `train_f` = the second series of SURVEY 8d, both classifiers trained through f_opt
+                    headline `value`); `config5_f16_256px` = BASELINE config 5's step (256-px patches, fp16 MFMA conv
+                    path) on this GPU; `train_f` = the second series of SURVEY 8d, both classifiers trained through f_opt
                     (DenseNet forward + backward), with its own roofline object.
 """
 import argparse
@@ -363,6 +364,90 @@ def from_host_series(args, model, optimizer, criterion, device, rank, world):
                         "stem kernel), float32 counts, int64 labels; timed region includes collate, staging and PCIe"}
 
 
+# ------------------------------------------------------------------------------------------ config 5 (fp16, 256 px)
+def config5_series(args, device, rank, world, steps=4, warmup=2):
+    """BASELINE config 5's step on this GPU: the same multimodal f + g step with 256-px patches and the fp16 MFMA conv path
+    (`DenseNet.mfma = 'f16'`: fp16 matrix operands incl. the stem, fp16 block buffers, fp32 accumulate), uint8 patches
+    resident in HBM, running statistics calibrated on one batch (a freshly initialised network with untouched statistics
+    overflows fp16).  Priced against HBM: its conv kernels multiply 16x faster than they can be fed."""
+    import torch
+    import torch.nn as nn
+    from gridnext_amd import distributed as gdist
+    from gridnext_amd import training as gtrain
+    P = 256
+    model = build_model(device, P)
+    gdist.broadcast_module(model)
+    for p in model.patch_classifier.parameters():
+        p.requires_grad = False
+    opt = torch.optim.Adam(model.corrector.parameters(), lr=1e-3)
+    crit = nn.CrossEntropyLoss()
+    gen = torch.Generator(device=device).manual_seed(900 + rank)
+    y = torch.randint(0, CLASSES + 1, (1, H, W), device=device, generator=gen)
+    x8 = torch.randint(0, 256, (1, H, W, 3, P, P), device=device, generator=gen, dtype=torch.uint8)
+    xc = torch.randint(0, 10, (1, GENES, H, W), device=device, generator=gen).float()
+    f_img = model.image_classifier
+    f_img.mfma = 'f16'
+    bns = [m for m in f_img.modules() if isinstance(m, nn.BatchNorm2d)]
+    moms = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    f_img.train()
+    with torch.no_grad():
+        f_img(x8.reshape(-1, 3, P, P)[:32])
+    for m, mo in zip(bns, moms):
+        m.momentum = mo
+    model.train()
+    model.patch_classifier.eval()
+    stepped = gdist.optimizer_params(opt)
+
+    def step():
+        loss, _, _ = gtrain._grid_loss(model, [x8, xc], y, crit, 1, True)
+        loss.backward()
+        gdist.allreduce_gradients(stepped)
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    f_img._probe = []
+    if gdist.is_active():
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    if gdist.is_active():
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if gdist.is_active():
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    probe, f_img._probe = f_img._probe, None
+    out = {"value": H * W * world * steps / elapsed, "unit": "spots/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+           "warmup": warmup, "dtype": "f16", "final_loss": float(last.item()), "fp16_block_buffers": bool(f_img._used_f16_buffers),
+           "workload": "BASELINE config 5 on one GPU: multimodal f (DenseNet-121 @256 px, fp16 MFMA conv path) + count MLP + hex g, "
+                       "1 array (4992 spots) per step, f frozen/eval, g trained; uint8 patches resident in HBM"}
+    kt = kernel_table(probe, P, steps)
+    for kind in kt:                                              # fp16 operands: half the bytes; priced against HBM
+        kk = kt[kind]
+        kk["algorithmic_bytes_per_launch_avg"] *= 0.5
+        gbs = kk["algorithmic_bytes_per_launch_avg"] / (kk["avg_launch_ms"] * 1e-3) / 1e9
+        kk.update({"bound": "hbm", "matrix_tflops": kk["achieved"], "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                   "frac": gbs / PEAK_HBM_GBS, "kernel": {"conv1x1": "conv1x1_h16_kernel", "conv3x3": "conv3x3_dma_kernel<H16, O16>"}.get(kind, kk["kernel"])})
+        kk.pop("algorithmic_gbs", None)
+    if kt:
+        order = sorted(kt, key=lambda k: -kt[k]["ms_per_step"])
+        out["roofline"] = dict(kt[order[0]])
+        if len(order) > 1:
+            out["roofline"]["second_kernel"] = kt[order[1]]
+    del model, x8, xc
+    torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------------------------------ one worker = one GPU
 def worker_main(args):
     import torch
@@ -550,6 +635,10 @@ def worker_main(args):
     #      pinned double-buffered prefetcher the training loops use; the timed region includes collate, staging and PCIe
     if (args.from_host or not args.no_series) and not args.train_f:
         result.setdefault("series", {})["from_host"] = from_host_series(args, model, optimizer, criterion, device, rank, world)
+
+    # ---- BASELINE config 5's geometry in the same run: 256-px patches, fp16 MFMA conv path (fp16 block buffers, fp16 stem)
+    if not args.no_series and not args.train_f and args.mfma == 'f32' and args.patch == 128:
+        result.setdefault("series", {})["config5_f16_256px"] = config5_series(args, device, rank, world)
 
     # ---- second series of SURVEY 8d in the same run: f trained (DenseNet forward + backward)
     if not args.train_f and not args.no_series and args.mfma == 'f32' and args.patch == 128:
