@@ -151,6 +151,22 @@ def kernel_table(probe, patch, steps):
     return kern
 
 
+def winograd_credit(k3, patch, steps):
+    """The Winograd launches execute 2/3 of the direct-convolution multiply-adds: `achieved` / `frac` become the EXECUTED
+    matrix FLOPs against the matrix peak; the direct-convolution credit (SURVEY 8d's algorithmic figure) moves to
+    `direct_conv_*`."""
+    ex = conv3x3_executed_flops_per_spot(patch) * H * W * steps
+    k3["kernel"] = "conv3x3_wino_kernel (S >= 8) + conv3x3_dma_kernel (S = 4)"
+    k3["algorithm"] = ("Winograd F(2,3) along x for maps of 8 x 8 and up: 2/3 of the direct multiply-adds. "
+                       "`achieved`/`frac` = executed matrix FLOPs; `direct_conv_*` = the same time credited with "
+                       "direct-convolution FLOPs (can exceed the peak, not a fraction of it)")
+    k3["direct_conv_tflops"] = k3["achieved"]
+    k3["direct_conv_flops_per_launch_avg"] = k3["flops_per_launch_avg"]
+    k3["achieved"] = ex / (k3["ms_per_step"] * steps * 1e-3) / 1e12
+    k3["frac"] = k3["achieved"] / PEAK_F32_MATRIX_TFLOPS
+    k3["flops_per_launch_avg"] = ex / max(k3["launches"], 1)
+
+
 def build_model(device, patch=128):
     import torch
     import gridnext_amd as ga
@@ -591,21 +607,11 @@ def worker_main(args):
                 if kind in tr:
                     kern[kind]["traffic"] = tr[kind]["hbm_bytes_per_launch"]
                     kern[kind]["traffic_source"] = "profiles/%s (PMC, separate passes)" % os.path.basename(tfile)
-        if getattr(f_img, 'winograd', False) and args.mfma == 'f32' and not args.train_f:
+        if getattr(f_img, 'winograd', False) and args.mfma == 'f32':
             # The Winograd launches execute 2/3 of the direct-convolution multiply-adds: `achieved` / `frac` are the
             # EXECUTED matrix FLOPs against the matrix peak (a fraction of peak must be work the pipe did); the
             # direct-convolution credit (the algorithmic figure of SURVEY 8d) is kept under `direct_conv_*`.
-            k3 = kern['conv3x3']
-            ex = conv3x3_executed_flops_per_spot(args.patch) * H * W * args.steps
-            k3["kernel"] = "conv3x3_wino_kernel (S >= 8) + conv3x3_dma_kernel (S = 4)"
-            k3["algorithm"] = ("Winograd F(2,3) along x for maps of 8 x 8 and up: 2/3 of the direct multiply-adds. "
-                               "`achieved`/`frac` = executed matrix FLOPs; `direct_conv_*` = the same time credited with "
-                               "direct-convolution FLOPs (can exceed the peak, not a fraction of it)")
-            k3["direct_conv_tflops"] = k3["achieved"]
-            k3["direct_conv_flops_per_launch_avg"] = k3["flops_per_launch_avg"]
-            k3["achieved"] = ex / (k3["ms_per_step"] * args.steps * 1e-3) / 1e12
-            k3["frac"] = k3["achieved"] / PEAK_F32_MATRIX_TFLOPS
-            k3["flops_per_launch_avg"] = ex / max(k3["launches"], 1)
+            winograd_credit(kern['conv3x3'], args.patch, args.steps)
         if args.mfma == 'f16':
             # config 5's kernels multiply 16x faster than they can be fed: they are priced against HBM (algorithmic bytes
             # per launch / launch time); the fp32-FLOP figure stays in `matrix_tflops` for reference
@@ -652,6 +658,8 @@ def worker_main(args):
                    "final_loss": loss_tf}
             if probe_tf:
                 kt = kernel_table(probe_tf, args.patch, args.series_steps)
+                if getattr(f_img, 'winograd', False) and 'conv3x3' in kt:
+                    winograd_credit(kt['conv3x3'], args.patch, args.series_steps)
                 order = sorted(kt, key=lambda k: -kt[k]["ms_per_step"])
                 ser["roofline"] = dict(kt[order[0]])
                 ser["roofline"]["other_kernels"] = {k: {f: kt[k][f] for f in ("kernel", "achieved", "frac", "ms_per_step",

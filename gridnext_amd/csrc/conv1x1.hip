@@ -646,15 +646,37 @@ __global__ __launch_bounds__(256) void slab_fold_kernel(const float* __restrict_
         part[((long)blockIdx.y * 2 + 1) * C + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
     }
 }
-// out[c] (+)= sum over the R rows of part[.][q][c], fixed order
-__global__ void slab_finish_kernel(const float* __restrict__ part, int R, int C, float* dbeta, float* dgamma,
-                                   int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] (+)= sum over the R rows of part[.][q][c], fixed order: 64 columns x 8 row lanes per workgroup, a lane sums its
+// contiguous eighth in index order, the eighths are combined in index order (one lane per column took 34 us per call - 256
+// dependent loads - 58 times a step)
+__global__ __launch_bounds__(512) void slab_finish_kernel(const float* __restrict__ part, int R, int C, float* dbeta,
+                                                          float* dgamma, int accumulate) {
+    __shared__ float red[2][8][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int per = (R + 7) / 8, b0 = rl * per, b1 = b0 + per < R ? b0 + per : R;
     float s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < R; ++b) { s1 += part[((long)b * 2 + 0) * C + c]; s2 += part[((long)b * 2 + 1) * C + c]; }
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + s1 : s1;
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + s2 : s2;
+    if (c < C) {
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float v1[8], v2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v1[u] = part[((long)(b + u) * 2 + 0) * C + c]; v2[u] = part[((long)(b + u) * 2 + 1) * C + c]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s1 += v1[u]; s2 += v2[u]; }
+        }
+        for (; b < b1; ++b) { s1 += part[((long)b * 2 + 0) * C + c]; s2 += part[((long)b * 2 + 1) * C + c]; }
+    }
+    red[0][rl][cl] = s1;
+    red[1][rl][cl] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { t1 += red[0][u][cl]; t2 += red[1][u][cl]; }
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + t1 : t1;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + t2 : t2;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ conv1x1, LDS-clamp form
@@ -1096,7 +1118,7 @@ GNX_EXPORT int gnx_conv1x1_dgrad_bnrelu_bwd(const float* dY, long lddy, const fl
                                                                            nullptr, bn);
     if (dgamma || dbeta) {
         slab_fold_kernel<<<dim3(gnx_cdiv(N, 64), C1_DGBN_R), 256, 0, stream>>>(slab, 2 * (M / 128), N, C1_DGBN_R, part);
-        slab_finish_kernel<<<gnx_cdiv(N, 64), 64, 0, stream>>>(part, C1_DGBN_R, N, dbeta, dgamma, accumulate);
+        slab_finish_kernel<<<gnx_cdiv(N, 64), 512, 0, stream>>>(part, C1_DGBN_R, N, dbeta, dgamma, accumulate);
     }
     return gnx_launch_status();
 }

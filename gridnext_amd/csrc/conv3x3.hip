@@ -559,20 +559,21 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_dma_kernel(const float* __res
     }
 }
 
-// slab[nblk][2][C] -> dbeta[c] (+)= sum_b slab[b][0][c], dgamma[c] (+)= sum_b slab[b][1][c].  64 columns per workgroup, four
-// row lanes per column each summing a contiguous quarter of the slabs in index order (16 loads in flight), combined in a
-// fixed order: deterministic.
-__global__ __launch_bounds__(256) void c3_adj_reduce_kernel(const float* __restrict__ slab, int nblk, int C,
-                                                            float* __restrict__ dbeta, float* __restrict__ dgamma,
-                                                            int accumulate) {
-    __shared__ float part[4][64];
-    const int cl = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
+// slab[nblk][2][C] -> dbeta[c] (+)= sum_b slab[b][0][c], dgamma[c] (+)= sum_b slab[b][1][c].  64 columns per workgroup, 16
+// row lanes per column each summing a contiguous sixteenth of the slabs in index order (16 loads in flight), combined in a
+// fixed order: deterministic.  (Four row lanes took 17 us per call - a chain of 64 dependent batches - 58 times a step.)
+constexpr int C3_ADJ_LANES = 16;
+__global__ __launch_bounds__(64 * C3_ADJ_LANES) void c3_adj_reduce_kernel(const float* __restrict__ slab, int nblk, int C,
+                                                                          float* __restrict__ dbeta,
+                                                                          float* __restrict__ dgamma, int accumulate) {
+    __shared__ float part[C3_ADJ_LANES][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + cl;                  // over 2 C values: q = idx / C, c = idx % C
     float s0 = 0.f;
     if (idx < 2 * C) {
         const int q = idx / C, c = idx - q * C;
-        const int per = (nblk + 3) / 4;
-        int b = lane4 * per;
+        const int per = (nblk + C3_ADJ_LANES - 1) / C3_ADJ_LANES;
+        int b = rl * per;
         const int be = b + per < nblk ? b + per : nblk;
         for (; b + 16 <= be; b += 16) {
             float v[16];
@@ -583,11 +584,13 @@ __global__ __launch_bounds__(256) void c3_adj_reduce_kernel(const float* __restr
         }
         for (; b < be; ++b) s0 += slab[((long)b * 2 + q) * C + c];
     }
-    part[lane4][cl] = s0;
+    part[rl][cl] = s0;
     __syncthreads();
-    if (lane4 == 0 && idx < 2 * C) {
+    if (rl == 0 && idx < 2 * C) {
         const int q = idx / C, c = idx - q * C;
-        const float tot = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+        float tot = 0.f;
+#pragma unroll
+        for (int u = 0; u < C3_ADJ_LANES; ++u) tot += part[u][cl];
         float* dst = q == 0 ? dbeta : dgamma;
         if (dst) dst[c] = accumulate ? dst[c] + tot : tot;
     }
@@ -915,7 +918,7 @@ GNX_EXPORT int gnx_conv3x3_dgrad_bnrelu_bwd(const float* dY, long lddy, const fl
     }
 #undef GNX_DMAA
     if (dgamma || dbeta)
-        c3_adj_reduce_kernel<<<gnx_cdiv(2 * N, 64), 256, 0, stream>>>(workspace, nblk, N, dbeta, dgamma, accumulate);
+        c3_adj_reduce_kernel<<<gnx_cdiv(2 * N, 64), 64 * C3_ADJ_LANES, 0, stream>>>(workspace, nblk, N, dbeta, dgamma, accumulate);
     return gnx_launch_status();
 }
 

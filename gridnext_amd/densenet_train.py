@@ -101,6 +101,7 @@ class _DenseNetFn(Function):
             tape.stem_out, tape.stats0 = stem_out, s0
         tape.layers = []          # per block: list of (bott, stats1, stats2, bottleneck stored activated?)
         act_ok = (not training) and gammas_nonzero(model)
+        w2u = model._winograd_conv2() if (act_ok and model.winograd and model.mfma == 'f32') else None
         tape.trans = []           # per block: stats of the transition BN (or None)
         for bi, ((c_in, layers, trans, c_total), s) in enumerate(zip(model._blocks, sizes)):
             buf = bufs[bi]
@@ -122,14 +123,23 @@ class _DenseNetFn(Function):
                     L.call('gnx_conv1x1_bnrelu_act', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid, M,
                            mid, cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s2[0]), L.ptr(s2[1]), st)
                     model._probe_mark('conv1x1', t0)
-                    # the direct form, not Winograd: a rounding-level change of a pre-activation that sits exactly at 0
-                    # flips a ReLU mask of the next layer and with it a visible part of a gradient (measured on the
-                    # closed-form test net: 1 % of one norm1.bias gradient); the frozen eval forward has no such cliff
-                    w2 = torch.empty((9, g, mid), device=dev, dtype=F32)
-                    L.call('gnx_repack_conv3x3', L.ptr(w2c), L.ptr(w2), g, mid, st)
+                    # conv2 on the ready operand as in the eval forward: Winograd F(2,3) along x for maps of 8 x 8 and up
+                    # (`model.winograd`), the direct form otherwise.  The backward is the adjoint of whichever ran (masks
+                    # and x_hat come from the stored activations).  Against a direct-form reference the outputs differ at
+                    # rounding level; only a pre-activation that a reference computes as EXACTLY 0 (closed-form nets with
+                    # integer weights) can flip a ReLU mask of the next layer - such tests set `model.winograd = False`.
+                    rc = L.ERR_UNSUPPORTED
                     t0 = model._probe_begin()
-                    L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2), _cols(buf, cin), c_total, M, g, mid, s,
-                           None, None, st)
+                    if w2u is not None and s >= 8:
+                        rc = L.query('gnx_conv3x3_winograd', L.ptr(bott), mid, L.ptr(w2u[layer]), _cols(buf, cin), c_total, M,
+                                     g, mid, s, st)
+                        if rc not in (0, L.ERR_UNSUPPORTED):
+                            raise RuntimeError("gnx_conv3x3_winograd failed (%d)" % rc)
+                    if rc == L.ERR_UNSUPPORTED:
+                        w2 = torch.empty((9, g, mid), device=dev, dtype=F32)
+                        L.call('gnx_repack_conv3x3', L.ptr(w2c), L.ptr(w2), g, mid, st)
+                        L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2), _cols(buf, cin), c_total, M, g, mid, s,
+                               None, None, st)
                     model._probe_mark('conv3x3', t0)
                 else:
                     L.call('gnx_conv1x1_bnrelu', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid, M, mid,

