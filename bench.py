@@ -320,7 +320,7 @@ def from_host_series(args, model, optimizer, criterion, device, rank, world):
     from gridnext_amd import distributed as gdist
     from gridnext_amd import prefetch
     from gridnext_amd import training as gtrain
-    steps, warmup = args.steps, max(args.warmup, 2)
+    steps, warmup = args.steps, max(args.warmup, 3)
     host = []
     for a in range(args.arrays):
         gen = torch.Generator().manual_seed(5000 + 1000 * rank + a)

@@ -72,6 +72,8 @@ SIGNATURES = {
     'gnx_conv0_wgrad': (_I, [_P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'gnx_softmax_rows': (_I, [_P, _L, _L, _I, _P, _L, _P, _P]),
     'gnx_gemm_f32': (_I, [_P, _L, _I, _P, _L, _I, _P, _P, _L, _L, _L, _L, _I, _P]),
+    'gnx_gemm_f32_workspace': (_L, [_L, _L, _L]),
+    'gnx_gemm_f32_ws': (_I, [_P, _L, _I, _P, _L, _I, _P, _P, _L, _L, _L, _L, _I, _P, _P]),
 }
 
 _lib = None

@@ -217,6 +217,122 @@ __global__ __launch_bounds__(256) void hexconv_bwd_weight_kernel(
     if (h == 0 && i < O) dst[7 * O * I + i] = bsum;
 }
 
+
+// ---- round 2: forward and data gradient on the matrix cores.  The scalar kernels above run 7 * I FMAs per output out of LDS
+// (17 us per launch on a 78 x 64 grid - five forward and four data-gradient launches were a sixth of a count-only step).
+// Both are, per tap, a [positions x CK] x [CK x CN] product (forward: contraction CK = input channels, data gradient:
+// CK = output channels and the neighbour map transposed): a workgroup takes 32 positions x 32 output columns, its four waves
+// split the seven taps (0,4 | 1,5 | 2,6 | 3), each wave multiplying with v_mfma_f32_32x32x2_f32 straight from global memory
+// - a lane loads 16 B of its position's neighbour row (channels 8 g + 4 h ..) and the four matching weights (L2) - and the
+// four partial 32 x 32 tiles are summed through LDS in a fixed order.  No operand staging, one barrier.  NG = CK / 8.
+template <int NG, bool BWD>
+__global__ __launch_bounds__(256) void hexconv_mfma_kernel(
+    const float* __restrict__ in, const float* __restrict__ k0, const float* __restrict__ k1,
+    const float* __restrict__ bias, float* __restrict__ out, HexGeom g, int IF, int OF) {
+    __shared__ float red[4][16][64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
+    const int npos = g.B * g.H * g.W;
+    const int base = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int CN = BWD ? IF : OF, LDI = BWD ? OF : IF, LDO = BWD ? IF : OF;      // output columns; row strides
+    const int pos = base + i;
+    const int xx = pos % g.W, yy = (pos / g.W) % g.H, b = pos / (g.W * g.H);
+    const int col = n0 + i;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int tap = wave + 4 * tt;
+        if (tap >= 7) break;                                   // wave-uniform
+        const int nb = pos < npos ? (BWD ? g.src(b, yy, xx, tap) : g.nbr(b, yy, xx, tap)) : -1;
+        float4 a[NG];
+        float w[NG][4];
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            a[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nb >= 0) a[q] = *reinterpret_cast<const float4*>(in + (size_t)nb * LDI + 8 * q + 4 * h);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = 8 * q + 4 * h + c;               // contraction channel
+                w[q][c] = col < CN ? (BWD ? load_w(k0, k1, IF, tap, k, col) : load_w(k0, k1, IF, tap, col, k)) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, w[q][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, w[q][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, w[q][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, w[q][3], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    const float bo = (!BWD && bias && col < CN) ? bias[col] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = wave + 4 * j;
+        const float v = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+        const int p = base + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (p < npos && col < CN) out[(size_t)p * LDO + col] = v + bo;
+    }
+}
+
+// ---- round 2, second form of the weight gradient: no staging at all.  A workgroup takes 32 positions; wave w owns taps
+// w and w + 4 for ALL of them (so the waves' results are disjoint: one slab per workgroup, a quarter of the slab traffic
+// and of the reduce) and feeds the MFMAs straight from global memory - lane (h, c): dy[position 2 pp + h][o = c] and
+// x[neighbour_t(position)][ch = c], both 128-B coalesced rows.  (The first form staged 64 x 7 neighbour rows element by
+// element, a division and a neighbour computation per float: 35 us per launch.)
+constexpr int HW2_POS = 32;
+__global__ __launch_bounds__(256) void hexconv_bwd_weight2_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+    HexGeom g, int I, int O, int IF, int OF, int i0, int o0) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, c = lane & 31;
+    const int npos = g.B * g.H * g.W;
+    const int base = blockIdx.x * HW2_POS;
+    const int ta = wave, tb = wave + 4;                         // tb == 7: this wave has one tap only
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float bsum = 0.f;
+#pragma unroll 4
+    for (int pp = 0; pp < HW2_POS / 2; ++pp) {
+        const int pos = base + 2 * pp + h;
+        float a = 0.f, b0 = 0.f, b1 = 0.f;
+        if (pos < npos) {
+            const int xx = pos % g.W, yy = (pos / g.W) % g.H, b = pos / (g.W * g.H);
+            if (c < O) a = dy[(size_t)pos * OF + o0 + c];
+            if (c < I) {
+                const int na = g.nbr(b, yy, xx, ta);
+                if (na >= 0) b0 = x[(size_t)na * IF + i0 + c];
+                if (tb < 7) {
+                    const int nb = g.nbr(b, yy, xx, tb);
+                    if (nb >= 0) b1 = x[(size_t)nb * IF + i0 + c];
+                }
+            }
+        }
+        bsum += a;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+        if (tb < 7) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    }
+    const int nout = 7 * O * I + O;
+    float* dst = partial + (size_t)blockIdx.x * nout;
+    if (c < I) {                                               // D[row = o][col = ch = c]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (o < O) {
+                dst[(ta * O + o) * I + c] = acc0[r];
+                if (tb < 7) dst[(tb * O + o) * I + c] = acc1[r];
+            }
+        }
+    }
+    if (wave == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);                      // the two position halves of output channel c
+        if (h == 0 && c < O) dst[7 * O * I + c] = bsum;
+    }
+}
+
 // fixed-order sum of the partial slabs, scattered into hexagdly's parameter layouts (accumulating or not)
 __global__ void hexconv_reduce_weight_kernel(const float* __restrict__ partial, int nblk, int I, int O,
                                              float* __restrict__ dk0, float* __restrict__ dk1,
@@ -253,6 +369,14 @@ int pow2_at_least(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 constexpr int HEX_CHUNK = 64;      // channels per launch, forward and data gradient (7 * 64 * 64 weights = 112 KB of LDS)
 constexpr int HEX_WCHUNK = 32;     // channels per launch, weight gradient (one 32 x 32 MFMA tile per tap)
 
+// the MFMA forward / data-gradient form takes contraction widths 8, 16, 32, 64 on 16-B aligned rows (GNX_HEX_R1 keeps the
+// scalar kernels: A/B timing and a second implementation for the tests)
+bool hex_mfma_ok(int CK, const float* in, long npos) {
+    static const bool r1 = getenv("GNX_HEX_R1") != nullptr;
+    return !r1 && (CK == 8 || CK == 16 || CK == 32 || CK == 64) && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
+           npos < (1L << 30);
+}
+
 }  // namespace
 
 GNX_EXPORT int gnx_hexconv_fwd(const float* x, const float* kernel0, const float* kernel1, const float* bias,
@@ -261,6 +385,14 @@ GNX_EXPORT int gnx_hexconv_fwd(const float* x, const float* kernel0, const float
     const long npos = (long)B * H * W;
     if (npos == 0) return GNX_OK;
     HexGeom g{B, H, W, mode};
+    if (hex_mfma_ok(I, x, npos)) {
+        dim3 grid(gnx_cdiv(npos, 32), gnx_cdiv(O, 32));
+        if (I == 8) hexconv_mfma_kernel<1, false><<<grid, 256, 0, stream>>>(x, kernel0, kernel1, bias, y, g, I, O);
+        else if (I == 16) hexconv_mfma_kernel<2, false><<<grid, 256, 0, stream>>>(x, kernel0, kernel1, bias, y, g, I, O);
+        else if (I == 32) hexconv_mfma_kernel<4, false><<<grid, 256, 0, stream>>>(x, kernel0, kernel1, bias, y, g, I, O);
+        else hexconv_mfma_kernel<8, false><<<grid, 256, 0, stream>>>(x, kernel0, kernel1, bias, y, g, I, O);
+        return gnx_launch_status();
+    }
     for (int o0 = 0; o0 < O; o0 += HEX_CHUNK)
         for (int i0 = 0; i0 < I; i0 += HEX_CHUNK) {         // input chunks in order: chunk k continues chunk k-1's sums
             const int oc = O - o0 < HEX_CHUNK ? O - o0 : HEX_CHUNK, ic = I - i0 < HEX_CHUNK ? I - i0 : HEX_CHUNK;
@@ -276,6 +408,14 @@ GNX_EXPORT int gnx_hexconv_bwd_data(const float* dy, const float* kernel0, const
     const long npos = (long)B * H * W;
     if (npos == 0) return GNX_OK;
     HexGeom g{B, H, W, mode};
+    if (hex_mfma_ok(O, dy, npos)) {
+        dim3 grid(gnx_cdiv(npos, 32), gnx_cdiv(I, 32));
+        if (O == 8) hexconv_mfma_kernel<1, true><<<grid, 256, 0, stream>>>(dy, kernel0, kernel1, nullptr, dx, g, I, O);
+        else if (O == 16) hexconv_mfma_kernel<2, true><<<grid, 256, 0, stream>>>(dy, kernel0, kernel1, nullptr, dx, g, I, O);
+        else if (O == 32) hexconv_mfma_kernel<4, true><<<grid, 256, 0, stream>>>(dy, kernel0, kernel1, nullptr, dx, g, I, O);
+        else hexconv_mfma_kernel<8, true><<<grid, 256, 0, stream>>>(dy, kernel0, kernel1, nullptr, dx, g, I, O);
+        return gnx_launch_status();
+    }
     for (int i0 = 0; i0 < I; i0 += HEX_CHUNK)
         for (int o0 = 0; o0 < O; o0 += HEX_CHUNK) {
             const int oc = O - o0 < HEX_CHUNK ? O - o0 : HEX_CHUNK, ic = I - i0 < HEX_CHUNK ? I - i0 : HEX_CHUNK;
@@ -298,16 +438,20 @@ GNX_EXPORT int gnx_hexconv_bwd_weight(const float* x, const float* dy, float* dk
     if (!x || !dy || !dkernel0 || !dkernel1 || !workspace || I <= 0 || O <= 0 || H <= 0 || W <= 0 || B < 0)
         return GNX_ERR_BAD_ARG;
     const long npos = (long)B * H * W;
-    const int nblk = gnx_cdiv(npos, HW_POS);
+    static const bool r1 = getenv("GNX_HEX_R1") != nullptr;
+    const int nblk = r1 ? gnx_cdiv(npos, HW_POS) : gnx_cdiv(npos, HW2_POS);
     HexGeom g{B, H, W, mode};
     // one (input chunk, output chunk) pair after the other on the stream, each through the same workspace
     for (int o0 = 0; o0 < O; o0 += HEX_WCHUNK)
         for (int i0 = 0; i0 < I; i0 += HEX_WCHUNK) {
             const int oc = O - o0 < HEX_WCHUNK ? O - o0 : HEX_WCHUNK, ic = I - i0 < HEX_WCHUNK ? I - i0 : HEX_WCHUNK;
             const int nout = 7 * oc * ic + oc;
-            if (nblk > 0) hexconv_bwd_weight_kernel<<<nblk, 256, 0, stream>>>(x, dy, workspace, g, ic, oc, I, O, i0, o0);
-            hexconv_reduce_weight_kernel<<<gnx_cdiv(nout, 256), 256, 0, stream>>>(workspace, 4 * nblk, ic, oc, dkernel0, dkernel1,
-                                                                                  dbias, accumulate, I, i0, o0);
+            if (nblk > 0) {
+                if (r1) hexconv_bwd_weight_kernel<<<nblk, 256, 0, stream>>>(x, dy, workspace, g, ic, oc, I, O, i0, o0);
+                else hexconv_bwd_weight2_kernel<<<nblk, 256, 0, stream>>>(x, dy, workspace, g, ic, oc, I, O, i0, o0);
+            }
+            hexconv_reduce_weight_kernel<<<gnx_cdiv(nout, 64), 64, 0, stream>>>(workspace, r1 ? 4 * nblk : nblk, ic, oc, dkernel0,
+                                                                                dkernel1, dbias, accumulate, I, i0, o0);
         }
     return gnx_launch_status();
 }

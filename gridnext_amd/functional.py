@@ -159,17 +159,21 @@ class _Linear(Function):
             assert Kx == K
             M = Bn * S
             y = torch.empty((M, N), device=dev, dtype=F32)
+            nws = L.query('gnx_gemm_f32_workspace', S, N, K)
+            ws = torch.empty(nws, device=dev, dtype=F32) if nws else None
             for b in range(Bn):
-                L.call('gnx_gemm_f32', L.ptr(x[b]), S, 1, L.ptr(w), K, 0, L.ptr(bias), L.ptr(y[b * S:]), N,
-                       S, N, K, 0, L.stream())
+                L.call('gnx_gemm_f32_ws', L.ptr(x[b]), S, 1, L.ptr(w), K, 0, L.ptr(bias), L.ptr(y[b * S:]), N,
+                       S, N, K, 0, L.ptr(ws), L.stream())
             ctx.ld = S
         else:
             x, ld = _rows(x)
             M = x.shape[0]
             assert x.shape[1] == K
             y = torch.empty((M, N), device=dev, dtype=F32)
-            L.call('gnx_gemm_f32', L.ptr(x), ld, 0, L.ptr(w), K, 0, L.ptr(bias), L.ptr(y), N, M, N, K, 0,
-                   L.stream())
+            nws = L.query('gnx_gemm_f32_workspace', M, N, K)
+            ws = torch.empty(nws, device=dev, dtype=F32) if nws else None
+            L.call('gnx_gemm_f32_ws', L.ptr(x), ld, 0, L.ptr(w), K, 0, L.ptr(bias), L.ptr(y), N, M, N, K, 0,
+                   L.ptr(ws), L.stream())
             ctx.ld = ld
         ctx.save_for_backward(x, w)
         ctx.kmajor, ctx.has_bias = bool(kmajor), bias is not None

@@ -95,6 +95,12 @@ int gnx_softmax_rows(const float* logits, long ld, long M, int C, float* probs, 
  * the permute+copy of gridnet_models.py:167-169); b_kmajor: B[k*ldb+n]. */
 int gnx_gemm_f32(const float* A, long lda, int a_kmajor, const float* B, long ldb, int b_kmajor, const float* bias,
                  float* C, long ldc, long M, long N, long K, int accumulate, gnx_stream_t stream);
+/* The same product given `workspace` (gnx_gemm_f32_workspace(M, N, K) floats; NULL allowed when that is 0): the
+ * 2000 -> 500 layer over a whole grid (gridnet_models.py:83-86 runs f on all 4992 B positions) then splits K over
+ * workgroups and sums the partial tiles in a fixed order. */
+long gnx_gemm_f32_workspace(long M, long N, long K);
+int gnx_gemm_f32_ws(const float* A, long lda, int a_kmajor, const float* B, long ldb, int b_kmajor, const float* bias,
+                    float* C, long ldc, long M, long N, long K, int accumulate, float* workspace, gnx_stream_t stream);
 
 /* ---- DenseNet-BC image spot classifier, forward (gridnext/densenet.py) ------------------------------------------------
  * conv1x1_bnrelu : _DenseLayer norm1->relu1->conv1 (:35-40) and _Transition norm->relu->conv->pool (:47-54, pool=1)

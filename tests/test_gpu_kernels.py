@@ -213,6 +213,29 @@ def test_linear_count_grid_in_place(GF):
     close(wd.grad, wr.grad, rtol=2e-3)
 
 
+@pytest.mark.parametrize("kmajor,S,K,N", [(True, 4992, 2000, 500), (True, 2308, 516, 260), (False, 2500, 1000, 384)])
+def test_linear_whole_grid_split_k_form(GF, kmajor, S, K, N):
+    """The first Linear of the count MLP over a whole grid (gemm_f32.hip, 256 x 128 tiles, K split over workgroups,
+    slabs summed in a fixed order) against fp64: ragged tiles in every dimension, bias, twice the same bits."""
+    from gridnext_amd import _lib as L
+    assert L.query('gnx_gemm_f32_workspace', S, N, K) > 0
+    g = torch.Generator().manual_seed(S + K + N)
+    w, b = torch.randn(N, K, generator=g) * 0.05, torch.randn(N, generator=g)
+    if kmajor:
+        x = torch.randint(0, 10, (1, K, S), generator=g).float()
+        rows = x[0].t()
+    else:
+        x = torch.randn(S, K, generator=g)
+        rows = x
+    ref = rows.double() @ w.double().t() + b.double()
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    y1 = GF.linear(xd, wd, bd, kmajor=kmajor)
+    y2 = GF.linear(xd, wd, bd, kmajor=kmajor)
+    assert torch.equal(y1, y2)
+    err = (y1.double().cpu() - ref).abs().max().item()
+    assert err <= 2e-6 * K ** 0.5 * ref.abs().max().item(), err
+
+
 def test_count_mlp_pipeline_vs_reference_fixture(GF):
     from gridnext_amd.synthetic import count_mlp
     g = load_golden('mlp_count')

@@ -90,7 +90,7 @@ if __name__ == '__main__':
     if args.only in ('', 'c1'):
         out.append(c1(3))
     if args.only in ('', 'c3'):
-        out.append(c3(10))
+        out.append(c3(40))        # the tutorials train g for 50-100 epochs; 10 would make a fifth of the call warm-up + graph capture
     if args.only in ('', 'c2'):
         out.append(c2(2048, 1))
     for r in out:

@@ -37,12 +37,15 @@ def main():
     ap.add_argument('--const', action='store_true', help='constant operands (low bit toggling) instead of randn')
     ap.add_argument('--clamp', action='store_true', help='conv1x1 in its folded LDS-clamp form (gnx_conv1x1_clamped_act)')
     ap.add_argument('--wino', action='store_true', help='conv3x3 in its Winograd F(2,3) form (prologue-free operand)')
+    ap.add_argument('--dense', action='store_true', help='operand rows exactly K wide (lda = K) instead of the block buffer stride')
     args = ap.parse_args()
     n = args.spots
     st = L.stream()
     torch.manual_seed(0)
     shapes = [(32, 64, 256), (32, 224, 256), (16, 128, 512), (16, 480, 512), (8, 256, 1024), (8, 992, 1024),
               (4, 512, 1024), (4, 992, 1024)]
+    if args.dense:
+        shapes = [(S, K, K) for S, K, _ in shapes]
     if args.only in ('', 'conv1x1'):
         for S, K, ct in shapes:
             M = n * S * S
@@ -143,8 +146,11 @@ def main():
         Wt = W.t().contiguous()
         bias = torch.randn(N, device=DEV)
         C = torch.empty(M, N, device=DEV)
+        nws = L.query('gnx_gemm_f32_workspace', M, N, K)
+        ws = torch.empty(nws, device=DEV) if nws else None
+        print('gemm workspace floats', nws)
         for bk, Bm, ldb in ((0, W, K), (1, Wt, N)):
-            ms = timeit(lambda: L.call('gnx_gemm_f32', L.ptr(A), M, 1, L.ptr(Bm), ldb, bk, L.ptr(bias), L.ptr(C), N, M, N, K, 0, st),
+            ms = timeit(lambda: L.call('gnx_gemm_f32_ws', L.ptr(A), M, 1, L.ptr(Bm), ldb, bk, L.ptr(bias), L.ptr(C), N, M, N, K, 0, L.ptr(ws), st),
                         args.reps)
             print("gemm kmajor-A M=%d N=%d K=%d b_kmajor=%d  %8.3f ms  %6.1f TFLOP/s" % (M, N, K, bk, ms, 2.0 * M * N * K / ms / 1e9))
     if args.only in ('', 'stem'):
