@@ -68,6 +68,7 @@ SIGNATURES = {
     'gnx_maxpool_bwd': (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
     'gnx_bnrelu_maxpool_argmax': (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P, _P]),
     'gnx_maxpool_bwd_argmax': (_I, [_P, _P, _L, _P, _L, _L, _I, _I, _I, _P]),
+    'gnx_maxpool_bwd_argmax_bnrelu': (_I, [_P, _P, _L, _P, _L, _P, _P, _L, _L, _I, _I, _I, _P]),
     'gnx_conv0_wgrad_workspace': (_L, [_L, _I, _I, _I, _I, _I, _I, _I]),
     'gnx_conv0_wgrad': (_I, [_P, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'gnx_softmax_rows': (_I, [_P, _L, _L, _I, _P, _L, _P, _P]),

@@ -846,10 +846,17 @@ __global__ __launch_bounds__(256) void maxpool_bwd_vec4_kernel(const float* __re
 // The adjoint by recorded window index (gnx_bnrelu_maxpool_argmax): element (y, x) receives window (oy, ox)'s gradient iff
 // that window's recorded maximum is this element.  No activation is recomputed, the conv0 map is not read (5.2 GB per
 // 128-px array), ties go where torch sends them.  4 channels per thread.
+// BN (template): also the norm0 -> relu0 adjoint for running statistics - dAct becomes the gradient of the conv0 map itself,
+//   dPre[e] = scale[c] * sum over the windows whose maximum is e of dOut[w] * [pooled[w] > 0]
+// (pooled[w] = relu(bn(pre[e])) for exactly those windows, so the ReLU mask is read off the POOLED map: a quarter of the
+// size, already in the block buffer - the 5.2 GB conv0 map of a 128-px array is neither kept nor re-read).
+template <bool BN>
 __global__ __launch_bounds__(256) void maxpool_bwd_argmax_kernel(const unsigned char* __restrict__ amax,
                                                                  const float* __restrict__ dOut, long lddo,
                                                                  float* __restrict__ dAct, long lda, long Min, int C4,
-                                                                 int Hi, int Wi, int Ho, int Wo) {
+                                                                 int Hi, int Wi, int Ho, int Wo,
+                                                                 const float* __restrict__ pooled, long ldp,
+                                                                 const float* __restrict__ scale) {
     const long total = Min * C4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long r = idx / C4;
@@ -865,12 +872,20 @@ __global__ __launch_bounds__(256) void maxpool_bwd_argmax_kernel(const unsigned 
                 const long o = (img * Ho + oy) * Wo + ox;
                 const unsigned li = 3 * (y - 2 * oy + 1) + (x - 2 * ox + 1);
                 const unsigned am = *reinterpret_cast<const unsigned*>(amax + o * (4L * C4) + c);
-                const float4 d = *reinterpret_cast<const float4*>(dOut + o * lddo + c);
+                float4 d = *reinterpret_cast<const float4*>(dOut + o * lddo + c);
+                if (BN) {
+                    const float4 a = *reinterpret_cast<const float4*>(pooled + o * ldp + c);
+                    d = make_float4(a.x > 0.f ? d.x : 0.f, a.y > 0.f ? d.y : 0.f, a.z > 0.f ? d.z : 0.f, a.w > 0.f ? d.w : 0.f);
+                }
                 if ((am & 0xffu) == li) g.x += d.x;
                 if (((am >> 8) & 0xffu) == li) g.y += d.y;
                 if (((am >> 16) & 0xffu) == li) g.z += d.z;
                 if ((am >> 24) == li) g.w += d.w;
             }
+        }
+        if (BN) {
+            const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+            g = make_float4(sc.x * g.x, sc.y * g.y, sc.z * g.z, sc.w * g.w);
         }
         *reinterpret_cast<float4*>(dAct + r * lda + c) = g;
     }
@@ -1202,8 +1217,27 @@ GNX_EXPORT int gnx_maxpool_bwd_argmax(const unsigned char* argmax, const float* 
         (reinterpret_cast<uintptr_t>(argmax) & 3) != 0)
         return GNX_ERR_UNSUPPORTED;
     const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
-    maxpool_bwd_argmax_kernel<<<ew_grid(imgs * Hi * Wi * (C / 4)), 256, 0, stream>>>(argmax, dOut, lddo, dAct, lda,
-                                                                                    imgs * Hi * Wi, C / 4, Hi, Wi, Ho, Wo);
+    maxpool_bwd_argmax_kernel<false><<<ew_grid(imgs * Hi * Wi * (C / 4)), 256, 0, stream>>>(
+        argmax, dOut, lddo, dAct, lda, imgs * Hi * Wi, C / 4, Hi, Wi, Ho, Wo, nullptr, 0, nullptr);
+    return gnx_launch_status();
+}
+
+// The same adjoint carried through norm0 -> relu0 with RUNNING statistics (training.py:126 keeps f in eval mode): dPre
+// [imgs*Hi*Wi][C] is the gradient of the conv0 map; `pooled` [imgs*Ho*Wo][C] (ldp) is the pooled ACTIVATED output of the
+// forward (the first C columns of block 1's buffer), `scale` the folded gamma / sqrt(var + eps).  The affine gradients of
+// norm0 come from gnx_bn_relu_bwd(relu = 2, dx = NULL) on (dOut, pooled).  4 | C, 16-B aligned operands.
+GNX_EXPORT int gnx_maxpool_bwd_argmax_bnrelu(const unsigned char* argmax, const float* dOut, long lddo, const float* pooled,
+                                             long ldp, const float* scale, float* dPre, long lda, long imgs, int C, int Hi,
+                                             int Wi, hipStream_t stream) {
+    if (!argmax || !dOut || !pooled || !scale || !dPre || imgs <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || lddo < C || lda < C ||
+        ldp < C)
+        return GNX_ERR_BAD_ARG;
+    if (C % 4 != 0 || lddo % 4 != 0 || lda % 4 != 0 || ldp % 4 != 0 || !al16b(dOut) || !al16b(dPre) || !al16b(pooled) ||
+        !al16b(scale) || (reinterpret_cast<uintptr_t>(argmax) & 3) != 0)
+        return GNX_ERR_UNSUPPORTED;
+    const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+    maxpool_bwd_argmax_kernel<true><<<ew_grid(imgs * Hi * Wi * (C / 4)), 256, 0, stream>>>(
+        argmax, dOut, lddo, dPre, lda, imgs * Hi * Wi, C / 4, Hi, Wi, Ho, Wo, pooled, ldp, scale);
     return gnx_launch_status();
 }
 

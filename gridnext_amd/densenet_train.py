@@ -46,10 +46,12 @@ def _bn(model_bn, X_ptr, ld, M, training, dev, st):
 
 
 def gammas_nonzero(model):
-    """True when no norm2 weight of the network is exactly zero (the activated-bottleneck form of the training forward
-    cannot recover x_hat where gamma == 0).  One device reduction and one host read per change of those weights: the
+    """True when no norm2 (and norm0) weight of the network is exactly zero (the activated-bottleneck form of the training
+    forward cannot recover x_hat where gamma == 0).  One device reduction and one host read per change of those weights: the
     answer is cached with the model's other derived tensors, keyed on the weights' versions."""
     ws = [l.norm2.weight for _, ls, _, _ in model._blocks for l in ls]
+    if hasattr(model.features, 'norm0'):
+        ws.append(model.features.norm0.weight)       # pool0's adjoint reads norm0's mask and x_hat off the pooled map
     key = model._key(ws)
     hit = model._cache.get('g2nz')
     if hit is not None and hit[0] == key:
@@ -99,6 +101,8 @@ class _DenseNetFn(Function):
                 L.call('gnx_bnrelu_maxpool', L.ptr(stem_out), c0, L.ptr(bufs[0]), ld1, N, c0, hs, hs, L.ptr(s0[0]),
                        L.ptr(s0[1]), st)
             tape.stem_out, tape.stats0 = stem_out, s0
+            if tape.pool_idx is not None and not training and ld1 % 4 == 0 and gammas_nonzero(model):
+                tape.stem_out = None      # running statistics: the backward works from the pooled map (5.2 GB per 128-px array freed)
         tape.layers = []          # per block: list of (bott, stats1, stats2, bottleneck stored activated?)
         act_ok = (not training) and gammas_nonzero(model)
         w2u = model._winograd_conv2() if (act_ok and model.winograd and model.mfma == 'f32') else None
@@ -398,15 +402,31 @@ class _DenseNetFn(Function):
             need = want(conv0.weight) or want(model.features.norm0.weight) or want(model.features.norm0.bias)
             if need:
                 s0 = tape.stats0
-                dAct = torch.empty((M0, c0), device=dev, dtype=F32)
-                if tape.pool_idx is not None:
-                    L.call('gnx_maxpool_bwd_argmax', tape.pool_idx.data_ptr(), L.ptr(dbufs[0]), c_total1, L.ptr(dAct), c0,
-                           N, c0, hs, hs, st)
-                else:
-                    L.call('gnx_maxpool_bwd', L.ptr(tape.stem_out), c0, L.ptr(bufs[0]), c_total1, L.ptr(dbufs[0]), c_total1,
-                           L.ptr(dAct), c0, N, c0, hs, hs, L.ptr(s0[0]), L.ptr(s0[1]), st)
                 dS = torch.empty((M0, c0), device=dev, dtype=F32)
-                bn_bwd(model.features.norm0, s0, L.ptr(dAct), c0, L.ptr(tape.stem_out), c0, L.ptr(dS), c0, M0, c0, 0)
+                rc = L.ERR_UNSUPPORTED
+                if tape.pool_idx is not None and not training and gammas_nonzero(model):
+                    # running statistics: pool0's adjoint carries norm0 -> relu0 with it (mask and x_hat from the pooled
+                    # activated map in block 1's buffer), the conv0 map is not read again
+                    rc = L.query('gnx_maxpool_bwd_argmax_bnrelu', tape.pool_idx.data_ptr(), L.ptr(dbufs[0]), c_total1,
+                                 L.ptr(bufs[0]), c_total1, L.ptr(s0[0]), L.ptr(dS), c0, N, c0, hs, hs, st)
+                    if rc not in (0, L.ERR_UNSUPPORTED):
+                        raise RuntimeError("gnx_maxpool_bwd_argmax_bnrelu failed (%d)" % rc)
+                    if rc == 0:
+                        hp = (hs + 2 - 3) // 2 + 1
+                        bn_bwd(model.features.norm0, s0, L.ptr(dbufs[0]), c_total1, L.ptr(bufs[0]), c_total1, None, c0,
+                               N * hp * hp, c0, 0, relu=2)
+                if rc == L.ERR_UNSUPPORTED:
+                    if tape.stem_out is None:
+                        raise RuntimeError("the conv0 map was not kept and gnx_maxpool_bwd_argmax_bnrelu refused the shapes")
+                    dAct = torch.empty((M0, c0), device=dev, dtype=F32)
+                    if tape.pool_idx is not None:
+                        L.call('gnx_maxpool_bwd_argmax', tape.pool_idx.data_ptr(), L.ptr(dbufs[0]), c_total1, L.ptr(dAct), c0,
+                               N, c0, hs, hs, st)
+                    else:
+                        L.call('gnx_maxpool_bwd', L.ptr(tape.stem_out), c0, L.ptr(bufs[0]), c_total1, L.ptr(dbufs[0]),
+                               c_total1, L.ptr(dAct), c0, N, c0, hs, hs, L.ptr(s0[0]), L.ptr(s0[1]), st)
+                    bn_bwd(model.features.norm0, s0, L.ptr(dAct), c0, L.ptr(tape.stem_out), c0, L.ptr(dS), c0, M0, c0, 0)
+                    del dAct
                 if want(conv0.weight):
                     ws = torch.empty(L.query('gnx_conv0_wgrad_workspace', N, P, P, c0, 7, 7, 2, 3), device=dev, dtype=F32)
                     L.call('gnx_conv0_wgrad', L.ptr(tape.x), L.ptr(dS), c0, L.ptr(grads[conv0.weight]), L.ptr(ws), N, P,

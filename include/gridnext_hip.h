@@ -248,6 +248,11 @@ int gnx_bnrelu_maxpool_argmax(const float* in, long ldi, float* out, long ldo, u
                               int Hi, int Wi, const float* scale, const float* shift, gnx_stream_t stream);
 int gnx_maxpool_bwd_argmax(const unsigned char* argmax, const float* dOut, long lddo, float* dAct, long lda, long imgs,
                            int C, int Hi, int Wi, gnx_stream_t stream);
+/* The same adjoint carried through norm0 -> relu0 (densenet.py:107-109) with running statistics: dPre = gradient of the
+ * conv0 map; the ReLU mask is read off the pooled activated output (`pooled`, ldp), `scale` = gamma / sqrt(var + eps). */
+int gnx_maxpool_bwd_argmax_bnrelu(const unsigned char* argmax, const float* dOut, long lddo, const float* pooled, long ldp,
+                                  const float* scale, float* dPre, long lda, long imgs, int C, int Hi, int Wi,
+                                  gnx_stream_t stream);
 long gnx_conv0_wgrad_workspace(long imgs, int H, int W, int O, int KH, int KW, int stride, int pad); /* floats */
 int gnx_conv0_wgrad(const float* x, const float* dS, long ldd, float* dW, float* workspace, long imgs, int H, int W,
                     int O, int KH, int KW, int stride, int pad, int accumulate, gnx_stream_t stream);
