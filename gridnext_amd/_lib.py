@@ -57,6 +57,7 @@ SIGNATURES = {
     'gnx_conv3x3_winograd': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _P]),
     'gnx_conv_stem': (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'gnx_conv_stem_bnrelu_maxpool': (_I, [_P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    'gnx_conv_stem_bnrelu_maxpool_argmax': (_I, [_P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     'gnx_bnrelu_maxpool': (_I, [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
     'gnx_bnrelu_avgpool': (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _P]),
     'gnx_wgrad_workspace': (_L, [_L, _I, _I, _I]),

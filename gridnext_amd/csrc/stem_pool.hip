@@ -241,12 +241,16 @@ constexpr int SP_LDT = 40;         // floats per position of the activated 32-ch
 // H16: the pooled output is stored as fp16 ([rows][ldo halves]): config 5 with fp16 block buffers.
 // U8: the patches are uint8 [imgs][3][H][W]; ToTensor (+ Normalize, nrm != NULL) happens between the load and the LDS
 // stash (a quarter of the input bytes: 245 MB instead of 981 MB per 128-px array).
-template <int WO, bool H16 = false, bool U8 = false>
+// IDX: also record, per pooled element, WHICH window element won (0..8 row-major in the 3 x 3 window, the first maximal one
+// of the scan - torch's rule, as gnx_bnrelu_maxpool_argmax records it) in amax [pooled rows][O] bytes: the f-trained step
+// then needs neither the conv0 map nor a second pass for its pool0 / norm0 adjoint.
+template <int WO, bool H16 = false, bool U8 = false, bool IDX = false>
 __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const void* __restrict__ xv, const float* __restrict__ w,
                                                              float* __restrict__ out, long ldo, int H, int Wd, int O,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift, long imgs,
-                                                             const float* __restrict__ nrm) {
+                                                             const float* __restrict__ nrm,
+                                                             unsigned char* __restrict__ amax = nullptr) {
     const float* __restrict__ x = reinterpret_cast<const float*>(xv);
     const uint8_t* __restrict__ x8 = reinterpret_cast<const uint8_t*>(xv);
     constexpr int CIN = 3, KH = 7, KW = 7, STRIDE = 2, PAD = 3;
@@ -336,9 +340,13 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const void* __restr
 
     for (long img = blockIdx.x; img < imgs; img += gridDim.x) {
         float4 carry[2][NIT], carry2[2][NIT];             // horizontal maxima of the last (and, WO = 128, second-last) row
+        unsigned cidx[2][NIT], cidx2[2][NIT];             // IDX: their column (0..2) per channel, one byte each
+        const float c0v = IDX ? -1.f : 0.f;               // IDX: "no such row" must lose against every real value (>= 0)
 #pragma unroll
-        for (int q = 0; q < NIT; ++q)
-            carry[0][q] = carry[1][q] = carry2[0][q] = carry2[1][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < NIT; ++q) {
+            carry[0][q] = carry[1][q] = carry2[0][q] = carry2[1][q] = make_float4(c0v, c0v, c0v, c0v);
+            cidx[0][q] = cidx[1][q] = cidx2[0][q] = cidx2[1][q] = 0u;
+        }
         for (int tt = 0; tt < ntt; ++tt) {
             __syncthreads();                              // previous tile's fragment and Ts reads are done
             stash_patch();
@@ -398,35 +406,70 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const void* __restr
 #pragma unroll
                 for (int q = 0; q < NIT; ++q) {
                     const int px = pxa + 32 * q;
-                    float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;        // horizontal maxima of the tile's rows
+                    float4 m0 = make_float4(c0v, c0v, c0v, c0v), m1 = m0;        // horizontal maxima of the tile's rows
+                    unsigned h0 = 0u, h1 = 0u;                                   // IDX: their columns, a byte per channel
+                    auto hmax = [](float4& m, unsigned& hx, const float4& v, unsigned col) {
+                        if (IDX) {                                               // strict >: the first maximum of the scan wins
+                            if (v.x > m.x) { m.x = v.x; hx = (hx & 0xffffff00u) | col; }
+                            if (v.y > m.y) { m.y = v.y; hx = (hx & 0xffff00ffu) | (col << 8); }
+                            if (v.z > m.z) { m.z = v.z; hx = (hx & 0xff00ffffu) | (col << 16); }
+                            if (v.w > m.w) { m.w = v.w; hx = (hx & 0x00ffffffu) | (col << 24); }
+                        } else {
+                            m = make_float4(fmaxf(m.x, v.x), fmaxf(m.y, v.y), fmaxf(m.z, v.z), fmaxf(m.w, v.w));
+                        }
+                    };
 #pragma unroll
                     for (int dx = -1; dx <= 1; ++dx) {
                         const int ox = 2 * px + dx;
                         if (ox < 0) continue;                                    // ox <= WO - 1 always
-                        const float4 v0 = ld4(&Ts[ox * SP_LDT + 4 * c4]);
-                        m0 = make_float4(fmaxf(m0.x, v0.x), fmaxf(m0.y, v0.y), fmaxf(m0.z, v0.z), fmaxf(m0.w, v0.w));
-                        if (RT == 2) {
-                            const float4 v1 = ld4(&Ts[(WO + ox) * SP_LDT + 4 * c4]);
-                            m1 = make_float4(fmaxf(m1.x, v1.x), fmaxf(m1.y, v1.y), fmaxf(m1.z, v1.z), fmaxf(m1.w, v1.w));
-                        }
+                        hmax(m0, h0, ld4(&Ts[ox * SP_LDT + 4 * c4]), (unsigned)(dx + 1));
+                        if (RT == 2) hmax(m1, h1, ld4(&Ts[(WO + ox) * SP_LDT + 4 * c4]), (unsigned)(dx + 1));
                     }
+                    // vertical: rows in scan order (ra, rb, rc) with their columns; window index = 3 row + column
+                    auto vmax = [](const float4& ra, unsigned ia, const float4& rb, unsigned ib, const float4& rc, unsigned ic,
+                                   float4& o4, unsigned& oi) {
+                        if (IDX) {
+                            o4 = ra; oi = ia;                                                      // row 0: index = column
+                            const unsigned jb = ib + 0x03030303u, jc = ic + 0x06060606u;
+                            if (rb.x > o4.x) { o4.x = rb.x; oi = (oi & 0xffffff00u) | (jb & 0x000000ffu); }
+                            if (rb.y > o4.y) { o4.y = rb.y; oi = (oi & 0xffff00ffu) | (jb & 0x0000ff00u); }
+                            if (rb.z > o4.z) { o4.z = rb.z; oi = (oi & 0xff00ffffu) | (jb & 0x00ff0000u); }
+                            if (rb.w > o4.w) { o4.w = rb.w; oi = (oi & 0x00ffffffu) | (jb & 0xff000000u); }
+                            if (rc.x > o4.x) { o4.x = rc.x; oi = (oi & 0xffffff00u) | (jc & 0x000000ffu); }
+                            if (rc.y > o4.y) { o4.y = rc.y; oi = (oi & 0xffff00ffu) | (jc & 0x0000ff00u); }
+                            if (rc.z > o4.z) { o4.z = rc.z; oi = (oi & 0xff00ffffu) | (jc & 0x00ff0000u); }
+                            if (rc.w > o4.w) { o4.w = rc.w; oi = (oi & 0x00ffffffu) | (jc & 0xff000000u); }
+                        } else {
+                            o4 = make_float4(fmaxf(fmaxf(ra.x, rb.x), rc.x), fmaxf(fmaxf(ra.y, rb.y), rc.y),
+                                             fmaxf(fmaxf(ra.z, rb.z), rc.z), fmaxf(fmaxf(ra.w, rb.w), rc.w));
+                        }
+                    };
                     if (RT == 2) {                        // rows 2tt, 2tt+1 + the carried row 2tt-1 -> pooled row tt
-                        const float4 cv = carry[pass][q];
-                        const float4 o4 = make_float4(fmaxf(fmaxf(cv.x, m0.x), m1.x), fmaxf(fmaxf(cv.y, m0.y), m1.y),
-                                                      fmaxf(fmaxf(cv.z, m0.z), m1.z), fmaxf(fmaxf(cv.w, m0.w), m1.w));
+                        float4 o4;
+                        unsigned oi = 0u;
+                        vmax(carry[pass][q], cidx[pass][q], m0, h0, m1, h1, o4, oi);
                         carry[pass][q] = m1;
-                        if (ch < O)
-                            store4(out, ((img * (Ho2 / 2) + tt) * (long)(WO / 2) + px) * ldo + ch, o4);
+                        cidx[pass][q] = h1;
+                        if (ch < O) {
+                            const long prow = (img * (Ho2 / 2) + tt) * (long)(WO / 2) + px;
+                            store4(out, prow * ldo + ch, o4);
+                            if (IDX) *reinterpret_cast<unsigned*>(amax + prow * O + ch) = oi;
+                        }
                     } else {                              // one row per tile: emit pooled row (tt-1)/2 on odd rows
                         if (tt & 1) {
-                            const float4 c2 = carry2[pass][q], c1 = carry[pass][q];
-                            const float4 o4 = make_float4(fmaxf(fmaxf(c2.x, c1.x), m0.x), fmaxf(fmaxf(c2.y, c1.y), m0.y),
-                                                          fmaxf(fmaxf(c2.z, c1.z), m0.z), fmaxf(fmaxf(c2.w, c1.w), m0.w));
-                            if (ch < O)
-                                store4(out, ((img * (Ho2 / 2) + (tt >> 1)) * (long)(WO / 2) + px) * ldo + ch, o4);
+                            float4 o4;
+                            unsigned oi = 0u;
+                            vmax(carry2[pass][q], cidx2[pass][q], carry[pass][q], cidx[pass][q], m0, h0, o4, oi);
+                            if (ch < O) {
+                                const long prow = (img * (Ho2 / 2) + (tt >> 1)) * (long)(WO / 2) + px;
+                                store4(out, prow * ldo + ch, o4);
+                                if (IDX) *reinterpret_cast<unsigned*>(amax + prow * O + ch) = oi;
+                            }
                         }
                         carry2[pass][q] = carry[pass][q];
+                        cidx2[pass][q] = cidx[pass][q];
                         carry[pass][q] = m0;
+                        cidx[pass][q] = h0;
                     }
                 }
             }
@@ -768,9 +811,10 @@ GNX_EXPORT int gnx_conv_stem(const float* x, const float* w, float* out, long ld
 template <bool H16, bool U8 = false>
 static int stem_pool_launch(const void* x, const float* w, float* out, long ldo, long imgs, int Cin, int H, int W, int O,
                             int KH, int KW, int stride, int pad, const float* scale, const float* shift, hipStream_t stream,
-                            const float* nrm = nullptr) {
+                            const float* nrm = nullptr, unsigned char* amax = nullptr) {
     if (!x || !w || !out || !scale || !shift || imgs < 0 || Cin <= 0 || O <= 0 || H <= 0 || W <= 0 || ldo < O)
         return GNX_ERR_BAD_ARG;
+    if (amax && (H16 || U8 || (reinterpret_cast<uintptr_t>(amax) & 3) != 0)) return GNX_ERR_UNSUPPORTED;
     if (Cin != 3 || KH != 7 || KW != 7 || stride != 2 || pad != 3 || O > 64 || O % 4 != 0 || ldo % 4 != 0 ||
         (reinterpret_cast<uintptr_t>(out) & (H16 ? 7 : 15)) != 0)
         return GNX_ERR_UNSUPPORTED;
@@ -791,6 +835,20 @@ static int stem_pool_launch(const void* x, const float* w, float* out, long ldo,
                 return GNX_ERR_LAUNCH;
             conf = true;
         }
+        if constexpr (!H16 && !U8) {
+            if (amax) {
+                static bool confi = false;
+                if (!confi) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel<64, false, false, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+                        return GNX_ERR_LAUNCH;
+                    confi = true;
+                }
+                conv_stem_pool_kernel<64, false, false, true><<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale,
+                                                                                                shift, imgs, nrm, amax);
+                return gnx_launch_status();
+            }
+        }
         conv_stem_pool_kernel<64, H16, U8><<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale, shift, imgs, nrm);
     } else {
         static bool conf = false;
@@ -800,6 +858,20 @@ static int stem_pool_launch(const void* x, const float* w, float* out, long ldo,
                 return GNX_ERR_LAUNCH;
             conf = true;
         }
+        if constexpr (!H16 && !U8) {
+            if (amax) {
+                static bool confi = false;
+                if (!confi) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pool_kernel<128, false, false, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+                        return GNX_ERR_LAUNCH;
+                    confi = true;
+                }
+                conv_stem_pool_kernel<128, false, false, true><<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale,
+                                                                                                 shift, imgs, nrm, amax);
+                return gnx_launch_status();
+            }
+        }
         conv_stem_pool_kernel<128, H16, U8><<<grid, 256, lds_bytes, stream>>>(x, w, out, ldo, H, W, O, scale, shift, imgs, nrm);
     }
     return gnx_launch_status();
@@ -808,6 +880,17 @@ GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool(const float* x, const float* w, floa
                                             int H, int W, int O, int KH, int KW, int stride, int pad, const float* scale,
                                             const float* shift, hipStream_t stream) {
     return stem_pool_launch<false>(x, w, out, ldo, imgs, Cin, H, W, O, KH, KW, stride, pad, scale, shift, stream);
+}
+// the same, also recording each pooled element's window index (0..8, torch's first-maximum rule) in argmax [pooled rows][O]
+// bytes: the forward of the f-trained step under running statistics (training.py:126) - its backward routes by index
+// (gnx_maxpool_bwd_argmax_bnrelu) and never needs the conv0 map
+GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool_argmax(const float* x, const float* w, float* out, long ldo,
+                                                   unsigned char* argmax, long imgs, int Cin, int H, int W, int O, int KH,
+                                                   int KW, int stride, int pad, const float* scale, const float* shift,
+                                                   hipStream_t stream) {
+    if (!argmax) return GNX_ERR_BAD_ARG;
+    return stem_pool_launch<false>(x, w, out, ldo, imgs, Cin, H, W, O, KH, KW, stride, pad, scale, shift, stream, nullptr,
+                                   argmax);
 }
 // the same with the pooled map stored as fp16 [rows][ldo halves] (config 5 with fp16 block buffers)
 GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool_h16(const float* x, const float* w, void* out16, long ldo, long imgs, int Cin,

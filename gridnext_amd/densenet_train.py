@@ -86,23 +86,38 @@ class _DenseNetFn(Function):
             L.call('gnx_conv_stem', L.ptr(x), L.ptr(w0), L.ptr(bufs[0]), ld1, N, 3, P, P, c0, 3, 3, 1, 1, st)
             tape.stem_out = tape.stats0 = None
         else:
-            stem_out = torch.empty((N * hs * hs, c0), device=dev, dtype=F32)
-            L.call('gnx_conv_stem', L.ptr(x), L.ptr(w0), L.ptr(stem_out), c0, N, 3, P, P, c0, 7, 7, 2, 3, st)
-            s0 = _bn(model.features.norm0, L.ptr(stem_out), c0, N * hs * hs, training, dev, st)
-            # pool0 records WHICH window element won (one byte per pooled element): its adjoint then routes by index, ties
-            # exactly as torch's max_pool2d and without re-reading the conv0 map
             hp = (hs + 2 - 3) // 2 + 1
-            tape.pool_idx = None
-            if c0 % 4 == 0:
+            tape.pool_idx = tape.stem_out = None
+            rc = L.ERR_UNSUPPORTED
+            if not training and c0 % 4 == 0 and ld1 % 4 == 0 and gammas_nonzero(model):
+                # Running statistics (training.py:126 keeps f in eval mode): norm0's map is known before conv0 runs, so stem,
+                # norm0, relu0 and pool0 are the eval forward's ONE kernel, which also records which window element won
+                # (a byte per pooled element).  The backward routes by that index and reads mask and x_hat off the pooled
+                # map: the 5.2 GB conv0 map of a 128-px array is never written.
+                s0 = _bn(model.features.norm0, None, c0, N * hs * hs, False, dev, st)
                 tape.pool_idx = torch.empty((N * hp * hp, c0), device=dev, dtype=torch.uint8)
-                L.call('gnx_bnrelu_maxpool_argmax', L.ptr(stem_out), c0, L.ptr(bufs[0]), ld1, tape.pool_idx.data_ptr(), N, c0,
-                       hs, hs, L.ptr(s0[0]), L.ptr(s0[1]), st)
-            else:
-                L.call('gnx_bnrelu_maxpool', L.ptr(stem_out), c0, L.ptr(bufs[0]), ld1, N, c0, hs, hs, L.ptr(s0[0]),
-                       L.ptr(s0[1]), st)
-            tape.stem_out, tape.stats0 = stem_out, s0
-            if tape.pool_idx is not None and not training and ld1 % 4 == 0 and gammas_nonzero(model):
-                tape.stem_out = None      # running statistics: the backward works from the pooled map (5.2 GB per 128-px array freed)
+                rc = L.query('gnx_conv_stem_bnrelu_maxpool_argmax', L.ptr(x), L.ptr(w0), L.ptr(bufs[0]), ld1,
+                             tape.pool_idx.data_ptr(), N, 3, P, P, c0, 7, 7, 2, 3, L.ptr(s0[0]), L.ptr(s0[1]), st)
+                if rc not in (0, L.ERR_UNSUPPORTED):
+                    raise RuntimeError("gnx_conv_stem_bnrelu_maxpool_argmax failed (%d)" % rc)
+            if rc == L.ERR_UNSUPPORTED:
+                stem_out = torch.empty((N * hs * hs, c0), device=dev, dtype=F32)
+                L.call('gnx_conv_stem', L.ptr(x), L.ptr(w0), L.ptr(stem_out), c0, N, 3, P, P, c0, 7, 7, 2, 3, st)
+                s0 = _bn(model.features.norm0, L.ptr(stem_out), c0, N * hs * hs, training, dev, st)
+                # pool0 records WHICH window element won (one byte per pooled element): its adjoint then routes by index, ties
+                # exactly as torch's max_pool2d and without re-reading the conv0 map
+                tape.pool_idx = None
+                if c0 % 4 == 0:
+                    tape.pool_idx = torch.empty((N * hp * hp, c0), device=dev, dtype=torch.uint8)
+                    L.call('gnx_bnrelu_maxpool_argmax', L.ptr(stem_out), c0, L.ptr(bufs[0]), ld1, tape.pool_idx.data_ptr(), N,
+                           c0, hs, hs, L.ptr(s0[0]), L.ptr(s0[1]), st)
+                else:
+                    L.call('gnx_bnrelu_maxpool', L.ptr(stem_out), c0, L.ptr(bufs[0]), ld1, N, c0, hs, hs, L.ptr(s0[0]),
+                           L.ptr(s0[1]), st)
+                tape.stem_out = stem_out
+                if tape.pool_idx is not None and not training and ld1 % 4 == 0 and gammas_nonzero(model):
+                    tape.stem_out = None  # running statistics: the backward works from the pooled map
+            tape.stats0 = s0
         tape.layers = []          # per block: list of (bott, stats1, stats2, bottleneck stored activated?)
         act_ok = (not training) and gammas_nonzero(model)
         w2u = model._winograd_conv2() if (act_ok and model.winograd and model.mfma == 'f32') else None

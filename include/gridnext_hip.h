@@ -158,6 +158,12 @@ int gnx_conv_stem(const float* x, const float* w, float* out, long ldc, long img
 int gnx_conv_stem_bnrelu_maxpool(const float* x, const float* w, float* out, long ldo, long imgs, int Cin, int H, int W,
                                  int O, int KH, int KW, int stride, int pad, const float* scale, const float* shift,
                                  gnx_stream_t stream);
+/* The same kernel also recording each pooled element's window index (0..8, first maximum of the scan as torch's
+ * max_pool2d, densenet.py:110) in argmax [imgs*(Ho/2)*(Wo/2)][O] bytes - the forward of the f-trained step under running
+ * statistics (training.py:126); gnx_maxpool_bwd_argmax_bnrelu is its adjoint. */
+int gnx_conv_stem_bnrelu_maxpool_argmax(const float* x, const float* w, float* out, long ldo, unsigned char* argmax,
+                                        long imgs, int Cin, int H, int W, int O, int KH, int KW, int stride, int pad,
+                                        const float* scale, const float* shift, gnx_stream_t stream);
 int gnx_bnrelu_maxpool(const float* in, long ldi, float* out, long ldo, long imgs, int C, int Hi, int Wi,
                        const float* scale, const float* shift, gnx_stream_t stream);
 int gnx_bnrelu_avgpool(const float* in, long ldi, float* out, long ldo, long imgs, int C, int S2,

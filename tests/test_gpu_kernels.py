@@ -700,6 +700,61 @@ def test_maxpool_backward_routes_ties_like_torch(L, C, Hi):
         close(dAct2, act.grad.permute(0, 2, 3, 1).reshape(-1, C), rtol=1e-6, atol=1e-7, what='dAct by index')
 
 
+@pytest.mark.parametrize("P", [128, 256])
+def test_fused_stem_records_pool0_winner_like_torch(L, P):
+    """gnx_conv_stem_bnrelu_maxpool_argmax (the f-trained step's stem under running statistics): pooled output bit-equal to
+    the plain fused stem, recorded window index == torch's max_pool2d indices on the kernel's own activated map where the
+    maximum is unique, and the first maximal element of the scan on patches with TIES (constant and all-zero patches: every
+    window element equal); then the index adjoint + norm0/relu0 (gnx_maxpool_bwd_argmax_bnrelu) against autograd."""
+    g = torch.Generator().manual_seed(P)
+    n, O = 4, 64
+    x = torch.rand(n, 3, P, P, generator=g)
+    x[1] = 0.0                                            # an all-zero background spot: conv0 map == 0 everywhere
+    x[2] = 0.5                                            # a constant patch: conv0 map constant away from the border
+    w = torch.randn(O, 3, 7, 7, generator=g) * 0.1
+    sc, sh = torch.rand(O, generator=g) + 0.5, torch.randn(O, generator=g) * 0.2 + 0.1
+    xd, wd, scd, shd = x.to(DEV), w.to(DEV), sc.to(DEV), sh.to(DEV)
+    hs, hp = P // 2, P // 4
+    pooled = torch.empty((n * hp * hp, O), device=DEV)
+    pooled2 = torch.empty_like(pooled)
+    amax = torch.full((n * hp * hp, O), 99, device=DEV, dtype=torch.uint8)
+    st = L.stream()
+    L.call('gnx_conv_stem_bnrelu_maxpool', L.ptr(xd), L.ptr(wd), L.ptr(pooled), O, n, 3, P, P, O, 7, 7, 2, 3, L.ptr(scd),
+           L.ptr(shd), st)
+    L.call('gnx_conv_stem_bnrelu_maxpool_argmax', L.ptr(xd), L.ptr(wd), L.ptr(pooled2), O, amax.data_ptr(), n, 3, P, P, O,
+           7, 7, 2, 3, L.ptr(scd), L.ptr(shd), st)
+    assert torch.equal(pooled, pooled2) and int(amax.max()) <= 8
+    # the kernel's own conv0 map is not observable; torch's conv on the device gives the same map up to rounding
+    pre = F.conv2d(xd, wd, stride=2, padding=3)
+    act = torch.relu(pre * scd.view(1, -1, 1, 1) + shd.view(1, -1, 1, 1))
+    mp, ind = F.max_pool2d(act, 3, 2, 1, return_indices=True)
+    close(pooled.reshape(n, hp, hp, O).permute(0, 3, 1, 2), mp, rtol=1e-5, atol=1e-5, what='pooled')
+    # window index -> flat index of the map
+    am = amax.reshape(n, hp, hp, O).permute(0, 3, 1, 2).long()
+    oy = torch.arange(hp, device=DEV).view(1, 1, hp, 1)
+    ox = torch.arange(hp, device=DEV).view(1, 1, 1, hp)
+    iy, ix = 2 * oy + am // 3 - 1, 2 * ox + am % 3 - 1
+    assert bool(((iy >= 0) & (iy < hs) & (ix >= 0) & (ix < hs)).all())          # never a padding element
+    mine = iy * hs + ix
+    # exact ties (patches 1 and 2, interior): torch's first maximum; elsewhere: equal unless the top two are within rounding
+    assert torch.equal(mine[1], ind[1])
+    inner = (slice(None), slice(2, hp - 2), slice(2, hp - 2))
+    assert int(am[2][inner].max()) == 0                  # constant interior (torch's own conv may not be bit-constant there)
+    picked = act.flatten(2).gather(2, mine.flatten(2)).reshape(mp.shape)
+    close(picked, mp, rtol=1e-5, atol=1e-5, what='value at the recorded index')
+    assert (mine[[0, 3]] != ind[[0, 3]]).float().mean().item() < 1e-4      # random patches: unique maxima but for rounding
+    # adjoint: d(conv0 map) by index + norm0/relu0 == autograd through relu(bn(.)) -> max_pool2d at the recorded winners
+    dO = torch.randn(n * hp * hp, O, generator=g).to(DEV)
+    dPre = torch.empty((n * hs * hs, O), device=DEV)
+    L.call('gnx_maxpool_bwd_argmax_bnrelu', amax.data_ptr(), L.ptr(dO), O, L.ptr(pooled), O, L.ptr(scd), L.ptr(dPre), O, n, O,
+           hs, hs, st)
+    want = torch.zeros(n, O, hs * hs, device=DEV)
+    dOm = dO.reshape(n, hp * hp, O).permute(0, 2, 1) * (pooled.reshape(n, hp * hp, O).permute(0, 2, 1) > 0)
+    want.scatter_add_(2, mine.flatten(2), dOm)
+    want = (want * scd.view(1, -1, 1)).permute(0, 2, 1).reshape(-1, O)
+    close(dPre, want, rtol=1e-6, atol=1e-7, what='d conv0 map')
+
+
 def test_uint8_patches_equal_float_patches_bit_for_bit(L):
     """patches kept as uint8 up to the stem's operand load.  ToTensor's u8 / 255 (and Normalize's (v - m) / s)
     inside the kernels must be the floats torch computes on the host: all 256 byte values x 3 channels through
