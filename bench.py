@@ -45,7 +45,7 @@ DENSENET121 = dict(growth_rate=32, block_config=(6, 12, 24, 16), num_init_featur
                    small_inputs=False)
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E
-PMC_TRAFFIC_FILES = ('r02b_pmc_traffic.json', 'r02a_pmc_traffic.json', 'r01l_pmc_traffic.json')   # newest first
+PMC_TRAFFIC_FILES = ('r02c_pmc_traffic.json', 'r02b_pmc_traffic.json', 'r02a_pmc_traffic.json', 'r01l_pmc_traffic.json')   # newest first
 SUB_H, SUB_W = 26, 16               # the sub-grid of the CPU leg (416 spots)
 
 
