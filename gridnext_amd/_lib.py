@@ -31,6 +31,8 @@ SIGNATURES = {
     'gnx_masked_ce_fwd': (_I, [_P, _L, _P, _L, _I, _I, _F, _P, _P, _P, _P, _P]),
     'gnx_masked_ce_bwd': (_I, [_P, _L, _P, _L, _I, _I, _P, _P, _F, _P, _L, _P]),
     'gnx_conv1x1_bnrelu': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _I, _I, _P]),
+    'gnx_conv1x1_workspace': (_L, [_L, _I, _I]),
+    'gnx_conv1x1_bnrelu_ws': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _P, _P]),
     'gnx_conv1x1_bnrelu_act': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _P, _P, _P]),
     'gnx_conv1x1_dgrad_bn_workspace': (_L, [_L, _I]),
     'gnx_conv1x1_dgrad_bnrelu_bwd': (_I, [_P, _L, _P, _P, _L, _P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),

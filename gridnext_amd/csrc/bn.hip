@@ -470,6 +470,202 @@ __global__ void slab_reduce_kernel(const float* __restrict__ partial, int nblk, 
     out[c] = accumulate ? out[c] + s : s;
 }
 
+
+// ------------------------------------------------------------------------------------------------ small-M single-launch forms
+// A DenseNet training step at batch 32 (BASELINE config 2) runs 121 BatchNorms forward and backward on matrices of 512 -
+// 32 768 rows; three launches each way (column sums, second moments, finalize | partial sums, reduce, dx) are latency, not
+// work: 18 / 28 us per BatchNorm.  For M <= BN_SMALL_M a workgroup of 16 channels x 256 row lanes does the whole thing - it
+// walks its column strip (<= 512 KB, L2-hot on the second walk) with 8 rows per lane in flight, reduces through LDS in a
+// fixed order and finishes: one launch, C / 16 workgroups.  Same two-pass arithmetic as the slab kernels; only the (fixed)
+// summation order differs.  (64 row lanes - 8 dependent load rounds per walk at M = 2048 - ran SLOWER than the three launches.)
+constexpr long BN_SMALL_M = 4992;    // one Visium grid (g, the count MLP) and blocks 3-4 of a batch of 32 patches; at 8192 rows a strip is 1 MB per workgroup and C / 16 workgroups are too few CUs
+constexpr int BN_SL = 256;                                     // row lanes
+
+// fixed-order sum over the row lanes of red[lane][16 channels]: 64 threads (4 groups x 16 channels) add 64 lanes each
+// (four interleaved chains, combined pairwise), then thread t < 16 adds the 4 groups pairwise.  Two barriers inside; every thread must call it.
+__device__ __forceinline__ float small_colsum(float (*red)[16], float (*grp)[16], int t) {
+    if (t < 64) {                                              // 64 lanes as 4 interleaved chains, combined pairwise
+        const int ch = t & 15, gq = t >> 4;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+        for (int l = 0; l < BN_SL / 4; l += 4) {
+            const int b = gq * (BN_SL / 4) + l;
+            s0 += red[b][ch]; s1 += red[b + 1][ch]; s2 += red[b + 2][ch]; s3 += red[b + 3][ch];
+        }
+        grp[gq][ch] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    float tot = 0.f;
+    if (t < 16) tot = (grp[0][t] + grp[1][t]) + (grp[2][t] + grp[3][t]);
+    __syncthreads();
+    return tot;
+}
+
+__global__ __launch_bounds__(1024) void bn_train_stats_small_kernel(
+    const float* __restrict__ x, long ld, long M, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    __shared__ float red[BN_SL][16];
+    __shared__ float grp[4][16];
+    __shared__ float bc[16];
+    const int t = threadIdx.x, cq = t & 3, rl = t >> 2;
+    const int c = blockIdx.x * 16 + 4 * cq;
+    const bool on = c < C;                                     // 4 | C: a quad is in or out as a whole
+    const float* px = x + (on ? c : 0);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long r = rl; r < M; r += BN_SL * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long rr = r + BN_SL * u;
+            v[u] = *reinterpret_cast<const float4*>(px + (rr < M ? rr : r) * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (r + BN_SL * u < M) { a[0] += v[u].x; a[1] += v[u].y; a[2] += v[u].z; a[3] += v[u].w; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rl][4 * cq + j] = a[j];
+    __syncthreads();
+    const float tot = small_colsum(red, grp, t);
+    if (t < 16) bc[t] = tot / (float)M;
+    __syncthreads();
+    const float mu[4] = {bc[4 * cq], bc[4 * cq + 1], bc[4 * cq + 2], bc[4 * cq + 3]};
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long r = rl; r < M; r += BN_SL * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long rr = r + BN_SL * u;
+            v[u] = *reinterpret_cast<const float4*>(px + (rr < M ? rr : r) * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (r + BN_SL * u < M) {
+                const float d0 = v[u].x - mu[0], d1 = v[u].y - mu[1], d2 = v[u].z - mu[2], d3 = v[u].w - mu[3];
+                q[0] = fmaf(d0, d0, q[0]); q[1] = fmaf(d1, d1, q[1]); q[2] = fmaf(d2, d2, q[2]); q[3] = fmaf(d3, d3, q[3]);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rl][4 * cq + j] = q[j];
+    __syncthreads();
+    const float m2 = small_colsum(red, grp, t);
+    if (blockIdx.x == 0 && t == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (t < 16) {
+        const int cc = blockIdx.x * 16 + t;
+        if (cc < C) {
+            const float mean = bc[t];
+            const float var = m2 / (float)M;
+            const float invstd = 1.0f / sqrtf(var + eps);
+            const float g = gamma ? gamma[cc] : 1.f, bt = beta ? beta[cc] : 0.f;
+            scale[cc] = g * invstd;
+            shift[cc] = bt - mean * g * invstd;
+            save_mean[cc] = mean;
+            save_invstd[cc] = invstd;
+            if (running_mean) running_mean[cc] = (1.f - momentum) * running_mean[cc] + momentum * mean;
+            if (running_var) {
+                const float unbiased = M > 1 ? m2 / (float)(M - 1) : var;
+                running_var[cc] = (1.f - momentum) * running_var[cc] + momentum * unbiased;
+            }
+        }
+    }
+}
+
+// backward of y = [relu](bn(x)), batch or running statistics, in one launch: sums, then dx (+)=
+__global__ __launch_bounds__(1024) void bn_bwd_small_kernel(
+    const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, float* __restrict__ dx, long lddx, long M,
+    int C, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, float* dgamma, float* dbeta, int relu, int training, int accumulate,
+    int dx_accumulate) {
+    __shared__ float red[BN_SL][16];
+    __shared__ float grp[4][16];
+    __shared__ float bc[2][16];
+    const int t = threadIdx.x, cq = t & 3, rl = t >> 2;
+    const int c = blockIdx.x * 16 + 4 * cq;
+    const bool on = c < C;
+    const int cc4 = on ? c : 0;
+    const float4 sc4 = *reinterpret_cast<const float4*>(scale + cc4), sh4 = *reinterpret_cast<const float4*>(shift + cc4);
+    const float4 mu4 = *reinterpret_cast<const float4*>(mean + cc4), is4 = *reinterpret_cast<const float4*>(invstd + cc4);
+    const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+    const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
+    const float* px = x + cc4;
+    const float* pd = dy + cc4;
+    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long r = rl; r < M; r += BN_SL * 4) {
+        float4 xv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long rr = r + BN_SL * u < M ? r + BN_SL * u : r;
+            xv[u] = *reinterpret_cast<const float4*>(px + rr * ldx);
+            dv[u] = *reinterpret_cast<const float4*>(pd + rr * lddy);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (r + BN_SL * u < M) {
+                const float xe[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, de[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float dz = de[j];
+                    if (relu && fmaf(xe[j], sc[j], sh[j]) <= 0.f) dz = 0.f;
+                    a1[j] += dz;
+                    a2[j] = fmaf(dz, (xe[j] - mu[j]) * is[j], a2[j]);
+                }
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rl][4 * cq + j] = a1[j];
+    __syncthreads();
+    const float t1 = small_colsum(red, grp, t);
+    if (t < 16) bc[0][t] = t1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rl][4 * cq + j] = a2[j];
+    __syncthreads();
+    const float t2 = small_colsum(red, grp, t);
+    if (t < 16) {
+        bc[1][t] = t2;
+        const int cc = blockIdx.x * 16 + t;
+        if (cc < C) {
+            if (dbeta) dbeta[cc] = accumulate ? dbeta[cc] + t1 : t1;
+            if (dgamma) dgamma[cc] = accumulate ? dgamma[cc] + t2 : t2;
+        }
+    }
+    __syncthreads();
+    if (!dx || !on) return;
+    const float invM = 1.0f / (float)M;
+    float s1[4], s2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1[j] = bc[0][4 * cq + j]; s2[j] = bc[1][4 * cq + j]; }
+    for (long r = rl; r < M; r += BN_SL * 4) {
+        float4 xv[4], dv[4], ov[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long rr = r + BN_SL * u < M ? r + BN_SL * u : r;
+            xv[u] = *reinterpret_cast<const float4*>(px + rr * ldx);
+            dv[u] = *reinterpret_cast<const float4*>(pd + rr * lddy);
+            if (dx_accumulate) ov[u] = *reinterpret_cast<const float4*>(dx + rr * lddx + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (r + BN_SL * u < M) {
+                const float xe[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, de[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float dz = de[j];
+                    if (relu && fmaf(xe[j], sc[j], sh[j]) <= 0.f) dz = 0.f;
+                    float g = dz;
+                    if (training) {
+                        const float xhat = (xe[j] - mu[j]) * is[j];
+                        g = dz - s1[j] * invM - xhat * s2[j] * invM;
+                    }
+                    o[j] = sc[j] * g;
+                }
+                if (dx_accumulate) { o[0] += ov[u].x; o[1] += ov[u].y; o[2] += ov[u].z; o[3] += ov[u].w; }
+                *reinterpret_cast<float4*>(dx + (r + BN_SL * u) * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+    }
+}
+
 inline int elementwise_grid(long total) {
     long b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -490,6 +686,13 @@ GNX_EXPORT int gnx_bn_train_stats(const float* x, long ld, long M, int C, const 
                                   float* save_invstd, float* workspace, hipStream_t stream) {
     if (!x || !scale || !shift || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0 || ld < C)
         return GNX_ERR_BAD_ARG;
+    static const bool no_small = getenv("GNX_BN_NO_SMALL") != nullptr;
+    if (!no_small && M <= BN_SMALL_M && C % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        bn_train_stats_small_kernel<<<gnx_cdiv(C, 16), 1024, 0, stream>>>(x, ld, M, C, gamma, beta, running_mean, running_var,
+                                                                        num_batches_tracked, momentum, eps, scale, shift,
+                                                                        save_mean, save_invstd);
+        return gnx_launch_status();
+    }
     const int nblk = slab_count(M);
     float* p_sum = workspace;
     float* p_m2 = workspace + (size_t)nblk * C;
@@ -546,6 +749,13 @@ GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long 
                              reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(save_mean) |
                              reinterpret_cast<uintptr_t>(save_invstd)) & 15) == 0;
         if (relu == 2 && (training || !v4all)) return GNX_ERR_UNSUPPORTED;     // activated-input form: eval statistics only
+        static const bool no_small = getenv("GNX_BN_NO_SMALL") != nullptr;
+        if (!no_small && v4all && relu != 2 && M <= BN_SMALL_M) {
+            bn_bwd_small_kernel<<<gnx_cdiv(C, 16), 1024, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale, shift, save_mean,
+                                                                    save_invstd, dgamma, dbeta, relu, training, accumulate,
+                                                                    dx_accumulate);
+            return gnx_launch_status();
+        }
         if (!training && v4all) {
             // one pass: dx and the dgamma/dbeta column sums together
             bn_bwd_eval_fused_kernel<<<grid, 256, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale, shift, save_mean,

@@ -34,7 +34,21 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
                                                       long M, int N, int K, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, int S_in, int vecA, int vecW,
                                                       const float* __restrict__ oscale,
-                                                      const float* __restrict__ oshift) {
+                                                      const float* __restrict__ oshift, int ldw = 0, int ksplit = 0,
+                                                      float* __restrict__ slabs = nullptr) {
+    // ksplit > 0 (small M: few 128-row tiles, a long K loop that is latency, not work): blockIdx.z owns k in [z ksplit,
+    // (z + 1) ksplit) and writes its partial tile to slabs[z][M][N]; conv1x1_split_reduce_kernel sums them in index order.
+    if (ldw == 0) ldw = K;
+    if (ksplit > 0) {
+        const int kz0 = blockIdx.z * ksplit;
+        A += kz0;
+        W += kz0;
+        if (scale) { scale += kz0; shift += kz0; }
+        K = K - kz0 < ksplit ? K - kz0 : ksplit;
+        out = slabs + (size_t)blockIdx.z * M * N;
+        ldc = N;
+        oscale = nullptr;
+    }
     __shared__ __attribute__((aligned(16))) float As[C1_BM * LDK];
     __shared__ __attribute__((aligned(16))) float Bs[C1_BN * LDK];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -122,9 +136,9 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
         for (int p = 0; p < 4; ++p) {
             const int n = n0 + r0 + 32 * p;
             if (FAST) {
-                rb[p] = ld4(W + (long)(n < N ? n : N - 1) * K + kc);
+                rb[p] = ld4(W + (long)(n < N ? n : N - 1) * ldw + kc);
             } else {
-                rb[p] = (n < N && valid > 0) ? ld4_safe(W + (long)n * K + k, valid, vecW)
+                rb[p] = (n < N && valid > 0) ? ld4_safe(W + (long)n * ldw + k, valid, vecW)
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -228,6 +242,41 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const float* __restrict__ 
                 if (row < M) out[row * ldc + col] = acc[mt][nt][r];
             }
         }
+}
+
+// out[m][n] = sum_z slabs[z][m][n] in index order (+ the consumer's folded BN + ReLU); 4 | N, 16-B accesses
+__global__ __launch_bounds__(256) void conv1x1_split_reduce_kernel(const float* __restrict__ slabs, int S, long M, int N,
+                                                                   float* __restrict__ out, long ldc,
+                                                                   const float* __restrict__ oscale,
+                                                                   const float* __restrict__ oshift) {
+    const long total = M * (N / 4);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long m = idx / (N / 4);
+        const int n = 4 * (int)(idx - m * (N / 4));
+        float4 v = ld4(slabs + m * N + n);
+        for (int z = 1; z < S; ++z) {
+            const float4 u = ld4(slabs + ((size_t)z * M + m) * N + n);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        if (oscale) {
+            const float4 sc = ld4(oscale + n), sh = ld4(oshift + n);
+            v = make_float4(fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), fmaxf(fmaf(v.y, sc.y, sh.y), 0.f),
+                            fmaxf(fmaf(v.z, sc.z, sh.z), 0.f), fmaxf(fmaf(v.w, sc.w, sh.w), 0.f));
+        }
+        *reinterpret_cast<float4*>(out + m * ldc + n) = v;
+    }
+}
+
+// K splits of the small-M form: 0 = not its shape.  Few row tiles (M <= 8192 at N <= 128: <= 64 workgroups) and a K loop of
+// >= 8 chunks; ~4 chunks per split, at most 16 splits.
+int conv1x1_small_splits(long M, int N, int K) {
+    if (M > 8192 || K < 256 || K % 32 != 0 || N % 4 != 0) return 0;
+    const long tiles = gnx_cdiv(M, C1_BM) * gnx_cdiv(N, C1_BN);
+    int s = K / 128;
+    while (s > 1 && tiles * s > 256) --s;
+    if (tiles * s < 32 && K / 64 <= 16) s = K / 64;            // block 4 at batch 32: 4 tiles - two chunks per split
+    if (s > 16) s = 16;
+    return s < 2 ? 0 : s;
 }
 
 // ------------------------------------------------------------------------------------------------ conv1x1, wave-specialised
@@ -967,7 +1016,7 @@ __global__ __launch_bounds__(256) void conv1x1_fold_kernel(const float* __restri
 // (S_in/2)^2 pooled positions.  scale/shift may both be NULL (no activation).
 static int conv1x1_launch(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
                           const float* scale, const float* shift, int pool, int S_in, const float* oscale,
-                          const float* oshift, hipStream_t stream) {
+                          const float* oshift, hipStream_t stream, float* workspace = nullptr) {
     if (!A || !W || !out || M < 0 || N <= 0 || K <= 0 || lda < K || ldc < N || (!scale) != (!shift) ||
         (!oscale) != (!oshift))
         return GNX_ERR_BAD_ARG;
@@ -977,6 +1026,22 @@ static int conv1x1_launch(const float* A, long lda, const float* W, float* out, 
     const int vecW = al16(W) && K % 4 == 0;
     dim3 grid(gnx_cdiv(M, C1_BM), gnx_cdiv(N, C1_BN));
     const bool fast = vecA && vecW;
+    // small M with a workspace: K split over blockIdx.z (a batch-32 training step: 40 of its 58 conv1 launches ran 16 or 4
+    // workgroups through 8-31 chunks each: 30-40 us of latency per launch)
+    static const bool no_split = getenv("GNX_C1_NO_SPLIT") != nullptr;
+    const int splits = (workspace && fast && !pool && !no_split && al16(out) && ldc % 4 == 0 && al16(workspace) &&
+                        (!oscale || (al16(oscale) && al16(oshift)))) ? conv1x1_small_splits(M, N, K) : 0;
+    if (splits > 1) {
+        const int ksplit = ((K / 32 + splits - 1) / splits) * 32;
+        const int nz = (K + ksplit - 1) / ksplit;
+        dim3 gs(grid.x, grid.y, nz);
+        conv1x1_kernel<false, true><<<gs, 256, 0, stream>>>(A, lda, W, out, ldc, M, N, K, scale, shift, S_in, vecA, vecW, nullptr,
+                                                            nullptr, K, ksplit, workspace);
+        long blocks = gnx_cdiv(M * (N / 4), 256);
+        if (blocks > 1024) blocks = 1024;
+        conv1x1_split_reduce_kernel<<<(unsigned)blocks, 256, 0, stream>>>(workspace, nz, M, N, out, ldc, oscale, oshift);
+        return gnx_launch_status();
+    }
     if (fast && M % 128 == 0 && N % 32 == 0 && K % 32 == 0 && K <= C1_KMAX && (!pool || (S_in % 2 == 0 && scale)) &&
         4 * M < (1L << 31) && lda < (1 << 16) && ldc < (1 << 16) && !getenv("GNX_NO_WS1")) {     // int row / lane offsets
         const size_t lds_ws = 4 * 128 * 32 * 4 + (scale ? 8 * (size_t)K : 0);
@@ -1024,6 +1089,18 @@ static int conv1x1_launch(const float* A, long lda, const float* W, float* out, 
 GNX_EXPORT int gnx_conv1x1_bnrelu(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
                                   const float* scale, const float* shift, int pool, int S_in, hipStream_t stream) {
     return conv1x1_launch(A, lda, W, out, ldc, M, N, K, scale, shift, pool, S_in, nullptr, nullptr, stream);
+}
+
+// floats of workspace gnx_conv1x1_bnrelu_ws can use for this shape (0: it would not split)
+GNX_EXPORT long gnx_conv1x1_workspace(long M, int N, int K) {
+    const int s = conv1x1_small_splits(M, N, K);
+    return s > 1 ? (long)s * M * N : 0;
+}
+// gnx_conv1x1_bnrelu (pool = 0) given a workspace: for matrices of few row tiles (small training batches) the K range is
+// split over workgroups and the partial tiles are summed in a fixed order.  workspace may be NULL (= the plain entry point).
+GNX_EXPORT int gnx_conv1x1_bnrelu_ws(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
+                                     const float* scale, const float* shift, float* workspace, hipStream_t stream) {
+    return conv1x1_launch(A, lda, W, out, ldc, M, N, K, scale, shift, 0, 0, nullptr, nullptr, stream, workspace);
 }
 
 // As gnx_conv1x1_bnrelu (pool = 0) with the CONSUMER's folded BN + ReLU applied at the store:

@@ -1026,13 +1026,36 @@ __global__ __launch_bounds__(256) void conv0_wgrad_kernel(const float* __restric
     }
 }
 
-__global__ void slab_sum_kernel(const float* __restrict__ slabs, int nslab, long n, float* __restrict__ out,
-                                int accumulate) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
+// out[idx] (+)= sum over the slabs, fixed order: 64 columns x 16 slab lanes per workgroup, a lane sums its contiguous
+// sixteenth in index order (16 loads in flight), the sixteenths are combined in index order.  (One lane per column walking
+// 2048 slabs took 0.5 ms - a thirtieth of a batch-32 DenseNet training step.)
+__global__ __launch_bounds__(1024) void slab_sum_kernel(const float* __restrict__ slabs, int nslab, long n,
+                                                        float* __restrict__ out, int accumulate) {
+    __shared__ float part[16][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long idx = (long)blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int b = 0; b < nslab; ++b) s += slabs[(long)b * n + idx];
-    out[idx] = accumulate ? out[idx] + s : s;
+    if (idx < n) {
+        const int per = (nslab + 15) / 16;
+        int b = sl * per;
+        const int be = b + per < nslab ? b + per : nslab;
+        for (; b + 16 <= be; b += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = slabs[(long)(b + u) * n + idx];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; b < be; ++b) s += slabs[(long)b * n + idx];
+    }
+    part[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && idx < n) {
+        float tot = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) tot += part[u][cl];
+        out[idx] = accumulate ? out[idx] + tot : tot;
+    }
 }
 
 bool al16b(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1272,6 +1295,6 @@ GNX_EXPORT int gnx_conv0_wgrad(const float* x, const float* dS, long ldd, float*
         conv0_wgrad_kernel<1, 3, 3><<<blocks, 256, lds_bytes, stream>>>(x, dS, ldd, workspace, H, W, Ho, Wo, O, KW, pad,
                                                                         tiles_x, tiles_y, ntiles);
     const long n = (long)O * 3 * KH * KW;
-    slab_sum_kernel<<<gnx_cdiv(n, 256), 256, 0, stream>>>(workspace, blocks * 4, n, dW, accumulate);
+    slab_sum_kernel<<<gnx_cdiv(n, 64), 1024, 0, stream>>>(workspace, blocks * 4, n, dW, accumulate);
     return gnx_launch_status();
 }

@@ -161,8 +161,10 @@ class _DenseNetFn(Function):
                                None, None, st)
                     model._probe_mark('conv3x3', t0)
                 else:
-                    L.call('gnx_conv1x1_bnrelu', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid, M, mid,
-                           cin, L.ptr(s1[0]), L.ptr(s1[1]), 0, 0, st)
+                    nws = L.query('gnx_conv1x1_workspace', M, mid, cin)       # small batches: K split over workgroups
+                    ws1 = torch.empty(nws, device=dev, dtype=F32) if nws else None
+                    L.call('gnx_conv1x1_bnrelu_ws', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid, M, mid,
+                           cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(ws1), st)
                     s2 = _bn(layer.norm2, L.ptr(bott), mid, M, training, dev, st)
                     w2 = torch.empty((9, g, mid), device=dev, dtype=F32)
                     L.call('gnx_repack_conv3x3', L.ptr(w2c), L.ptr(w2), g, mid, st)

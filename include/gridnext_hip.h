@@ -109,6 +109,12 @@ int gnx_gemm_f32_ws(const float* A, long lda, int a_kmajor, const float* B, long
  * bnrelu_maxpool : norm0->relu0->pool0 (:106-110);  bnrelu_avgpool : norm_final->relu->adaptive_avg_pool (:153-156) */
 int gnx_conv1x1_bnrelu(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
                        const float* scale, const float* shift, int pool, int S_in, gnx_stream_t stream);
+/* The same (pool = 0) given `workspace` (gnx_conv1x1_workspace(M, N, K) floats; 0 = the shape does not split, NULL allowed):
+ * on matrices of few 128-row tiles - a batch of 32 patches, train_spotwise at the tutorial's batch size (training.py:11-98) -
+ * the K range is split over workgroups and the partial tiles are summed in a fixed order. */
+long gnx_conv1x1_workspace(long M, int N, int K);
+int gnx_conv1x1_bnrelu_ws(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
+                          const float* scale, const float* shift, float* workspace, gnx_stream_t stream);
 /* conv1x1_bnrelu_act: conv1x1_bnrelu (pool = 0) storing relu(out_scale[n] * y + out_shift[n]) -- _DenseLayer's norm2->relu2
  * (:38-39) folded into conv1's store in eval mode, so conv2 reads a ready operand (scale = shift = NULL below). */
 int gnx_conv1x1_bnrelu_act(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,

@@ -47,19 +47,19 @@ def c1(epochs):
     return {"config": "C1 count-MLP train_spotwise batch 128", "spots_per_s": epochs * 22528 / dt, "seconds": dt}
 
 
-def c2(n_train, epochs):
+def c2(n_train, epochs, batch=32):
     g = torch.Generator(device=DEV).manual_seed(0)
     x = torch.rand((n_train + 64, 3, 128, 128), generator=g, device=DEV)
     y = torch.randint(0, 8, (n_train + 64,), device=DEV)
-    dl = {'train': DataLoader(TensorDataset(x[:n_train], y[:n_train]), batch_size=32, shuffle=True),
-          'val': DataLoader(TensorDataset(x[n_train:], y[n_train:]), batch_size=32)}
+    dl = {'train': DataLoader(TensorDataset(x[:n_train], y[:n_train]), batch_size=batch, shuffle=True),
+          'val': DataLoader(TensorDataset(x[n_train:], y[n_train:]), batch_size=batch)}
     f = ga.DenseNet(num_classes=8, small_inputs=False, growth_rate=32, block_config=(6, 12, 24, 16),
                     num_init_features=64, bn_size=4, drop_rate=0)
     opt = torch.optim.Adam(f.parameters(), lr=1e-3)
-    ga.train_spotwise(f, {'train': DataLoader(TensorDataset(x[:64], y[:64]), batch_size=32), 'val': dl['val']},
+    ga.train_spotwise(f, {'train': DataLoader(TensorDataset(x[:2 * batch], y[:2 * batch]), batch_size=batch), 'val': dl['val']},
                       nn.CrossEntropyLoss(), opt, num_epochs=1)
     dt = timed(lambda: ga.train_spotwise(f, dl, nn.CrossEntropyLoss(), opt, num_epochs=epochs))
-    return {"config": "C2 DenseNet-121 @128px train_spotwise batch 32 (fwd+bwd+Adam, train-mode BN)",
+    return {"config": "C2 DenseNet-121 @128px train_spotwise batch %d (fwd+bwd+Adam, train-mode BN)" % batch,
             "spots_per_s": epochs * (n_train + 64) / dt, "seconds": dt}
 
 
@@ -93,5 +93,8 @@ if __name__ == '__main__':
         out.append(c3(40))        # the tutorials train g for 50-100 epochs; 10 would make a fifth of the call warm-up + graph capture
     if args.only in ('', 'c2'):
         out.append(c2(2048, 1))
+    if args.only == 'c2batch':                                # beyond the tutorial's batch of 32: what the kernels do when fed
+        for b in (32, 128, 512, 2048):
+            out.append(c2(max(2048, 4 * b), 1, b))
     for r in out:
         print(json.dumps(r))
