@@ -10,6 +10,8 @@ HBM).  The tape holds the raw (pre-BN) tensors only: stem output, the dense-bloc
 1x1-conv output; every BN+ReLU is re-evaluated inside the consuming kernel's operand load, forward and backward.
 One autograd node covers the whole network; gradients are returned for every parameter that requires one.
 """
+import struct
+
 import torch
 from torch.autograd import Function
 
@@ -43,6 +45,33 @@ def _bn(model_bn, X_ptr, ld, M, training, dev, st):
                L.ptr(model_bn.running_var), float(model_bn.eps), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]),
                L.ptr(stats[3]), st)
     return stats
+
+
+def relayout_weights(model, kind, dev, st):
+    """{weight: re-laid-out copy} for every conv weight of one kind (0: conv2 -> [tap][N][K], 1: conv2 -> [8 - tap][K][N] for
+    the data gradient, 2: conv1 / transition conv -> [K][N]) in ONE launch (`gnx_relayout_weights_batch`; a training step
+    needs all three after every optimizer step - 3 x 58 small launches otherwise).  Destinations and the device-side pointer
+    table persist with the model (rebuilt when a weight's storage moves); the CONTENT is refreshed by every call."""
+    layers = [l for _, ls, _, _ in model._blocks for l in ls]
+    if kind == 2:
+        weights = [l.conv1.weight for l in layers] + [t.conv.weight for _, _, t, _ in model._blocks if t is not None]
+    else:
+        weights = [l.conv2.weight for l in layers]
+    key = (str(dev),) + tuple(w.data_ptr() for w in weights)
+    plans = model.__dict__.setdefault('_relayout_plans', {})
+    hit = plans.get(kind)
+    if hit is None or hit[0] != key:
+        dsts, rows = {}, []
+        for w in weights:
+            n, k = w.shape[0], w.shape[1]
+            shape = (9, n, k) if kind == 0 else ((9, k, n) if kind == 1 else (k, n))
+            d = torch.empty(shape, device=dev, dtype=F32)
+            dsts[w] = d
+            rows.append(struct.pack('<QQii', w.data_ptr(), d.data_ptr(), n, k))
+        table = torch.frombuffer(bytearray(b''.join(rows)), dtype=torch.uint8).to(dev)
+        hit = plans[kind] = (key, dsts, table, len(weights))
+    L.call('gnx_relayout_weights_batch', hit[2].data_ptr(), hit[3], kind, st)
+    return hit[1]
 
 
 def gammas_nonzero(model):
@@ -118,6 +147,7 @@ class _DenseNetFn(Function):
                 if tape.pool_idx is not None and not training and ld1 % 4 == 0 and gammas_nonzero(model):
                     tape.stem_out = None  # running statistics: the backward works from the pooled map
             tape.stats0 = s0
+        w2r = relayout_weights(model, 0, dev, st)            # conv2 weights tap-major, all layers, one launch
         tape.layers = []          # per block: list of (bott, stats1, stats2, bottleneck stored activated?)
         act_ok = (not training) and gammas_nonzero(model)
         w2u = model._winograd_conv2() if (act_ok and model.winograd and model.mfma == 'f32') else None
@@ -130,7 +160,6 @@ class _DenseNetFn(Function):
                 cin = c_in + li * g
                 s1 = _bn(layer.norm1, L.ptr(buf), c_total, M, training, dev, st)
                 bott = torch.empty((M, mid), device=dev, dtype=F32)
-                w2c = layer.conv2.weight.detach().contiguous()
                 # Eval statistics (training.py:126 puts f in eval mode even when it is trained): norm2's affine map is known
                 # before conv1 runs, so the bottleneck is stored ACTIVATED - conv2 then runs its prologue-free LDS-DMA
                 # form and its weight gradient needs no prologue; the BN adjoint recovers mask and
@@ -155,10 +184,8 @@ class _DenseNetFn(Function):
                         if rc not in (0, L.ERR_UNSUPPORTED):
                             raise RuntimeError("gnx_conv3x3_winograd failed (%d)" % rc)
                     if rc == L.ERR_UNSUPPORTED:
-                        w2 = torch.empty((9, g, mid), device=dev, dtype=F32)
-                        L.call('gnx_repack_conv3x3', L.ptr(w2c), L.ptr(w2), g, mid, st)
-                        L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2), _cols(buf, cin), c_total, M, g, mid, s,
-                               None, None, st)
+                        L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2r[layer.conv2.weight]), _cols(buf, cin), c_total,
+                               M, g, mid, s, None, None, st)
                     model._probe_mark('conv3x3', t0)
                 else:
                     nws = L.query('gnx_conv1x1_workspace', M, mid, cin)       # small batches: K split over workgroups
@@ -166,10 +193,8 @@ class _DenseNetFn(Function):
                     L.call('gnx_conv1x1_bnrelu_ws', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid, M, mid,
                            cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(ws1), st)
                     s2 = _bn(layer.norm2, L.ptr(bott), mid, M, training, dev, st)
-                    w2 = torch.empty((9, g, mid), device=dev, dtype=F32)
-                    L.call('gnx_repack_conv3x3', L.ptr(w2c), L.ptr(w2), g, mid, st)
-                    L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2), _cols(buf, cin), c_total, M, g, mid, s,
-                           L.ptr(s2[0]), L.ptr(s2[1]), st)
+                    L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2r[layer.conv2.weight]), _cols(buf, cin), c_total, M,
+                           g, mid, s, L.ptr(s2[0]), L.ptr(s2[1]), st)
                 recs.append((bott, s1, s2, activated))
             tape.layers.append(recs)
             if trans is not None:
@@ -251,6 +276,8 @@ class _DenseNetFn(Function):
                    st)
             model._probe_mark('wgrad3x3' if taps == 9 else ('wgrad_trans' if pool else 'wgrad1x1'), t0)
 
+        w2b = relayout_weights(model, 1, dev, st)            # conv2 weights for the data gradient, all layers, one launch
+        w1ts = relayout_weights(model, 2, dev, st)           # conv1 / transition weights transposed, one launch
         # ---- classifier
         c_last = model.num_features
         if model.classify:
@@ -300,8 +327,7 @@ class _DenseNetFn(Function):
                 # conv2: weight gradient (no prologue when the bottleneck was stored activated), then data gradient
                 # (adjoint conv with flipped taps)
                 wgrad(layer.conv2.weight, dy2, c_total, L.ptr(bott), mid, None if activated else s2, M, g, mid, s, 9, 0)
-                wb = torch.empty((9, mid, g), device=dev, dtype=F32)
-                L.call('gnx_repack_conv3x3_bwd', L.ptr(layer.conv2.weight.detach().contiguous()), L.ptr(wb), g, mid, st)
+                wb = w2b[layer.conv2.weight]
                 # conv2's data gradient and norm2 -> relu2's adjoint: ONE kernel where the bottleneck was stored activated
                 # (eval statistics) and the shape is the LDS-DMA kernel's; otherwise the product, then the adjoint pass
                 rc = L.ERR_UNSUPPORTED
@@ -328,8 +354,7 @@ class _DenseNetFn(Function):
                     model._probe_mark('bn2_bwd', t0)
                 # conv1
                 wgrad(layer.conv1.weight, L.ptr(tB), mid, L.ptr(buf), c_total, s1, M, mid, cin, s, 1, 0)
-                w1t = torch.empty((cin, mid), device=dev, dtype=F32)
-                L.call('gnx_transpose_weight', L.ptr(layer.conv1.weight.detach().contiguous()), L.ptr(w1t), mid, cin, st)
+                w1t = w1ts[layer.conv1.weight]
                 # conv1's data gradient + norm1/relu1 backward, accumulated into the block-buffer gradient: one kernel where
                 # the statistics are the running ones and the tiles are whole (3 passes over [M][cin] instead of 5)
                 rc = L.ERR_UNSUPPORTED
@@ -374,9 +399,7 @@ class _DenseNetFn(Function):
                 if rc == L.ERR_UNSUPPORTED:
                     wgrad(p_trans.conv.weight, L.ptr(dbuf), c_total, L.ptr(bufs[bi - 1]), p_total, stt, M, c_out, p_total,
                           ps, 1, 1)
-                wt = torch.empty((p_total, c_out), device=dev, dtype=F32)
-                L.call('gnx_transpose_weight', L.ptr(p_trans.conv.weight.detach().contiguous()), L.ptr(wt), c_out,
-                       p_total, st)
+                wt = w1ts[p_trans.conv.weight]
                 dPool = torch.empty((M, p_total), device=dev, dtype=F32)
                 L.call('gnx_conv1x1_bnrelu', L.ptr(dbuf), c_total, L.ptr(wt), L.ptr(dPool), p_total, M, p_total, c_out,
                        None, None, 0, 0, st)

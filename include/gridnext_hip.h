@@ -244,6 +244,10 @@ int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long ldx, const
                      float* dW, float* workspace, long M, int N, int K, int S, int taps, int pool, int accumulate,
                      gnx_stream_t stream);
 int gnx_transpose_weight(const float* w, float* wt, int N, int K, gnx_stream_t stream);
+/* Every weight re-layout of one kind for a whole network in one launch (a training step re-lays all conv weights out after
+ * each optimizer step: 3 x 58 launches for DenseNet-121).  `table`: n entries {const float* src; float* dst; int N; int K;}
+ * (24 bytes each, DEVICE memory); kind 0 = gnx_repack_conv3x3, 1 = gnx_repack_conv3x3_bwd, 2 = gnx_transpose_weight. */
+int gnx_relayout_weights_batch(const void* table, int n, int kind, gnx_stream_t stream);
 int gnx_repack_conv3x3_bwd(const float* w, float* wb, int N, int K, gnx_stream_t stream);
 int gnx_rows_broadcast(const float* in, long ldi, float* out, long ldo, long imgs, int C, int S2, float alpha,
                        gnx_stream_t stream);
