@@ -45,7 +45,6 @@ DENSENET121 = dict(growth_rate=32, block_config=(6, 12, 24, 16), num_init_featur
                    small_inputs=False)
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E
-PMC_TRAFFIC_FILES = ('r02c_pmc_traffic.json', 'r02b_pmc_traffic.json', 'r02a_pmc_traffic.json', 'r01l_pmc_traffic.json')   # newest first
 SUB_H, SUB_W = 26, 16               # the sub-grid of the CPU leg (416 spots)
 
 
@@ -149,6 +148,29 @@ def kernel_table(probe, patch, steps):
                       "algorithmic_gbs": bytes_per_spot(patch) * H * W * steps / (ms * 1e-3) / 1e9,
                       "ms_per_step": ms / steps}
     return kern
+
+
+def pmc_traffic_table(suffix=''):
+    """{kind: {hbm_bytes_per_launch, ...}} from the newest profiles/r*_pmc_traffic<suffix>.json, with its file name; HBM
+    bytes per launch from rocprofv3 PMC passes of the same command (FETCH_SIZE and WRITE_SIZE in separate runs, KiB units,
+    FETCH doubled for 16-B/lane loads as MI355X_MICROARCH.md prescribes): tools/pmc_traffic.py, profiles/README.md."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic%s.json' % suffix)), reverse=True)
+    for f in files:
+        try:
+            with open(f) as fh:
+                return json.load(fh), os.path.basename(f)
+        except (OSError, ValueError):
+            continue
+    return {}, None
+
+
+def attach_traffic(kern, suffix):
+    table, name = pmc_traffic_table(suffix)
+    for kind in kern:
+        if kind in table:
+            kern[kind]["traffic"] = table[kind]["hbm_bytes_per_launch"]
+            kern[kind]["traffic_source"] = "profiles/%s (PMC, separate passes)" % name
 
 
 def winograd_credit(k3, patch, steps):
@@ -454,6 +476,7 @@ def config5_series(args, device, rank, world, steps=4, warmup=2):
         kk.update({"bound": "hbm", "matrix_tflops": kk["achieved"], "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "frac": gbs / PEAK_HBM_GBS, "kernel": {"conv1x1": "conv1x1_h16_kernel", "conv3x3": "conv3x3_dma_kernel<H16, O16>"}.get(kind, kk["kernel"])})
         kk.pop("algorithmic_gbs", None)
+    attach_traffic(kt, '_f16_256')
     if kt:
         order = sorted(kt, key=lambda k: -kt[k]["ms_per_step"])
         out["roofline"] = dict(kt[order[0]])
@@ -598,15 +621,10 @@ def worker_main(args):
         # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in separate
         # runs, KiB units, FETCH doubled for 16-B/lane loads as MI355X_MICROARCH.md prescribes): tools/pmc_traffic.py,
         # profiles/README.md
-        tfile = next((os.path.join(ROOT, 'profiles', f) for f in PMC_TRAFFIC_FILES
-                      if os.path.exists(os.path.join(ROOT, 'profiles', f))), None)
-        if tfile and args.patch == 128 and args.mfma == 'f32' and not args.train_f:
-            with open(tfile) as fh:
-                tr = json.load(fh)
-            for kind in kern:
-                if kind in tr:
-                    kern[kind]["traffic"] = tr[kind]["hbm_bytes_per_launch"]
-                    kern[kind]["traffic_source"] = "profiles/%s (PMC, separate passes)" % os.path.basename(tfile)
+        if args.patch == 128 and args.mfma == 'f32':
+            attach_traffic(kern, '_trainf' if args.train_f else '')
+        elif args.patch == 256 and args.mfma == 'f16' and not args.train_f:
+            attach_traffic(kern, '_f16_256')
         if getattr(f_img, 'winograd', False) and args.mfma == 'f32':
             # The Winograd launches execute 2/3 of the direct-convolution multiply-adds: `achieved` / `frac` are the
             # EXECUTED matrix FLOPs against the matrix peak (a fraction of peak must be work the pipe did); the
@@ -660,6 +678,7 @@ def worker_main(args):
                 kt = kernel_table(probe_tf, args.patch, args.series_steps)
                 if getattr(f_img, 'winograd', False) and 'conv3x3' in kt:
                     winograd_credit(kt['conv3x3'], args.patch, args.series_steps)
+                attach_traffic(kt, '_trainf')
                 order = sorted(kt, key=lambda k: -kt[k]["ms_per_step"])
                 ser["roofline"] = dict(kt[order[0]])
                 ser["roofline"]["other_kernels"] = {k: {f: kt[k][f] for f in ("kernel", "achieved", "frac", "ms_per_step",

@@ -14,11 +14,22 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
-GROUPS = [                                   # first match wins
+def _targs(n, kernel):
+    """template arguments of `kernel` in a demangled name, as a list of strings ([] if it is another kernel)"""
+    m = re.search(re.escape(kernel) + r'<([^>]*)>', n)
+    return [a.strip() for a in m.group(1).split(',')] if m else []
+
+
+GROUPS = [                                   # first match wins; names as bench.py's kernel kinds
+    ('dgrad1x1_bn1', lambda n: 'conv1x1_ws_kernel<false, false, 4, true>' in n),
+    ('dgrad3x3_bn2', lambda n: len(_targs(n, 'conv3x3_dma_kernel')) >= 7 and _targs(n, 'conv3x3_dma_kernel')[6] == 'true'),
+    ('wgrad1x1', lambda n: 'wgrad1_t_kernel' in n),
+    ('wgrad3x3', lambda n: 'wgrad9_t_kernel' in n),
     ('conv1x1', lambda n: 'conv1x1_ws_kernel<true, false' in n or 'conv1x1_ws_kernel<false, false' in n
-        or 'conv1x1_kernel<false' in n),
+        or 'conv1x1_kernel<false' in n or 'conv1x1_h16' in n),
     ('transition', lambda n: 'conv1x1_ws_kernel<true, true' in n or 'conv1x1_kernel<true' in n),
     ('conv3x3', lambda n: 'conv3x3_' in n),
     ('stem', lambda n: 'conv_stem' in n),

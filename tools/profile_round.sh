@@ -12,6 +12,16 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_fetch -o r --o
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_write -o r --output-format csv -- $B --no-kernel-timing > $R/gpurun_out/${tag}_write.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA -d $R/gpurun_out/${tag}_mfma -o r --output-format csv -- $B --no-kernel-timing > $R/gpurun_out/${tag}_mfma.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_trainf -o r --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --train-f --no-series --no-kernel-timing > $R/gpurun_out/${tag}_trainf.log 2>&1 || exit 1
+# the f-trained series and config 5 (fp16, 256 px): HBM bytes per launch of their dominant kernels
+T="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --train-f --no-series --no-kernel-timing"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_tf_fetch -o r --output-format csv -- $T > $R/gpurun_out/${tag}_tf_fetch.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_tf_write -o r --output-format csv -- $T > $R/gpurun_out/${tag}_tf_write.log 2>&1 || exit 1
+F="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --mfma f16 --patch 256 --no-series --no-kernel-timing"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_h_fetch -o r --output-format csv -- $F > $R/gpurun_out/${tag}_h_fetch.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_h_write -o r --output-format csv -- $F > $R/gpurun_out/${tag}_h_write.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_h_stats -o r --output-format csv -- $F > $R/gpurun_out/${tag}_h_stats.log 2>&1 || exit 1
 cd $R
 python3 tools/pmc_traffic.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write > gpurun_out/${tag}_pmc_traffic.json
+python3 tools/pmc_traffic.py gpurun_out/${tag}_tf_fetch gpurun_out/${tag}_tf_write > gpurun_out/${tag}_pmc_traffic_trainf.json
+python3 tools/pmc_traffic.py gpurun_out/${tag}_h_fetch gpurun_out/${tag}_h_write > gpurun_out/${tag}_pmc_traffic_f16_256.json
 echo done
