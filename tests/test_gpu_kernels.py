@@ -43,7 +43,10 @@ def L():
                                              # wider than one launch takes (64 x 64 forward / 32 x 32 weight gradient):
                                              # tiled over channel chunks - many classes, classify=False feature inputs
                                              (1, 9, 7, 40, 32, True), (2, 6, 5, 64, 64, True), (1, 7, 6, 150, 70, True),
-                                             (1, 5, 6, 33, 130, False)])
+                                             (1, 5, 6, 33, 130, False),
+                                             # every contraction width of the MFMA forward / data-gradient form (8, 16, 32, 64),
+                                             # ragged position tiles, both addressings
+                                             (2, 7, 5, 8, 16, False), (1, 11, 3, 16, 8, True), (3, 5, 9, 8, 8, True)])
 def test_hexconv_fwd_bwd(GF, B, H, W, I, O, oddr):
     from oracle import hexconv as ohex
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + I)
