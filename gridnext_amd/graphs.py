@@ -68,6 +68,14 @@ def wanted(model, fused_ok, device):
     return True
 
 
+def wanted_spotwise(model, device):
+    """Graph the spot loop's step of this model?  (An MLP classifier on a HIP device; GNX_GRAPH=0 turns it off.)"""
+    if os.environ.get('GNX_GRAPH', '') == '0' or torch.device(device).type != 'cuda':
+        return False
+    from . import functional as GF
+    return GF.is_hip_sequential(model)
+
+
 class GridStepGraph:
     """One captured step for one (phase, shapes).  `step_fn(inputs, labels) -> (loss, correct, n_fg)` is the eager step
     WITHOUT the backward; `train` adds `loss.backward()` to the capture."""

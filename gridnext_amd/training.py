@@ -114,6 +114,16 @@ def train_spotwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
     model.to(device)
     fused_ok = _plain_ce(criterion)
     hip_mlp = GF.is_hip_sequential(model)
+    # an MLP step is ~40 kernels of a few microseconds: launched one by one the loop is bound by the host (1 ms per batch of
+    # 128 against ~0.15 ms of kernel time).  Forward, fused CE and backward of each (phase, batch shape) are captured into a
+    # hipGraph and replayed (graphs.py); zero_grad, all-reduce, optimizer and statistics stay eager
+    stepper = None
+    if hip_mlp and fused_ok and graphs.wanted_spotwise(model, device):
+        def _spot_step(inputs, labels):
+            outputs = GF.sequential_forward(model, inputs.reshape(inputs.shape[0], -1))
+            loss, stats, _ = GF.masked_cross_entropy(outputs, labels, 1, label_base=0)
+            return loss, stats[1], None
+        stepper = graphs.GridStepGraphs(_spot_step, model.parameters())
 
     for epoch in range(num_epochs):
         _banner(epoch, num_epochs)
@@ -131,22 +141,33 @@ def train_spotwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
                 batch_size = labels.size(0)
                 inputs, labels = _to_device(inputs, device), labels.to(device)
                 optimizer.zero_grad()
-                with torch.set_grad_enabled(phase == 'train'):
-                    if hip_mlp and torch.is_tensor(inputs) and inputs.is_cuda:
-                        outputs = GF.sequential_forward(model, inputs.reshape(batch_size, -1))
-                    else:
-                        outputs = model(inputs)
-                    if fused_ok and outputs.is_cuda and outputs.dim() == 2:
-                        loss, stats, _ = GF.masked_cross_entropy(outputs, labels, 1, label_base=0)
-                        correct = stats[1]
-                    else:
-                        loss = criterion(outputs, labels)
-                        correct = torch.sum(torch.max(outputs, 1)[1] == labels.data)
-                    if phase == 'train':
-                        loss.backward()
-                        gdist.allreduce_gradients(gdist.optimizer_params(optimizer))
-                        optimizer.step()
-                meter.add(loss if outputs.is_cuda else loss.item(), batch_size, correct, batch_size)
+                replayed = None
+                if stepper is not None and torch.is_tensor(inputs) and inputs.is_cuda:
+                    replayed = stepper.run(phase == 'train', inputs, labels)
+                if replayed is not None:
+                    loss, correct, _ = replayed
+                    on_device = True
+                else:
+                    with torch.set_grad_enabled(phase == 'train'):
+                        if hip_mlp and torch.is_tensor(inputs) and inputs.is_cuda:
+                            outputs = GF.sequential_forward(model, inputs.reshape(batch_size, -1))
+                        else:
+                            outputs = model(inputs)
+                        if fused_ok and outputs.is_cuda and outputs.dim() == 2:
+                            loss, stats, _ = GF.masked_cross_entropy(outputs, labels, 1, label_base=0)
+                            correct = stats[1]
+                        else:
+                            loss = criterion(outputs, labels)
+                            correct = torch.sum(torch.max(outputs, 1)[1] == labels.data)
+                        if phase == 'train':
+                            loss.backward()
+                    on_device = outputs.is_cuda
+                    del outputs
+                if phase == 'train':
+                    gdist.allreduce_gradients(gdist.optimizer_params(optimizer))
+                    optimizer.step()
+                meter.add(loss if on_device else loss.item(), batch_size, correct, batch_size)
+                loss = correct = None
             loss_sum, n_right, _, seen = meter.totals()
             n_items = meter.n_items(len(dataloaders[phase].dataset), seen)
             epoch_loss, epoch_acc = loss_sum / n_items, n_right / n_items

@@ -838,6 +838,34 @@ def test_prefetcher_feeds_the_grid_loop_from_host_memory():
             break                                                                     # consumer leaves early: no hang
 
 
+def test_graph_replayed_spot_loop_equals_the_eager_loop(monkeypatch):
+    """train_spotwise with an MLP classifier: forward (train-mode BatchNorm1d: running statistics updated in the kernels),
+    fused CE and backward of each (phase, batch shape) replayed from a hipGraph must leave EXACTLY the eager loop's histories,
+    weights and buffers - including the ragged last batch (its own shape) and a validation phase."""
+    import gridnext_amd as ga
+    from gridnext_amd.synthetic import count_mlp
+    G, C = 40, 6
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randint(0, 10, (300, G), generator=gen).float().to(DEV)
+    y = torch.randint(0, C, (300,), generator=gen).to(DEV)
+    results = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('GNX_GRAPH', flag)
+        torch.manual_seed(9)
+        f = count_mlp(G, C)
+        dl = {'train': DataLoader(TensorDataset(x[:230], y[:230]), batch_size=32, shuffle=True,
+                                  generator=torch.Generator().manual_seed(4)),
+              'val': DataLoader(TensorDataset(x[230:], y[230:]), batch_size=32)}
+        opt = torch.optim.Adam(f.parameters(), lr=1e-3)
+        (f, vh, th), _ = quiet(ga.train_spotwise, f, dl, nn.CrossEntropyLoss(), opt, num_epochs=3)
+        results.append((th, vh, {k: v.clone() for k, v in f.state_dict().items()}))
+    (th0, vh0, sd0), (th1, vh1, sd1) = results
+    assert th0 == th1 and vh0 == vh1
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+
+
+
 @pytest.mark.parametrize("accum,fopt", [(1, False), (3, False), (2, True)])
 def test_graph_replayed_grid_loop_equals_the_eager_loop(monkeypatch, accum, fopt):
     """graphs.py: the count-only f + g step captured into a hipGraph (forward, fused CE, backward) and replayed must leave
