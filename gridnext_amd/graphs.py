@@ -69,11 +69,14 @@ def wanted(model, fused_ok, device):
 
 
 def wanted_spotwise(model, device):
-    """Graph the spot loop's step of this model?  (An MLP classifier on a HIP device; GNX_GRAPH=0 turns it off.)"""
+    """Graph the spot loop's step of this model?  An MLP classifier or a DenseNet on a HIP device (GNX_GRAPH=0 turns it
+    off).  A DenseNet step at the tutorial's batch of 32 is ~1 200 launches whose enqueue time equals their GPU time; replayed,
+    the host is out of the step.  The stepper is given `model.invalidate_cache` (GridStepGraphs.drop_derived)."""
     if os.environ.get('GNX_GRAPH', '') == '0' or torch.device(device).type != 'cuda':
         return False
     from . import functional as GF
-    return GF.is_hip_sequential(model)
+    from .densenet import DenseNet
+    return GF.is_hip_sequential(model) or (isinstance(model, DenseNet) and model.mfma == 'f32')
 
 
 class GridStepGraph:
@@ -146,8 +149,13 @@ class GridStepGraph:
 class GridStepGraphs:
     """The per-loop-call collection: `run(phase_is_train, inputs, labels, eager_fn)`."""
 
-    def __init__(self, step_fn, params):
+    def __init__(self, step_fn, params, drop_derived=None):
+        """drop_derived: called right before a capture and after every replay - for a model that caches tensors derived from
+        its weights (DenseNet: folded BatchNorm vectors, re-laid-out weights).  Before a capture, so that they are recomputed
+        INSIDE it from the live parameters (a replay after an optimizer step must not multiply with capture-time copies);
+        after a replay, so that nothing outside the graph keeps using tensors that live in its memory pool."""
         self.step_fn, self.params = step_fn, list(params)
+        self.drop_derived = drop_derived
         self.table = {}
 
     def run(self, train, inputs, labels):
@@ -162,5 +170,10 @@ class GridStepGraphs:
             st.seen += 1
             if st.seen <= WARMUP:
                 return None                                    # eager warm-up batch
+            if self.drop_derived is not None:
+                self.drop_derived()
             st.capture(inputs, labels)
-        return st.replay(inputs, labels)
+        out = st.replay(inputs, labels)
+        if self.drop_derived is not None:
+            self.drop_derived()
+        return out

@@ -118,12 +118,13 @@ def train_spotwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
     # 128 against ~0.15 ms of kernel time).  Forward, fused CE and backward of each (phase, batch shape) are captured into a
     # hipGraph and replayed (graphs.py); zero_grad, all-reduce, optimizer and statistics stay eager
     stepper = None
-    if hip_mlp and fused_ok and graphs.wanted_spotwise(model, device):
+    if fused_ok and graphs.wanted_spotwise(model, device):
         def _spot_step(inputs, labels):
-            outputs = GF.sequential_forward(model, inputs.reshape(inputs.shape[0], -1))
+            outputs = (GF.sequential_forward(model, inputs.reshape(inputs.shape[0], -1)) if hip_mlp else model(inputs))
             loss, stats, _ = GF.masked_cross_entropy(outputs, labels, 1, label_base=0)
             return loss, stats[1], None
-        stepper = graphs.GridStepGraphs(_spot_step, model.parameters())
+        stepper = graphs.GridStepGraphs(_spot_step, model.parameters(),
+                                        drop_derived=getattr(model, 'invalidate_cache', None))
 
     for epoch in range(num_epochs):
         _banner(epoch, num_epochs)

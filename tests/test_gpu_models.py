@@ -866,6 +866,37 @@ def test_graph_replayed_spot_loop_equals_the_eager_loop(monkeypatch):
 
 
 
+def test_graph_replayed_densenet_spot_loop_equals_the_eager_loop(monkeypatch):
+    """train_spotwise with a DenseNet (BASELINE config 2's loop): the whole training step - taped forward with train-mode
+    BatchNorm, fused CE, backward - and the validation step (eval forward: folded statistics and re-laid-out weights are
+    recomputed inside the graph from the live parameters) replayed from hipGraphs == the eager loop, bit for bit, over
+    epochs in which the weights change between the phases."""
+    import gridnext_amd as ga
+    gen = torch.Generator().manual_seed(8)
+    x = torch.rand(52, 3, 32, 32, generator=gen).to(DEV)
+    y = torch.randint(0, 5, (52,), generator=gen).to(DEV)
+    results = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('GNX_GRAPH', flag)
+        torch.manual_seed(3)
+        f = ga.DenseNet(**TINY_LARGE)
+        dl = {'train': DataLoader(TensorDataset(x[:36], y[:36]), batch_size=8, shuffle=True,
+                                  generator=torch.Generator().manual_seed(2)),
+              'val': DataLoader(TensorDataset(x[36:], y[36:]), batch_size=4)}
+        opt = torch.optim.Adam(f.parameters(), lr=1e-3)
+        (f, vh, th), _ = quiet(ga.train_spotwise, f, dl, nn.CrossEntropyLoss(), opt, num_epochs=3)
+        f.eval()
+        with torch.no_grad():
+            after = f(x[:6]).clone()                      # an eager eval forward after the loop: no stale derived tensors
+        results.append((th, vh, {k: v.clone() for k, v in f.state_dict().items()}, after))
+    (th0, vh0, sd0, a0), (th1, vh1, sd1, a1) = results
+    assert th0 == th1 and vh0 == vh1
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+    assert torch.equal(a0, a1)
+
+
+
 @pytest.mark.parametrize("accum,fopt", [(1, False), (3, False), (2, True)])
 def test_graph_replayed_grid_loop_equals_the_eager_loop(monkeypatch, accum, fopt):
     """graphs.py: the count-only f + g step captured into a hipGraph (forward, fused CE, backward) and replayed must leave
