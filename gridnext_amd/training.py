@@ -143,7 +143,10 @@ def train_spotwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
                 inputs, labels = _to_device(inputs, device), labels.to(device)
                 optimizer.zero_grad()
                 replayed = None
-                if stepper is not None and torch.is_tensor(inputs) and inputs.is_cuda:
+                # (a DenseNet step keeps its whole tape in the graph's memory pool: only batches that are launch-bound anyway -
+                # up to 64 patches of 128 px - are graphed; larger ones are GPU-bound on large kernels and stay eager)
+                if stepper is not None and torch.is_tensor(inputs) and inputs.is_cuda and \
+                        (hip_mlp or inputs.numel() <= 64 * 3 * 128 * 128):
                     replayed = stepper.run(phase == 'train', inputs, labels)
                 if replayed is not None:
                     loss, correct, _ = replayed
