@@ -323,7 +323,8 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
                                                             long rows_in, const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ oscale,
-                                                            const float* __restrict__ oshift, C1BnBwd bn = C1BnBwd()) {
+                                                            const float* __restrict__ oshift, C1BnBwd bn = C1BnBwd(),
+                                                            int tile_runs = 0) {
     constexpr int OPB = 128 * 32 * 4;                      // bytes of one operand chunk
     extern __shared__ __attribute__((aligned(16))) float lds_f[];  // [buffer][A | B] then scale[K], shift[K]
     char* const lds = reinterpret_cast<char*>(lds_f);
@@ -331,16 +332,23 @@ __global__ __launch_bounds__(64 * (4 + NP), NP == 4 ? 4 : 3) void conv1x1_ws_ker
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int nk = K >> 5;
     const int G = gridDim.x;
-    const int mine = (T - (int)blockIdx.x + G - 1) / G;    // tiles of this workgroup (gridDim.x <= T)
-    const int total = mine * nk;                           // chunks = barriers, the same number for all 8 waves
-    // Workgroup -> tile order.  With several column tiles per row tile (transitions: N = 256 / 512) the column tiles of one
-    // row tile read the same (4x pooled) activation rows: put them on the SAME XCD (workgroup b runs on XCD b % 8, one L2
-    // per XCD) so those rows come from HBM once - measured 6.6 GB per transition launch before, 1.9x the algorithmic bytes.
-    // Full rounds of G tiles only; a partial last round keeps the plain order (every workgroup with blockIdx.x < rest works).
     const int bx = blockIdx.x;
+    // Workgroup -> tile order.  One column tile per row tile (conv1 of a dense layer: N = 128): round-robin, so that at any
+    // moment the chip reads one contiguous window of A.  Several column tiles per row tile all read the same A rows:
+    //  * default (forward transitions): the column tiles of one row tile go to workgroups of the same round on the SAME XCD
+    //    (workgroup b runs on XCD b % 8, one L2 per XCD) - measured 6.6 GB per transition launch before, 1.9x algorithmic;
+    //  * tile_runs (conv1's fused data gradient, cin > 128): a workgroup takes a CONTIGUOUS run of the column-fastest tile
+    //    list, so consecutive tiles of a workgroup share their dY rows.  The fabric-side fetch counter shows dY requested once
+    //    per column tile either way (1.3-1.5x the algorithmic bytes at cin = 288 ... 896: the Infinity Cache serves it, the
+    //    counter does not tell), but the kernel runs 5 % faster this way.
+    const bool runs = tilesN > 1 && tile_runs;
+    const int run0 = (int)((long)bx * T / G), run1 = (int)((long)(bx + 1) * T / G);
+    const int mine = runs ? run1 - run0 : (T - bx + G - 1) / G;      // tiles of this workgroup (gridDim.x <= T)
+    const int total = mine * nk;                           // chunks = barriers, the same number for all 8 waves
     const int jmap = (tilesN > 1 && G % (8 * tilesN) == 0)
                          ? tilesN * ((bx & 7) + 8 * (bx / (8 * tilesN))) + (bx >> 3) % tilesN : bx;
     auto tile_of = [&](int round) {
+        if (runs) return round < mine ? run0 + round : T;
         const int base = round * G;
         return base + (base + G <= T ? jmap : bx);
     };
@@ -1014,6 +1022,14 @@ __global__ __launch_bounds__(256) void conv1x1_fold_kernel(const float* __restri
 
 // out[M][N] (ldc) = act(A[M][K] (lda)) . W[N][K]^T ; pool != 0: A is on an S_in x S_in grid per image and M counts the
 // (S_in/2)^2 pooled positions.  scale/shift may both be NULL (no activation).
+// conv1's fused data gradient: workgroups take contiguous runs of the column-fastest tile list (GNX_C1_RUNS=0: the XCD
+// placement the forward transitions keep).  Same box, same run: 52.5 -> 50.0 ms per f-trained step; the forward transitions
+// measured no better with runs (2.97 ms either way within noise), so they keep their order.
+static int c1_tile_runs() {
+    static const int v = getenv("GNX_C1_RUNS") ? atoi(getenv("GNX_C1_RUNS")) : 1;
+    return v;
+}
+
 static int conv1x1_launch(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
                           const float* scale, const float* shift, int pool, int S_in, const float* oscale,
                           const float* oshift, hipStream_t stream, float* workspace = nullptr) {
@@ -1192,7 +1208,7 @@ GNX_EXPORT int gnx_conv1x1_dgrad_bnrelu_bwd(const float* dY, long lddy, const fl
     C1BnBwd bn = {X, (int)ldx, scale, shift, mean, invstd, slab};
     conv1x1_ws_kernel<false, false, 4, true><<<wgs, 512, lds_ws, stream>>>(dY, (int)lddy, Wt, dX, (int)lddx, K, N, tilesN,
                                                                            (int)T, 0, 4 * M, nullptr, nullptr, nullptr,
-                                                                           nullptr, bn);
+                                                                           nullptr, bn, c1_tile_runs());
     if (dgamma || dbeta) {
         slab_fold_kernel<<<dim3(gnx_cdiv(N, 64), C1_DGBN_R), 256, 0, stream>>>(slab, 2 * (M / 128), N, C1_DGBN_R, part);
         slab_finish_kernel<<<gnx_cdiv(N, 64), 512, 0, stream>>>(part, C1_DGBN_R, N, dbeta, dgamma, accumulate);
