@@ -501,6 +501,9 @@ __device__ __forceinline__ float small_colsum(float (*red)[16], float (*grp)[16]
     return tot;
 }
 
+// KEEP (M <= 8 BN_SL = 2048 rows: blocks 3-4 of a batch of 32 patches): a lane's <= 8 rows stay in registers between the two
+// walks - no second round of loads.
+template <bool KEEP>
 __global__ __launch_bounds__(1024) void bn_train_stats_small_kernel(
     const float* __restrict__ x, long ld, long M, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
@@ -513,6 +516,17 @@ __global__ __launch_bounds__(1024) void bn_train_stats_small_kernel(
     const bool on = c < C;                                     // 4 | C: a quad is in or out as a whole
     const float* px = x + (on ? c : 0);
     float a[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 kv[8];                                              // KEEP: this lane's rows rl + BN_SL u
+    if (KEEP) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long rr = rl + BN_SL * u;
+            kv[u] = *reinterpret_cast<const float4*>(px + (rr < M ? rr : 0) * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (rl + BN_SL * u < M) { a[0] += kv[u].x; a[1] += kv[u].y; a[2] += kv[u].z; a[3] += kv[u].w; }
+    } else
     for (long r = rl; r < M; r += BN_SL * 8) {
         float4 v[8];
 #pragma unroll
@@ -532,6 +546,14 @@ __global__ __launch_bounds__(1024) void bn_train_stats_small_kernel(
     __syncthreads();
     const float mu[4] = {bc[4 * cq], bc[4 * cq + 1], bc[4 * cq + 2], bc[4 * cq + 3]};
     float q[4] = {0.f, 0.f, 0.f, 0.f};
+    if (KEEP) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (rl + BN_SL * u < M) {
+                const float d0 = kv[u].x - mu[0], d1 = kv[u].y - mu[1], d2 = kv[u].z - mu[2], d3 = kv[u].w - mu[3];
+                q[0] = fmaf(d0, d0, q[0]); q[1] = fmaf(d1, d1, q[1]); q[2] = fmaf(d2, d2, q[2]); q[3] = fmaf(d3, d3, q[3]);
+            }
+    } else
     for (long r = rl; r < M; r += BN_SL * 8) {
         float4 v[8];
 #pragma unroll
@@ -571,7 +593,8 @@ __global__ __launch_bounds__(1024) void bn_train_stats_small_kernel(
     }
 }
 
-// backward of y = [relu](bn(x)), batch or running statistics, in one launch: sums, then dx (+)=
+// backward of y = [relu](bn(x)), batch or running statistics, in one launch: sums, then dx (+)=.  KEEP as above (x and dy rows)
+template <bool KEEP>
 __global__ __launch_bounds__(1024) void bn_bwd_small_kernel(
     const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, float* __restrict__ dx, long lddx, long M,
     int C, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
@@ -591,6 +614,27 @@ __global__ __launch_bounds__(1024) void bn_bwd_small_kernel(
     const float* px = x + cc4;
     const float* pd = dy + cc4;
     float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 kx[8], kd[8];                                       // KEEP: this lane's rows rl + BN_SL u of x and dy
+    if (KEEP) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long rr = rl + BN_SL * u < M ? rl + BN_SL * u : 0;
+            kx[u] = *reinterpret_cast<const float4*>(px + rr * ldx);
+            kd[u] = *reinterpret_cast<const float4*>(pd + rr * lddy);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (rl + BN_SL * u < M) {
+                const float xe[4] = {kx[u].x, kx[u].y, kx[u].z, kx[u].w}, de[4] = {kd[u].x, kd[u].y, kd[u].z, kd[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float dz = de[j];
+                    if (relu && fmaf(xe[j], sc[j], sh[j]) <= 0.f) dz = 0.f;
+                    a1[j] += dz;
+                    a2[j] = fmaf(dz, (xe[j] - mu[j]) * is[j], a2[j]);
+                }
+            }
+    } else
     for (long r = rl; r < M; r += BN_SL * 4) {
         float4 xv[4], dv[4];
 #pragma unroll
@@ -635,6 +679,30 @@ __global__ __launch_bounds__(1024) void bn_bwd_small_kernel(
     float s1[4], s2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { s1[j] = bc[0][4 * cq + j]; s2[j] = bc[1][4 * cq + j]; }
+    if (KEEP) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long r = rl + BN_SL * u;
+            if (r >= M) continue;
+            const float xe[4] = {kx[u].x, kx[u].y, kx[u].z, kx[u].w}, de[4] = {kd[u].x, kd[u].y, kd[u].z, kd[u].w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float dz = de[j];
+                if (relu && fmaf(xe[j], sc[j], sh[j]) <= 0.f) dz = 0.f;
+                float g = dz;
+                if (training) {
+                    const float xhat = (xe[j] - mu[j]) * is[j];
+                    g = dz - s1[j] * invM - xhat * s2[j] * invM;
+                }
+                o[j] = sc[j] * g;
+            }
+            float4* dst = reinterpret_cast<float4*>(dx + r * lddx + c);
+            if (dx_accumulate) { const float4 ov = *dst; o[0] += ov.x; o[1] += ov.y; o[2] += ov.z; o[3] += ov.w; }
+            *dst = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
     for (long r = rl; r < M; r += BN_SL * 4) {
         float4 xv[4], dv[4], ov[4];
 #pragma unroll
@@ -688,9 +756,14 @@ GNX_EXPORT int gnx_bn_train_stats(const float* x, long ld, long M, int C, const 
         return GNX_ERR_BAD_ARG;
     static const bool no_small = getenv("GNX_BN_NO_SMALL") != nullptr;
     if (!no_small && M <= BN_SMALL_M && C % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
-        bn_train_stats_small_kernel<<<gnx_cdiv(C, 16), 1024, 0, stream>>>(x, ld, M, C, gamma, beta, running_mean, running_var,
-                                                                        num_batches_tracked, momentum, eps, scale, shift,
-                                                                        save_mean, save_invstd);
+        if (M <= 8 * BN_SL)
+            bn_train_stats_small_kernel<true><<<gnx_cdiv(C, 16), 1024, 0, stream>>>(x, ld, M, C, gamma, beta, running_mean,
+                                                                                  running_var, num_batches_tracked, momentum,
+                                                                                  eps, scale, shift, save_mean, save_invstd);
+        else
+            bn_train_stats_small_kernel<false><<<gnx_cdiv(C, 16), 1024, 0, stream>>>(x, ld, M, C, gamma, beta, running_mean,
+                                                                                   running_var, num_batches_tracked, momentum,
+                                                                                   eps, scale, shift, save_mean, save_invstd);
         return gnx_launch_status();
     }
     const int nblk = slab_count(M);
@@ -751,9 +824,14 @@ GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long 
         if (relu == 2 && (training || !v4all)) return GNX_ERR_UNSUPPORTED;     // activated-input form: eval statistics only
         static const bool no_small = getenv("GNX_BN_NO_SMALL") != nullptr;
         if (!no_small && v4all && relu != 2 && M <= BN_SMALL_M) {
-            bn_bwd_small_kernel<<<gnx_cdiv(C, 16), 1024, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale, shift, save_mean,
-                                                                    save_invstd, dgamma, dbeta, relu, training, accumulate,
-                                                                    dx_accumulate);
+            if (M <= 8 * BN_SL)
+                bn_bwd_small_kernel<true><<<gnx_cdiv(C, 16), 1024, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale, shift,
+                                                                              save_mean, save_invstd, dgamma, dbeta, relu,
+                                                                              training, accumulate, dx_accumulate);
+            else
+                bn_bwd_small_kernel<false><<<gnx_cdiv(C, 16), 1024, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale, shift,
+                                                                               save_mean, save_invstd, dgamma, dbeta, relu,
+                                                                               training, accumulate, dx_accumulate);
             return gnx_launch_status();
         }
         if (!training && v4all) {
