@@ -27,7 +27,8 @@ Rank 0 prints ONE JSON line (contract in the task description) with
                     patches, DataLoader, pinned double-buffered H2D prefetcher; PCIe inside the timed region - never the
                     headline `value`); `config5_f16_256px` = BASELINE config 5's step (256-px patches, fp16 MFMA conv
                     path) on this GPU; `train_f` = the second series of SURVEY 8d, both classifiers trained through f_opt
-                    (DenseNet forward + backward), with its own roofline object.
+                    (DenseNet forward + backward), with its own roofline object; `other_configs` = BASELINE configs 1-3
+                    through the product's training loops (N = 1 only).
 """
 import argparse
 import json
@@ -487,6 +488,27 @@ def config5_series(args, device, rank, world, steps=4, warmup=2):
     return out
 
 
+# ------------------------------------------------------------------------------------------ configs 1-3
+def other_configs(device):
+    """BASELINE configs 1-3 driven through train_spotwise / train_gridwise on synthetic, device-resident data
+    (tools/bench_configs.py): C1 count-MLP spot loop (batch 128), C2 DenseNet-121 @128 px spot loop (batch 32, train-mode
+    BatchNorm, forward + backward + Adam), C3 count f (frozen) + hex g grid loop (batch 1).  Loop output is swallowed."""
+    import contextlib
+    import io
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import bench_configs as bc
+    out = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        for key, fn in (("config1_count_mlp_spotwise_b128", lambda: bc.c1(3)),
+                        ("config3_count_f_hex_g_gridwise_b1", lambda: bc.c3(40)),
+                        ("config2_densenet121_spotwise_b32", lambda: bc.c2(2048, 1))):
+            r = fn()
+            out[key] = {"value": r["spots_per_s"], "unit": "spots/s", "seconds": r["seconds"], "workload": r["config"]}
+            torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------------------------------ one worker = one GPU
 def worker_main(args):
     import torch
@@ -684,6 +706,10 @@ def worker_main(args):
                 ser["roofline"]["other_kernels"] = {k: {f: kt[k][f] for f in ("kernel", "achieved", "frac", "ms_per_step",
                                                                                "launches")} for k in order[1:]}
             result.setdefault("series", {})["train_f"] = ser
+
+    # ---- the other BASELINE configs through the product's own loops (tools/bench_configs.py), single process only
+    if world == 1 and not args.no_series and not args.train_f and args.mfma == 'f32' and args.patch == 128:
+        result.setdefault("series", {})["other_configs"] = other_configs(device)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if gdist.is_active():
