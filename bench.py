@@ -679,37 +679,51 @@ def worker_main(args):
 
     # ---- the real loop feed: arrays in pageable HOST memory, uint8 patches, through a DataLoader and the
     #      pinned double-buffered prefetcher the training loops use; the timed region includes collate, staging and PCIe
+    def optional(name, fn):
+        """An optional series must never cost the headline line: in a single process its failure is recorded instead of
+        raised (with several ranks a failure still ends the run - the ranks are inside collectives together)."""
+        try:
+            result.setdefault("series", {})[name] = fn()
+        except Exception as exc:                                  # noqa: BLE001
+            if world > 1:
+                raise
+            result.setdefault("series", {})[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            torch.cuda.empty_cache()
+
     if (args.from_host or not args.no_series) and not args.train_f:
-        result.setdefault("series", {})["from_host"] = from_host_series(args, model, optimizer, criterion, device, rank, world)
+        optional("from_host", lambda: from_host_series(args, model, optimizer, criterion, device, rank, world))
 
     # ---- BASELINE config 5's geometry in the same run: 256-px patches, fp16 MFMA conv path (fp16 block buffers, fp16 stem)
     if not args.no_series and not args.train_f and args.mfma == 'f32' and args.patch == 128:
-        result.setdefault("series", {})["config5_f16_256px"] = config5_series(args, device, rank, world)
+        optional("config5_f16_256px", lambda: config5_series(args, device, rank, world))
 
     # ---- second series of SURVEY 8d in the same run: f trained (DenseNet forward + backward)
     if not args.train_f and not args.no_series and args.mfma == 'f32' and args.patch == 128:
         free, _ = torch.cuda.mem_get_info(device)
         if tape_bytes(args.patch, H * W) < free:
-            el, loss_tf, probe_tf = run_series(True, args.series_steps, 1, not args.no_kernel_timing)
-            ser = {"value": H * W * world * args.series_steps / el, "unit": "spots/s",
-                   "ms_per_step": 1e3 * el / args.series_steps, "steps": args.series_steps, "warmup": 1,
-                   "workload": "the same step with both classifiers trained through f_opt (Adam, lr 1e-4): DenseNet-121 "
-                               "forward with tape + full backward, eval-mode BN (training.py:126)",
-                   "final_loss": loss_tf}
-            if probe_tf:
-                kt = kernel_table(probe_tf, args.patch, args.series_steps)
-                if getattr(f_img, 'winograd', False) and 'conv3x3' in kt:
-                    winograd_credit(kt['conv3x3'], args.patch, args.series_steps)
-                attach_traffic(kt, '_trainf')
-                order = sorted(kt, key=lambda k: -kt[k]["ms_per_step"])
-                ser["roofline"] = dict(kt[order[0]])
-                ser["roofline"]["other_kernels"] = {k: {f: kt[k][f] for f in ("kernel", "achieved", "frac", "ms_per_step",
-                                                                               "launches")} for k in order[1:]}
-            result.setdefault("series", {})["train_f"] = ser
+            def train_f_series():
+                el, loss_tf, probe_tf = run_series(True, args.series_steps, 1, not args.no_kernel_timing)
+                ser = {"value": H * W * world * args.series_steps / el, "unit": "spots/s",
+                       "ms_per_step": 1e3 * el / args.series_steps, "steps": args.series_steps, "warmup": 1,
+                       "workload": "the same step with both classifiers trained through f_opt (Adam, lr 1e-4): DenseNet-121 "
+                                   "forward with tape + full backward, eval-mode BN (training.py:126)",
+                       "final_loss": loss_tf}
+                if probe_tf:
+                    kt = kernel_table(probe_tf, args.patch, args.series_steps)
+                    if getattr(f_img, 'winograd', False) and 'conv3x3' in kt:
+                        winograd_credit(kt['conv3x3'], args.patch, args.series_steps)
+                    attach_traffic(kt, '_trainf')
+                    order = sorted(kt, key=lambda k: -kt[k]["ms_per_step"])
+                    ser["roofline"] = dict(kt[order[0]])
+                    ser["roofline"]["other_kernels"] = {k: {f: kt[k][f] for f in ("kernel", "achieved", "frac",
+                                                                                   "ms_per_step", "launches")}
+                                                        for k in order[1:]}
+                return ser
+            optional("train_f", train_f_series)
 
     # ---- the other BASELINE configs through the product's own loops (tools/bench_configs.py), single process only
     if world == 1 and not args.no_series and not args.train_f and args.mfma == 'f32' and args.patch == 128:
-        result.setdefault("series", {})["other_configs"] = other_configs(device)
+        optional("other_configs", lambda: other_configs(device))
     if rank == 0:
         print(json.dumps(result), flush=True)
     if gdist.is_active():
