@@ -507,10 +507,13 @@ template <bool KEEP>
 __global__ __launch_bounds__(1024) void bn_train_stats_small_kernel(
     const float* __restrict__ x, long ld, long M, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
-    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+    float* __restrict__ y = nullptr, long ldy = 0, int relu = 0) {
+    // y != NULL: also y = [relu](scale x + shift) - the apply pass of the BatchNorm rides on the statistics launch
     __shared__ float red[BN_SL][16];
     __shared__ float grp[4][16];
     __shared__ float bc[16];
+    __shared__ float ss[2][16];
     const int t = threadIdx.x, cq = t & 3, rl = t >> 2;
     const int c = blockIdx.x * 16 + 4 * cq;
     const bool on = c < C;                                     // 4 | C: a quad is in or out as a whole
@@ -582,6 +585,8 @@ __global__ __launch_bounds__(1024) void bn_train_stats_small_kernel(
             const float g = gamma ? gamma[cc] : 1.f, bt = beta ? beta[cc] : 0.f;
             scale[cc] = g * invstd;
             shift[cc] = bt - mean * g * invstd;
+            ss[0][t] = g * invstd;
+            ss[1][t] = bt - mean * g * invstd;
             save_mean[cc] = mean;
             save_invstd[cc] = invstd;
             if (running_mean) running_mean[cc] = (1.f - momentum) * running_mean[cc] + momentum * mean;
@@ -589,6 +594,33 @@ __global__ __launch_bounds__(1024) void bn_train_stats_small_kernel(
                 const float unbiased = M > 1 ? m2 / (float)(M - 1) : var;
                 running_var[cc] = (1.f - momentum) * running_var[cc] + momentum * unbiased;
             }
+        }
+    }
+    if (!y) return;
+    __syncthreads();
+    if (!on) return;
+    const float sc[4] = {ss[0][4 * cq], ss[0][4 * cq + 1], ss[0][4 * cq + 2], ss[0][4 * cq + 3]};
+    const float sh[4] = {ss[1][4 * cq], ss[1][4 * cq + 1], ss[1][4 * cq + 2], ss[1][4 * cq + 3]};
+    auto apply = [&](const float4& v, long r) {
+        float o[4] = {fmaf(v.x, sc[0], sh[0]), fmaf(v.y, sc[1], sh[1]), fmaf(v.z, sc[2], sh[2]), fmaf(v.w, sc[3], sh[3])};
+        if (relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+        *reinterpret_cast<float4*>(y + r * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+    };
+    if (KEEP) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (rl + BN_SL * u < M) apply(kv[u], rl + BN_SL * u);
+    } else {
+        for (long r = rl; r < M; r += BN_SL * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long rr = r + BN_SL * u;
+                v[u] = *reinterpret_cast<const float4*>(px + (rr < M ? rr : r) * ld);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (r + BN_SL * u < M) apply(v[u], r + BN_SL * u);
         }
     }
 }
@@ -782,6 +814,37 @@ GNX_EXPORT int gnx_bn_train_stats(const float* x, long ld, long M, int C, const 
                                                                  momentum, eps, scale, shift, save_mean,
                                                                  save_invstd);
     return gnx_launch_status();
+}
+
+GNX_EXPORT int gnx_scale_shift_relu(const float* x, long ldx, float* y, long ldy, long M, int C, const float* scale,
+                                    const float* shift, int relu, hipStream_t stream);
+
+// gnx_bn_train_stats followed by gnx_scale_shift_relu (y = [relu](scale x + shift)) - in ONE launch where the matrix is small
+// enough for the single-launch statistics form (M <= 4992 rows, 4 | C, 16-B aligned rows of x and y), otherwise the two calls.
+GNX_EXPORT int gnx_bn_train_stats_apply(const float* x, long ld, long M, int C, const float* gamma, const float* beta,
+                                        float* running_mean, float* running_var, long long* num_batches_tracked,
+                                        float momentum, float eps, float* scale, float* shift, float* save_mean,
+                                        float* save_invstd, float* y, long ldy, int relu, float* workspace,
+                                        hipStream_t stream) {
+    if (!x || !y || !scale || !shift || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0 || ld < C || ldy < C)
+        return GNX_ERR_BAD_ARG;
+    static const bool no_small = getenv("GNX_BN_NO_SMALL") != nullptr;
+    if (!no_small && M <= BN_SMALL_M && C % 4 == 0 && ld % 4 == 0 && ldy % 4 == 0 &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+        if (M <= 8 * BN_SL)
+            bn_train_stats_small_kernel<true><<<gnx_cdiv(C, 16), 1024, 0, stream>>>(
+                x, ld, M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, save_mean,
+                save_invstd, y, ldy, relu);
+        else
+            bn_train_stats_small_kernel<false><<<gnx_cdiv(C, 16), 1024, 0, stream>>>(
+                x, ld, M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, save_mean,
+                save_invstd, y, ldy, relu);
+        return gnx_launch_status();
+    }
+    const int rc = gnx_bn_train_stats(x, ld, M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                                      scale, shift, save_mean, save_invstd, workspace, stream);
+    if (rc != GNX_OK) return rc;
+    return gnx_scale_shift_relu(x, ld, y, ldy, M, C, scale, shift, relu, stream);
 }
 
 // Eval-mode fold: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale

@@ -74,16 +74,19 @@ class _BNReLU(Function):
         if training:
             if momentum is None:
                 raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not on the GridNext path")
+            # statistics and the apply pass in one call (one launch for a matrix of one Visium grid)
             ws = torch.empty(L.query('gnx_bn_workspace', M, C), device=dev, dtype=F32)
-            L.call('gnx_bn_train_stats', L.ptr(x), ld, M, C, L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
+            y = torch.empty((M, C), device=dev, dtype=F32)
+            L.call('gnx_bn_train_stats_apply', L.ptr(x), ld, M, C, L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
                    L.ptr(running_var), L.ptr(num_batches_tracked, torch.int64), float(momentum), float(eps),
-                   L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(ws), L.stream())
+                   L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(y), C, 1 if relu else 0,
+                   L.ptr(ws), L.stream())
         else:
             L.call('gnx_bn_fold_eval', C, L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var),
                    float(eps), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.stream())
-        y = torch.empty((M, C), device=dev, dtype=F32)
-        L.call('gnx_scale_shift_relu', L.ptr(x), ld, L.ptr(y), C, M, C, L.ptr(stats[0]), L.ptr(stats[1]),
-               1 if relu else 0, L.stream())
+            y = torch.empty((M, C), device=dev, dtype=F32)
+            L.call('gnx_scale_shift_relu', L.ptr(x), ld, L.ptr(y), C, M, C, L.ptr(stats[0]), L.ptr(stats[1]),
+                   1 if relu else 0, L.stream())
         ctx.save_for_backward(x, stats)
         ctx.cfg = (ld, bool(training), bool(relu), gamma is not None)
         return y
