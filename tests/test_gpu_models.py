@@ -866,6 +866,34 @@ def test_graph_replayed_spot_loop_equals_the_eager_loop(monkeypatch):
 
 
 
+def test_graph_replay_with_host_fed_batches(monkeypatch):
+    """The real feed: the dataset lives in host memory, so the pinned prefetcher's producer thread page-locks buffers and
+    issues host -> device copies on its side stream WHILE the training thread captures and replays the step graphs
+    (capture mode thread_local).  Histories and weights == the eager loop on the same feed."""
+    import gridnext_amd as ga
+    from gridnext_amd.synthetic import count_mlp
+    G, C = 64, 5
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randint(0, 10, (420, G), generator=gen).float()              # host tensors
+    y = torch.randint(0, C, (420,), generator=gen)
+    results = []
+    for flag in ('0', '1'):
+        monkeypatch.setenv('GNX_GRAPH', flag)
+        torch.manual_seed(21)
+        f = count_mlp(G, C)
+        dl = {'train': DataLoader(TensorDataset(x[:340], y[:340]), batch_size=20, shuffle=True,
+                                  generator=torch.Generator().manual_seed(6)),
+              'val': DataLoader(TensorDataset(x[340:], y[340:]), batch_size=20)}
+        opt = torch.optim.Adam(f.parameters(), lr=1e-3)
+        (f, vh, th), _ = quiet(ga.train_spotwise, f, dl, nn.CrossEntropyLoss(), opt, num_epochs=2)
+        results.append((th, vh, {k: v.clone() for k, v in f.state_dict().items()}))
+    (th0, vh0, sd0), (th1, vh1, sd1) = results
+    assert th0 == th1 and vh0 == vh1
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+
+
+
 def test_graph_replayed_densenet_spot_loop_equals_the_eager_loop(monkeypatch):
     """train_spotwise with a DenseNet (BASELINE config 2's loop): the whole training step - taped forward with train-mode
     BatchNorm, fused CE, backward - and the validation step (eval forward: folded statistics and re-laid-out weights are
