@@ -35,13 +35,16 @@ def _shapes(obj):
 
 def _static_like(obj):
     if torch.is_tensor(obj):
-        return torch.empty_like(obj)
+        # a batch stacked into a persistent buffer of its loader (prefetch._collate_device) IS static: the graph reads it
+        # in place and the second copy of the batch (40 MB for a count grid) does not happen
+        return obj if getattr(obj, '_gnx_stable', False) else torch.empty_like(obj)
     return [_static_like(o) for o in obj]
 
 
 def _copy_into(dst, src):
     if torch.is_tensor(dst):
-        dst.copy_(src, non_blocking=True)
+        if dst is not src and not (dst.data_ptr() == src.data_ptr() and dst.shape == src.shape):
+            dst.copy_(src, non_blocking=True)
     else:
         for d, s in zip(dst, src):
             _copy_into(d, s)

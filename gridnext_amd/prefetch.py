@@ -80,6 +80,16 @@ def _default_collate_loader(loader):
             and loader.collate_fn is default_collate and not getattr(loader, 'pin_memory', False))
 
 
+def _epoch_index_batches(loader):
+    """The index batches of one epoch of `loader`, drawn as its own iterator would draw them: a DataLoader iterator first takes
+    one number from the loader's generator (its worker base seed, torch/utils/data/dataloader.py `_BaseDataLoaderIter`), then
+    the sampler permutes - skipping that draw would give another order than the plain loader for the same seed.  Drawn
+    eagerly in the calling (training) thread, so the random-number stream is consumed at the same point of the program."""
+    it = iter(loader.batch_sampler)
+    torch.empty((), dtype=torch.int64).random_(generator=loader.generator)
+    return [list(b) for b in it]
+
+
 def _collate_pinned(ring, slot, samples, counter):
     """default_collate's structure (tensors stacked along a new batch dimension, sequences collated element-wise into
     LISTS, numbers to tensors) with every tensor stacked straight into a pinned buffer of ring slot `slot`."""
@@ -99,6 +109,28 @@ def _collate_pinned(ring, slot, samples, counter):
     return default_collate(samples)
 
 
+def _collate_device(bufs, samples, counter, device):
+    """default_collate's structure for samples that already live on the device, every tensor stacked into a PERSISTENT
+    buffer of this loader (keyed by position, shape, dtype; marked `_gnx_stable`): no allocation per batch, and a step graph
+    (graphs.py) can take the buffer as its static input instead of copying the batch a second time.  A batch is therefore
+    only valid until the next one is drawn - which is how the training loops use it."""
+    first = samples[0]
+    if torch.is_tensor(first) and first.is_cuda:
+        i = counter[0]
+        counter[0] += 1
+        key = (i, (len(samples),) + tuple(first.shape), first.dtype)
+        buf = bufs.get(key)
+        if buf is None:
+            buf = bufs[key] = torch.empty(key[1], dtype=first.dtype, device=device)
+            buf._gnx_stable = True
+        return torch.stack(samples, 0, out=buf)
+    if isinstance(first, (list, tuple)):
+        return [_collate_device(bufs, [smp[k] for smp in samples], counter, device) for k in range(len(first))]
+    from torch.utils.data._utils.collate import default_collate
+    counter[0] += 1
+    return default_collate(samples)
+
+
 class DevicePrefetcher:
     """Iterate `loader` one batch ahead of the consumer, delivering device tensors.
 
@@ -112,6 +144,8 @@ class DevicePrefetcher:
         self.bytes_moved = 0
         self._ring = None                  # the pinned ring outlives an epoch (one iterator at a time uses it)
         self._ring_busy = False
+        self._dev_bufs = {}                # device-resident data: persistent collate buffers
+        self._dev_busy = False
 
     def __len__(self):
         return len(self.loader)
@@ -136,10 +170,23 @@ class DevicePrefetcher:
         return cached
 
     def __iter__(self):
-        if self.device.type != 'cuda' or self._resident():
+        if self.device.type != 'cuda':
             yield from self.loader
             return
+        if self._resident():
+            if self._dev_busy or not _default_collate_loader(self.loader):
+                yield from self.loader
+                return
+            self._dev_busy = True
+            try:
+                dataset = self.loader.dataset
+                for idx in _epoch_index_batches(self.loader):
+                    yield _collate_device(self._dev_bufs, [dataset[k] for k in idx], [0], self.device)
+            finally:
+                self._dev_busy = False
+            return
         own_collate = _default_collate_loader(self.loader)
+        epoch_batches = iter(_epoch_index_batches(self.loader)) if own_collate else None
         q = queue.Queue(maxsize=self.depth)
         if self._ring_busy:                                       # a second iterator alongside the first: its own ring
             ring, owns = _PinnedRing(self.depth + 2), False
@@ -157,7 +204,7 @@ class DevicePrefetcher:
             try:
                 torch.cuda.set_device(self.device)
                 if own_collate:
-                    dataset, index_batches = self.loader.dataset, iter(self.loader.batch_sampler)
+                    dataset, index_batches = self.loader.dataset, epoch_batches
                 else:
                     it = iter(self.loader)
                 n = 0

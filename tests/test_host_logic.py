@@ -433,3 +433,21 @@ def test_prefetcher_is_transparent_on_the_cpu_and_keeps_batch_structure():
     assert len(flat) == 3
     doubled = prefetch._map(got[0], lambda t: t * 2)
     assert isinstance(doubled[0], list) and torch.equal(doubled[1], got[0][1] * 2)
+
+
+def test_prefetcher_draws_an_epoch_in_the_loaders_own_order():
+    """prefetch._epoch_index_batches (the own-collate path of the pinned prefetcher) == the batches a plain DataLoader
+    iterator yields for the same generator state, epoch after epoch, and it leaves the generator where the loader would."""
+    import torch
+    from torch.utils.data import DataLoader, TensorDataset
+    from gridnext_amd import prefetch
+    data = TensorDataset(torch.arange(23))
+    for shuffle in (True, False):
+        g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+        plain = DataLoader(data, batch_size=4, shuffle=shuffle, generator=g1)
+        mine = DataLoader(data, batch_size=4, shuffle=shuffle, generator=g2)
+        for _ in range(3):
+            want = [b[0].tolist() for b in plain]
+            got = prefetch._epoch_index_batches(mine)
+            assert got == want
+        assert torch.equal(g1.get_state(), g2.get_state())
