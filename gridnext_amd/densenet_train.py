@@ -64,6 +64,11 @@ def relayout_weights(model, kind, dev, st):
     if hit is None or hit[0] != key:
         dsts, rows = {}, []
         for w in weights:
+            # the device table holds RAW pointers read as dense fp32 [N][K][taps]: anything else (channels_last weights
+            # after model.to(memory_format=...), half weights) would be re-laid-out silently wrong
+            if not (w.is_contiguous() and w.dtype == F32):
+                raise TypeError("gridnext_amd.DenseNet: conv weights must be contiguous float32 (got %s, strides %s)"
+                                % (w.dtype, tuple(w.stride())))
             n, k = w.shape[0], w.shape[1]
             shape = (9, n, k) if kind == 0 else ((9, k, n) if kind == 1 else (k, n))
             d = torch.empty(shape, device=dev, dtype=F32)

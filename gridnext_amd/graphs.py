@@ -55,8 +55,6 @@ def wanted(model, fused_ok, device):
     flag = os.environ.get('GNX_GRAPH', '')
     if flag == '0' or not fused_ok or torch.device(device).type != 'cuda' or not hasattr(model, 'forward_nhwc'):
         return False
-    if flag == '1':
-        return True
     from .densenet import DenseNet
     from . import functional as GF
     fs = [getattr(model, n) for n in ('image_classifier', 'count_classifier') if hasattr(model, n)] or \
@@ -64,9 +62,13 @@ def wanted(model, fused_ok, device):
     for f in fs:
         if isinstance(f, DenseNet):
             if f.training or any(p.requires_grad for p in f.parameters()):
-                return False                                   # tape, version checks, cache invalidation: host-side state
-            return False                                       # frozen DenseNet: the step is GPU-bound, nothing to gain
-        if not GF.is_hip_sequential(f):
+                # tape, version checks, cache invalidation, a host read of the gamma != 0 check: host-side state that a
+                # capture cannot hold - refused even under GNX_GRAPH=1 (the grid stepper has no drop_derived hook)
+                return False
+            if flag != '1':
+                return False                                   # frozen DenseNet: the step is GPU-bound, nothing to gain
+            continue
+        if not GF.is_hip_sequential(f) and flag != '1':
             return False                                       # an arbitrary user module: do not guess
     return True
 
@@ -92,6 +94,7 @@ class GridStepGraph:
         self.graph = None
         self.out_grads = None
         self.seen = 0
+        self.failed = False
 
     def ready(self):
         return self.graph is not None
@@ -104,16 +107,22 @@ class GridStepGraph:
         for p in self.params:
             p.grad = None                                      # the captured backward then CREATES its gradient tensors
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-            with torch.set_grad_enabled(self.train):
-                loss, correct, n_fg = self.step_fn(self.s_inputs, self.s_labels)
-                if self.train:
-                    loss.backward()
-        self.outs = (loss.detach(), correct, n_fg)
-        self.s_grads = [p.grad for p in self.params]           # graph-owned; None where a parameter got no gradient
-        for p, g in zip(self.params, keep):
-            p.grad = g                                         # capture ran nothing: the caller's gradients are untouched
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                with torch.set_grad_enabled(self.train):
+                    loss, correct, n_fg = self.step_fn(self.s_inputs, self.s_labels)
+                    if self.train:
+                        loss.backward()
+            self.outs = (loss.detach(), correct, n_fg)
+            self.s_grads = [p.grad for p in self.params]       # graph-owned; None where a parameter got no gradient
+            self.graph = graph                                 # only a COMPLETED capture makes this entry ready()
+        except Exception:
+            self.failed = True                                 # this (phase, shapes) stays eager for the rest of the call
+            raise
+        finally:
+            for p, g in zip(self.params, keep):
+                p.grad = g                                     # capture ran nothing: the caller's gradients are untouched
 
     def replay(self, inputs, labels):
         """Returns the step's (loss, correct, n_fg) as the graph's STATIC output tensors: valid until the next replay of
@@ -169,13 +178,20 @@ class GridStepGraphs:
             if len(self.table) >= MAX_GRAPHS:
                 return None
             st = self.table[key] = GridStepGraph(self.step_fn, self.params, train)
+        if st.failed:
+            return None
         if not st.ready():
             st.seen += 1
             if st.seen <= WARMUP:
                 return None                                    # eager warm-up batch
             if self.drop_derived is not None:
                 self.drop_derived()
-            st.capture(inputs, labels)
+            try:
+                st.capture(inputs, labels)
+            except Exception as exc:                           # e.g. a host synchronisation inside the step: stay eager
+                import warnings
+                warnings.warn("gridnext_amd.graphs: step capture failed (%s); this step shape runs eagerly" % (exc,))
+                return None
         out = st.replay(inputs, labels)
         if self.drop_derived is not None:
             self.drop_derived()

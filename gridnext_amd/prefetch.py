@@ -47,7 +47,10 @@ class _PinnedRing:
         key = (index, tuple(shape), dtype)
         buf = self.slots[slot].get(key)
         if buf is None:
-            buf = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+            try:
+                buf = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+            except RuntimeError:                              # the host refuses to page-lock more: pageable staging
+                buf = torch.empty(tuple(shape), dtype=dtype)  # (the copy out of it is then synchronous, still correct)
             self.slots[slot][key] = buf
         return buf
 
@@ -72,11 +75,15 @@ def _default_collate_loader(loader):
     stack them into a fresh pageable tensor (measured on the GPU box: 61 ms for one 245 MB uint8 array, nearly all of it
     page faults of the new allocation; the copy into an existing pinned buffer takes < 1 ms)."""
     try:
-        from torch.utils.data import DataLoader
+        from torch.utils.data import DataLoader, IterableDataset
         from torch.utils.data._utils.collate import default_collate
     except ImportError:                                       # pragma: no cover
         return False
+    # map-style datasets only: torch gives a loader over an IterableDataset a BatchSampler over an ENDLESS sampler
+    # (`_InfiniteConstantSampler`), so `batch_sampler is not None` holds there too and drawing "one epoch" of index batches
+    # from it would never return.  Such loaders are iterated as they are.
     return (isinstance(loader, DataLoader) and loader.num_workers == 0 and loader.batch_sampler is not None
+            and not isinstance(loader.dataset, IterableDataset)
             and loader.collate_fn is default_collate and not getattr(loader, 'pin_memory', False))
 
 
@@ -137,7 +144,11 @@ class DevicePrefetcher:
         for inputs, labels in DevicePrefetcher(loader, device):
             ...
 
-    depth: batches in flight ahead of the consumer (2 = double buffering)."""
+    depth: batches in flight ahead of the consumer (2 = double buffering).
+
+    Pinned footprint: depth + 1 page-locked copies of one batch per loader (a uint8 128-px Visium array: 3 x 285 MB; float
+    patches: 3 x 1 GB), allocated before the first batch is delivered and kept across epochs so that no step waits for
+    page-locking.  `close()` releases them (the training loops call it when they return)."""
 
     def __init__(self, loader, device, depth=2):
         self.loader, self.device, self.depth = loader, torch.device(device), max(1, int(depth))
@@ -150,19 +161,38 @@ class DevicePrefetcher:
     def __len__(self):
         return len(self.loader)
 
+    def close(self):
+        """Release the pinned staging ring and the persistent device collate buffers (no iterator may be active)."""
+        if not self._ring_busy:
+            self._ring = None
+        if not self._dev_busy:
+            self._dev_bufs = {}
+
     def _resident(self):
-        """True when the loader's data already live on the device (decided once per loader from its first sample, without
-        touching the sampler, so no random numbers are drawn): then the loader is iterated as it is."""
+        """True when the loader's data already live on the device.  Decided once per loader from the tensors a
+        TensorDataset-like dataset HOLDS (`.tensors`, also through `.datasets` of the stacking datasets): no sample is drawn,
+        so nothing is decoded (a PatchGridDataset item is a whole array of JPEGs), no transform runs and no random number
+        is consumed.  Any other dataset takes the general path, which passes device-resident batches through untouched."""
         cached = getattr(self.loader, '_gnx_resident', None)
         if cached is None:
-            cached = False
-            dataset = getattr(self.loader, 'dataset', None)
-            if dataset is not None:
-                try:
-                    flat = _tensors(dataset[0], [])
-                    cached = bool(flat) and all(t.is_cuda for t in flat)
-                except Exception:                                # an exotic dataset: just take the general path
-                    cached = False
+            def held(ds, depth=0):
+                ts = getattr(ds, 'tensors', None)
+                if isinstance(ts, (list, tuple)) and ts and all(torch.is_tensor(t) for t in ts):
+                    return list(ts)
+                subs = getattr(ds, 'datasets', None)
+                if subs is None:
+                    subs = [getattr(ds, a) for a in ('image_dataset', 'count_dataset', 'dataset') if hasattr(ds, a)]
+                if isinstance(subs, (list, tuple)) and subs and depth < 4:
+                    out = []
+                    for sub in subs:
+                        got = held(sub, depth + 1)
+                        if got is None:
+                            return None
+                        out += got
+                    return out
+                return None
+            flat = held(getattr(self.loader, 'dataset', None))
+            cached = bool(flat) and all(t.is_cuda for t in flat)
             try:
                 self.loader._gnx_resident = cached
             except Exception:
@@ -189,10 +219,10 @@ class DevicePrefetcher:
         epoch_batches = iter(_epoch_index_batches(self.loader)) if own_collate else None
         q = queue.Queue(maxsize=self.depth)
         if self._ring_busy:                                       # a second iterator alongside the first: its own ring
-            ring, owns = _PinnedRing(self.depth + 2), False
+            ring, owns = _PinnedRing(self.depth + 1), False
         else:
             if self._ring is None:
-                self._ring = _PinnedRing(self.depth + 2)
+                self._ring = _PinnedRing(self.depth + 1)
             ring, owns = self._ring, True
             self._ring_busy = True
             ring.events = [None] * len(ring.slots)
@@ -298,3 +328,12 @@ def wrap(loader, device):
     except Exception:                                          # a loader without a __dict__: a fresh wrapper per epoch
         pass
     return pf
+
+
+def release(dataloaders):
+    """Drop the pinned rings / device collate buffers `wrap` attached to these loaders (a dict or an iterable of loaders)."""
+    loaders = dataloaders.values() if isinstance(dataloaders, dict) else dataloaders
+    for loader in loaders:
+        pf = getattr(loader, '_gnx_prefetcher', None)
+        if isinstance(pf, DevicePrefetcher):
+            pf.close()

@@ -185,6 +185,7 @@ def train_spotwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
         if gdist.rank() == 0:
             print()
     _finish(since, keeper.best_loss)
+    prefetch.release(dataloaders)                   # the loaders' pinned staging rings
     model.load_state_dict(keeper.best_wts)
     return model, val_history, train_history
 
@@ -277,5 +278,6 @@ def train_gridwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
         if gdist.rank() == 0:
             print()
     _finish(since, keeper.best_loss)
+    prefetch.release(dataloaders)                   # the loaders' pinned staging rings
     model.load_state_dict(keeper.best_wts)
     return model, val_history, train_history

@@ -451,3 +451,28 @@ def test_prefetcher_draws_an_epoch_in_the_loaders_own_order():
             got = prefetch._epoch_index_batches(mine)
             assert got == want
         assert torch.equal(g1.get_state(), g2.get_state())
+
+
+def test_prefetcher_leaves_iterable_dataset_loaders_alone():
+    """A DataLoader over an IterableDataset has a batch_sampler too (over torch's endless _InfiniteConstantSampler): the
+    own-collate path must refuse it - drawing 'an epoch' of index batches from it would never return."""
+    from torch.utils.data import DataLoader, IterableDataset, TensorDataset
+    from gridnext_amd import prefetch
+
+    class Stream(IterableDataset):
+        def __iter__(self):
+            for k in range(5):
+                yield torch.full((3,), float(k)), torch.tensor(k)
+
+    it_loader = DataLoader(Stream(), batch_size=2)
+    assert it_loader.batch_sampler is not None                   # the trap
+    assert not prefetch._default_collate_loader(it_loader)
+    map_loader = DataLoader(TensorDataset(torch.zeros(4, 3), torch.zeros(4)), batch_size=2)
+    assert prefetch._default_collate_loader(map_loader)
+    # residency is read off the tensors a dataset HOLDS: no sample is drawn (no decode, no transform, no RNG draw)
+    class Exploding(TensorDataset):
+        def __getitem__(self, i):
+            raise AssertionError("the residency probe must not index the dataset")
+    pf = prefetch.DevicePrefetcher(DataLoader(Exploding(torch.zeros(4, 3), torch.zeros(4)), batch_size=2), 'cpu')
+    assert pf._resident() is False
+    pf.close()
