@@ -238,6 +238,15 @@ int gnx_conv3x3_f16_dma_h(const void* A16, long lda16, const void* Wr16, void* o
                           gnx_stream_t stream);
 int gnx_bnrelu_avgpool_h16(const void* in16, long ldi, float* out, long ldo, long imgs, int C, int S2, const float* scale,
                            const float* shift, gnx_stream_t stream);
+/* One whole dense layer of config 5 in ONE kernel (gridnext/densenet.py:35-44: cat -> norm1 -> relu1 -> conv1 -> norm2 ->
+ * relu2 -> conv2) on the fp16 block buffer X16 [n_img * S * S][ld16]: reads columns [0, K), writes the layer's 32 new columns
+ * [K, K + 32); the 128-channel bottleneck lives in LDS only.  gnx_dense_layer_f16_pack rounds conv1.weight [128][K] and
+ * conv2.weight [32][128][3][3] (fp32, torch layouts) to fp16 ONCE into the MFMA-fragment order the kernel streams
+ * (w1p: 128 * K halves, w2p: 36 864 halves).  bn_size * growth_rate = 128, growth_rate = 32; S in {4, 8, 16, 32, 64};
+ * 32 | K; 8 | ld16; 128 | n_img * S * S; anything else: GNX_ERR_UNSUPPORTED (callers fall back to the two-kernel pair). */
+int gnx_dense_layer_f16_pack(const float* w1, const float* w2, void* w1p, void* w2p, int K, gnx_stream_t stream);
+int gnx_dense_layer_f16(void* X16, long ld16, long n_img, int S, int K, const void* w1p, const void* w2p, const float* scale1,
+                        const float* shift1, const float* scale2, const float* shift2, gnx_stream_t stream);
 
 /* ---- DenseNet-BC backward (the gradients torch.autograd derives for gridnext/densenet.py) -----------------------------
  * Data gradients reuse gnx_conv1x1_bnrelu / gnx_conv3x3_bnrelu with weights transformed by gnx_transpose_weight

@@ -583,6 +583,65 @@ def test_fp16_block_buffer_kernels(L):
     assert torch.equal(p32, p16)
 
 
+def _dense_layer_ref(x16, W1, W2, sc1, sh1, sc2, sh2):
+    """densenet.py:35-44 on fp16 values with the fused kernel's rounding points (operands fp16, sums exact in double):
+    x16 [n, S, S, K] halves -> [n, S, S, 32] double."""
+    a = torch.relu(torch.addcmul(sh1, x16.float(), sc1)).half()                   # norm1 -> relu1, rounded once
+    y = torch.einsum('nyxk,ok->nyxo', a.double(), W1.half().double())             # conv1 (1x1)
+    b = torch.relu(y.float() * sc2 + sh2).half()                                  # norm2 -> relu2, the fp16 bottleneck
+    o = F.conv2d(b.double().permute(0, 3, 1, 2), W2.half().double(), padding=1)   # conv2 (3x3, pad 1)
+    return o.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("S,n,K,ct", [(64, 2, 64, 104), (64, 3, 96, 136), (64, 260, 64, 104), (32, 4, 128, 168),
+                                      (32, 300, 224, 264), (16, 8, 256, 296), (16, 520, 96, 136), (8, 16, 512, 552),
+                                      (8, 1040, 64, 104), (4, 64, 992, 1032), (4, 4160, 64, 104)])
+def test_dense_layer_f16_fused(L, S, n, K, ct):
+    """gnx_dense_layer_f16 (one kernel per dense layer, bottleneck in LDS only) against the layer evaluated in double on the
+    same fp16 values with the same rounding points.  Tolerance 3e-3 of the output range: the fp16 rounding of the output
+    (2^-11 relative) plus bottleneck values that round the other way when conv1's fp32 sum runs in another order.  Also: the
+    input columns and everything beyond the 32 new columns stay untouched.  Shapes: every map size the kernel takes, K from
+    2 to 31 stages, single-step and swept images, fewer and more work units than compute units (260 ... 4160 images)."""
+    g = torch.Generator().manual_seed(S * 1000 + K + n)
+    x = torch.randn(n, S, S, ct, generator=g).half()
+    x[:, :, :, K:] = 7.0
+    W1 = torch.randn(128, K, generator=g) * (1.0 / K ** 0.5)
+    W2 = torch.randn(32, 128, 3, 3, generator=g) * 0.05
+    sc1, sh1 = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+    sc1[::7] *= -1.0                                                               # negative scales too
+    sc2, sh2 = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.5
+    st = L.stream()
+    H = torch.float16
+    X = x.reshape(-1, ct).to(DEV)
+    W1d, W2d = W1.to(DEV), W2.to(DEV)
+    w1p = torch.empty(128 * K, device=DEV, dtype=H)
+    w2p = torch.empty(9 * 8 * 512, device=DEV, dtype=H)
+    L.call('gnx_dense_layer_f16_pack', L.ptr(W1d), L.ptr(W2d), L.ptr(w1p, H), L.ptr(w2p, H), K, st)
+    d = [v.to(DEV) for v in (sc1, sh1, sc2, sh2)]
+    L.call('gnx_dense_layer_f16', L.ptr(X, H), ct, n, S, K, L.ptr(w1p, H), L.ptr(w2p, H), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]),
+           L.ptr(d[3]), st)
+    torch.cuda.synchronize()
+    got = X.cpu().reshape(n, S, S, ct)
+    assert torch.equal(got[..., :K], x[..., :K]), "input columns changed"
+    assert float(got[..., K + 32:].float().min()) == 7.0 and float(got[..., K + 32:].float().max()) == 7.0
+    pick = sorted(set(i for i in (0, 1, 2, 3, 255, 256, 257, 511, 512, n // 2, n - 2, n - 1) if 0 <= i < n))
+    ref = _dense_layer_ref(x[pick][..., :K], W1, W2, sc1, sh1, sc2, sh2)
+    out = got[pick][..., K:K + 32].double()
+    assert torch.isfinite(out).all()
+    err = (out - ref).abs().max().item()
+    tol = 3e-3 * ref.abs().max().item()
+    assert err <= tol, "S=%d n=%d K=%d: max abs err %.3e > %.3e" % (S, n, K, err, tol)
+    # every image, cheaply: the column sums of the new channels against the same sums of a second launch on a permuted
+    # batch (a work unit is an image or a tile of whole images: the result must not depend on which workgroup ran it)
+    if n >= 16:
+        perm = torch.randperm(n, generator=g)
+        X2 = x[perm].reshape(-1, ct).to(DEV)
+        L.call('gnx_dense_layer_f16', L.ptr(X2, H), ct, n, S, K, L.ptr(w1p, H), L.ptr(w2p, H), L.ptr(d[0]), L.ptr(d[1]),
+               L.ptr(d[2]), L.ptr(d[3]), st)
+        torch.cuda.synchronize()
+        assert torch.equal(X2.cpu().reshape(n, S, S, ct), got[perm]), "result depends on the image's position in the batch"
+
+
 @pytest.mark.parametrize("n,O,P", [(3, 64, 128), (300, 64, 128), (2, 32, 128), (3, 64, 256), (270, 64, 256), (2, 32, 256)])
 def test_stem_fused_with_norm0_relu0_pool0(L, n, O, P):
     """conv0 -> norm0 -> relu0 -> pool0 in one kernel (128- and 256-px geometry) vs torch; other geometries must say
