@@ -41,16 +41,33 @@ constexpr int DL_SLOT = 8192;                  // 128 px x 32 channels: byte(px,
 constexpr int DL_AR = DL_BT + DL_BT_BYTES;
 constexpr int DL_Z = DL_AR + DL_NS * DL_SLOT;  // 4 KB of zeros (masked fragment lanes; immediates reach 7 * 512 + 256 + 16)
 constexpr int DL_OT = DL_Z + 4096;             // norm2: scale[128], shift[128]
-constexpr int DL_LDS = DL_OT + 1024;
+constexpr int DL_CT = DL_OT + 1024;             // norm1 constants of the stage in each ring slot: [slot][16-B column 4][scale 8 | shift 8] floats
+constexpr int DL_LDS = DL_CT + DL_NS * 256;
 static_assert(DL_LDS <= 160 * 1024, "LDS");
 constexpr int DL_PF = 3;                       // W1 fragment stages in flight ahead of their use
+
+// Diagnostic build only (tools/ubench/dl_stamps.py compiles this file with -DGNX_DL_STAMP into its own library): per
+// workgroup, wave 0 and wave 4 sum the shader cycles they spend in each segment of a step and leave them in a buffer of
+// their own.  In the product build the macros are empty: no stamp executes.
+#ifdef GNX_DL_STAMP
+#define GNX_DL_STAMP_PARAM , unsigned long long* __restrict__ stamps
+#define DL_T0() unsigned long long dl_t = __builtin_readcyclecounter(), dl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define DL_LAP(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); dl_acc[k] += n_ - dl_t; dl_t = n_; } while (0)
+#define DL_OUT(base) do { if (stamps && lane == 0) for (int q_ = 0; q_ < 8; ++q_) stamps[(long)blockIdx.x * 16 + (base) + q_] = dl_acc[q_]; } while (0)
+#else
+#define GNX_DL_STAMP_PARAM
+#define DL_T0() do {} while (0)
+#define DL_LAP(k) do {} while (0)
+#define DL_OUT(base) do {} while (0)
+#endif
 
 template <int S>
 __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restrict__ X, long ld, int n_units, int K,
                                                               const _Float16* __restrict__ w1p,
                                                               const _Float16* __restrict__ w2p,
                                                               const float* __restrict__ sc1, const float* __restrict__ sh1,
-                                                              const float* __restrict__ sc2, const float* __restrict__ sh2) {
+                                                              const float* __restrict__ sc2, const float* __restrict__ sh2
+                                                              GNX_DL_STAMP_PARAM) {
     constexpr int J = S >= 16 ? S * S / 128 : 1;           // steps per unit
     constexpr int LOG2S = S == 64 ? 6 : S == 32 ? 5 : S == 16 ? 4 : S == 8 ? 3 : 2;
     __shared__ __attribute__((aligned(16))) char lds[DL_LDS];
@@ -82,64 +99,92 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
         }
         // issue cursor: the stage whose DMA goes out next.  Past this workgroup's last stage it re-reads the workgroup's
         // first unit into slots nobody will read: cheaper than a branch around every issue (and vmcnt stays countable).
-        int cu = bid, cj = 0, cs = 0, cslot = 0;
+        // A stage = two 1-KB pieces per wave (16 px x 32 channels each) + the stage's norm1 constants (scale / shift of its 32
+        // channels, 256 B into the slot's side area: 16 lanes of ONE wave - the waves take turns): the constants travel
+        // with the data.
+        int cu = bid, cj = 0, cs = 0, cslot = 0, cturn = 0;
         const unsigned voffA = (unsigned)(((lane & 15) * ld + 8 * (lane >> 4)) * 2);
+        // constants piece, lane l < 16: 16-B column q = l >> 2 of the stage, {scale lo, scale hi, shift lo, shift hi}[l & 3]
+        const float* const csrc = ((lane & 2) ? sh1 : sc1) + 8 * ((lane >> 2) & 3) + 4 * (lane & 1);
+        const _Float16* pbase = X + ((long)bid * J * 128 + 32 * pw) * ld;                 // this wave's rows of the cursor's step
+        const long step_stride = 128 * ld;
         auto issue = [&]() {
-            const long row0 = ((long)cu * J + cj) * 128 + 32 * pw;
+            if (cturn == pw && lane < 16) dma16_global(csrc + 32 * cs, lb + DL_CT + cslot * 256);
+            cturn = (cturn + 1) & 3;
 #pragma unroll
             for (int g2 = 0; g2 < 2; ++g2) {
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(X + (row0 + 16 * g2) * ld, 0,
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(pbase) + 16 * g2 * ld, 0,
                                                                                     (unsigned)(16 * ld * 2), 0x00020000);
                 dma16_buf(rs, voffA, cs * 64, lb + DL_AR + cslot * DL_SLOT + (2 * pw + g2) * 1024);
             }
             cslot = cslot == DL_NS - 1 ? 0 : cslot + 1;
             if (++cs == nst) {
                 cs = 0;
+                pbase += step_stride;
                 if (++cj == J) {
                     cj = 0;
                     cu += G;
                     if (cu >= n_units) cu = bid;
+                    pbase = X + ((long)cu * J * 128 + 32 * pw) * ld;
                 }
             }
         };
         // norm1 + relu1 in place on this wave's own 32 px x 32 channels of a slot (the pieces it fetched: its own vmcnt wait
-        // is all the synchronisation that needs).  Half a wave per 16-B column: the channel set is then uniform per
-        // instruction and scale / shift are scalar loads (their own counter - a vector load here would retire in order behind
-        // the DMAs in flight and stall on them).
-        int as = 0, aslot = 0;                                 // stage (within its step) and slot activated next
+        // is all the synchronisation the data needs), lane = (pixel, 16-B column) as the DMA wrote them: a lane's 8 channels
+        // are the same in both pieces, their scale / shift come from the slot's side area (confirmed landed by the wave
+        // that fetched them one barrier earlier).  fp32 fma on the fp16 value, rounded once to fp16 (v_fma_mix), relu packed.
+        int aslot = 0;
         auto activate = [&]() {
-            const int k0 = 32 * as;
-            if (lane < 32) {
-                char* base = lds + DL_AR + aslot * DL_SLOT + (2 * pw + (lane >> 4)) * 1024 + (lane & 15) * 16;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    half8 v = *reinterpret_cast<half8*>(base + c * 256);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const float a = fmaf((float)v[q], sc1[k0 + 8 * c + q], sh1[k0 + 8 * c + q]);
-                        v[q] = (_Float16)fmaxf(a, 0.f);
-                    }
-                    *reinterpret_cast<half8*>(base + c * 256) = v;
-                }
-            }
+            const float* ct = reinterpret_cast<const float*>(lds + DL_CT + aslot * 256) + 16 * (lane >> 4);
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(ct), s1 = *reinterpret_cast<const f32x4*>(ct + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(ct + 8), b1 = *reinterpret_cast<const f32x4*>(ct + 12);
+            char* base = lds + DL_AR + aslot * DL_SLOT + 2 * pw * 1024 + lane * 16;
+            const u32x4 v0 = *reinterpret_cast<u32x4*>(base), v1 = *reinterpret_cast<u32x4*>(base + 1024);
+            u32x4 o0, o1;
+            auto act2 = [](unsigned x, float sa, float ba, float sb, float bb) {      // two halves of one register
+                unsigned r;
+                asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+                    "v_fma_mixhi_f16 %0, %1, %4, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                    "v_pk_max_f16 %0, %0, 0"
+                    : "=&v"(r) : "v"(x), "v"(sa), "v"(ba), "v"(sb), "v"(bb));
+                return r;
+            };
+            o0[0] = act2(v0[0], s0[0], b0[0], s0[1], b0[1]); o0[1] = act2(v0[1], s0[2], b0[2], s0[3], b0[3]);
+            o0[2] = act2(v0[2], s1[0], b1[0], s1[1], b1[1]); o0[3] = act2(v0[3], s1[2], b1[2], s1[3], b1[3]);
+            o1[0] = act2(v1[0], s0[0], b0[0], s0[1], b0[1]); o1[1] = act2(v1[1], s0[2], b0[2], s0[3], b0[3]);
+            o1[2] = act2(v1[2], s1[0], b1[0], s1[1], b1[1]); o1[3] = act2(v1[3], s1[2], b1[2], s1[3], b1[3]);
+            *reinterpret_cast<u32x4*>(base) = o0;
+            *reinterpret_cast<u32x4*>(base + 1024) = o1;
             aslot = aslot == DL_NS - 1 ? 0 : aslot + 1;
-            as = as + 1 == nst ? 0 : as + 1;
         };
 #pragma unroll
         for (int q = 0; q < DL_NS - 1; ++q) issue();           // stages 0..4
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // W2 and stage 0 have landed (stages 1..4: 8 pieces)
+        // W2, stage 0 and the constants of stages 0 and 1 have landed (left in flight: at most the 2 pieces of stage 1 and the
+        // 6 of stages 2..4; a wave whose turn for constants falls in 2..4 waits for one piece more: never less than needed)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        lds_barrier();                                         // B_init: every wave's constants of stage 0 are visible
         activate();
+        DL_T0();
         for (int u = bid; u < n_units; u += G)
             for (int j = 0; j < J; ++j) {
                 for (int s = 0; s < nst; ++s) {
                     lds_barrier();                             // B_t: stage t is visible, stage t - 1 is consumed
+                    DL_LAP(0);
                     issue();                                   // stage t + 5 into the slot of stage t - 1
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage t + 1 has landed (t + 2..t + 5 in flight)
+                    DL_LAP(1);
+                    // stage t + 1 and - where they were this wave's to fetch - the constants of stage t + 2 have landed (in
+                    // flight: the 8 pieces of t + 2..t + 5, and one constants piece among them or none)
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    DL_LAP(2);
                     activate();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    DL_LAP(3);
                 }
                 lds_barrier();                                 // E: the step's bottleneck tile is complete
+                DL_LAP(4);
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wave == 4) DL_OUT(8);
         return;
     }
 
@@ -164,15 +209,18 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
         load_w(fr[2], 2);
     };
     preload_w();
+    lds_barrier();                                             // B_init
     f32x16 c1[4], a0, a1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
     const unsigned laneA = lb + DL_AR + (i >> 4) * 1024 + h * 256 + (i & 15) * 16;
     int slot = 0;
+    DL_T0();
     // one stage: the 8 operand fragments (4 pixel blocks x 2 k-steps) are requested together, each MFMA waits for its own
     auto stage = [&](auto ph_c, int s) {
         constexpr int P = decltype(ph_c)::value;
         lds_barrier();                                         // B_t
+        DL_LAP(0);
         load_w(fr[(P + DL_PF) & 3], s + DL_PF);
         const unsigned ab = laneA + slot * DL_SLOT;
         f32x4 av[8];
@@ -187,6 +235,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                                                                __builtin_bit_cast(half8, av[n]), c1[n & 3], 0, 0, 0);
         });
         slot = slot == DL_NS - 1 ? 0 : slot + 1;
+        DL_LAP(1);
     };
 
     for (int u = bid; u < n_units; u += G)
@@ -221,7 +270,9 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                     *reinterpret_cast<half4*>(lds + DL_BT + (px >> 4) * 4096 + (4 * nb + g) * 256 + (px & 15) * 16 + 8 * h) = o;
                 }
             }
+            DL_LAP(2);
             lds_barrier();                                     // E
+            DL_LAP(3);
             // ---- conv2, scatter form
             const long R0 = ((long)u * J + j) * 128;
             auto tap3 = [&](f32x16& acc, int O_rel, int dy) {  // the three dx taps of row offset dy into the block at O_rel
@@ -310,7 +361,9 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
 #pragma unroll 1
             for (int dy = lo1; dy <= hi1; ++dy) tap3(a1, O1, dy);
             if (s1) store(a1, O1);
+            DL_LAP(4);
         }
+    if (wave == 0) DL_OUT(0);
 }
 
 // W1 [128][K] fp32 -> fragment order halves: ((nb * K/16 + ks) * 64 + lane) * 8 + q = W[32 nb + (lane & 31)][16 ks + 8 (lane >> 5) + q]
@@ -342,6 +395,11 @@ GNX_EXPORT int gnx_dense_layer_f16_pack(const float* w1, const float* w2, void* 
     return gnx_launch_status();
 }
 
+#ifdef GNX_DL_STAMP
+static unsigned long long* g_dl_stamps = nullptr;
+GNX_EXPORT void gnx_dense_layer_f16_set_stamps(void* buf) { g_dl_stamps = reinterpret_cast<unsigned long long*>(buf); }
+#endif
+
 // The dense layer on an fp16 block buffer X16 [n_img * S * S][ld16]: reads columns [0, K), writes columns [K, K + 32).
 // bn_size * growth = 128 and growth = 32 are fixed; S in {4, 8, 16, 32, 64}; 32 | K; 8 | ld16, K + 32 <= ld16; X16 16-B
 // aligned; n_img * S * S a multiple of 128.  scale / shift: the folded running-statistics BatchNorms (norm1: K, norm2: 128).
@@ -366,8 +424,14 @@ GNX_EXPORT int gnx_dense_layer_f16(void* X16, long ld16, long n_img, int S, int 
     _Float16* X = reinterpret_cast<_Float16*>(X16);
     const _Float16* w1 = reinterpret_cast<const _Float16*>(w1p);
     const _Float16* w2 = reinterpret_cast<const _Float16*>(w2p);
+#ifdef GNX_DL_STAMP
+#define GNX_DL_STAMP_ARG , g_dl_stamps
+#else
+#define GNX_DL_STAMP_ARG
+#endif
 #define GNX_DL(SS)                                                                                                   \
-    dense_layer_f16_kernel<SS><<<grid, 512, 0, stream>>>(X, ld16, (int)units, K, w1, w2, scale1, shift1, scale2, shift2); \
+    dense_layer_f16_kernel<SS><<<grid, 512, 0, stream>>>(X, ld16, (int)units, K, w1, w2, scale1, shift1, scale2, shift2 \
+                                                          GNX_DL_STAMP_ARG);                                          \
     return gnx_launch_status()
     switch (S) {
         case 4: GNX_DL(4);

@@ -63,6 +63,7 @@ class DenseNet(nn.Module):
                                     # same arithmetic type, 1.5x fewer matrix operations, rounding-level differences)
         self.f16_buffers = True     # mfma = 'f16' only: the block buffers themselves in fp16 where the shapes allow
         self.f16_stem = True        # ... and, with fp16 block buffers, conv0's matrix operands in fp16 too
+        self.f16_fused = True       # ... and every dense layer as ONE kernel, the bottleneck in LDS only (gnx_dense_layer_f16)
         self.input_norm = None      # (mean[3], std[3]) of a torchvision Normalize to apply to UINT8 input patches after the
                                     # u8 / 255 of ToTensor (fused into the stem's operand load); float inputs are taken as
                                     # already transformed by the dataset, as in the reference
@@ -206,6 +207,26 @@ class DenseNet(nn.Module):
         self._cache['w1h'] = (key, table)
         return table
 
+    def _dense_f16_packed(self):
+        """{layer: (w1p, w2p)}: conv1 / conv2 weights rounded to fp16 once, in the MFMA-fragment order gnx_dense_layer_f16
+        streams (csrc/dense_layer_f16.hip); refreshed with the weights."""
+        layers = [l for _, ls, _, _ in self._blocks for l in ls]
+        key = self._key([w for l in layers for w in (l.conv1.weight, l.conv2.weight)])
+        hit = self._cache.get('dlp')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        table = {}
+        st = L.stream()
+        for l in layers:
+            w1, w2 = l.conv1.weight.detach().contiguous(), l.conv2.weight.detach().contiguous()
+            k = w1.shape[1]
+            w1p = torch.empty(w1.shape[0] * k, device=w1.device, dtype=torch.float16)
+            w2p = torch.empty(w2.numel(), device=w1.device, dtype=torch.float16)
+            L.call('gnx_dense_layer_f16_pack', L.ptr(w1), L.ptr(w2), L.ptr(w1p, torch.float16), L.ptr(w2p, torch.float16), k, st)
+            table[l] = (w1p, w2p)
+        self._cache['dlp'] = (key, table)
+        return table
+
     def _trans_f16(self):
         """{transition: conv weight [c_out][c_in] rounded to fp16} (config 5's two-step transitions), refreshed with the weights."""
         trs = [t for _, _, t, _ in self._blocks if t is not None]
@@ -281,7 +302,7 @@ class DenseNet(nn.Module):
             s = s // 2
         return hs, sizes
 
-    def _auto_chunk(self, P, n):
+    def _auto_chunk(self, P, n, elem_bytes=4):
         if self.atonce is not None:
             return max(1, min(int(self.atonce), n))
         hs, sizes = self._geometry(P)
@@ -293,7 +314,7 @@ class DenseNet(nn.Module):
         per_spot += sizes[0] * sizes[0] * self.bn_size * self.growth_rate
         # Later blocks have few positions per spot (S=4: 16), so a launch only fills 256 CUs when thousands of
         # spots go through together: size chunks by HBM (288 GB), not by cache - a whole 128-px array is 17 GB.
-        budget = 40 * 1024 ** 3 // 4               # floats
+        budget = 40 * 1024 ** 3 // elem_bytes      # elements
         return max(1, min(n, max(32, budget // max(per_spot, 1))))
 
     # ------------------------------------------------------------------ optional per-kernel timing (bench.py)
@@ -397,12 +418,19 @@ class DenseNet(nn.Module):
             raise ValueError("DenseNet.mfma must be 'f32' or 'f16'")
         sfx = '_f16' if self.mfma == 'f16' else ''
         hs, sizes = self._geometry(P)
-        chunk = self._auto_chunk(P, N)
+        # (fp16 block buffers hold twice the spots in the same bytes: a whole 256-px array - 34 GB - is then one chunk)
+        chunk = self._auto_chunk(P, N, 2 if (self.mfma == 'f16' and self.f16_buffers) else 4)
         mid = self.bn_size * self.growth_rate
+        # the fused dense-layer kernel (fp16 block buffers) takes: growth 32, bottleneck 128, maps of 4..64, 32 | channels
+        fused_ok = bool(sfx) and self.f16_buffers and self.f16_fused and self.growth_rate == 32 and mid == 128 and \
+            all(s in (4, 8, 16, 32, 64) for s in sizes) and all(blk[0] % 32 == 0 for blk in self._blocks)
         if sfx and self.atonce is None and chunk >= 8:
-            # fp16 path: chunks of whole 128-row tiles whose element offsets fit 32 bits (what its DMA kernels index with)
-            lim = min((2 ** 31 - 1) // (sz * sz * max(mid, blk[3])) for blk, sz in zip(self._blocks, sizes))
-            chunk = max(8, min(chunk, lim) // 8 * 8)
+            if fused_ok:
+                chunk = chunk // 8 * 8                          # whole 128-row tiles; it indexes with 64 bits
+            else:
+                # two-kernel fp16 path: chunks of whole 128-row tiles whose element offsets fit 32 bits (its DMA kernels)
+                lim = min((2 ** 31 - 1) // (sz * sz * max(mid, blk[3])) for blk, sz in zip(self._blocks, sizes))
+                chunk = max(8, min(chunk, lim) // 8 * 8)
         conv0 = self.features.conv0
         c0 = conv0.out_channels
         def sub_range(bi, n):
@@ -425,14 +453,17 @@ class DenseNet(nn.Module):
         use_h = bool(sfx) and self.f16_buffers and not self.small_inputs and P in (128, 256) and c0 % 4 == 0 and \
             self.growth_rate == 32 and mid % 128 == 0 and N % 8 == 0 and chunk % 8 == 0 and \
             all(s in (4, 8, 16, 32, 64) for s in sizes) and \
-            all(sub_range(bi, min(chunk, N)) * sizes[bi] ** 2 * max(mid, self._blocks[bi][3]) < 2 ** 31
-                for bi in range(len(sizes)))
+            (fused_ok or all(sub_range(bi, min(chunk, N)) * sizes[bi] ** 2 * max(mid, self._blocks[bi][3]) < 2 ** 31
+                             for bi in range(len(sizes))))
+        fused = use_h and fused_ok
         self._used_f16_buffers = use_h                          # introspection (tests, bench)
-        w1h = self._conv1_f16() if use_h else None
+        self._used_f16_fused = fused
+        w1h = self._conv1_f16() if (use_h and not fused) else None
+        dlp = self._dense_f16_packed() if fused else None
         # workspace for one chunk
         bufs = [torch.empty((chunk * s * s, c_total), device=dev, dtype=torch.float16 if use_h else F32)
                 for (_, _, _, c_total), s in zip(self._blocks, sizes)]
-        bott = torch.empty((chunk * sizes[0] * sizes[0], mid), device=dev, dtype=F32)
+        bott = torch.empty((1 if fused else chunk * sizes[0] * sizes[0], mid), device=dev, dtype=F32)
         bott16 = bott.view(torch.float16)                       # the same memory as [rows][2 mid] halves (fp16 path)
         stem_out = None                                         # conv0 map: only the unfused stem needs it
         feats = torch.empty((N, self.num_features), device=dev, dtype=F32)
@@ -455,6 +486,13 @@ class DenseNet(nn.Module):
                         sc1, sh1 = fold[layer.norm1]
                         sc2, sh2 = fold[layer.norm2]
                         t0 = self._probe_begin()
+                        if fused:
+                            # norm1 .. conv2 in one kernel: K columns in, 32 columns out, the bottleneck never leaves the CU
+                            L.call('gnx_dense_layer_f16', L.ptr(rows, torch.float16), c_total, nu, s, cin,
+                                   L.ptr(dlp[layer][0], torch.float16), L.ptr(dlp[layer][1], torch.float16),
+                                   L.ptr(sc1), L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), st)
+                            self._probe_mark('dense_layer', t0)
+                            continue
                         if use_h:
                             L.call('gnx_conv1x1_bnrelu_h16', L.ptr(rows, torch.float16), c_total,
                                    L.ptr(w1h[layer], torch.float16), L.ptr(bott16, torch.float16), mid, M, mid, cin,

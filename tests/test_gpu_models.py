@@ -507,7 +507,11 @@ def test_fp16_block_buffers_config5_128px():
         assert not m._used_f16_buffers
         m.f16_buffers = True
         out16h = m(x).cpu()
-        assert m._used_f16_buffers
+        assert m._used_f16_buffers and m._used_f16_fused          # every dense layer as ONE kernel (gnx_dense_layer_f16)
+        m.f16_fused = False
+        out16h_pair = m(x).cpu()                                  # the two-kernel pair it replaces, same fp16 buffers
+        assert m._used_f16_buffers and not m._used_f16_fused
+        m.f16_fused = True
         out16h_odd = m(x[:23]).cpu()                              # 23 spots: not whole tiles -> fp32 buffers
         assert not m._used_f16_buffers
     scale = out32.abs().max().item()
@@ -515,6 +519,9 @@ def test_fp16_block_buffers_config5_128px():
     e16h = (out16h - out32).abs().max().item() / scale
     print("fp16 path vs fp32: fp32 buffers %.2e, fp16 buffers %.2e" % (e16, e16h))
     assert e16 < 2e-2 and e16h < 3e-2 and e16h > 1e-6
+    e_pair = (out16h - out16h_pair).abs().max().item() / scale    # same operands, other summation order / rounding points
+    print("fused dense layers vs the two-kernel pair: %.2e" % e_pair)
+    assert e_pair < 5e-3
     assert (out16h_odd - out16[:23]).abs().max().item() / scale < 1e-3     # other kernels for ragged tiles: rounding only
     top = out32.topk(2, dim=1).values
     decided = (top[:, 0] - top[:, 1]) > 5e-2

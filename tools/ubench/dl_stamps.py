@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Where a step of gnx_dense_layer_f16 spends its cycles (diagnostic; runs on the GPU box).
+
+Compiles csrc/dense_layer_f16.hip with -DGNX_DL_STAMP into tools/ubench/build/libdl_stamp.so (the product library has no
+stamps), runs one launch per shape and prints, per step and averaged over workgroups, the shader cycles wave 0 (consumer)
+and wave 4 (producer) spent in each segment.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SRC = os.path.join(ROOT, 'gridnext_amd', 'csrc', 'dense_layer_f16.hip')
+OUT = os.path.join(HERE, 'build', 'libdl_stamp.so')
+
+
+def main():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DGNX_DL_STAMP',
+                    '-I', os.path.dirname(SRC), SRC, '-o', OUT], check=True)
+    lib = ctypes.CDLL(OUT)
+    P, I, Lg = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+    lib.gnx_dense_layer_f16_pack.argtypes = [P, P, P, P, I, P]
+    lib.gnx_dense_layer_f16.argtypes = [P, Lg, Lg, I, I, P, P, P, P, P, P, P]
+    lib.gnx_dense_layer_f16_set_stamps.argtypes = [P]
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1664
+    dev = 'cuda:0'
+    H = torch.float16
+    st = torch.cuda.current_stream().cuda_stream
+    for S, K, ct in [(64, 64, 256), (64, 224, 256), (32, 480, 512), (16, 992, 1024), (8, 992, 1024)]:
+        M = n * S * S
+        X = torch.randn(M, ct, device=dev).to(H)
+        W1 = torch.randn(128, K, device=dev) / K ** 0.5
+        W2 = torch.randn(32, 128, 3, 3, device=dev) * 0.05
+        sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1
+        osc, osh = torch.rand(128, device=dev) + 0.5, torch.randn(128, device=dev) * 0.1
+        w1p, w2p = torch.empty(128 * K, device=dev, dtype=H), torch.empty(9 * 8 * 512, device=dev, dtype=H)
+        lib.gnx_dense_layer_f16_pack(W1.data_ptr(), W2.data_ptr(), w1p.data_ptr(), w2p.data_ptr(), K, st)
+        stamps = torch.zeros(256 * 16, device=dev, dtype=torch.int64)
+        lib.gnx_dense_layer_f16_set_stamps(stamps.data_ptr())
+        for _ in range(3):
+            lib.gnx_dense_layer_f16(X.data_ptr(), ct, n, S, K, w1p.data_ptr(), w2p.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                    osc.data_ptr(), osh.data_ptr(), st)
+        torch.cuda.synchronize()
+        units = n if S >= 16 else n * S * S // 128
+        J = S * S // 128 if S >= 16 else 1
+        t = stamps.view(256, 16).double().cpu()
+        steps = torch.tensor([len(range(b, units, 256)) * J for b in range(256)], dtype=torch.double).clamp(min=1)
+        per = (t / steps[:, None]).mean(0)
+        nst = K // 32
+        print("S=%2d K=%4d (%2d stages/step)  consumer: barrier %6.0f  stage-body %6.0f  epilogue %5.0f  E-barrier %5.0f  conv2 %6.0f | "
+              "producer: barrier %6.0f  issue %5.0f  dma-wait %6.0f  activate %5.0f  E %6.0f   [cycles per step]" %
+              (S, K, nst, per[0], per[1], per[2], per[3], per[4], per[8], per[9], per[10], per[11], per[12]), flush=True)
+        del X
+
+
+if __name__ == '__main__':
+    main()
