@@ -112,8 +112,17 @@ def dgrad1x1_bytes_per_spot(patch):
     return sum(s * s * 4 * (128 + 3 * k) for s, k in _conv1x1_layers(patch))
 
 
+def dense_layer_bytes_per_spot(patch):
+    """The fused dense layer (gnx_dense_layer_f16): K channels of the block buffer in, the layer's 32 new channels out - the
+    128-channel bottleneck stays in LDS.  In 4-byte units like the other tables (the fp16 series halves them): 26.6 MB per
+    spot at 256 px in fp16."""
+    return sum(s * s * 4 * (k + 32) for s, k in _conv1x1_layers(patch))
+
+
 # kind -> (kernel name, FLOPs per spot, algorithmic bytes per spot)           (backward kinds: the f-trained series)
 KINDS = {
+    'dense_layer': ('dense_layer_f16_kernel', lambda patch: conv1x1_flops_per_spot(patch) + conv3x3_flops_per_spot(patch),
+                    dense_layer_bytes_per_spot),
     'conv1x1': ('conv1x1_ws_kernel', conv1x1_flops_per_spot, conv1x1_bytes_per_spot),
     'conv3x3': ('conv3x3_dma_kernel', conv3x3_flops_per_spot, conv3x3_bytes_per_spot),
     'wgrad3x3': ('wgrad 3x3 (gnx_wgrad_bnrelu, taps = 9: slab kernel + fixed-order reduce)', conv3x3_flops_per_spot,
@@ -228,11 +237,13 @@ def _host_cpu():
     return max(1, n_phys), model
 
 
-def cpu_leg(model, patch, mfma, device, timed_steps=2):
+def cpu_leg(model, patch, mfma, device, timed_steps=2, sub_hw=None, u8=False):
     """The CPU oracle (oracle/, kind 'port') and the HIP path on the SAME bounded sample and the SAME weights: a 26x16
-    = 416-spot sub-grid of synthetic array 0, tutorial mode.  Returns (cpu_baseline, ce_vs_ref).
+    = 416-spot sub-grid of synthetic array 0 (`sub_hw`: another sub-grid), tutorial mode.  Returns (cpu_baseline, ce_vs_ref).
     The HIP side runs first (forward + masked CE), on copies of the trainable parts so the benchmark model is untouched;
-    the oracle then does 1 warm-up + `timed_steps` timed training steps (forward, CE, backward, Adam on the corrector)."""
+    the oracle then does 1 warm-up + `timed_steps` timed training steps (forward, CE, backward, Adam on the corrector);
+    timed_steps = 0: the comparison only (cpu_baseline None).  u8: the HIP side gets uint8 patches (ToTensor inside the stem
+    kernel), the oracle the same bytes / 255."""
     import copy
     import torch
     import gridnext_amd as ga
@@ -242,12 +253,18 @@ def cpu_leg(model, patch, mfma, device, timed_steps=2):
 
     cores, cpu_model = _host_cpu()
     torch.set_num_threads(cores)
+    SUB_H, SUB_W = sub_hw or (globals()['SUB_H'], globals()['SUB_W'])
     gen = torch.Generator().manual_seed(12345)
-    x_img = torch.rand((1, SUB_H, SUB_W, 3, patch, patch), generator=gen)
+    if u8:
+        x_img8 = torch.randint(0, 256, (1, SUB_H, SUB_W, 3, patch, patch), generator=gen, dtype=torch.uint8)
+        x_img = x_img8.float() / 255
+    else:
+        x_img = torch.rand((1, SUB_H, SUB_W, 3, patch, patch), generator=gen)
     x_cnt = torch.randint(0, 10, (1, GENES, SUB_H, SUB_W), generator=gen).float()
     y = torch.randint(0, CLASSES + 1, (1, SUB_H, SUB_W), generator=gen)
     x_img *= (y > 0).float().view(1, SUB_H, SUB_W, 1, 1, 1)
     x_cnt *= (y > 0).float().view(1, 1, SUB_H, SUB_W)
+    x_hip = (x_img8 * (y > 0).to(torch.uint8).view(1, SUB_H, SUB_W, 1, 1, 1)) if u8 else x_img
 
     # ---- HIP path on the sub-grid: the benchmark model's own image f (frozen: shared), copies of count f and corrector
     sub = ga.GridNetHexMM(model.image_classifier, copy.deepcopy(model.count_classifier), (3, patch, patch), (GENES,),
@@ -257,7 +274,7 @@ def cpu_leg(model, patch, mfma, device, timed_steps=2):
     sub.patch_classifier.eval()
     state = {k: v.detach().cpu().clone() for k, v in sub.state_dict().items()}
     with torch.no_grad():
-        logits = sub.forward_nhwc([x_img.to(device), x_cnt.to(device)])
+        logits = sub.forward_nhwc([x_hip.to(device), x_cnt.to(device)])
         loss_hip, stats, preds = GF.masked_cross_entropy(logits.reshape(-1, CLASSES), y.to(device), 1)
     torch.cuda.synchronize()
     loss_hip, preds_hip = float(loss_hip.item()), preds.cpu()
@@ -292,7 +309,7 @@ def cpu_leg(model, patch, mfma, device, timed_steps=2):
     t0 = time.time()
     for _ in range(timed_steps):
         step()
-    dt = (time.time() - t0) / timed_steps
+    dt = (time.time() - t0) / max(timed_steps, 1)
     n = SUB_H * SUB_W
 
     rows = out_ref.permute(0, 2, 3, 1).reshape(-1, CLASSES)
@@ -307,6 +324,10 @@ def cpu_leg(model, patch, mfma, device, timed_steps=2):
                     "forward + masked CE in tutorial mode (image f eval, count f and g train-mode BN)"
                     % (SUB_H, SUB_W, n, patch, GENES),
           "dtype": mfma, "gate": "abs_diff <= 1e-4 (f32)" if mfma == 'f32' else "reported only (fp16 operands)"}
+    if decided.any():
+        ce["agreement_rate"] = agree / int(decided.sum())
+    if timed_steps == 0:
+        return None, ce
     base = {"value": n / dt, "unit": "spots/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
             "sample": "1 warm-up (%.1f s) + %d timed training steps (%.1f s each) on a %dx%d sub-grid (%d spots of %d px, "
                       "%d genes), torch CPU threads = physical cores" % (warm, timed_steps, dt, SUB_H, SUB_W, n, patch, GENES)}
@@ -469,13 +490,19 @@ def config5_series(args, device, rank, world, steps=4, warmup=2):
            "warmup": warmup, "dtype": "f16", "final_loss": float(last.item()), "fp16_block_buffers": bool(f_img._used_f16_buffers),
            "workload": "BASELINE config 5 on one GPU: multimodal f (DenseNet-121 @256 px, fp16 MFMA conv path) + count MLP + hex g, "
                        "1 array (4992 spots) per step, f frozen/eval, g trained; uint8 patches resident in HBM"}
+    # SURVEY 8d for this config: dCE and agreement rate after g against the fp32 CPU oracle (13 x 8 = 104-spot sub-grid, the
+    # same state_dict - calibrated statistics included - uint8 patches on the HIP side); reported, no 1e-4 claim
+    if rank == 0 and not getattr(args, 'no_cpu_baseline', False):
+        _, out["ce_vs_ref"] = cpu_leg(model, P, 'f16', device, timed_steps=0, sub_hw=(13, 8), u8=True)
+        out["fused_dense_layers"] = bool(getattr(f_img, '_used_f16_fused', False))
     kt = kernel_table(probe, P, steps)
     for kind in kt:                                              # fp16 operands: half the bytes; priced against HBM
         kk = kt[kind]
         kk["algorithmic_bytes_per_launch_avg"] *= 0.5
         gbs = kk["algorithmic_bytes_per_launch_avg"] / (kk["avg_launch_ms"] * 1e-3) / 1e9
         kk.update({"bound": "hbm", "matrix_tflops": kk["achieved"], "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                   "frac": gbs / PEAK_HBM_GBS, "kernel": {"conv1x1": "conv1x1_h16_kernel", "conv3x3": "conv3x3_dma_kernel<H16, O16>"}.get(kind, kk["kernel"])})
+                   "frac": gbs / PEAK_HBM_GBS, "kernel": {"conv1x1": "conv1x1_h16_kernel", "conv3x3": "conv3x3_dma_kernel<H16, O16>",
+                                                          "dense_layer": "dense_layer_f16_kernel"}.get(kind, kk["kernel"])})
         kk.pop("algorithmic_gbs", None)
     attach_traffic(kt, '_f16_256')
     if kt:
@@ -656,8 +683,11 @@ def worker_main(args):
             # config 5's kernels multiply 16x faster than they can be fed: they are priced against HBM (algorithmic bytes
             # per launch / launch time); the fp32-FLOP figure stays in `matrix_tflops` for reference
             h16 = bool(getattr(f_img, '_used_f16_buffers', False))     # block buffers in fp16: every operand is 2 B
-            for kind, name in (('conv1x1', 'conv1x1_h16_kernel' if h16 else 'conv1x1_f16_kernel'),
+            for kind, name in (('dense_layer', 'dense_layer_f16_kernel (norm1 .. conv2 in one kernel, bottleneck in LDS)'),
+                               ('conv1x1', 'conv1x1_h16_kernel' if h16 else 'conv1x1_f16_kernel'),
                                ('conv3x3', 'conv3x3_dma_kernel<H16, O16>' if h16 else 'conv3x3_dma_kernel<H16> / conv3x3_f16_kernel')):
+                if kind not in kern:
+                    continue
                 kk = kern[kind]
                 if h16:
                     kk["algorithmic_bytes_per_launch_avg"] *= 0.5

@@ -50,12 +50,14 @@ constexpr int DL_PF = 3;                       // W1 fragment stages in flight a
 // workgroup, wave 0 and wave 4 sum the shader cycles they spend in each segment of a step and leave them in a buffer of
 // their own.  In the product build the macros are empty: no stamp executes.
 #ifdef GNX_DL_STAMP
-#define GNX_DL_STAMP_PARAM , unsigned long long* __restrict__ stamps
+#define GNX_DL_STAMP_PARAM , unsigned long long* __restrict__ stamps, int abl
+#define DL_ABL(bit) (abl & (bit))
 #define DL_T0() unsigned long long dl_t = __builtin_readcyclecounter(), dl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define DL_LAP(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); dl_acc[k] += n_ - dl_t; dl_t = n_; } while (0)
-#define DL_OUT(base) do { if (stamps && lane == 0) for (int q_ = 0; q_ < 8; ++q_) stamps[(long)blockIdx.x * 16 + (base) + q_] = dl_acc[q_]; } while (0)
+#define DL_OUT(base) do { if (stamps && lane == 0) for (int q_ = 0; q_ < 8; ++q_) stamps[(long)blockIdx.x * 24 + (base) + q_] = dl_acc[q_]; } while (0)
 #else
 #define GNX_DL_STAMP_PARAM
+#define DL_ABL(bit) false
 #define DL_T0() do {} while (0)
 #define DL_LAP(k) do {} while (0)
 #define DL_OUT(base) do {} while (0)
@@ -77,6 +79,36 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
     const int nst = K >> 5;                                // stages per step
     const unsigned lb = lds_addr(lds);
 
+    // norm1 + relu1 in place on NP 1-KB pieces (16 px x 32 channels each, piece p at `base + p * 1024`) of a landed stage, lane =
+    // (pixel, 16-B column) as the DMA wrote them: a lane's 8 channels are the same in every piece, their scale / shift come from
+    // the slot's side area `ct`.  fp32 fma on the fp16 value, rounded once to fp16 (v_fma_mix), relu packed.
+    auto activate_pieces = [&](auto np_c, char* base, const float* ct) {
+        constexpr int NP = decltype(np_c)::value;
+        if (DL_ABL(1)) return;
+        u32x4 v[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) v[p] = *reinterpret_cast<u32x4*>(base + p * 1024);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(ct), s1 = *reinterpret_cast<const f32x4*>(ct + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(ct + 8), b1 = *reinterpret_cast<const f32x4*>(ct + 12);
+        auto act2 = [](unsigned x, float sa, float ba, float sb, float bb) {          // two halves of one register
+            unsigned r;
+            asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mixhi_f16 %0, %1, %4, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                "v_pk_max_f16 %0, %0, 0"
+                : "=&v"(r) : "v"(x), "v"(sa), "v"(ba), "v"(sb), "v"(bb));
+            return r;
+        };
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            u32x4 o;
+            o[0] = act2(v[p][0], s0[0], b0[0], s0[1], b0[1]);
+            o[1] = act2(v[p][1], s0[2], b0[2], s0[3], b0[3]);
+            o[2] = act2(v[p][2], s1[0], b1[0], s1[1], b1[1]);
+            o[3] = act2(v[p][3], s1[2], b1[2], s1[3], b1[3]);
+            *reinterpret_cast<u32x4*>(base + p * 1024) = o;
+        }
+    };
+
     if (wave >= 4) {
         // ================================================================= producers
         const int pw = wave - 4;
@@ -97,85 +129,90 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                 dma16_buf(rW2, lane * 16, piece * 1024, lb + DL_W2 + piece * 1024);
             }
         }
-        // issue cursor: the stage whose DMA goes out next.  Past this workgroup's last stage it re-reads the workgroup's
-        // first unit into slots nobody will read: cheaper than a branch around every issue (and vmcnt stays countable).
-        // A stage = two 1-KB pieces per wave (16 px x 32 channels each) + the stage's norm1 constants (scale / shift of its 32
-        // channels, 256 B into the slot's side area: 16 lanes of ONE wave - the waves take turns): the constants travel
-        // with the data.
-        int cu = bid, cj = 0, cs = 0, cslot = 0, cturn = 0;
-        const unsigned voffA = (unsigned)(((lane & 15) * ld + 8 * (lane >> 4)) * 2);
-        // constants piece, lane l < 16: 16-B column q = l >> 2 of the stage, {scale lo, scale hi, shift lo, shift hi}[l & 3]
-        const float* const csrc = ((lane & 2) ? sh1 : sc1) + 8 * ((lane >> 2) & 3) + 4 * (lane & 1);
-        const _Float16* pbase = X + ((long)bid * J * 128 + 32 * pw) * ld;                 // this wave's rows of the cursor's step
-        const long step_stride = 128 * ld;
-        auto issue = [&]() {
-            if (cturn == pw && lane < 16) dma16_global(csrc + 32 * cs, lb + DL_CT + cslot * 256);
-            cturn = (cturn + 1) & 3;
+        // Waves 4, 5 are LOADERS, waves 6, 7 ACTIVATORS: the DMA issue of a stage (~100 cycles per 1-KB piece) and its
+        // norm1 + relu1 pass (an LDS round trip) then run side by side instead of one after the other in each wave - stamped,
+        // the serial form spent 250 + 540 cycles per stage and was what every wave of the workgroup waited for.
+        if (pw < 2) {
+            // ---- loaders.  A stage = four 1-KB pieces per loader (16 px x 32 channels each; loader l: pixels 64 l .. 64 l + 63)
+            // + the stage's norm1 constants (scale / shift of its 32 channels, 256 B into the slot's side area: 16 lanes, the two
+            // loaders take turns): the constants travel with the data.  Past this workgroup's last stage the cursor re-reads the
+            // workgroup's first unit into slots nobody will read: cheaper than a branch around every issue (and vmcnt stays
+            // countable).
+            int cu = bid, cj = 0, cs = 0, cslot = 0, cturn = 0;
+            const unsigned voffA = (unsigned)(((lane & 15) * ld + 8 * (lane >> 4)) * 2);
+            // constants piece, lane l < 16: 16-B column q = l >> 2 of the stage, {scale lo, scale hi, shift lo, shift hi}[l & 3]
+            const float* const csrc = ((lane & 2) ? sh1 : sc1) + 8 * ((lane >> 2) & 3) + 4 * (lane & 1);
+            const _Float16* pbase = X + ((long)bid * J * 128 + 64 * pw) * ld;             // this wave's rows of the cursor's step
+            const long step_stride = 128 * ld;
+            auto issue = [&]() {
+                if (DL_ABL(4) && cslot != 99) { cslot = cslot == DL_NS - 1 ? 0 : cslot + 1; return; }
+                if (cturn == pw && lane < 16) dma16_global(csrc + 32 * cs, lb + DL_CT + cslot * 256);
+                cturn ^= 1;
 #pragma unroll
-            for (int g2 = 0; g2 < 2; ++g2) {
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(pbase) + 16 * g2 * ld, 0,
-                                                                                    (unsigned)(16 * ld * 2), 0x00020000);
-                dma16_buf(rs, voffA, cs * 64, lb + DL_AR + cslot * DL_SLOT + (2 * pw + g2) * 1024);
-            }
-            cslot = cslot == DL_NS - 1 ? 0 : cslot + 1;
-            if (++cs == nst) {
-                cs = 0;
-                pbase += step_stride;
-                if (++cj == J) {
-                    cj = 0;
-                    cu += G;
-                    if (cu >= n_units) cu = bid;
-                    pbase = X + ((long)cu * J * 128 + 32 * pw) * ld;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<_Float16*>(pbase) + 16 * g4 * ld, 0, (unsigned)(16 * ld * 2), 0x00020000);
+                    dma16_buf(rs, voffA, cs * 64, lb + DL_AR + cslot * DL_SLOT + (4 * pw + g4) * 1024);
                 }
-            }
-        };
-        // norm1 + relu1 in place on this wave's own 32 px x 32 channels of a slot (the pieces it fetched: its own vmcnt wait
-        // is all the synchronisation the data needs), lane = (pixel, 16-B column) as the DMA wrote them: a lane's 8 channels
-        // are the same in both pieces, their scale / shift come from the slot's side area (confirmed landed by the wave
-        // that fetched them one barrier earlier).  fp32 fma on the fp16 value, rounded once to fp16 (v_fma_mix), relu packed.
+                cslot = cslot == DL_NS - 1 ? 0 : cslot + 1;
+                if (++cs == nst) {
+                    cs = 0;
+                    pbase += step_stride;
+                    if (++cj == J) {
+                        cj = 0;
+                        cu += G;
+                        if (cu >= n_units) cu = bid;
+                        pbase = X + ((long)cu * J * 128 + 64 * pw) * ld;
+                    }
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < DL_NS - 1; ++q) issue();       // stages 0..4
+            // W2, stages 0 and 1 and their constants have landed (left in flight: the 12 pieces of stages 2..4, and one or two
+            // constants pieces among them: then a piece more is waited for - never less than needed)
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            lds_barrier();                                     // B_init
+            DL_T0();
+            for (int u = bid; u < n_units; u += G)
+                for (int j = 0; j < J; ++j) {
+                    for (int s = 0; s < nst; ++s) {
+                        lds_barrier();                         // B_t: stage t - 1 is consumed
+                        DL_LAP(0);
+                        issue();                               // stage t + 5 into the slot of stage t - 1
+                        DL_LAP(1);
+                        // stage t + 2 and its constants have landed: the activators take it after the next barrier
+                        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                        DL_LAP(2);
+                    }
+                    lds_barrier();                             // E
+                    DL_LAP(4);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (wave == 4) DL_OUT(8);
+            return;
+        }
+        // ---- activators: norm1 + relu1 on pixels 64..127 of a landed stage (activator a: the two pieces 64 + 32 a ..); the
+        // consumer waves, idle for most of a stage, take a piece each of pixels 0..63 behind their MFMAs: the pass is an LDS
+        // round trip (~200 cycles per piece, stamped), and the stage's barrier waits for its slowest wave.
+        const int aw = pw - 2;
         int aslot = 0;
         auto activate = [&]() {
-            const float* ct = reinterpret_cast<const float*>(lds + DL_CT + aslot * 256) + 16 * (lane >> 4);
-            const f32x4 s0 = *reinterpret_cast<const f32x4*>(ct), s1 = *reinterpret_cast<const f32x4*>(ct + 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(ct + 8), b1 = *reinterpret_cast<const f32x4*>(ct + 12);
-            char* base = lds + DL_AR + aslot * DL_SLOT + 2 * pw * 1024 + lane * 16;
-            const u32x4 v0 = *reinterpret_cast<u32x4*>(base), v1 = *reinterpret_cast<u32x4*>(base + 1024);
-            u32x4 o0, o1;
-            auto act2 = [](unsigned x, float sa, float ba, float sb, float bb) {      // two halves of one register
-                unsigned r;
-                asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
-                    "v_fma_mixhi_f16 %0, %1, %4, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-                    "v_pk_max_f16 %0, %0, 0"
-                    : "=&v"(r) : "v"(x), "v"(sa), "v"(ba), "v"(sb), "v"(bb));
-                return r;
-            };
-            o0[0] = act2(v0[0], s0[0], b0[0], s0[1], b0[1]); o0[1] = act2(v0[1], s0[2], b0[2], s0[3], b0[3]);
-            o0[2] = act2(v0[2], s1[0], b1[0], s1[1], b1[1]); o0[3] = act2(v0[3], s1[2], b1[2], s1[3], b1[3]);
-            o1[0] = act2(v1[0], s0[0], b0[0], s0[1], b0[1]); o1[1] = act2(v1[1], s0[2], b0[2], s0[3], b0[3]);
-            o1[2] = act2(v1[2], s1[0], b1[0], s1[1], b1[1]); o1[3] = act2(v1[3], s1[2], b1[2], s1[3], b1[3]);
-            *reinterpret_cast<u32x4*>(base) = o0;
-            *reinterpret_cast<u32x4*>(base + 1024) = o1;
+            activate_pieces(std::integral_constant<int, 2>{}, lds + DL_AR + aslot * DL_SLOT + (4 + 2 * aw) * 1024 + lane * 16,
+                            reinterpret_cast<const float*>(lds + DL_CT + aslot * 256) + 16 * (lane >> 4));
             aslot = aslot == DL_NS - 1 ? 0 : aslot + 1;
         };
-#pragma unroll
-        for (int q = 0; q < DL_NS - 1; ++q) issue();           // stages 0..4
-        // W2, stage 0 and the constants of stages 0 and 1 have landed (left in flight: at most the 2 pieces of stage 1 and the
-        // 6 of stages 2..4; a wave whose turn for constants falls in 2..4 waits for one piece more: never less than needed)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        lds_barrier();                                         // B_init: every wave's constants of stage 0 are visible
-        activate();
+        // (Tried and dropped, measured: an L2 touch-prefetch from these waves - one dword per pixel row of the stage 7 or 13
+        // stages ahead of the loaders, never waited for - made every shape 5-15 % SLOWER; DMA pieces of 8 rows x 128 B instead
+        // of 16 rows x 64 B moved the DMA stream alone from 4.0 to 4.3 TB/s and the whole kernel not at all.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of W2
+        lds_barrier();                                         // B_init: stages 0 and 1 are in the LDS
+        activate();                                            // stage 0 (the consumers: their pieces of it)
         DL_T0();
         for (int u = bid; u < n_units; u += G)
             for (int j = 0; j < J; ++j) {
                 for (int s = 0; s < nst; ++s) {
-                    lds_barrier();                             // B_t: stage t is visible, stage t - 1 is consumed
+                    lds_barrier();                             // B_t: stage t is visible to the consumers; stage t + 1 has landed
                     DL_LAP(0);
-                    issue();                                   // stage t + 5 into the slot of stage t - 1
-                    DL_LAP(1);
-                    // stage t + 1 and - where they were this wave's to fetch - the constants of stage t + 2 have landed (in
-                    // flight: the 8 pieces of t + 2..t + 5, and one constants piece among them or none)
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    DL_LAP(2);
                     activate();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     DL_LAP(3);
@@ -183,8 +220,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                 lds_barrier();                                 // E: the step's bottleneck tile is complete
                 DL_LAP(4);
             }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (wave == 4) DL_OUT(8);
+        if (wave == 6) DL_OUT(16);
         return;
     }
 
@@ -210,6 +246,12 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
     };
     preload_w();
     lds_barrier();                                             // B_init
+    // this wave's share of the norm1 + relu1 pass: piece `wave` (pixels 16 wave .. 16 wave + 15) of the NEXT stage's slot
+    auto activate_mine = [&](int sl) {
+        activate_pieces(std::integral_constant<int, 1>{}, lds + DL_AR + sl * DL_SLOT + wave * 1024 + lane * 16,
+                        reinterpret_cast<const float*>(lds + DL_CT + sl * 256) + 16 * (lane >> 4));
+    };
+    activate_mine(0);
     f32x16 c1[4], a0, a1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
@@ -224,6 +266,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
         load_w(fr[(P + DL_PF) & 3], s + DL_PF);
         const unsigned ab = laneA + slot * DL_SLOT;
         f32x4 av[8];
+        if (!DL_ABL(2)) {
         static_for<0, 8>([&](auto n_c) {
             constexpr int n = decltype(n_c)::value;            // n = 4 ks + rb
             av[n] = lds_read4<(n & 3) * 2048 + (n >> 2) * 512>(ab);
@@ -234,7 +277,9 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             c1[n & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fr[P][n >> 2]),
                                                                __builtin_bit_cast(half8, av[n]), c1[n & 3], 0, 0, 0);
         });
+        }
         slot = slot == DL_NS - 1 ? 0 : slot + 1;
+        activate_mine(slot);                                   // behind the MFMAs: stage t + 1 (landed before B_t)
         DL_LAP(1);
     };
 
@@ -257,17 +302,25 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             }
             preload_w();                                       // the next step's first stages (the same weights)
             // ---- norm2 + relu2, rounded to fp16, into the bottleneck tile
+            if (!DL_ABL(16))
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 osc = *reinterpret_cast<const f32x4*>(lds + DL_OT + (32 * nb + 8 * g + 4 * h) * 4);
                 const f32x4 osh = *reinterpret_cast<const f32x4*>(lds + DL_OT + 512 + (32 * nb + 8 * g + 4 * h) * 4);
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb) {
-                    half4 o;
+                    unsigned o[2];                             // fp32 fma rounded once to fp16 (v_fma_mix), relu packed
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) o[q] = (_Float16)fmaxf(fmaf(c1[rb][4 * g + q], osc[q], osh[q]), 0.f);
+                    for (int q = 0; q < 2; ++q)
+                        asm("v_fma_mixlo_f16 %0, %1, %2, %3\n\t"
+                            "v_fma_mixhi_f16 %0, %4, %5, %6\n\t"
+                            "v_pk_max_f16 %0, %0, 0"
+                            : "=&v"(o[q])
+                            : "v"(c1[rb][4 * g + 2 * q]), "v"(osc[2 * q]), "v"(osh[2 * q]), "v"(c1[rb][4 * g + 2 * q + 1]),
+                              "v"(osc[2 * q + 1]), "v"(osh[2 * q + 1]));
                     const int px = 32 * rb + i;
-                    *reinterpret_cast<half4*>(lds + DL_BT + (px >> 4) * 4096 + (4 * nb + g) * 256 + (px & 15) * 16 + 8 * h) = o;
+                    *reinterpret_cast<uint2*>(lds + DL_BT + (px >> 4) * 4096 + (4 * nb + g) * 256 + (px & 15) * 16 + 8 * h) =
+                        make_uint2(o[0], o[1]);
                 }
             }
             DL_LAP(2);
@@ -289,7 +342,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                 const unsigned aW = lb + DL_W2 + (dy + 1) * 3 * 8192 + lane * 16;
                 // 24 (dx, k-step) products; the fragment pairs of the next D are in flight while one multiplies (a ring of
                 // D + 2 register pairs: a pair is overwritten two MFMAs after the MFMA that read it)
-                constexpr int D = 4, NSL = D + 2, NE = 24;
+                constexpr int D = 6, NSL = D + 2, NE = 24;
                 f32x4 ra[NSL], rw[NSL];
                 auto request = [&](auto e_c) {
                     constexpr int e = decltype(e_c)::value, dxi = e / 8, ks = e % 8;
@@ -355,6 +408,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             }
             if (z0) zero(a0);
             if (z1) zero(a1);
+            if (DL_ABL(8)) { hi0 = lo0 - 1; hi1 = lo1 - 1; }
 #pragma unroll 1
             for (int dy = lo0; dy <= hi0; ++dy) tap3(a0, O0, dy);
             if (s0) store(a0, O0);
@@ -396,8 +450,13 @@ GNX_EXPORT int gnx_dense_layer_f16_pack(const float* w1, const float* w2, void* 
 }
 
 #ifdef GNX_DL_STAMP
+// ablation bits (diagnostic): 1 no norm1 pass, 2 no conv1 reads / MFMAs, 4 no DMA issue, 8 no conv2 taps, 16 no epilogue
 static unsigned long long* g_dl_stamps = nullptr;
-GNX_EXPORT void gnx_dense_layer_f16_set_stamps(void* buf) { g_dl_stamps = reinterpret_cast<unsigned long long*>(buf); }
+static int g_dl_abl = 0;
+GNX_EXPORT void gnx_dense_layer_f16_set_stamps(void* buf, int abl) {
+    g_dl_stamps = reinterpret_cast<unsigned long long*>(buf);
+    g_dl_abl = abl;
+}
 #endif
 
 // The dense layer on an fp16 block buffer X16 [n_img * S * S][ld16]: reads columns [0, K), writes columns [K, K + 32).
@@ -425,7 +484,7 @@ GNX_EXPORT int gnx_dense_layer_f16(void* X16, long ld16, long n_img, int S, int 
     const _Float16* w1 = reinterpret_cast<const _Float16*>(w1p);
     const _Float16* w2 = reinterpret_cast<const _Float16*>(w2p);
 #ifdef GNX_DL_STAMP
-#define GNX_DL_STAMP_ARG , g_dl_stamps
+#define GNX_DL_STAMP_ARG , g_dl_stamps, g_dl_abl
 #else
 #define GNX_DL_STAMP_ARG
 #endif

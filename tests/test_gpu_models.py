@@ -583,6 +583,53 @@ def test_full_size_multimodal_array_config4():
     assert m.count_classifier[0].weight.grad is not None          # GridNetHexMM quirk: the count f still gets gradients
 
 
+def test_config5_grid_level_fp16_path_against_oracle_after_g():
+    """BASELINE config 5 as a GRID-level step: GridNetHexMM with the image f on the fp16-MFMA path - uint8
+    patches, fp16 block buffers, every dense layer as one fused kernel, statistics as loaded - + count MLP + hex g on a
+    small grid, against the fp32 CPU oracle with the same state_dict AFTER g: the masked CE within 2e-2, the same label on
+    every foreground spot whose top-2 margin exceeds 5e-2 (SURVEY 8d's reporting for the fp16 path; no 1e-4 claim)."""
+    import gridnext_amd as ga
+    from gridnext_amd import functional as GF
+    from gridnext_amd.synthetic import count_mlp
+    from oracle import densenet as odn, gridnet as ogn, masked_ce as oce
+    torch.manual_seed(0)
+    C, G, P, H, W = 8, 50, 128, 4, 6                               # 24 spots: whole 128-row tiles on every map
+    cfg = odn.DenseNetCfg(num_classes=C, **odn.DENSENET121)
+    f_img = ga.DenseNet(num_classes=C, **odn.DENSENET121)
+    f_img.load_state_dict(odn.closed_form_state(cfg))
+    m = ga.GridNetHexMM(f_img, count_mlp(G, C), (3, P, P), (G,), (H, W), C)
+    o_img = odn.DenseNet(num_classes=C, **odn.DENSENET121)
+    o_img.load_named_state(f_img.state_dict())
+    om = ogn.GridNetHexMM(o_img, count_mlp(G, C), (3, P, P), (G,), (H, W), C)
+    om.count_classifier.load_state_dict(m.count_classifier.state_dict())
+    om.corrector.load_state_dict(m.corrector.state_dict())
+    gen = torch.Generator().manual_seed(21)
+    x8 = torch.randint(0, 256, (2, H, W, 3, P, P), generator=gen, dtype=torch.uint8)
+    xc = torch.randint(0, 10, (2, G, H, W), generator=gen).float()
+    y = torch.randint(0, C + 1, (2, H, W), generator=gen)
+    for mod in (m, om):
+        mod.train()                                               # the tutorial's modes: g and the count f in train mode,
+        mod.patch_classifier.eval()                               # the image f in eval mode (training.py:126)
+    m.to(DEV)
+    f_img.mfma = 'f16'
+    with torch.no_grad():
+        logits = m.forward_nhwc([x8.to(DEV), xc.to(DEV)])
+        loss, stats, preds = GF.masked_cross_entropy(logits.reshape(-1, C), y.to(DEV), 1)
+        assert f_img._used_f16_buffers and f_img._used_f16_fused
+        ref = om([x8.float() / 255, xc])
+        ref_loss, _, _ = oce.masked_ce(ref, y, 1)
+    rows = ref.permute(0, 2, 3, 1).reshape(-1, C)
+    fg = y.reshape(-1) > 0
+    top = rows.topk(2, dim=1).values
+    decided = fg & ((top[:, 0] - top[:, 1]) > 5e-2)
+    agree = (preds.cpu()[decided] == rows.argmax(1)[decided]).float().mean().item()
+    d_ce = abs(loss.item() - ref_loss.item())
+    print("config 5 grid level: CE hip %.5f oracle %.5f |d| %.2e, agreement %.3f on %d decided foreground spots"
+          % (loss.item(), ref_loss.item(), d_ce, agree, int(decided.sum())))
+    assert int(stats[0]) == int(fg.sum())
+    assert d_ce < 2e-2 and agree >= 0.95
+
+
 # ----------------------------------------------------------------------------------------------- round 2 additions
 def test_cartesian_gridnet_forward_and_loop_match_reference():
     """`GridNet` with the Cartesian nn.Conv2d corrector (gridnet_models.py:51-66, :111-117): the one g whose fixture is
