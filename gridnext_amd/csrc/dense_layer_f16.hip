@@ -109,9 +109,108 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
         }
     };
 
+    // ---- conv2 of one step, scatter form: the step's bottleneck tile (LDS) into every output block it touches.  At S = 64 ALL
+    // eight waves take part (after the step's E barrier the loaders and activators have nothing else to do, and two waves per
+    // SIMD hide each other's LDS latency: stamped, four waves alone needed ~58 cycles per MFMA); smaller maps: waves 0-3.
+    auto conv2_step = [&](int u, int j, f32x16& a0, f32x16& a1) {
+            const long R0 = ((long)u * J + j) * 128;
+            auto tap3 = [&](f32x16& acc, int O_rel, int dy) {  // the three dx taps of row offset dy into the block at O_rel
+                const int o = O_rel + i;
+                const int pin = S >= 16 ? 128 * j + o : (o & (S * S - 1));
+                const int y = pin >> LOG2S, x = pin & (S - 1);
+                unsigned aA[3];
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int r = o + dy * S + dx;
+                    const bool ok = (unsigned)(y + dy) < (unsigned)S && (unsigned)(x + dx) < (unsigned)S && (unsigned)r < 128u;
+                    aA[dx + 1] = ok ? lb + DL_BT + (r >> 4) * 4096 + (r & 15) * 16 + h * 256 : lb + DL_Z + h * 256;
+                }
+                const unsigned aW = lb + DL_W2 + (dy + 1) * 3 * 8192 + lane * 16;
+                // 24 (dx, k-step) products; the fragment pairs of the next D are in flight while one multiplies (a ring of
+                // D + 2 register pairs: a pair is overwritten two MFMAs after the MFMA that read it)
+                constexpr int D = 6, NSL = D + 2, NE = 24;
+                f32x4 ra[NSL] = {}, rw[NSL] = {};
+                auto request = [&](auto e_c) {
+                    constexpr int e = decltype(e_c)::value, dxi = e / 8, ks = e % 8;
+                    if (!DL_ABL(256)) ra[e % NSL] = lds_read4<ks * 512>(aA[dxi]);
+                    if (!DL_ABL(128)) rw[e % NSL] = lds_read4<dxi * 8192 + ks * 1024>(aW);
+                };
+                static_for<0, D>(request);
+                static_for<0, NE>([&](auto e_c) {
+                    constexpr int e = decltype(e_c)::value;
+                    if constexpr (e + D < NE) request(std::integral_constant<int, e + D>{});
+                    constexpr int younger = 2 * (e + D < NE ? D : NE - 1 - e);
+                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ra[e % NSL]), "+v"(rw[e % NSL]) : "n"(younger));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, rw[e % NSL]),
+                                                                 __builtin_bit_cast(half8, ra[e % NSL]), acc, 0, 0, 0);
+                });
+            };
+            auto store = [&](const f32x16& acc, int O_rel) {
+                _Float16* p = X + (R0 + O_rel + i) * ld + K + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    half4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = (_Float16)acc[4 * g + q];
+                    *reinterpret_cast<half4*>(p + 8 * g) = o;
+                }
+            };
+            auto zero = [&](f32x16& acc) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            };
+            // Which blocks this wave works on in this step: accumulator a0 on the block at O0 with row offsets dy = lo0..hi0,
+            // a1 on the block at O1 with lo1..hi1 (an empty range: nothing); zN: the accumulator starts from zero in this
+            // step (else it is carried in from the previous one); sN: it is complete after this step and goes to HBM.
+            int O0, lo0, hi0, O1 = 0, lo1 = 0, hi1 = -1;
+            bool z0, z1 = false, s0, s1 = false;
+            if constexpr (S == 64) {
+                // a step = image rows 2j, 2j + 1; a block = half a row; the step touches output rows 2j - 1 .. 2j + 2, i.e. eight
+                // blocks, one per wave: wave (ph, xh) owns the rows congruent to ph mod 4 (x half xh), so a row that waits for the
+                // next step stays with its wave.  Rows 2j - 1 and 2j are finished here (their dy = -1 / 0 taps came last step),
+                // rows 2j + 1 and 2j + 2 are opened.
+                const int xh = wave & 1, m = ((wave >> 1) - 2 * j + 1) & 3;
+                O0 = (m == 0 ? -64 : m == 1 ? 0 : m == 2 ? 64 : 128) + 32 * xh;
+                lo0 = m == 0 ? 1 : m == 1 ? 0 : -1;
+                hi0 = m == 0 ? (j == 0 ? 0 : 1) : m == 1 ? 1 : m == 2 ? 0 : (j == J - 1 ? -2 : -1);
+                z0 = m >= 2 || (m == 1 && j == 0);
+                s0 = m == 0 ? j != 0 : m == 1 ? true : m == 2 ? j == J - 1 : false;
+            } else if constexpr (S >= 16) {
+                // S = 32: a block = one image row, a step = 4 rows; S = 16: a block = two rows, a step = 8 rows - there the
+                // head's own block still lacks the dy = -1 taps of its second row and the tail's block the dy = +1 taps of
+                // its first (their other lanes are outside the tile: zeros).
+                if (wave >= 4) return;
+                const int role = (wave + j) & 3;
+                if (role == 0) {
+                    O0 = -32; lo0 = 1; hi0 = j == 0 ? 0 : 1; z0 = false; s0 = j != 0;
+                    O1 = 0; lo1 = S == 16 ? -1 : 0; hi1 = 1; z1 = j == 0; s1 = true;
+                } else if (role == 3) {
+                    O0 = 96; lo0 = -1; hi0 = S == 16 ? 1 : 0; z0 = true; s0 = j == J - 1;
+                    O1 = 128; lo1 = -1; hi1 = j == J - 1 ? -2 : -1; z1 = true;
+                } else {
+                    O0 = 32 * role; lo0 = -1; hi0 = 1; z0 = true; s0 = true;
+                }
+            } else {
+                if (wave >= 4) return;
+                O0 = 32 * wave; lo0 = -1; hi0 = 1; z0 = true; s0 = true;
+            }
+            if (z0) zero(a0);
+            if (z1) zero(a1);
+            if (DL_ABL(8)) { hi0 = lo0 - 1; hi1 = lo1 - 1; }
+#pragma unroll 1
+            for (int dy = lo0; dy <= hi0; ++dy) tap3(a0, O0, dy);
+            if (s0) store(a0, O0);
+#pragma unroll 1
+            for (int dy = lo1; dy <= hi1; ++dy) tap3(a1, O1, dy);
+            if (s1) store(a1, O1);
+    };
+
     if (wave >= 4) {
         // ================================================================= producers
         const int pw = wave - 4;
+        f32x16 pa0, pa1;                                       // conv2 accumulators (S = 64: these waves take part)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { pa0[r] = 0.f; pa1[r] = 0.f; }
         {
             const int pt = t - 256;                            // 0..255
             reinterpret_cast<f32x4*>(lds + DL_Z)[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -185,6 +284,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                         DL_LAP(2);
                     }
                     lds_barrier();                             // E
+                    if constexpr (S == 64) conv2_step(u, j, pa0, pa1);
                     DL_LAP(4);
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -218,6 +318,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                     DL_LAP(3);
                 }
                 lds_barrier();                                 // E: the step's bottleneck tile is complete
+                if constexpr (S == 64) conv2_step(u, j, pa0, pa1);
                 DL_LAP(4);
             }
         if (wave == 6) DL_OUT(16);
@@ -326,95 +427,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             DL_LAP(2);
             lds_barrier();                                     // E
             DL_LAP(3);
-            // ---- conv2, scatter form
-            const long R0 = ((long)u * J + j) * 128;
-            auto tap3 = [&](f32x16& acc, int O_rel, int dy) {  // the three dx taps of row offset dy into the block at O_rel
-                const int o = O_rel + i;
-                const int pin = S >= 16 ? 128 * j + o : (o & (S * S - 1));
-                const int y = pin >> LOG2S, x = pin & (S - 1);
-                unsigned aA[3];
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int r = o + dy * S + dx;
-                    const bool ok = (unsigned)(y + dy) < (unsigned)S && (unsigned)(x + dx) < (unsigned)S && (unsigned)r < 128u;
-                    aA[dx + 1] = ok ? lb + DL_BT + (r >> 4) * 4096 + (r & 15) * 16 + h * 256 : lb + DL_Z + h * 256;
-                }
-                const unsigned aW = lb + DL_W2 + (dy + 1) * 3 * 8192 + lane * 16;
-                // 24 (dx, k-step) products; the fragment pairs of the next D are in flight while one multiplies (a ring of
-                // D + 2 register pairs: a pair is overwritten two MFMAs after the MFMA that read it)
-                constexpr int D = 6, NSL = D + 2, NE = 24;
-                f32x4 ra[NSL], rw[NSL];
-                auto request = [&](auto e_c) {
-                    constexpr int e = decltype(e_c)::value, dxi = e / 8, ks = e % 8;
-                    ra[e % NSL] = lds_read4<ks * 512>(aA[dxi]);
-                    rw[e % NSL] = lds_read4<dxi * 8192 + ks * 1024>(aW);
-                };
-                static_for<0, D>(request);
-                static_for<0, NE>([&](auto e_c) {
-                    constexpr int e = decltype(e_c)::value;
-                    if constexpr (e + D < NE) request(std::integral_constant<int, e + D>{});
-                    constexpr int younger = 2 * (e + D < NE ? D : NE - 1 - e);
-                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ra[e % NSL]), "+v"(rw[e % NSL]) : "n"(younger));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, rw[e % NSL]),
-                                                                 __builtin_bit_cast(half8, ra[e % NSL]), acc, 0, 0, 0);
-                });
-            };
-            auto store = [&](const f32x16& acc, int O_rel) {
-                _Float16* p = X + (R0 + O_rel + i) * ld + K + 4 * h;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    half4 o;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) o[q] = (_Float16)acc[4 * g + q];
-                    *reinterpret_cast<half4*>(p + 8 * g) = o;
-                }
-            };
-            auto zero = [&](f32x16& acc) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            };
-            // Which blocks this wave works on in this step: accumulator a0 on the block at O0 with row offsets dy = lo0..hi0,
-            // a1 on the block at O1 with lo1..hi1 (an empty range: nothing); zN: the accumulator starts from zero in this
-            // step (else it is carried in from the previous one); sN: it is complete after this step and goes to HBM.
-            int O0, lo0, hi0, O1 = 0, lo1 = 0, hi1 = -1;
-            bool z0, z1 = false, s0, s1 = false;
-            if constexpr (S == 64) {
-                // a step = image rows 2j, 2j + 1; a block = half a row.  Head waves finish rows 2j - 1 and 2j, tail waves open
-                // rows 2j + 1 and 2j + 2 and are the next step's head waves.
-                const int xh = wave & 1;
-                if ((((wave >> 1) + j) & 1) == 0) {
-                    O0 = -64 + 32 * xh; lo0 = 1; hi0 = j == 0 ? 0 : 1; z0 = false; s0 = j != 0;
-                    O1 = 32 * xh; lo1 = 0; hi1 = 1; z1 = j == 0; s1 = true;
-                } else {
-                    O0 = 64 + 32 * xh; lo0 = -1; hi0 = 0; z0 = true; s0 = j == J - 1;
-                    O1 = 128 + 32 * xh; lo1 = -1; hi1 = j == J - 1 ? -2 : -1; z1 = true;
-                }
-            } else if constexpr (S >= 16) {
-                // S = 32: a block = one image row, a step = 4 rows; S = 16: a block = two rows, a step = 8 rows - there the
-                // head's own block still lacks the dy = -1 taps of its second row and the tail's block the dy = +1 taps of
-                // its first (their other lanes are outside the tile: zeros).
-                const int role = (wave + j) & 3;
-                if (role == 0) {
-                    O0 = -32; lo0 = 1; hi0 = j == 0 ? 0 : 1; z0 = false; s0 = j != 0;
-                    O1 = 0; lo1 = S == 16 ? -1 : 0; hi1 = 1; z1 = j == 0; s1 = true;
-                } else if (role == 3) {
-                    O0 = 96; lo0 = -1; hi0 = S == 16 ? 1 : 0; z0 = true; s0 = j == J - 1;
-                    O1 = 128; lo1 = -1; hi1 = j == J - 1 ? -2 : -1; z1 = true;
-                } else {
-                    O0 = 32 * role; lo0 = -1; hi0 = 1; z0 = true; s0 = true;
-                }
-            } else {
-                O0 = 32 * wave; lo0 = -1; hi0 = 1; z0 = true; s0 = true;
-            }
-            if (z0) zero(a0);
-            if (z1) zero(a1);
-            if (DL_ABL(8)) { hi0 = lo0 - 1; hi1 = lo1 - 1; }
-#pragma unroll 1
-            for (int dy = lo0; dy <= hi0; ++dy) tap3(a0, O0, dy);
-            if (s0) store(a0, O0);
-#pragma unroll 1
-            for (int dy = lo1; dy <= hi1; ++dy) tap3(a1, O1, dy);
-            if (s1) store(a1, O1);
+            conv2_step(u, j, a0, a1);
             DL_LAP(4);
         }
     if (wave == 0) DL_OUT(0);

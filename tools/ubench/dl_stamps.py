@@ -46,7 +46,7 @@ def main():
             lib.gnx_dense_layer_f16(X.data_ptr(), ct, n, S, K, w1p.data_ptr(), w2p.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                                     osc.data_ptr(), osh.data_ptr(), st)
         # ablations first, timed WITHOUT stamps (a NULL stamp buffer): what the launch costs when a part is left out
-        names = {0: 'full', 1: '-norm1', 2: '-conv1', 4: '-dma', 8: '-conv2', 16: '-epilogue', 3: '-norm1-conv1', 24: '-conv2-epi',
+        names = {0: 'full', 128: 'conv2 -Wreads', 256: 'conv2 -Areads', 384: 'conv2 -reads', 1: '-norm1', 2: '-conv1', 4: '-dma', 8: '-conv2', 16: '-epilogue', 3: '-norm1-conv1', 24: '-conv2-epi',
                  27: 'dma+sync only', 31: 'sync only'}
         line = []
         for abl, nm in names.items():
