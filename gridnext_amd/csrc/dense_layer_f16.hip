@@ -109,6 +109,10 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
         }
     };
 
+    // (Tried and dropped, measured: conv2 cut into jobs of 24 MFMAs run one per stage behind the NEXT step's conv1 stages, so
+    // that stage barriers - and with them the loaders' refills - keep passing during conv2: S = 32 / 16 layers got 12-37 %
+    // SLOWER, S = 64 / 8 unchanged.  A stage's period is set by its slowest wave, and the consumer waves are no faster per stage
+    // than the DMA stream: added to their stages the jobs add to the step instead of hiding in it.)
     // ---- conv2 of one step, scatter form: the step's bottleneck tile (LDS) into every output block it touches.  At S = 64 ALL
     // eight waves take part (after the step's E barrier the loaders and activators have nothing else to do, and two waves per
     // SIMD hide each other's LDS latency: stamped, four waves alone needed ~58 cycles per MFMA); smaller maps: waves 0-3.
