@@ -13,7 +13,9 @@ kernels of csrc/conv1x1.hip, conv3x3.hip and stem_pool.hip through the C ABI:
   * BN+ReLU are folded into the operand load of the following conv; the transition averages 2x2 first;
   * a whole array's spots go through each kernel together (chunks only when activations would exceed ~40 GB,
     or when the caller sets `atonce` / GridNet.atonce_patch_limit).
-`efficient=True` (checkpointing, :36-40) is accepted and ignored: 288 GB of HBM make recompute unnecessary.
+`efficient=True` (checkpointing, :36-40): on the gradient path the forward keeps no tape and the backward recomputes it
+(densenet_train._RecomputeFn); independently of the flag, a batch whose tape would exceed `tape_budget` bytes goes through in
+recomputed chunks when BatchNorm runs on running statistics (train_gridwise always: training.py:126).
 """
 import math
 from collections import OrderedDict
@@ -57,6 +59,9 @@ class DenseNet(nn.Module):
         self.drop_rate = float(drop_rate or 0)      # dropout after conv2 (:42-43): identity outside training mode
         self.growth_rate, self.block_config = growth_rate, tuple(block_config)
         self.bn_size, self.small_inputs, self.classify = bn_size, small_inputs, classify
+        self.efficient = bool(efficient)      # gradient path: no tape in the forward, recompute in the backward (:12-18, :36-40)
+        self.tape_budget = 150 * 1024 ** 3    # bytes of tape one backward may hold (eval-statistics gradient path): beyond
+                                              # it the batch is cut into recomputed chunks (a 256-px array: 3 chunks)
         self.atonce = None          # spots per chunk in eval mode (None = auto)
         self.mfma = 'f32'           # 'f16': fp16 matrix-core operands in the eval forward (BASELINE config 5)
         self.winograd = True        # eval forward: conv2 as Winograd F(2,3) along x where the shape allows (fp32 path;

@@ -530,7 +530,88 @@ class _DenseNetFn(Function):
         return tuple(out)
 
 
+class _RecomputeFn(Function):
+    """The same forward WITHOUT a tape; the backward runs the taped forward again on the saved input chunk and then its
+    backward - what `cp.checkpoint` around a chunk (/root/reference/gridnext/gridnet_models.py:88-104) and `efficient=True`
+    (/root/reference/gridnext/densenet.py:12-18, :36-40) do in the reference.  Memory: only the chunk's INPUT lives between
+    forward and backward; one tape exists at a time, inside backward.
+    BatchNorm running statistics (train mode only): updated exactly ONCE per chunk - the recompute starts from the
+    statistics the first forward started from, so it reproduces that forward bit for bit (the reference's reentrant
+    checkpoint runs the update twice).  Parameter gradients are accumulated straight into `.grad` by the inner backward, as
+    a reentrant checkpoint does; nothing is returned for them."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        ctx.model, ctx.x = model, x
+        ctx.bn_state = None
+        if model.training:
+            ctx.bn_state = [(m, m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone())
+                            for m in model._bn_modules()]
+        with torch.no_grad():
+            out = _DenseNetFn.apply(model, x, *params)          # its tape dies with this call
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, x = ctx.model, ctx.x
+        after = None
+        if ctx.bn_state is not None:
+            after = [(m, m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone())
+                     for m, _, _, _ in ctx.bn_state]
+            for m, rm, rv, nb in ctx.bn_state:
+                m.running_mean.copy_(rm)
+                m.running_var.copy_(rv)
+                m.num_batches_tracked.copy_(nb)
+            model.invalidate_cache()
+        with torch.enable_grad():
+            out = _DenseNetFn.apply(model, x.detach(), *list(model.parameters()))
+        if after is not None:                                    # later chunks may have moved the statistics on: keep theirs
+            for m, rm, rv, nb in after:
+                m.running_mean.copy_(rm)
+                m.running_var.copy_(rv)
+                m.num_batches_tracked.copy_(nb)
+            model.invalidate_cache()
+        torch.autograd.backward(out, dout)
+        ctx.x = ctx.bn_state = None
+        return (None, None) + (None,) * len(list(model.parameters()))
+
+
+def tape_bytes_per_spot(model, P):
+    """HBM one spot holds on the tape of the f-trained forward, plus its share of the backward's scratch (bytes): block
+    buffers, one bottleneck per dense layer, the largest block's gradient buffers, the float patch."""
+    hs, sizes = model._geometry(P)
+    mid = model.bn_size * model.growth_rate
+    total, biggest = 0, 0
+    for (c_in, layers, trans, c_total), s in zip(model._blocks, sizes):
+        block = s * s * c_total
+        total += block + len(layers) * s * s * mid
+        biggest = max(biggest, 2 * block + 2 * s * s * mid)
+    return 4 * (total + biggest + 3 * P * P)
+
+
 def densenet_autograd(model, x):
-    """Differentiable DenseNet forward (training-mode BN when model.training, running-stat BN otherwise)."""
+    """Differentiable DenseNet forward (training-mode BN when model.training, running-stat BN otherwise).
+    Memory control (the reference's `efficient=True` and chunk checkpointing): with `model.efficient`, or when the tape of
+    the whole batch would exceed `model.tape_budget` bytes under running statistics (where chunks are independent), the
+    batch goes through in chunks whose forward keeps no tape and whose backward recomputes it (`_RecomputeFn`)."""
     params = list(model.parameters())
-    return _DenseNetFn.apply(model, x, *params)
+    n = x.shape[0]
+    per = tape_bytes_per_spot(model, x.shape[2])
+    chunk = n
+    budget = getattr(model, 'tape_budget', None)
+    if not model.training and budget and per * n > budget:
+        chunk = max(8, int(budget // per) // 8 * 8)
+    if chunk >= n:
+        if getattr(model, 'efficient', False):
+            return _RecomputeFn.apply(model, x, *params)
+        return _DenseNetFn.apply(model, x, *params)
+    return torch.cat([_RecomputeFn.apply(model, x.narrow(0, s0, min(chunk, n - s0)), *params) for s0 in range(0, n, chunk)], 0)
+
+
+def densenet_recompute(model, x):
+    """One chunk, forward without tape, recompute in backward (GridNet.atonce_patch_limit on the gradient path)."""
+    if not x.is_cuda:
+        raise RuntimeError("gridnext_amd.DenseNet runs on a HIP device only (input is on %s)" % x.device)
+    if model.training and model.drop_rate > 0:
+        raise NotImplementedError("gridnext_amd.DenseNet: train-mode dropout is not implemented")
+    return _RecomputeFn.apply(model, x.contiguous(), *list(model.parameters()))

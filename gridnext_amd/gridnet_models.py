@@ -83,9 +83,13 @@ class GridNet(nn.Module):
                     f.atonce = keep                # the user's own setting is not ours to change
             if lim is None or lim >= n:
                 return f(spots)
-            # gradient / train-mode path: one tape per chunk of `atonce_patch_limit` spots, as the reference's checkpointed
-            # chunks (:88-104) - in train mode BatchNorm batch statistics are per chunk there too.  Nothing is recomputed.
-            return torch.cat([f(spots.narrow(0, s0, min(lim, n - s0))) for s0 in range(0, n, lim)], 0)
+            # gradient / train-mode path: chunks of `atonce_patch_limit` spots, each CHECKPOINTED as in the reference (:88-104):
+            # its forward keeps no tape, its backward recomputes it - one tape alive at a time.  In train mode BatchNorm
+            # batch statistics are per chunk there too (running statistics move once per chunk here, twice there).
+            from .densenet_train import densenet_recompute
+            if spots.dtype not in (torch.uint8, torch.float32):
+                spots = spots.float()
+            return torch.cat([densenet_recompute(f, spots.narrow(0, s0, min(lim, n - s0))) for s0 in range(0, n, lim)], 0)
         if lim is None or lim >= n:
             return _spot_rows(f, spots, count_grid)
         if spots is None:

@@ -630,6 +630,48 @@ def test_config5_grid_level_fp16_path_against_oracle_after_g():
     assert d_ce < 2e-2 and agree >= 0.95
 
 
+@pytest.mark.parametrize("train_bn", [False, True])
+def test_recomputed_chunks_give_the_taped_gradients_bit_for_bit(train_bn):
+    """Bounded-memory f-trained step (gridnet_models.py:88-104 + densenet.py:36-40): chunks whose forward
+    keeps no tape and whose backward recomputes it must give EXACTLY the outputs, parameter gradients and running
+    statistics of the same chunks with one tape each (the kernels are deterministic and the recompute starts from the
+    statistics the first forward started from).  Also: `efficient=True` and the automatic `tape_budget` chunking."""
+    import gridnext_amd as ga
+    from gridnext_amd import densenet_train as dt
+    g = load_golden('densenet_tiny_large')
+    x = torch.rand(24, 3, 32, 32, generator=torch.Generator().manual_seed(31)).to(DEV)
+    n, lim = 24, 8
+
+    def run(mode):
+        m = ga.DenseNet(**TINY_LARGE)
+        m.load_state_dict(sub(g, 'sd'))
+        m.to(DEV).train(train_bn)
+        if mode == 'taped':
+            out = torch.cat([m(x.narrow(0, s0, min(lim, n - s0))) for s0 in range(0, n, lim)], 0)
+        elif mode == 'recompute':
+            out = torch.cat([dt.densenet_recompute(m, x.narrow(0, s0, min(lim, n - s0))) for s0 in range(0, n, lim)], 0)
+        elif mode == 'efficient':
+            m.efficient = True
+            out = torch.cat([m(x.narrow(0, s0, min(lim, n - s0))) for s0 in range(0, n, lim)], 0)
+        else:                                                     # automatic chunking under a small tape budget
+            m.tape_budget = dt.tape_bytes_per_spot(m, x.shape[2]) * lim
+            out = m(x)
+        (out * torch.linspace(-1, 1, out.numel(), device=DEV).reshape(out.shape)).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}, \
+            {k: v.clone() for k, v in m.state_dict().items() if 'running' in k or 'tracked' in k}
+
+    ref = run('taped')
+    modes = ['recompute', 'efficient'] + ([] if train_bn else ['auto'])
+    for mode in modes:
+        got = run(mode)
+        assert torch.equal(got[0], ref[0]), mode
+        for k in ref[1]:
+            assert torch.equal(got[1][k], ref[1][k]), (mode, k)
+        for k in ref[2]:
+            assert torch.equal(got[2][k], ref[2][k]), (mode, k)
+
+
 # ----------------------------------------------------------------------------------------------- round 2 additions
 def test_cartesian_gridnet_forward_and_loop_match_reference():
     """`GridNet` with the Cartesian nn.Conv2d corrector (gridnet_models.py:51-66, :111-117): the one g whose fixture is
