@@ -175,12 +175,47 @@ def pmc_traffic_table(suffix=''):
     return {}, None
 
 
+# which sources a kernel kind is built from: its PMC figure is only attached while they still hash to what the passes saw
+KIND_SOURCES = {
+    'dense_layer': ('dense_layer_f16.hip', 'fwd_common.h', 'common.h'),
+    'conv1x1': ('conv1x1.hip', 'densenet_f16.hip', 'fwd_common.h', 'common.h'),
+    'transition': ('conv1x1.hip', 'densenet_f16.hip', 'fwd_common.h', 'common.h'),
+    'conv3x3': ('conv3x3.hip', 'fwd_common.h', 'common.h'),
+    'stem': ('stem_pool.hip', 'fwd_common.h', 'common.h'),
+    'dgrad1x1_bn1': ('conv1x1.hip', 'fwd_common.h', 'common.h'),
+    'dgrad3x3_bn2': ('conv3x3.hip', 'fwd_common.h', 'common.h'),
+    'wgrad1x1': ('densenet_bwd.hip', 'common.h'),
+    'wgrad3x3': ('densenet_bwd.hip', 'common.h'),
+}
+
+
+def _source_hash(name):
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, 'gridnext_amd', 'csrc', name), 'rb') as fh:
+            return hashlib.sha1(fh.read()).hexdigest()
+    except OSError:
+        return None
+
+
 def attach_traffic(kern, suffix):
+    """PMC traffic per launch from the newest profiles/r*_pmc_traffic<suffix>.json - but only for kernels whose sources are
+    the ones those passes profiled (the file records their sha1): after a kernel change without a new pass the field stays
+    null and says why."""
     table, name = pmc_traffic_table(suffix)
+    recorded = table.get('_sources')
     for kind in kern:
-        if kind in table:
-            kern[kind]["traffic"] = table[kind]["hbm_bytes_per_launch"]
-            kern[kind]["traffic_source"] = "profiles/%s (PMC, separate passes)" % name
+        if kind not in table:
+            continue
+        if recorded is None:
+            kern[kind]["traffic_source"] = "profiles/%s predates source hashing: not attached" % name
+            continue
+        stale = [f for f in KIND_SOURCES.get(kind, ()) if recorded.get(f) != _source_hash(f)]
+        if stale:
+            kern[kind]["traffic_source"] = "profiles/%s is older than %s: not attached (re-run the PMC passes)" % (name, ", ".join(stale))
+            continue
+        kern[kind]["traffic"] = table[kind]["hbm_bytes_per_launch"]
+        kern[kind]["traffic_source"] = "profiles/%s (PMC, separate passes; sources unchanged since)" % name
 
 
 def winograd_credit(k3, patch, steps):
@@ -197,6 +232,57 @@ def winograd_credit(k3, patch, steps):
     k3["achieved"] = ex / (k3["ms_per_step"] * steps * 1e-3) / 1e12
     k3["frac"] = k3["achieved"] / PEAK_F32_MATRIX_TFLOPS
     k3["flops_per_launch_avg"] = ex / max(k3["launches"], 1)
+
+
+class _RankDiag:
+    """What a multi-GPU run needs in its line to explain a bad scaling point: every rank's own step time (before the MAX that
+    the headline takes), the time inside the gradient all-reduce (HIP events on the launch stream around
+    `distributed.allreduce_gradients`), the RCCL version, and - for host-fed series - every rank's H2D rate."""
+
+    def __init__(self, device):
+        import torch
+        from gridnext_amd import distributed as gdist
+        self.torch, self.gdist, self.device = torch, gdist, device
+        self.events = []
+
+    def allreduce(self, params):
+        if not self.gdist.is_active():
+            return
+        t = self.torch
+        e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        e0.record()
+        self.gdist.allreduce_gradients(params)
+        e1.record()
+        self.events.append((e0, e1))
+
+    def reset(self):
+        self.events = []
+
+    def report(self, elapsed_own, steps, extra=None):
+        """Call after torch.cuda.synchronize(); elapsed_own = this rank's own wall time of the timed steps (s)."""
+        t, gdist = self.torch, self.gdist
+        world = gdist.world_size()
+        ar_ms = sum(a.elapsed_time(b) for a, b in self.events) / max(steps, 1) if self.events else 0.0
+        vals = [1e3 * elapsed_own / max(steps, 1), ar_ms] + list(extra or [])
+        table = [vals]
+        if gdist.is_active():
+            mine = t.tensor(vals, dtype=t.float64, device=self.device)
+            allv = [t.zeros_like(mine) for _ in range(world)]
+            t.distributed.all_gather(allv, mine)
+            table = [v.tolist() for v in allv]
+        per_rank = [r[0] for r in table]
+        out = {"per_rank_ms_per_step": {"min": min(per_rank), "max": max(per_rank), "all": per_rank},
+               "allreduce_ms_per_step": {"max": max(r[1] for r in table), "all": [r[1] for r in table],
+                                         "timed_with": "HIP events around distributed.allreduce_gradients" if gdist.is_active()
+                                         else "no collective (1 process)"}}
+        if extra:
+            out["extra_per_rank"] = [r[2:] for r in table]
+        try:
+            out["rccl_version"] = ".".join(str(v) for v in t.cuda.nccl.version()) if gdist.is_active() and \
+                t.distributed.get_backend() == 'nccl' else None
+        except Exception:                                          # noqa: BLE001
+            out["rccl_version"] = None
+        return out
 
 
 def build_model(device, patch=128):
@@ -388,18 +474,20 @@ def from_host_series(args, model, optimizer, criterion, device, rank, world):
     model.patch_classifier.eval()
     pf = prefetch.DevicePrefetcher(DataLoader(Arrays(), batch_size=1), device)
     it = iter(pf)
+    diag = _RankDiag(device)
 
     def step():
         inputs, labels = next(it)
         loss, _, _ = gtrain._grid_loss(model, inputs, labels, criterion, 1, True)
         loss.backward()
-        gdist.allreduce_gradients(stepped)
+        diag.allreduce(stepped)
         optimizer.step()
         optimizer.zero_grad()
         return loss
 
     for _ in range(warmup):
         step()
+    diag.reset()
     if gdist.is_active():
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -407,9 +495,15 @@ def from_host_series(args, model, optimizer, criterion, device, rank, world):
     for _ in range(steps):
         last = step()
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0
     if gdist.is_active():
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
+    # every rank's own feed rate: bytes its prefetcher moved over PCIe during its own timed steps
+    # (the producer thread runs batches ahead of the consumer, so bytes are counted per batch, not per interval)
+    per_batch = pf.bytes_moved / float(steps + warmup)
+    rank_diag = diag.report(own, steps, extra=[per_batch * steps / max(own, 1e-9) / 1e9])
+    rank_diag["h2d_gb_per_s_per_rank"] = [e[0] for e in rank_diag.pop("extra_per_rank")]
     if gdist.is_active():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -417,7 +511,7 @@ def from_host_series(args, model, optimizer, criterion, device, rank, world):
     for _ in it:                                                  # exhaust (nothing left) so the producer thread ends
         pass
     return {"value": H * W * world * steps / elapsed, "unit": "spots/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
-            "warmup": warmup, "final_loss": float(last.item()),
+            "warmup": warmup, "final_loss": float(last.item()), "ranks": rank_diag,
             "h2d_bytes_per_step": pf.bytes_moved // (steps + warmup),
             "workload": "the headline step fed from pageable host memory: Dataset -> DataLoader(batch_size=1) -> pinned "
                         "double-buffered H2D prefetcher (side stream, one batch ahead); uint8 patches (ToTensor fused into the "
@@ -492,7 +586,7 @@ def config5_series(args, device, rank, world, steps=4, warmup=2):
                        "1 array (4992 spots) per step, f frozen/eval, g trained; uint8 patches resident in HBM"}
     # SURVEY 8d for this config: dCE and agreement rate after g against the fp32 CPU oracle (13 x 8 = 104-spot sub-grid, the
     # same state_dict - calibrated statistics included - uint8 patches on the HIP side); reported, no 1e-4 claim
-    if rank == 0 and not getattr(args, 'no_cpu_baseline', False):
+    if rank == 0 and world == 1 and not getattr(args, 'no_cpu_baseline', False):
         _, out["ce_vs_ref"] = cpu_leg(model, P, 'f16', device, timed_steps=0, sub_hw=(13, 8), u8=True)
         out["fused_dense_layers"] = bool(getattr(f_img, '_used_f16_fused', False))
     kt = kernel_table(probe, P, steps)
@@ -670,6 +764,8 @@ def worker_main(args):
             m.momentum = mo
         f_img.eval()
 
+    diag = _RankDiag(device)
+
     def run_series(train_f, steps, warmup, probe_on):
         """`warmup` untimed + `steps` timed steps; returns (seconds for the timed steps - max over ranks -, last loss,
         probe records)."""
@@ -690,7 +786,7 @@ def worker_main(args):
             inputs, labels = arrays[i % len(arrays)]
             loss, correct, n_fg = gtrain._grid_loss(model, inputs, labels, criterion, 1, True)
             loss.backward()
-            gdist.allreduce_gradients(stepped)
+            diag.allreduce(stepped)
             optimizer.step()
             optimizer.zero_grad()
             if f_opt is not None:
@@ -701,6 +797,7 @@ def worker_main(args):
         f_img._probe = None
         for i in range(warmup):
             step(i)
+        diag.reset()
         if probe_on:
             f_img._probe = []                                       # (kind, start_event, end_event) per timed launch
         if gdist.is_active():
@@ -710,6 +807,7 @@ def worker_main(args):
         for i in range(steps):
             last = step(warmup + i)
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0
         if gdist.is_active():
             torch.distributed.barrier()
         elapsed = time.perf_counter() - t0
@@ -717,6 +815,7 @@ def worker_main(args):
             t = torch.tensor([elapsed], dtype=torch.float64, device=device)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(t.item())
+        run_series.last_ranks = diag.report(own, steps)
         probe, f_img._probe = f_img._probe, None
         return elapsed, float(last.item()), probe
 
@@ -749,7 +848,7 @@ def worker_main(args):
                    "arrays_per_gpu_per_step": 1, "spots_per_array": H * W, "parallelism": "dp%d" % world,
                    "final_loss": last_loss},
         "rccl_ranks": world, "backend": (torch.distributed.get_backend() if gdist.is_active() else "none (1 process)"),
-        "devices": names,
+        "devices": names, "ranks": run_series.last_ranks,
     }
     if probe:
         kern = kernel_table(probe, args.patch, args.steps)

@@ -10,6 +10,13 @@ message is 27 144 floats (108.6 KB): a single latency-bound call; with f trainab
 Semantics: per-rank batch = the reference's batch (1 array); averaging gradients over ranks equals the
 reference's gradient accumulation over `world` arrays with each array's foreground-mean weighted equally.
 BatchNorm statistics stay per-rank (as they are per-batch in the reference).
+
+Optional EXACT "one batch of `world` arrays" emulation: `convert_sync_batchnorm(model)` +
+`set_sync_batchnorm(True)`.  Train-mode BatchNorms (g's two BatchNorm2d(32); in multimodal mode the count MLP's
+BatchNorm1d, which the GridNetHexMM quirk leaves in train mode) then normalise with statistics over ALL ranks' rows -
+an all-reduce of (sum x, sum x^2, n), 2 x 32 + 1 numbers per layer, and of (sum dy, sum dy x_hat) in the backward - and
+the loss is the mean over the foreground spots of all ranks (an all-reduce of n_fg): the step equals the reference's
+step on a single batch of `world` arrays.
 """
 import os
 
@@ -159,3 +166,108 @@ class ShardedSampler(Sampler):
         while len(order) < self.per_rank * self.world:
             order += order[:self.per_rank * self.world - len(order)]
         return iter(order[self.rank::self.world])
+
+
+# ------------------------------------------------------------------------------------------------ exact B = world emulation
+_SYNC_BN = False
+
+
+def set_sync_batchnorm(enabled=True):
+    """Switch the exact batch-of-`world`-arrays emulation on or off (see the module docstring)."""
+    global _SYNC_BN
+    _SYNC_BN = bool(enabled)
+
+
+def sync_active():
+    return _SYNC_BN and is_active()
+
+
+class _SyncBNRows(torch.autograd.Function):
+    """BatchNorm (+ ReLU) over the rows of x [M, C] with statistics over the rows of every rank.  Plain torch arithmetic
+    (the sums in float64) and two small all-reduces: an optional mode for exactness, not a hot path."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, relu):
+        M, C = x.shape
+        xd = x.double()
+        pack = torch.cat([xd.sum(0), (xd * xd).sum(0), torch.full((1,), float(M), dtype=torch.float64, device=x.device)])
+        dist.all_reduce(pack, op=dist.ReduceOp.SUM)
+        n = pack[-1]
+        mean = pack[:C] / n
+        var = (pack[C:2 * C] / n - mean * mean).clamp_min(0.0)
+        invstd = (var + bn.eps).rsqrt()
+        with torch.no_grad():
+            if bn.track_running_stats and bn.running_mean is not None:
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked.item() + 1)
+                bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+                bn.running_var.mul_(1 - mom).add_((var * n / (n - 1).clamp_min(1)).to(bn.running_var.dtype), alpha=mom)
+                bn.num_batches_tracked.add_(1)
+        xhat = ((xd - mean) * invstd).to(x.dtype)
+        y = xhat * gamma + beta if gamma is not None else xhat
+        if relu:
+            y = y.clamp_min(0)
+        ctx.save_for_backward(xhat, gamma, invstd.to(x.dtype), y if relu else None)
+        ctx.n, ctx.relu = float(n.item()), relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, gamma, invstd, y = ctx.saved_tensors
+        if ctx.relu:
+            dy = dy * (y > 0)
+        C = xhat.shape[1]
+        dyd = dy.double()
+        sums = torch.cat([dyd.sum(0), (dyd * xhat.double()).sum(0)])
+        dbeta, dgamma = sums[:C].to(dy.dtype), sums[C:].to(dy.dtype)     # this rank's rows: the gradient all-reduce sums them
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        g = gamma if gamma is not None else torch.ones_like(invstd)
+        dx = (g * invstd) * (dy - (sums[:C] / ctx.n).to(dy.dtype) - xhat * (sums[C:] / ctx.n).to(dy.dtype))
+        return dx, (dgamma if gamma is not None else None), (dbeta if gamma is not None else None), None, None
+
+
+def sync_batch_norm_rows(x2d, bn, relu=False):
+    return _SyncBNRows.apply(x2d, bn.weight, bn.bias, bn, relu)
+
+
+class _SyncMixin:
+    _gnx_is_sync = True
+
+    def forward(self, x):
+        if not (self.training and sync_active()):
+            return super().forward(x)
+        if x.dim() == 2:
+            return sync_batch_norm_rows(x, self)
+        c = x.shape[1]
+        rows = x.movedim(1, -1).reshape(-1, c)
+        return sync_batch_norm_rows(rows, self).reshape(x.movedim(1, -1).shape).movedim(-1, 1)
+
+
+class SyncBatchNorm1d(_SyncMixin, torch.nn.BatchNorm1d):
+    pass
+
+
+class SyncBatchNorm2d(_SyncMixin, torch.nn.BatchNorm2d):
+    pass
+
+
+def convert_sync_batchnorm(module):
+    """Give every BatchNorm1d / BatchNorm2d under `module` the all-rank statistics (in place: same parameters, buffers and
+    state_dict keys; plain behaviour whenever `sync_active()` is false or the module is in eval mode)."""
+    for m in module.modules():
+        if type(m) is torch.nn.BatchNorm1d:
+            m.__class__ = SyncBatchNorm1d
+        elif type(m) is torch.nn.BatchNorm2d:
+            m.__class__ = SyncBatchNorm2d
+    return module
+
+
+def global_foreground_mean(loss, n_fg):
+    """Turn this rank's mean-over-its-foreground loss into its share of the mean over ALL ranks' foreground spots, scaled by
+    the world size so that the gradient all-reduce - which averages - yields the gradient of that global mean."""
+    if not sync_active():
+        return loss
+    n_local = n_fg.detach().to(torch.float64).reshape(1) if torch.is_tensor(n_fg) else \
+        torch.tensor([float(n_fg)], dtype=torch.float64, device=loss.device)
+    n_tot = n_local.clone()
+    dist.all_reduce(n_tot, op=dist.ReduceOp.SUM)
+    return loss * (n_local * world_size() / n_tot.clamp_min(1)).to(loss.dtype).squeeze(0)

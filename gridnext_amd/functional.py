@@ -113,6 +113,11 @@ def batch_norm_relu(x2d, bn, relu):
     """BatchNorm1d/2d semantics of torch over the rows of x2d [M, C], optionally fused with ReLU.
     Uses (and, in training mode, updates) the module's own parameters and buffers."""
     training = bn.training or not bn.track_running_stats
+    if training and getattr(bn, '_gnx_is_sync', False):
+        from . import distributed as gdist
+        if gdist.sync_active():                     # exact batch-of-`world` emulation: statistics over every rank's rows
+            x2 = x2d if x2d.dim() == 2 else x2d.reshape(-1, x2d.shape[-1])
+            return gdist.sync_batch_norm_rows(x2, bn, relu)
     return _BNReLU.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                          training, bn.momentum, bn.eps, relu)
 

@@ -224,7 +224,7 @@ def train_gridwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
     # launch-bound models (count-only f + g: ~60 kernels of 5-20 us per array): the step is captured once per phase and input
     # shape into a hipGraph and replayed (graphs.py); optimizer, all-reduce and statistics stay eager
     stepper = None
-    if graphs.wanted(model, fused_ok, device):
+    if graphs.wanted(model, fused_ok, device) and not gdist.sync_active():    # (collectives inside the step: not capturable)
         stepper = graphs.GridStepGraphs(lambda i, l: _grid_loss(model, i, l, criterion, accum_iters, fused_ok),
                                         model.parameters())
 
@@ -249,6 +249,7 @@ def train_gridwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
                         loss, correct, n_fg = replayed              # forward, loss and (train) backward: one graph launch
                     else:
                         loss, correct, n_fg = _grid_loss(model, inputs, labels, criterion, accum_iters, fused_ok)
+                        loss = gdist.global_foreground_mean(loss, n_fg)    # (identity unless the exact-batch mode is on)
                         if phase == 'train':
                             loss.backward()
                     if phase == 'train':

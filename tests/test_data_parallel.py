@@ -135,3 +135,88 @@ def test_two_rank_gloo_training_matches_gradient_accumulation(tmp_path):
         if 'running' in k or 'num_batches' in k:
             continue                      # BN statistics stay per-rank (documented)
         assert torch.allclose(r0['state']['corrector.' + k], v, rtol=1e-4, atol=1e-6), k
+
+
+# ---------------------------------------------------------------------------------------------- exact B = world emulation
+def _make_mm_problem():
+    from oracle import densenet as odn, gridnet as ogn
+    from oracle.mlp import count_mlp
+    torch.manual_seed(15)
+    G, H, W, C, P = 10, 5, 4, 3, 16
+    f_img = odn.DenseNet(growth_rate=4, block_config=(2,), num_init_features=8, bn_size=2, num_classes=C, small_inputs=True)
+    m = ogn.GridNetHexMM(f_img, count_mlp(G, C), (3, P, P), (G,), (H, W), C)
+    for p in m.patch_classifier.parameters():             # the tutorial's recipe: freezes the IMAGE f only (the MM quirk)
+        p.requires_grad = False
+    gen = torch.Generator().manual_seed(16)
+    xi = torch.rand((4, H, W, 3, P, P), generator=gen)
+    xc = torch.randint(0, 10, (4, G, H, W), generator=gen).float()
+    y = torch.randint(0, C + 1, (4, H, W), generator=gen)
+    y[1, :3] = 0                                          # unequal foreground counts: the two weightings differ
+    return m, xi, xc, y
+
+
+class _MMData(torch.utils.data.Dataset):
+    def __init__(self, xi, xc, y):
+        self.xi, self.xc, self.y = xi, xc, y
+
+    def __len__(self):
+        return self.y.shape[0]
+
+    def __getitem__(self, i):
+        return (self.xi[i], self.xc[i]), self.y[i]
+
+
+def _sync_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import contextlib
+    import io
+    from gridnext_amd import distributed as gdist
+    from gridnext_amd.training import train_gridwise
+    gdist.init_from_env(backend='gloo')
+    m, xi, xc, y = _make_mm_problem()
+    gdist.broadcast_module(m)
+    gdist.convert_sync_batchnorm(m.corrector)
+    gdist.convert_sync_batchnorm(m.count_classifier)
+    gdist.set_sync_batchnorm(True)
+    data = _MMData(xi, xc, y)
+    dl = {'train': DataLoader(data, batch_size=1, sampler=gdist.ShardedSampler(data)),
+          'val': DataLoader(data, batch_size=1, sampler=gdist.ShardedSampler(data))}
+    params = list(m.corrector.parameters()) + list(m.count_classifier.parameters())
+    opt = torch.optim.SGD(params, lr=0.05)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m, vh, th = train_gridwise(m, dl, nn.CrossEntropyLoss(), opt, num_epochs=2)
+    torch.save({'state': m.state_dict(), 'vh': vh, 'th': th}, os.path.join(out_dir, 'sync_rank%d.pt' % rank))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sync_batchnorm_equals_one_batch_of_two_arrays(tmp_path):
+    """SURVEY 8e's exact B = world emulation: with `convert_sync_batchnorm` + `set_sync_batchnorm(True)` two ranks holding
+    one array each take the same steps as ONE process on batches of two arrays - train-mode BatchNorm statistics over both
+    arrays (g's BatchNorm2d(32) pair and, by the GridNetHexMM quirk, the count MLP's BatchNorm1d), the loss a mean over the
+    foreground spots of both (unequal counts here) - weights, running statistics and reported histories included."""
+    import contextlib
+    import io
+    port = _free_port()
+    mp.spawn(_sync_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(str(tmp_path / 'sync_rank0.pt'))
+    r1 = torch.load(str(tmp_path / 'sync_rank1.pt'))
+    for k in r0['state']:
+        assert torch.equal(r0['state'][k], r1['state'][k]), k            # running statistics too: they are global now
+    torch.set_num_threads(1)
+    from gridnext_amd.training import train_gridwise
+    m, xi, xc, y = _make_mm_problem()
+    data = _MMData(xi, xc, y)
+    dl = {'train': DataLoader(data, batch_size=2), 'val': DataLoader(data, batch_size=2)}
+    params = list(m.corrector.parameters()) + list(m.count_classifier.parameters())
+    opt = torch.optim.SGD(params, lr=0.05)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m, vh, th = train_gridwise(m, dl, nn.CrossEntropyLoss(), opt, num_epochs=2)
+    np.testing.assert_allclose(r0['th'], th, rtol=2e-5)
+    np.testing.assert_allclose(r0['vh'], vh, rtol=2e-5)
+    for k, v in m.state_dict().items():
+        assert torch.allclose(r0['state'][k].float(), v.float(), rtol=2e-4, atol=2e-6), k

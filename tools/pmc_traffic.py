@@ -58,10 +58,22 @@ def collect(d, counter):
     return per
 
 
+def source_hashes():
+    """sha1 of every kernel source at the time of the PMC passes: bench.py attaches a traffic figure to a kernel only while
+    the sources that kernel is built from still hash to these (a kernel change without a new pass must not ship a stale ratio)."""
+    import hashlib
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gridnext_amd', 'csrc')
+    out = {}
+    for f in sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h'))):
+        with open(f, 'rb') as fh:
+            out[os.path.basename(f)] = hashlib.sha1(fh.read()).hexdigest()
+    return out
+
+
 def main():
     fetch = collect(sys.argv[1], 'FETCH_SIZE')
     write = collect(sys.argv[2], 'WRITE_SIZE')
-    out = {}
+    out = {'_sources': source_hashes()}
     for g, _ in GROUPS:
         if g not in fetch or g not in write:
             continue
