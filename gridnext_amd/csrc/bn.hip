@@ -786,8 +786,7 @@ GNX_EXPORT int gnx_bn_train_stats(const float* x, long ld, long M, int C, const 
                                   float* save_invstd, float* workspace, hipStream_t stream) {
     if (!x || !scale || !shift || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0 || ld < C)
         return GNX_ERR_BAD_ARG;
-    static const bool no_small = getenv("GNX_BN_NO_SMALL") != nullptr;
-    if (!no_small && M <= BN_SMALL_M && C % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    if (M <= BN_SMALL_M && C % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         if (M <= 8 * BN_SL)
             bn_train_stats_small_kernel<true><<<gnx_cdiv(C, 16), 1024, 0, stream>>>(x, ld, M, C, gamma, beta, running_mean,
                                                                                   running_var, num_batches_tracked, momentum,
@@ -828,8 +827,7 @@ GNX_EXPORT int gnx_bn_train_stats_apply(const float* x, long ld, long M, int C, 
                                         hipStream_t stream) {
     if (!x || !y || !scale || !shift || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0 || ld < C || ldy < C)
         return GNX_ERR_BAD_ARG;
-    static const bool no_small = getenv("GNX_BN_NO_SMALL") != nullptr;
-    if (!no_small && M <= BN_SMALL_M && C % 4 == 0 && ld % 4 == 0 && ldy % 4 == 0 &&
+    if (M <= BN_SMALL_M && C % 4 == 0 && ld % 4 == 0 && ldy % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
         if (M <= 8 * BN_SL)
             bn_train_stats_small_kernel<true><<<gnx_cdiv(C, 16), 1024, 0, stream>>>(
@@ -885,8 +883,7 @@ GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long 
                              reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(save_mean) |
                              reinterpret_cast<uintptr_t>(save_invstd)) & 15) == 0;
         if (relu == 2 && (training || !v4all)) return GNX_ERR_UNSUPPORTED;     // activated-input form: eval statistics only
-        static const bool no_small = getenv("GNX_BN_NO_SMALL") != nullptr;
-        if (!no_small && v4all && relu != 2 && M <= BN_SMALL_M) {
+        if (v4all && relu != 2 && M <= BN_SMALL_M) {
             if (M <= 8 * BN_SL)
                 bn_bwd_small_kernel<true><<<gnx_cdiv(C, 16), 1024, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale, shift,
                                                                               save_mean, save_invstd, dgamma, dbeta, relu,

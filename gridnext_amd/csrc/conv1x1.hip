@@ -1025,10 +1025,7 @@ __global__ __launch_bounds__(256) void conv1x1_fold_kernel(const float* __restri
 // conv1's fused data gradient: workgroups take contiguous runs of the column-fastest tile list (GNX_C1_RUNS=0: the XCD
 // placement the forward transitions keep).  Same box, same run: 52.5 -> 50.0 ms per f-trained step; the forward transitions
 // measured no better with runs (2.97 ms either way within noise), so they keep their order.
-static int c1_tile_runs() {
-    static const int v = getenv("GNX_C1_RUNS") ? atoi(getenv("GNX_C1_RUNS")) : 1;
-    return v;
-}
+static int c1_tile_runs() { return 1; }
 
 static int conv1x1_launch(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
                           const float* scale, const float* shift, int pool, int S_in, const float* oscale,
@@ -1044,8 +1041,7 @@ static int conv1x1_launch(const float* A, long lda, const float* W, float* out, 
     const bool fast = vecA && vecW;
     // small M with a workspace: K split over blockIdx.z (a batch-32 training step: 40 of its 58 conv1 launches ran 16 or 4
     // workgroups through 8-31 chunks each: 30-40 us of latency per launch)
-    static const bool no_split = getenv("GNX_C1_NO_SPLIT") != nullptr;
-    const int splits = (workspace && fast && !pool && !no_split && al16(out) && ldc % 4 == 0 && al16(workspace) &&
+    const int splits = (workspace && fast && !pool && al16(out) && ldc % 4 == 0 && al16(workspace) &&
                         (!oscale || (al16(oscale) && al16(oshift)))) ? conv1x1_small_splits(M, N, K) : 0;
     if (splits > 1) {
         const int ksplit = ((K / 32 + splits - 1) / splits) * 32;
@@ -1059,7 +1055,7 @@ static int conv1x1_launch(const float* A, long lda, const float* W, float* out, 
         return gnx_launch_status();
     }
     if (fast && M % 128 == 0 && N % 32 == 0 && K % 32 == 0 && K <= C1_KMAX && (!pool || (S_in % 2 == 0 && scale)) &&
-        4 * M < (1L << 31) && lda < (1 << 16) && ldc < (1 << 16) && !getenv("GNX_NO_WS1")) {     // int row / lane offsets
+        4 * M < (1L << 31) && lda < (1 << 16) && ldc < (1 << 16)) {     // int row / lane offsets
         const size_t lds_ws = 4 * 128 * 32 * 4 + (scale ? 8 * (size_t)K : 0);
         static bool conf = false;
         if (!conf) {
@@ -1080,16 +1076,15 @@ static int conv1x1_launch(const float* A, long lda, const float* W, float* out, 
         const int tilesN = (N + 127) / 128;
         const long T = (M / 128) * tilesN;
         // NP = producer waves: 4 (two 8-wave workgroups per CU) or 8 (one 12-wave workgroup per CU)
-        static const int np8 = getenv("GNX_WS_NP8") ? 1 : 0;
-        const int np = (!pool && np8) ? 8 : 4;
-        const int per_cu = np == 4 ? 2 : 1;
+        // (4 producer waves, two 8-wave workgroups per CU: 8 in one 12-wave workgroup per CU measured slower)
+        const int per_cu = 2;
         const int wgs = (int)(T < 256 * per_cu ? T : 256 * per_cu);
 #define GNX_WS(ACTV, POOLV, NPV)                                                                                     \
     conv1x1_ws_kernel<ACTV, POOLV, NPV><<<wgs, 64 * (4 + NPV), lds_ws, stream>>>(                                     \
         A, (int)lda, W, out, (int)ldc, K, N, tilesN, (int)T, S_in, 4 * M, scale, shift, oscale, oshift)
         if (pool) GNX_WS(true, true, 4);
-        else if (scale) { if (np == 8) GNX_WS(true, false, 8); else GNX_WS(true, false, 4); }
-        else { if (np == 8) GNX_WS(false, false, 8); else GNX_WS(false, false, 4); }
+        else if (scale) GNX_WS(true, false, 4);
+        else GNX_WS(false, false, 4);
 #undef GNX_WS
         return gnx_launch_status();
     }
@@ -1150,7 +1145,7 @@ GNX_EXPORT int gnx_conv1x1_clamped_act(const float* A, long lda, const float* Wf
     if (!A || !Wf || !bounds || !out || !out_scale || !out_shift_f || M < 0 || N <= 0 || K <= 0 || lda < K || ldc < N)
         return GNX_ERR_BAD_ARG;
     if (M % 128 != 0 || N % 128 != 0 || K % 32 != 0 || !al16(A) || !al16(Wf) || !al16(bounds) || lda % 4 != 0 ||
-        M >= (1L << 29) || lda >= (1 << 16) || ldc >= (1 << 16) || getenv("GNX_NO_CLAMP1"))
+        M >= (1L << 29) || lda >= (1 << 16) || ldc >= (1 << 16))
         return GNX_ERR_UNSUPPORTED;
     if (M == 0) return GNX_OK;
     constexpr int lds_bytes = 5 * 128 * 32 * 4;

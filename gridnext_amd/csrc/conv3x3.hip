@@ -887,8 +887,7 @@ GNX_EXPORT int gnx_conv3x3_dgrad_bnrelu_bwd(const float* dY, long lddy, const fl
         S <= 0 || lddy < K || lda < N || lddx < N || (M % ((long)S * S)) != 0)
         return GNX_ERR_BAD_ARG;
     if (K != 32 || N != 128 || (M % C3_BM) != 0 || !al16(dY) || !al16(Wb) || lddy % 4 != 0 ||
-        M * (lddy > lddx ? (lddy > lda ? lddy : lda) : (lddx > lda ? lddx : lda)) >= (1L << 31) || getenv("GNX_NO_DMA") ||
-        getenv("GNX_NO_C3ADJ"))
+        M * (lddy > lddx ? (lddy > lda ? lddy : lda) : (lddx > lda ? lddx : lda)) >= (1L << 31))
         return GNX_ERR_UNSUPPORTED;
     if (M == 0) return GNX_OK;
     C3BnAdj bn = {A_act, (int)lda, scale, shift, mean, invstd, workspace};
@@ -955,13 +954,11 @@ GNX_EXPORT int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, flo
     } while (0)
     const bool fast = vecA && vecW;      // aligned pointers/leading dimensions and K % 4 == 0
     // LDS-DMA persistent form for prologue-free inputs (the eval forward's pre-activated bottleneck)
-    if (!scale && fast && N == C3_BN && (K & 63) == 0 && (M % C3_BM) == 0 && M * (lda > ldc ? lda : ldc) < (1L << 31) &&
-        !getenv("GNX_NO_DMA")) {
+    if (!scale && fast && N == C3_BN && (K & 63) == 0 && (M % C3_BM) == 0 && M * (lda > ldc ? lda : ldc) < (1L << 31)) {
         // variant 1 = 4 waves (128-row tiles), 2 = 8 waves (256-row tiles).  Measured sustained (tools/kbench.py --noact
         // --reps 300): 2 wins wherever its tiles fill the chip (139 vs 133 TFLOP/s), 1 where they quantise badly (S = 4 at
         // 4992 spots: 82 vs 107).  (A third variant - 64-B LDS rows, two 4-wave workgroups per CU - measured like 1.)
-        static const int forced = getenv("GNX_DMA_VARIANT") ? atoi(getenv("GNX_DMA_VARIANT")) : -1;
-        const int variant = forced >= 0 ? forced : (M / 256 >= 1024 ? 2 : 1);
+        const int variant = M / 256 >= 1024 ? 2 : 1;
 #define GNX_DMA(SS)                                                                                              \
     do {                                                                                                         \
         if constexpr (SS <= 32) {                                                                                \
@@ -993,8 +990,7 @@ GNX_EXPORT int gnx_conv3x3_bnrelu(const float* A, long lda, const float* Wr, flo
     }
     // the same kernel in its data-gradient shape (dX = conv3x3(dY, W^T): K = 32 channels in, N = 128 out): column tiles
     // of 32 take the place of K chunks
-    if (!scale && fast && K == 32 && (N & 63) == 0 && (M % C3_BM) == 0 && M * (lda > ldc ? lda : ldc) < (1L << 31) &&
-        !getenv("GNX_NO_DMA")) {
+    if (!scale && fast && K == 32 && (N & 63) == 0 && (M % C3_BM) == 0 && M * (lda > ldc ? lda : ldc) < (1L << 31)) {
 #define GNX_DMAG(SS)                                                                                             \
     do {                                                                                                         \
         if constexpr (SS <= 32) {                                                                                \

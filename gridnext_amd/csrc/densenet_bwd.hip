@@ -1128,10 +1128,9 @@ GNX_EXPORT int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long
     const int nsplit = wgrad_splits(M, N, K);
     const long ntiles = (M + WG_BM - 1) / WG_BM;
     const long tps = (ntiles + nsplit - 1) / nsplit;
-    // round 2: transposed-image kernels for the dense layers' own shapes (GNX_WGRAD_R1 keeps the r1 kernels: A/B timing)
-    static const bool r1_kernels = getenv("GNX_WGRAD_R1") != nullptr;
+    // round 2: transposed-image kernels for the dense layers' own shapes
     const bool aligned = al16b(X) && al16b(dY) && ldx % 4 == 0 && lddy % 4 == 0 && (!scale || (al16b(scale) && al16b(shift)));
-    if (!r1_kernels && aligned && !pool) {
+    if (aligned && !pool) {
         const long total = (long)taps * N * K;
         // 128 < K: the 128 x 256 workgroup (K <= 128 would leave half of it multiplying zeros: the r1 kernel keeps those)
         const int ns1 = taps == 1 ? wgrad1_t_splits(M, N, K) : 0;
@@ -1176,7 +1175,7 @@ GNX_EXPORT int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long
                                                              tps, vec, vecY);                                      \
     } while (0)
     // register-prefetched form where the shape allows (see wgrad_pf_kernel)
-    const bool pf = !pool && vec && vecY && K % 4 == 0 && N % (32 * nt) == 0 && !getenv("GNX_NO_WGRAD_PF");
+    const bool pf = !pool && vec && vecY && K % 4 == 0 && N % (32 * nt) == 0;
 #define GNX_WGPF(T, NTT, NXX)                                                                                         \
     do {                                                                                                              \
         static size_t conf = 0;                                                                                       \
@@ -1189,13 +1188,9 @@ GNX_EXPORT int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long
         wgrad_pf_kernel<T, NTT, NXX><<<grid, 256, lds_bytes, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M,  \
                                                                        N, K, S, tps);                                 \
     } while (0)
-    const int strip_rows = WG_BM + 2 * halo;
     // 3x3: the 144 accumulator registers + a prefetched strip (68 more) leave one wave per SIMD - measured slower (56 vs
-    // 51 ms per step) than the plain kernel at two workgroups per CU, so only GNX_WGRAD_PF9 enables it
-    static const bool pf9 = getenv("GNX_WGRAD_PF9") != nullptr;
+    // 51 ms per step) than the plain kernel at two workgroups per CU: not instantiated
     if (pf && taps == 1) GNX_WGPF(1, 4, 8);
-    else if (pf && pf9 && taps == 9 && strip_rows <= 8 * 13) GNX_WGPF(9, 1, 13);       // S <= 16
-    else if (pf && pf9 && taps == 9 && strip_rows <= 8 * 17) GNX_WGPF(9, 1, 17);       // S <= 32
     else if (taps == 9) GNX_WG(9, 1, false);
     else if (pool) GNX_WG(1, 4, true);
     else GNX_WG(1, 4, false);
@@ -1316,7 +1311,7 @@ GNX_EXPORT int gnx_conv0_wgrad(const float* x, const float* dS, long ldd, float*
     const int PH = 7 * stride + KH, PW = (15 * stride + 8 + 1) & ~1;
     const size_t lds_bytes = ((size_t)3 * PH * PW + 64 + 128 * 64) * sizeof(float);
     const bool fastld = stride == 2 && pad == 3 && W % 4 == 0 && O == 64 && Ho % 8 == 0 && Wo % 16 == 0 && ldd % 4 == 0 &&
-                        al16b(x) && al16b(dS) && !getenv("GNX_NO_CONV0_PF");
+                        al16b(x) && al16b(dS);
     if (fastld) {
         const size_t lds_fast = ((size_t)3 * PH * 44 + 64 + 128 * 64) * sizeof(float);
         conv0_wgrad_kernel<2, 7, 3, true><<<blocks, 256, lds_fast, stream>>>(x, dS, ldd, workspace, H, W, Ho, Wo, O, KW,

@@ -689,8 +689,7 @@ GNX_EXPORT int gnx_conv1x1_bnrelu_h16(const void* A16, long lda16, const void* W
         return GNX_ERR_UNSUPPORTED;
     if (M == 0) return GNX_OK;
     // 256-row tiles (a weight chunk staged per 256 rows instead of 128) once they still fill the chip twice over
-    static const bool m128_only = getenv("GNX_H16_M128") != nullptr;
-    if (!m128_only && M >= 256L * 512 && K >= 192) {       // (measured: +3..6 % from K = 224 up, -4 % at K = 128)
+    if (M >= 256L * 512 && K >= 192) {       // (measured: +3..6 % from K = 224 up, -4 % at K = 128)
         dim3 grid(gnx_cdiv(M, 256), gnx_cdiv(N, 128));
         conv1x1_h16_m256_kernel<<<grid, 256, 0, stream>>>(reinterpret_cast<const _Float16*>(A16), lda16,
                                                           reinterpret_cast<const _Float16*>(W16),

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float* __r
 int gemm_wide_splits(long M, long N, long K) {
     if (M < 2048 || N < 256 || K < 512) return 0;
     const long tiles = gnx_cdiv(M, WM) * gnx_cdiv(N, WN), nkt = gnx_cdiv(K, TK);
-    static const int target = getenv("GNX_GW_WGS") ? atoi(getenv("GNX_GW_WGS")) : 512;
+    const int target = 512;
     long s = target / tiles;
     if (s > nkt / 4) s = nkt / 4;                              // at least 4 K tiles per workgroup
     if (s > 16) s = 16;
@@ -417,10 +417,8 @@ static int gemm_f32_impl(const float* A, long lda, int a_kmajor, const float* B,
     const int a_vec = aligned16(A) && (lda % 4 == 0);
     const int b_vec = aligned16(B) && (ldb % 4 == 0);
     // whole-grid batches: the LDS-transposed forms (need float4-able rows on both operands: K-major rows are M / N long);
-    // GNX_GEMM_R1 keeps the round-1 kernel (A/B timing)
-    static const bool small_only = getenv("GNX_GEMM_R1") != nullptr;
     const long a_bytes = 4 * ((a_kmajor ? K : M) * lda + 16), b_bytes = 4 * ((b_kmajor ? K : N) * ldb + 16);
-    const bool t_ok = !small_only && a_vec && b_vec && (a_kmajor ? M % 4 == 0 : K % 4 == 0) &&
+    const bool t_ok = a_vec && b_vec && (a_kmajor ? M % 4 == 0 : K % 4 == 0) &&
                       (b_kmajor ? N % 4 == 0 : K % 4 == 0) && a_bytes < (1L << 31) && b_bytes < (1L << 31) &&
                       (K + 2 * TK) * (lda > ldb ? lda : ldb) < (1L << 29);       // 32-bit byte offsets, one tile past the end
     int splits = t_ok ? gemm_wide_splits(M, N, K) : 0;
@@ -429,15 +427,10 @@ static int gemm_f32_impl(const float* A, long lda, int a_kmajor, const float* B,
         const long units8 = (gnx_cdiv(M, WM) * splits + 7) / 8 * 8;
         const long nwg = units8 * gnx_cdiv(N, WN);
         if (nwg > (1L << 30)) return GNX_ERR_UNSUPPORTED;
-        static const int occ = getenv("GNX_GW_OCC") ? atoi(getenv("GNX_GW_OCC")) : 2;
 #define GNX_LAUNCHW(AK, BKM)                                                                                               \
     do {                                                                                                                   \
-        if (occ == 1)                                                                                                      \
-            gemm_f32_wide_kernel<AK, BKM, 1><<<(unsigned)nwg, 256, 0, stream>>>(A, lda, B, ldb, bias, C, ldc, M, N, K,     \
-                                                                               accumulate, splits, workspace);            \
-        else                                                                                                               \
-            gemm_f32_wide_kernel<AK, BKM, 2><<<(unsigned)nwg, 256, 0, stream>>>(A, lda, B, ldb, bias, C, ldc, M, N, K,     \
-                                                                               accumulate, splits, workspace);            \
+        gemm_f32_wide_kernel<AK, BKM, 2><<<(unsigned)nwg, 256, 0, stream>>>(A, lda, B, ldb, bias, C, ldc, M, N, K,         \
+                                                                           accumulate, splits, workspace);                \
     } while (0)
         if (!a_kmajor && !b_kmajor) GNX_LAUNCHW(false, false);
         else if (a_kmajor && !b_kmajor) GNX_LAUNCHW(true, false);

@@ -153,69 +153,9 @@ __global__ __launch_bounds__(256) void hexconv_bwd_data_kernel(
     }
 }
 
-// Weight gradient on the matrix cores (round 2; the r1 kernel ran 7 * I * O scalar dot products per workgroup out of LDS:
-// 45 us per layer, the largest item of a count-only step).  dW_t[o][i] = sum_pos dy[pos][o] * x[nbr_t(pos)][i] is, per tap,
-// a [O x positions] x [positions x I] product: a workgroup takes 64 positions, stages dy [64][32] and the seven neighbour
-// rows of each position [64][7][32] (channels past O / I and neighbours outside the grid as zeros), and each of its four
-// waves multiplies its 16 positions with v_mfma_f32_32x32x2_f32 - position pair (2p, 2p + 1) per instruction, seven taps
-// sharing the dy fragment - into seven 32 x 32 accumulators.  partial[(4 blk + wave)][t][o][i] and [7 O I + o] (= sum dy) are
-// the slabs the fixed-order reduce below sums: deterministic, no atomics.
-constexpr int HW_POS = 64;         // positions per workgroup (16 per wave)
-__global__ __launch_bounds__(256) void hexconv_bwd_weight_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
-    HexGeom g, int I, int O, int IF, int OF, int i0, int o0) {
-    __shared__ __attribute__((aligned(16))) float dys[HW_POS * 32];            // [position][o]
-    __shared__ __attribute__((aligned(16))) float xs[HW_POS * 7 * 32];         // [position][tap][i]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
-    const int npos = g.B * g.H * g.W;
-    const int base = blockIdx.x * HW_POS;
-    for (int idx = t; idx < HW_POS * 32; idx += 256) {
-        const int pl = idx >> 5, o = idx & 31;
-        const int pos = base + pl;
-        dys[idx] = (pos < npos && o < O) ? dy[(size_t)pos * OF + o0 + o] : 0.f;
-    }
-    for (int idx = t; idx < HW_POS * 7 * 32; idx += 256) {
-        const int ch = idx & 31, q = idx >> 5;                 // q = position * 7 + tap
-        const int pl = q / 7, tap = q - 7 * pl;
-        const int pos = base + pl;
-        float v = 0.f;
-        if (pos < npos && ch < I) {
-            const int xx = pos % g.W, yy = (pos / g.W) % g.H, b = pos / (g.W * g.H);
-            const int n = g.nbr(b, yy, xx, tap);
-            if (n >= 0) v = x[(size_t)n * IF + i0 + ch];
-        }
-        xs[idx] = v;
-    }
-    __syncthreads();
-    f32x16 acc[7];
-#pragma unroll
-    for (int a = 0; a < 7; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-    float bsum = 0.f;
-#pragma unroll
-    for (int pp = 0; pp < 8; ++pp) {                           // this wave's positions 16 wave + 2 pp + h
-        const int pl = 16 * wave + 2 * pp + h;
-        const float a = dys[pl * 32 + i];                      // A[o = i][kk = h]
-        bsum += a;
-#pragma unroll
-        for (int tap = 0; tap < 7; ++tap)                      // B[kk = h][ch = i]
-            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs[(pl * 7 + tap) * 32 + i], acc[tap], 0, 0, 0);
-    }
-    const int nout = 7 * O * I + O;
-    float* dst = partial + (size_t)(4 * blockIdx.x + wave) * nout;
-    if (i < I) {                                               // D[row = o][col = ch = i]
-#pragma unroll
-        for (int tap = 0; tap < 7; ++tap)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (o < O) dst[(tap * O + o) * I + i] = acc[tap][r];
-            }
-    }
-    bsum += __shfl_xor(bsum, 32, 64);                          // the two position halves of output channel i
-    if (h == 0 && i < O) dst[7 * O * I + i] = bsum;
-}
+// Weight gradient: hexconv_bwd_weight2_kernel below (its first matrix-core form - 64 positions per workgroup, 7 neighbour rows
+// of every position staged element by element, a slab per wave - was removed in round 3).
+constexpr int HW_POS = 64;         // (workspace sizing keeps the first version's slab count: an upper bound)
 
 
 // ---- round 2: forward and data gradient on the matrix cores.  The scalar kernels above run 7 * I FMAs per output out of LDS
@@ -369,11 +309,10 @@ int pow2_at_least(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 constexpr int HEX_CHUNK = 64;      // channels per launch, forward and data gradient (7 * 64 * 64 weights = 112 KB of LDS)
 constexpr int HEX_WCHUNK = 32;     // channels per launch, weight gradient (one 32 x 32 MFMA tile per tap)
 
-// the MFMA forward / data-gradient form takes contraction widths 8, 16, 32, 64 on 16-B aligned rows (GNX_HEX_R1 keeps the
-// scalar kernels: A/B timing and a second implementation for the tests)
+// the MFMA forward / data-gradient form takes contraction widths 8, 16, 32, 64 on 16-B aligned rows (other widths:
+// the scalar kernels)
 bool hex_mfma_ok(int CK, const float* in, long npos) {
-    static const bool r1 = getenv("GNX_HEX_R1") != nullptr;
-    return !r1 && (CK == 8 || CK == 16 || CK == 32 || CK == 64) && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
+    return (CK == 8 || CK == 16 || CK == 32 || CK == 64) && (reinterpret_cast<uintptr_t>(in) & 15) == 0 &&
            npos < (1L << 30);
 }
 
@@ -438,8 +377,7 @@ GNX_EXPORT int gnx_hexconv_bwd_weight(const float* x, const float* dy, float* dk
     if (!x || !dy || !dkernel0 || !dkernel1 || !workspace || I <= 0 || O <= 0 || H <= 0 || W <= 0 || B < 0)
         return GNX_ERR_BAD_ARG;
     const long npos = (long)B * H * W;
-    static const bool r1 = getenv("GNX_HEX_R1") != nullptr;
-    const int nblk = r1 ? gnx_cdiv(npos, HW_POS) : gnx_cdiv(npos, HW2_POS);
+    const int nblk = gnx_cdiv(npos, HW2_POS);
     HexGeom g{B, H, W, mode};
     // one (input chunk, output chunk) pair after the other on the stream, each through the same workspace
     for (int o0 = 0; o0 < O; o0 += HEX_WCHUNK)
@@ -447,10 +385,9 @@ GNX_EXPORT int gnx_hexconv_bwd_weight(const float* x, const float* dy, float* dk
             const int oc = O - o0 < HEX_WCHUNK ? O - o0 : HEX_WCHUNK, ic = I - i0 < HEX_WCHUNK ? I - i0 : HEX_WCHUNK;
             const int nout = 7 * oc * ic + oc;
             if (nblk > 0) {
-                if (r1) hexconv_bwd_weight_kernel<<<nblk, 256, 0, stream>>>(x, dy, workspace, g, ic, oc, I, O, i0, o0);
-                else hexconv_bwd_weight2_kernel<<<nblk, 256, 0, stream>>>(x, dy, workspace, g, ic, oc, I, O, i0, o0);
+                hexconv_bwd_weight2_kernel<<<nblk, 256, 0, stream>>>(x, dy, workspace, g, ic, oc, I, O, i0, o0);
             }
-            hexconv_reduce_weight_kernel<<<gnx_cdiv(nout, 64), 64, 0, stream>>>(workspace, r1 ? 4 * nblk : nblk, ic, oc, dkernel0,
+            hexconv_reduce_weight_kernel<<<gnx_cdiv(nout, 64), 64, 0, stream>>>(workspace, nblk, ic, oc, dkernel0,
                                                                                 dkernel1, dbias, accumulate, I, i0, o0);
         }
     return gnx_launch_status();

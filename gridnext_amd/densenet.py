@@ -72,9 +72,6 @@ class DenseNet(nn.Module):
         self.input_norm = None      # (mean[3], std[3]) of a torchvision Normalize to apply to UINT8 input patches after the
                                     # u8 / 255 of ToTensor (fused into the stem's operand load); float inputs are taken as
                                     # already transformed by the dataset, as in the reference
-        self.l3_blocking = False    # option: run each dense block over Infinity-Cache-sized sub-ranges of spots
-                                    # (measured r01: slower - 15x more, smaller launches; kept for experiments)
-        self.l3_budget = 160 * 1024 * 1024
 
         feats = OrderedDict()
         if small_inputs:
@@ -439,18 +436,7 @@ class DenseNet(nn.Module):
         conv0 = self.features.conv0
         c0 = conv0.out_channels
         def sub_range(bi, n):
-            # L3 blocking: run a block's whole layer chain over a sub-range of spots whose buffers fit the
-            # 256 MiB Infinity Cache (so the 2*L re-reads of the block buffer are served on-die), but never so
-            # few spots that a launch has fewer than ~512 workgroups.
-            _, _, _, c_total = self._blocks[bi]
-            s = sizes[bi]
-            per_spot = s * s * (c_total + mid) + (hs * hs * c0 if (bi == 0 and hs is not None) else 0)
-            fit = max(1, self.l3_budget // (4 * per_spot))
-            fill = -(-512 * 128 // (s * s))
-            sub = n if not self.l3_blocking else max(1, min(n, max(fit, fill)))
-            if sub >= 8:
-                sub -= sub % 8                              # whole 128-row tiles down to the 4 x 4 maps (16 rows per spot)
-            return sub
+            return n                                            # (a block's whole layer chain over all the chunk's spots)
 
         # config 5 with fp16 BLOCK BUFFERS: the concatenated features live in HBM as fp16 (as under the reference's autocast),
         # every kernel of the chain reads / writes halves.  Taken when every launch of the call has a shape those kernels

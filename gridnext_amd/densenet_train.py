@@ -289,7 +289,7 @@ class _DenseNetFn(Function):
         # (a fork / join per LAYER cost more than it gave: 2 369 against 2 505; branches of 2, 4 or 8 layers: the same +2 %).
         # Each layer then keeps its own gradient-of-bottleneck buffer until the join.
         side = None
-        if torch.cuda.is_current_stream_capturing() and not os.environ.get('GNX_NO_WGRAD_STREAM'):
+        if torch.cuda.is_current_stream_capturing():
             side = model.__dict__.get('_wgrad_stream')
             if side is None or side.device != dev:
                 side = model.__dict__['_wgrad_stream'] = torch.cuda.Stream(device=dev)

@@ -476,3 +476,25 @@ def test_prefetcher_leaves_iterable_dataset_loaders_alone():
     pf = prefetch.DevicePrefetcher(DataLoader(Exploding(torch.zeros(4, 3), torch.zeros(4)), batch_size=2), 'cpu')
     assert pf._resident() is False
     pf.close()
+
+
+def test_count_grid_dataset_matches_reference_in_splotch_mode():
+    """Classic-ST / Splotch mode (`Visium=False`, reference count_datasets.py:281-303 -> utils.py:88-166, :234-244): Cartesian
+    float coordinates rounded to grid positions, one-hot annotation matrix.  Expected tensors were produced by the reference's
+    own CountGridDataset (tools/gen_golden_datasets.py) - including its reader's row-sum filter (utils.py:238: only annotation
+    rows marking exactly one spot survive, every other spot gets the first surviving class), pinned as it is.  Without
+    annotation files the reference raises (its label grid is never created, utils.py:164); here that case returns the counts
+    with an all-background label grid - recorded as a deliberate difference."""
+    from gridnext_amd.count_datasets import CountGridDataset
+    g = load_golden('count_datasets_splotch')
+    files = os.path.join(ROOT, 'tests', 'golden', 'files')
+    cf, af = [os.path.join(files, 'st0.counts.tsv')], [os.path.join(files, 'st0.annot.tsv')]
+    x, y = CountGridDataset(cf, af, Visium=False, h_st=6, w_st=5)[0]
+    assert x.dtype == torch.float32 and y.dtype == torch.int64 and x.shape == (5, 6, 5) and y.shape == (6, 5)
+    assert np.array_equal(x.numpy(), g['st_grid_x']) and np.array_equal(y.numpy(), g['st_grid_y'])
+    assert int((y > 0).sum()) == 6 and sorted(np.unique(y.numpy())) == [0, 1, 2]
+    xs, _ = CountGridDataset(cf, af, Visium=False, h_st=6, w_st=5, select_genes=['G4', 'G0'])[0]
+    assert np.array_equal(xs.numpy(), g['st_grid_sel_x'])
+    assert str(g['st_grid_noannot_error']) == 'UnboundLocalError'          # what the reference does without annotations
+    x0, y0 = CountGridDataset(cf, None, Visium=False, h_st=6, w_st=5)[0]
+    assert np.array_equal(x0.numpy(), g['st_grid_x']) and int(y0.abs().sum()) == 0

@@ -260,3 +260,45 @@ def test_masked_ce_on_reference_saved_maps():
     close(sm[:, fg], torch.from_numpy(g['smax_saved'])[:, fg], rtol=1e-5, atol=1e-7)
     t, p, s = oce.fgd_softmax_argmax(z, lab)
     assert t.numel() == int(fg.sum()) and s.shape == (t.numel(), 7)
+
+
+@pytest.mark.parametrize("tag", ["gridwise_hexoddr_fopt", "gridwise_hexmm_tutorial"])
+def test_oracle_running_statistics_after_one_epoch(tag):
+    """The oracle's loop and models against the reference's one-epoch BatchNorm buffers (tools/gen_golden_epoch0.py): the
+    statistics the validation phase runs on, pinned directly instead of through a loss tolerance."""
+    from oracle import densenet as odn, gridnet as ogn, loops
+    from oracle.mlp import count_mlp
+    g, e0 = load_golden(tag), load_golden(tag + '_epoch0')
+    C = 5
+    torch.set_num_threads(1)
+    if tag == 'gridwise_hexoddr_fopt':
+        G, H, W = 24, 8, 6
+        m = ogn.GridNetHexOddr(count_mlp(G, C), (G,), (H, W), C, use_bn=True, atonce_patch_limit=7)
+        m.load_state_dict(sub(g, 'init'))
+        x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+        data = [(x[i], y[i]) for i in range(5)]
+        kw = dict(f_opt=torch.optim.Adam(m.patch_classifier.parameters(), lr=1e-4))
+    else:
+        G, H, W, P = 20, 6, 4, 32
+        f_img = odn.DenseNet(growth_rate=4, block_config=(2, 2), num_init_features=8, bn_size=2, num_classes=C, small_inputs=False)
+        m = ogn.GridNetHexMM(f_img, count_mlp(G, C), (3, P, P), (G,), (H, W), C)
+        _load_grid_state(m, sub(g, 'init'), densenet_prefixes=('patch_classifier', 'image_classifier'))
+        xi, xc, y = torch.from_numpy(g['x_img']), torch.from_numpy(g['x_cnt']), torch.from_numpy(g['y'])
+        data = [((xi[i], xc[i]), y[i]) for i in range(4)]
+        for p in m.patch_classifier.parameters():
+            p.requires_grad = False
+        kw = {}
+    from torch.utils.data import DataLoader
+    dl = {'train': DataLoader(data[:3], batch_size=1, shuffle=False), 'val': DataLoader(data[3:], batch_size=1, shuffle=False)}
+    opt = torch.optim.Adam(m.corrector.parameters(), lr=1e-3)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m, vh, th = loops.train_gridwise(m, dl, torch.nn.CrossEntropyLoss(), opt, num_epochs=1, **kw)
+    assert abs(th[0] - float(e0['train_loss'])) <= 1e-6 and abs(vh[0] - float(e0['val_loss'])) <= 1e-5
+    got = m.state_dict()
+    for k, ref in sub(e0, 'buf').items():
+        for pre in ('patch_classifier', 'image_classifier'):      # the oracle DenseNet keeps flat buffer names
+            if k.startswith(pre + '.features'):
+                k = pre + '.' + k[len(pre) + 1:].replace('.', '__')
+        np.testing.assert_allclose(got[k].numpy(), ref, rtol=1e-5, atol=1e-7, err_msg=k)

@@ -73,3 +73,41 @@ out['grid_y'] = np.stack([y.numpy() for y in gy])
 np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'count_datasets.npz'), **out)
 print('spots', out['spot_len'], 'classes', out['spot_classes'], 'grid', out['grid_x'].shape, out['grid_y'].shape,
       'fg', int((out['grid_y'] > 0).sum()))
+
+# ---- classic-ST / Splotch mode (Visium=False): coordinates are Cartesian floats "x_y" rounded to the nearest grid position
+# (utils.py:147-149), annotations a one-hot matrix (annotations x spot coordinate strings, utils.py:234-244).  As shipped, the
+# reference's reader keeps only annotation ROWS whose sum is exactly one (utils.py:238) and labels every spot by the argmax over
+# the rows that survive - all-zero columns therefore get class 0.  The fixture pins that behaviour as it is: rows 'A' and 'C'
+# mark one spot each and survive, row 'B' marks three spots and is dropped.
+st_out = {}
+Hs, Ws = 6, 5
+rng2 = np.random.RandomState(7)
+coords = [(0.98, 1.03), (2.04, 0.97), (3.01, 3.96), (1.02, 4.99), (3.97, 2.02), (0.03, 0.01)]
+cstrs = ['%.2f_%.2f' % c for c in coords]
+st_counts = rng2.poisson(4.0, size=(G, len(coords)))
+st_cfile = os.path.join(FILES, 'st0.counts.tsv')
+with open(st_cfile, 'w') as fh:
+    fh.write('\t'.join([''] + cstrs) + '\n')
+    for gi, gname in enumerate(genes):
+        fh.write('\t'.join([gname] + [str(v) for v in st_counts[gi]]) + '\n')
+onehot = np.zeros((3, len(coords)), dtype=int)
+onehot[0, 1] = 1                      # A: one spot
+onehot[1, [0, 2, 4]] = 1              # B: three spots (row sum 3: dropped by the reader)
+onehot[2, 3] = 1                      # C: one spot
+st_afile = os.path.join(FILES, 'st0.annot.tsv')
+with open(st_afile, 'w') as fh:
+    fh.write('\t'.join([''] + cstrs) + '\n')
+    for name, row in zip(['A', 'B', 'C'], onehot):
+        fh.write('\t'.join([name] + [str(v) for v in row]) + '\n')
+gd_st = CountGridDataset([st_cfile], [st_afile], Visium=False, h_st=Hs, w_st=Ws)
+x, y = gd_st[0]
+st_out['st_grid_x'], st_out['st_grid_y'] = x.numpy(), y.numpy()
+try:                                   # without annotation files the reference's reader never creates its label grid
+    CountGridDataset([st_cfile], None, Visium=False, h_st=Hs, w_st=Ws)[0]
+    st_out['st_grid_noannot_error'] = np.array('')
+except Exception as exc:               # (utils.py:164: UnboundLocalError) - recorded, not reproduced
+    st_out['st_grid_noannot_error'] = np.array(type(exc).__name__)
+gd_sel = CountGridDataset([st_cfile], [st_afile], Visium=False, h_st=Hs, w_st=Ws, select_genes=['G4', 'G0'])
+st_out['st_grid_sel_x'] = gd_sel[0][0].numpy()
+np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'count_datasets_splotch.npz'), **st_out)
+print('splotch grid', st_out['st_grid_x'].shape, 'labels', np.unique(st_out['st_grid_y']), 'filled', int((st_out['st_grid_x'].sum(0) > 0).sum()))
