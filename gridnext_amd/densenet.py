@@ -56,7 +56,8 @@ class DenseNet(nn.Module):
                  num_classes=10, small_inputs=True, efficient=False, classify=True):
         super().__init__()
         assert 0 < compression <= 1, 'compression of densenet should be between 0 and 1'
-        self.drop_rate = float(drop_rate or 0)      # dropout after conv2 (:42-43): identity outside training mode
+        self.drop_rate = float(drop_rate or 0)      # dropout after conv2 (:42-43): a keep-mask on the layer's 32 new columns in
+                                                    # training mode (densenet_train), identity otherwise
         self.growth_rate, self.block_config = growth_rate, tuple(block_config)
         self.bn_size, self.small_inputs, self.classify = bn_size, small_inputs, classify
         self.efficient = bool(efficient)      # gradient path: no tape in the forward, recompute in the backward (:12-18, :36-40)
@@ -113,6 +114,7 @@ class DenseNet(nn.Module):
                 param.data.fill_(0)
             elif 'classifier' in name and 'bias' in name:
                 param.data.fill_(0)
+        self._dropout_mask = None   # test hook: callable (layer index, rows, columns, device) -> bool keep-mask [rows][columns]
         self._cache = {}
         self._cache_epoch = 0       # part of every cache key; bumped by invalidate_cache()
         self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_cache())
@@ -394,12 +396,6 @@ class DenseNet(nn.Module):
         if x.dtype not in (torch.uint8, torch.float32):
             x = x.float()
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if self.training and self.drop_rate > 0:
-            # F.dropout(new_features, p, training=self.training) (:42-43) is the identity in eval mode - which is how every
-            # grid-level use runs f (training.py:126) - so a network built with drop_rate > 0 loads and runs frozen or
-            # fine-tuned under train_gridwise.  Training-mode dropout (train_spotwise on such a network) is not built.
-            raise NotImplementedError("gridnext_amd.DenseNet: train-mode dropout (drop_rate=%g with model.train()) is not "
-                                      "implemented; eval mode - where dropout is the identity - works" % self.drop_rate)
         if self.training or needs_grad:
             from .densenet_train import densenet_autograd       # training / gradient path
             return densenet_autograd(self, x)

@@ -97,6 +97,14 @@ def gammas_nonzero(model):
     return ok
 
 
+def _dropout_keep(model, index, rows, cols, dev):
+    """Keep-mask [rows][cols] (bool) of dense layer `index`'s dropout: Bernoulli(1 - p) from torch's device generator (Philox;
+    graph-capture safe), or whatever the test hook `model._dropout_mask` returns."""
+    if model._dropout_mask is not None:
+        return model._dropout_mask(index, rows, cols, dev)
+    return torch.rand((rows, cols), device=dev) >= model.drop_rate
+
+
 class _DenseNetFn(Function):
     @staticmethod
     def forward(ctx, model, x, *params):
@@ -158,6 +166,7 @@ class _DenseNetFn(Function):
         act_ok = (not training) and gammas_nonzero(model)
         w2u = model._winograd_conv2() if (act_ok and model.winograd and model.mfma == 'f32') else None
         tape.trans = []           # per block: stats of the transition BN (or None)
+        n_drop = 0
         for bi, ((c_in, layers, trans, c_total), s) in enumerate(zip(model._blocks, sizes)):
             buf = bufs[bi]
             M = N * s * s
@@ -201,7 +210,15 @@ class _DenseNetFn(Function):
                     s2 = _bn(layer.norm2, L.ptr(bott), mid, M, training, dev, st)
                     L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2r[layer.conv2.weight]), _cols(buf, cin), c_total, M,
                            g, mid, s, L.ptr(s2[0]), L.ptr(s2[1]), st)
-                recs.append((bott, s1, s2, activated))
+                keep = None
+                if training and model.drop_rate > 0:
+                    # F.dropout(new_features, p, training) (densenet.py:42-43): the layer's 32 new columns times a keep-mask
+                    # / (1 - p), in place in the block buffer - later layers read the dropped features, as after the
+                    # reference's concatenation; the backward applies the same factor to the columns' gradient
+                    keep = _dropout_keep(model, n_drop, M, g, dev)
+                    n_drop += 1
+                    buf[:, cin:cin + g].mul_(keep.to(F32).mul_(1.0 / (1.0 - model.drop_rate)))
+                recs.append((bott, s1, s2, activated, keep))
             tape.layers.append(recs)
             if trans is not None:
                 nxt = bufs[bi + 1]
@@ -355,8 +372,10 @@ class _DenseNetFn(Function):
             tC = torch.empty((M, c_total), device=dev, dtype=F32)
             for li in range(len(layers) - 1, -1, -1):
                 layer = layers[li]
-                bott, s1, s2, activated = tape.layers[bi][li]
+                bott, s1, s2, activated, keep = tape.layers[bi][li]
                 cin = c_in + li * g
+                if keep is not None:                               # dropout's adjoint on this layer's gradient columns
+                    dbuf[:, cin:cin + g].mul_(keep.to(F32).mul_(1.0 / (1.0 - model.drop_rate)))
                 dy2 = _cols(dbuf, cin)
                 if side is not None:
                     tB = torch.empty((M, mid), device=dev, dtype=F32)      # this layer's own: read by its deferred wgrad
@@ -544,6 +563,8 @@ class _RecomputeFn(Function):
     def forward(ctx, model, x, *params):
         ctx.model, ctx.x = model, x
         ctx.bn_state = None
+        # train-mode dropout: the recompute must draw the masks the first forward drew
+        ctx.rng = torch.cuda.get_rng_state(x.device) if (model.training and model.drop_rate > 0) else None
         if model.training:
             ctx.bn_state = [(m, m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone())
                             for m in model._bn_modules()]
@@ -563,8 +584,14 @@ class _RecomputeFn(Function):
                 m.running_var.copy_(rv)
                 m.num_batches_tracked.copy_(nb)
             model.invalidate_cache()
+        rng_now = None
+        if ctx.rng is not None:
+            rng_now = torch.cuda.get_rng_state(x.device)
+            torch.cuda.set_rng_state(ctx.rng, x.device)
         with torch.enable_grad():
             out = _DenseNetFn.apply(model, x.detach(), *list(model.parameters()))
+        if rng_now is not None:
+            torch.cuda.set_rng_state(rng_now, x.device)
         if after is not None:                                    # later chunks may have moved the statistics on: keep theirs
             for m, rm, rv, nb in after:
                 m.running_mean.copy_(rm)
@@ -612,6 +639,4 @@ def densenet_recompute(model, x):
     """One chunk, forward without tape, recompute in backward (GridNet.atonce_patch_limit on the gradient path)."""
     if not x.is_cuda:
         raise RuntimeError("gridnext_amd.DenseNet runs on a HIP device only (input is on %s)" % x.device)
-    if model.training and model.drop_rate > 0:
-        raise NotImplementedError("gridnext_amd.DenseNet: train-mode dropout is not implemented")
     return _RecomputeFn.apply(model, x.contiguous(), *list(model.parameters()))

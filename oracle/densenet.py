@@ -159,9 +159,12 @@ def _bn(sd, prefix, x, training, momentum=0.1, eps=1e-5):
     return y
 
 
-def forward(sd, x, cfg, training=False, return_features=False):
-    """DenseNet.forward (densenet.py:152-159). `sd` BN buffers are updated in place when training."""
+def forward(sd, x, cfg, training=False, return_features=False, dropout_masks=None):
+    """DenseNet.forward (densenet.py:152-159). `sd` BN buffers are updated in place when training.
+    dropout_masks: optional iterator of keep-masks (N, growth, S, S), one per dense layer in order, used INSTEAD of
+    F.dropout's own random mask (densenet.py:42-43: new_features * mask / (1 - p)) so a test can give both sides the same one."""
     feats = None
+    masks = iter(dropout_masks) if dropout_masks is not None else None
     for kind, p, ci, co in stages(cfg):
         if kind == 'stem':
             if cfg.small_inputs:
@@ -175,7 +178,9 @@ def forward(sd, x, cfg, training=False, return_features=False):
             h = F.conv2d(h, sd[p + '.conv1.weight'])
             h = F.relu(_bn(sd, p + '.norm2', h, training))
             h = F.conv2d(h, sd[p + '.conv2.weight'], None, padding=1)
-            if cfg.drop_rate > 0:
+            if cfg.drop_rate > 0 and training and masks is not None:
+                h = h * next(masks).to(h.dtype) / (1.0 - cfg.drop_rate)
+            elif cfg.drop_rate > 0:
                 h = F.dropout(h, p=cfg.drop_rate, training=training)
             feats = torch.cat([feats, h], dim=1)
         elif kind == 'transition':

@@ -826,12 +826,15 @@ def test_fp16_mfma_conv_path_config5_at_256px(buffers):
     assert agree >= 0.95, agree
 
 
-def test_dropout_network_runs_in_eval_mode_and_refuses_train_mode():
-    """densenet.py:42-43: dropout after conv2 is the identity unless the module is in training mode.  A network built with
-    drop_rate > 0 therefore loads reference weights and runs frozen or fine-tuned under train_gridwise (f is always in eval
-    mode there, training.py:126); train-mode dropout is the documented refusal."""
+def test_dropout_identity_in_eval_mode_and_reference_masks_in_train_mode():
+    """densenet.py:42-43: `F.dropout(new_features, p, training=self.training)` after conv2.  Eval mode (every grid-level use,
+    training.py:126): the identity - a network built with drop_rate > 0 loads reference weights and runs frozen or fine-tuned.
+    Train mode (train_spotwise on such a network): the layer's new columns times keep-mask / (1 - p), and the same factor on
+    their gradient.  With the SAME masks injected on both sides the HIP path must give the oracle's outputs, gradients and
+    running statistics; with its own generator the keep rate must be 1 - p and two seeds must differ."""
     import gridnext_amd as ga
     from gridnext_amd import functional as GF
+    from oracle import densenet as odn
     g = load_golden('densenet_tiny_large')
     m = ga.DenseNet(drop_rate=0.2, **TINY_LARGE)
     m.load_state_dict(sub(g, 'sd'))
@@ -844,9 +847,57 @@ def test_dropout_network_runs_in_eval_mode_and_refuses_train_mode():
     loss.backward()
     ref = sub(g, 'evalgrad')
     close(m.classifier.weight.grad, ref['classifier.weight'], rtol=2e-3, atol=2e-6, what='grad')
-    m.train()
-    with pytest.raises(NotImplementedError, match='dropout'):
-        m(x)
+    # ---- train mode, the same keep-masks on both sides
+    p_drop = 0.3
+    cfg = odn.DenseNetCfg(drop_rate=p_drop, **TINY_LARGE)
+    gen = torch.Generator().manual_seed(77)
+    n, P = 6, 32
+    xt = torch.rand(n, 3, P, P, generator=gen)
+    labels = torch.randint(0, 5, (n,), generator=gen)
+    sizes = [8, 8, 4, 4]                                          # maps of the 2 + 2 dense layers at 32 px
+    masks = [torch.rand(n, 4, s_, s_, generator=gen) >= p_drop for s_ in sizes]
+    sd = {k: v.clone() for k, v in sub(g, 'sd').items()}
+    ref_sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
+              for k, v in sd.items()}
+    ref_out = odn.forward(ref_sd, xt, cfg, training=True, dropout_masks=masks)
+    nn.functional.cross_entropy(ref_out, labels).backward()
+    mt = ga.DenseNet(drop_rate=p_drop, **TINY_LARGE)
+    mt.load_state_dict(sd)
+    mt.to(DEV).train()
+    mt._dropout_mask = lambda idx, rows, cols, dev: masks[idx].permute(0, 2, 3, 1).reshape(rows, cols).to(dev)
+    out = mt(xt.to(DEV))
+    nn.functional.cross_entropy(out, labels.to(DEV)).backward()
+    close(out, ref_out, rtol=2e-4, what='train-mode output with dropout')
+    for k, p_ in mt.named_parameters():
+        close(p_.grad, ref_sd[k].grad, rtol=2e-3, atol=2e-6, what='grad ' + k)
+    for k, v in mt.state_dict().items():
+        if 'running' in k:
+            close(v, ref_sd[k], rtol=1e-4, atol=1e-6, what=k)
+    # ---- its own generator: keep rate 1 - p, different seeds differ, same seed repeats
+    from gridnext_amd import densenet_train as dt
+    mt._dropout_mask = None
+    torch.manual_seed(1)
+    keep = dt._dropout_keep(mt, 0, 4096, 32, torch.device(DEV))
+    assert keep.dtype == torch.bool and abs(keep.float().mean().item() - (1 - p_drop)) < 0.01
+    torch.manual_seed(1)
+    a = mt(xt.to(DEV)).detach().clone()
+    torch.manual_seed(1)
+    b = mt(xt.to(DEV)).detach().clone()
+    torch.manual_seed(2)
+    c = mt(xt.to(DEV)).detach().clone()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    # ---- and under recompute the backward redraws the forward's masks (saved generator state): the taped gradients
+    res = []
+    for recompute in (False, True):
+        mr = ga.DenseNet(drop_rate=p_drop, **TINY_LARGE)
+        mr.load_state_dict(sd)
+        mr.to(DEV).train()
+        mr.efficient = recompute
+        torch.manual_seed(5)
+        o = mr(xt.to(DEV))
+        nn.functional.cross_entropy(o, labels.to(DEV)).backward()
+        res.append((o.detach(), [p_.grad.clone() for p_ in mr.parameters()]))
+    assert torch.equal(res[0][0], res[1][0]) and all(torch.equal(u, v) for u, v in zip(res[0][1], res[1][1]))
 
 
 def test_checkpoint_round_trip_through_the_hip_modules(tmp_path):
