@@ -79,18 +79,26 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
     const int nst = K >> 5;                                // stages per step
     const unsigned lb = lds_addr(lds);
 
-    // norm1 + relu1 in place on NP 1-KB pieces (16 px x 32 channels each, piece p at `base + p * 1024`) of a landed stage, lane =
-    // (pixel, 16-B column) as the DMA wrote them: a lane's 8 channels are the same in every piece, their scale / shift come from
-    // the slot's side area `ct`.  fp32 fma on the fp16 value, rounded once to fp16 (v_fma_mix), relu packed.
-    auto activate_pieces = [&](auto np_c, char* base, const float* ct) {
+    // norm1 + relu1 in place on 1-KB pieces (16 px x 32 channels each) of a landed stage, lane = (pixel, 16-B column) as the DMA
+    // wrote them: a lane's 8 channels are the same in every piece, their scale / shift come from the slot's side area.  fp32
+    // fma on the fp16 value, rounded once to fp16 (v_fma_mix), relu packed.  The pass is an LDS round trip whose latency
+    // (read ~150 cycles, write ~100) every wave of the workgroup used to wait out before the stage's barrier (stamped: ~450
+    // cycles per piece, whatever the piece count).  It is therefore SPLIT over two stages: a wave requests the raw pieces of
+    // stage t + 2 (and their constants) right after barrier B_t - they arrive behind its other work - and applies the
+    // arithmetic and the write first thing after B_{t+1}, long before B_{t+2} needs them.
+    struct ActRegs { f32x4 s0, s1, b0, b1; };
+    auto act_request = [&](auto np_c, unsigned base, unsigned ct, f32x4 (&v)[decltype(np_c)::value], ActRegs& c) {
+        constexpr int NP = decltype(np_c)::value;
+        static_for<0, NP>([&](auto p_c) { v[decltype(p_c)::value] = lds_read4<decltype(p_c)::value * 1024>(base); });
+        c.s0 = lds_read4<0>(ct);
+        c.s1 = lds_read4<16>(ct);
+        c.b0 = lds_read4<32>(ct);
+        c.b1 = lds_read4<48>(ct);
+    };
+    auto act_apply = [&](auto np_c, char* base, f32x4 (&v)[decltype(np_c)::value], const ActRegs& c) {
         constexpr int NP = decltype(np_c)::value;
         if (DL_ABL(1)) return;
-        u32x4 v[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) v[p] = *reinterpret_cast<u32x4*>(base + p * 1024);
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(ct), s1 = *reinterpret_cast<const f32x4*>(ct + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(ct + 8), b1 = *reinterpret_cast<const f32x4*>(ct + 12);
-        auto act2 = [](unsigned x, float sa, float ba, float sb, float bb) {          // two halves of one register
+        auto act2 = [](float x, float sa, float ba, float sb, float bb) {              // two halves of one register
             unsigned r;
             asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
                 "v_fma_mixhi_f16 %0, %1, %4, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
@@ -101,10 +109,10 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             u32x4 o;
-            o[0] = act2(v[p][0], s0[0], b0[0], s0[1], b0[1]);
-            o[1] = act2(v[p][1], s0[2], b0[2], s0[3], b0[3]);
-            o[2] = act2(v[p][2], s1[0], b1[0], s1[1], b1[1]);
-            o[3] = act2(v[p][3], s1[2], b1[2], s1[3], b1[3]);
+            o[0] = act2(v[p][0], c.s0[0], c.b0[0], c.s0[1], c.b0[1]);
+            o[1] = act2(v[p][1], c.s0[2], c.b0[2], c.s0[3], c.b0[3]);
+            o[2] = act2(v[p][2], c.s1[0], c.b1[0], c.s1[1], c.b1[1]);
+            o[3] = act2(v[p][3], c.s1[2], c.b1[2], c.s1[3], c.b1[3]);
             *reinterpret_cast<u32x4*>(base + p * 1024) = o;
         }
     };
@@ -271,9 +279,9 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             };
 #pragma unroll
             for (int q = 0; q < DL_NS - 1; ++q) issue();       // stages 0..4
-            // W2, stages 0 and 1 and their constants have landed (left in flight: the 12 pieces of stages 2..4, and one or two
-            // constants pieces among them: then a piece more is waited for - never less than needed)
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            // W2, stages 0, 1 and 2 and their constants have landed (left in flight: the 8 pieces of stages 3 and 4, and a
+            // constants piece among them or none: then a piece more is waited for - never less than needed)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             lds_barrier();                                     // B_init
             DL_T0();
             for (int u = bid; u < n_units; u += G)
@@ -283,8 +291,8 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                         DL_LAP(0);
                         issue();                               // stage t + 5 into the slot of stage t - 1
                         DL_LAP(1);
-                        // stage t + 2 and its constants have landed: the activators take it after the next barrier
-                        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                        // stage t + 3 and its constants have landed: its raw pieces are requested after the next barrier
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                         DL_LAP(2);
                     }
                     lds_barrier();                             // E
@@ -299,26 +307,35 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
         // consumer waves, idle for most of a stage, take a piece each of pixels 0..63 behind their MFMAs: the pass is an LDS
         // round trip (~200 cycles per piece, stamped), and the stage's barrier waits for its slowest wave.
         const int aw = pw - 2;
-        int aslot = 0;
-        auto activate = [&]() {
-            activate_pieces(std::integral_constant<int, 2>{}, lds + DL_AR + aslot * DL_SLOT + (4 + 2 * aw) * 1024 + lane * 16,
-                            reinterpret_cast<const float*>(lds + DL_CT + aslot * 256) + 16 * (lane >> 4));
-            aslot = aslot == DL_NS - 1 ? 0 : aslot + 1;
+        int aslot = 0;                                         // slot whose pieces are held in registers (requested last stage)
+        f32x4 av2[2];
+        ActRegs ac;
+        const unsigned abase = lb + DL_AR + (4 + 2 * aw) * 1024 + lane * 16, actb = lb + DL_CT + 64 * (lane >> 4);
+        auto request = [&](int sl) {
+            act_request(std::integral_constant<int, 2>{}, abase + sl * DL_SLOT, actb + sl * 256, av2, ac);
+        };
+        auto apply = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av2[0]), "+v"(av2[1]), "+v"(ac.s0), "+v"(ac.s1), "+v"(ac.b0), "+v"(ac.b1));
+            act_apply(std::integral_constant<int, 2>{}, lds + DL_AR + aslot * DL_SLOT + (4 + 2 * aw) * 1024 + lane * 16, av2, ac);
         };
         // (Tried and dropped, measured: an L2 touch-prefetch from these waves - one dword per pixel row of the stage 7 or 13
         // stages ahead of the loaders, never waited for - made every shape 5-15 % SLOWER; DMA pieces of 8 rows x 128 B instead
         // of 16 rows x 64 B moved the DMA stream alone from 4.0 to 4.3 TB/s and the whole kernel not at all.)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of W2
-        lds_barrier();                                         // B_init: stages 0 and 1 are in the LDS
-        activate();                                            // stage 0 (the consumers: their pieces of it)
+        lds_barrier();                                         // B_init: stages 0, 1 and 2 are in the LDS
+        request(0);
+        apply();                                               // stage 0 (the consumers: their pieces of it)
+        aslot = 1;
+        request(1);
         DL_T0();
         for (int u = bid; u < n_units; u += G)
             for (int j = 0; j < J; ++j) {
                 for (int s = 0; s < nst; ++s) {
-                    lds_barrier();                             // B_t: stage t is visible to the consumers; stage t + 1 has landed
+                    lds_barrier();                             // B_t: stage t is visible to the consumers; stage t + 2 has landed
                     DL_LAP(0);
-                    activate();
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    apply();                                   // stage t + 1, requested during the last stage
+                    aslot = aslot == DL_NS - 1 ? 0 : aslot + 1;
+                    request(aslot);                            // stage t + 2: arrives while the others work
                     DL_LAP(3);
                 }
                 lds_barrier();                                 // E: the step's bottleneck tile is complete
@@ -351,12 +368,23 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
     };
     preload_w();
     lds_barrier();                                             // B_init
-    // this wave's share of the norm1 + relu1 pass: piece `wave` (pixels 16 wave .. 16 wave + 15) of the NEXT stage's slot
-    auto activate_mine = [&](int sl) {
-        activate_pieces(std::integral_constant<int, 1>{}, lds + DL_AR + sl * DL_SLOT + wave * 1024 + lane * 16,
-                        reinterpret_cast<const float*>(lds + DL_CT + sl * 256) + 16 * (lane >> 4));
+    // this wave's share of the norm1 + relu1 pass: piece `wave` (pixels 16 wave .. 16 wave + 15) of the stage after next
+    f32x4 cv1[1];
+    ActRegs cc;
+    const unsigned cbase = lb + DL_AR + wave * 1024 + lane * 16, cctb = lb + DL_CT + 64 * (lane >> 4);
+    int hslot = 0;                                             // slot whose piece is held in registers
+    auto request_mine = [&](int sl) {
+        act_request(std::integral_constant<int, 1>{}, cbase + sl * DL_SLOT, cctb + sl * 256, cv1, cc);
     };
-    activate_mine(0);
+    auto apply_mine = [&]() {
+        act_apply(std::integral_constant<int, 1>{}, lds + DL_AR + hslot * DL_SLOT + wave * 1024 + lane * 16, cv1, cc);
+    };
+    request_mine(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cv1[0]), "+v"(cc.s0), "+v"(cc.s1), "+v"(cc.b0), "+v"(cc.b1));
+    apply_mine();
+    hslot = 1;
+    request_mine(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cv1[0]), "+v"(cc.s0), "+v"(cc.s1), "+v"(cc.b0), "+v"(cc.b1));
     f32x16 c1[4], a0, a1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
@@ -368,8 +396,11 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
         constexpr int P = decltype(ph_c)::value;
         lds_barrier();                                         // B_t
         DL_LAP(0);
+        apply_mine();                                          // stage t + 1's piece, requested during the last stage
+        hslot = hslot == DL_NS - 1 ? 0 : hslot + 1;
         load_w(fr[(P + DL_PF) & 3], s + DL_PF);
-        const unsigned ab = laneA + slot * DL_SLOT;
+        request_mine(hslot);                                   // stage t + 2's: older than the fragment reads below, so the
+        const unsigned ab = laneA + slot * DL_SLOT;            // counted waits there cover it
         f32x4 av[8];
         if (!DL_ABL(2)) {
         static_for<0, 8>([&](auto n_c) {
@@ -384,7 +415,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
         });
         }
         slot = slot == DL_NS - 1 ? 0 : slot + 1;
-        activate_mine(slot);                                   // behind the MFMAs: stage t + 1 (landed before B_t)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cv1[0]), "+v"(cc.s0), "+v"(cc.s1), "+v"(cc.b0), "+v"(cc.b1));
         DL_LAP(1);
     };
 
