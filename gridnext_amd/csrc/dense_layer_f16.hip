@@ -36,13 +36,13 @@ constexpr int DL_W2 = 0;                       // [tap 9][kstep 8][lane 64][8 ha
 constexpr int DL_W2_BYTES = 9 * 8 * 1024;
 constexpr int DL_BT = DL_W2 + DL_W2_BYTES;     // bottleneck tile: byte(px, chunk) = (px >> 4) * 4096 + chunk * 256 + (px & 15) * 16
 constexpr int DL_BT_BYTES = 128 * 256;
-constexpr int DL_NS = 6;                       // input stage ring
+constexpr int DL_NS = 4;                       // activated input stages in the LDS (stage s of a step: slot s & 3)
 constexpr int DL_SLOT = 8192;                  // 128 px x 32 channels: byte(px, chunk) = (px >> 4) * 1024 + chunk * 256 + (px & 15) * 16
 constexpr int DL_AR = DL_BT + DL_BT_BYTES;
 constexpr int DL_Z = DL_AR + DL_NS * DL_SLOT;  // 4 KB of zeros (masked fragment lanes; immediates reach 7 * 512 + 256 + 16)
 constexpr int DL_OT = DL_Z + 4096;             // norm2: scale[128], shift[128]
-constexpr int DL_CT = DL_OT + 1024;             // norm1 constants of the stage in each ring slot: [slot][16-B column 4][scale 8 | shift 8] floats
-constexpr int DL_LDS = DL_CT + DL_NS * 256;
+constexpr int DL_CT = DL_OT + 1024;            // norm1 of the whole layer: [stage][16-B column 4][scale 8 | shift 8] floats (K <= 1024)
+constexpr int DL_LDS = DL_CT + 8192;
 static_assert(DL_LDS <= 160 * 1024, "LDS");
 constexpr int DL_PF = 3;                       // W1 fragment stages in flight ahead of their use
 
@@ -79,42 +79,24 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
     const int nst = K >> 5;                                // stages per step
     const unsigned lb = lds_addr(lds);
 
-    // norm1 + relu1 in place on 1-KB pieces (16 px x 32 channels each) of a landed stage, lane = (pixel, 16-B column) as the DMA
-    // wrote them: a lane's 8 channels are the same in every piece, their scale / shift come from the slot's side area.  fp32
-    // fma on the fp16 value, rounded once to fp16 (v_fma_mix), relu packed.  The pass is an LDS round trip whose latency
-    // (read ~150 cycles, write ~100) every wave of the workgroup used to wait out before the stage's barrier (stamped: ~450
-    // cycles per piece, whatever the piece count).  It is therefore SPLIT over two stages: a wave requests the raw pieces of
-    // stage t + 2 (and their constants) right after barrier B_t - they arrive behind its other work - and applies the
-    // arithmetic and the write first thing after B_{t+1}, long before B_{t+2} needs them.
+    // norm1 + relu1 on raw input pieces (16 px x 32 channels of fp16 each; a lane holds 16 B = 8 channels of one pixel): fp32
+    // fma on the fp16 value, rounded once to fp16 (v_fma_mix), relu packed.
     struct ActRegs { f32x4 s0, s1, b0, b1; };
-    auto act_request = [&](auto np_c, unsigned base, unsigned ct, f32x4 (&v)[decltype(np_c)::value], ActRegs& c) {
-        constexpr int NP = decltype(np_c)::value;
-        static_for<0, NP>([&](auto p_c) { v[decltype(p_c)::value] = lds_read4<decltype(p_c)::value * 1024>(base); });
-        c.s0 = lds_read4<0>(ct);
-        c.s1 = lds_read4<16>(ct);
-        c.b0 = lds_read4<32>(ct);
-        c.b1 = lds_read4<48>(ct);
+    auto act2 = [](unsigned x, float sa, float ba, float sb, float bb) {                  // two halves of one register
+        unsigned r;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %1, %4, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_pk_max_f16 %0, %0, 0"
+            : "=&v"(r) : "v"(x), "v"(sa), "v"(ba), "v"(sb), "v"(bb));
+        return r;
     };
-    auto act_apply = [&](auto np_c, char* base, f32x4 (&v)[decltype(np_c)::value], const ActRegs& c) {
-        constexpr int NP = decltype(np_c)::value;
-        if (DL_ABL(1)) return;
-        auto act2 = [](float x, float sa, float ba, float sb, float bb) {              // two halves of one register
-            unsigned r;
-            asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
-                "v_fma_mixhi_f16 %0, %1, %4, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-                "v_pk_max_f16 %0, %0, 0"
-                : "=&v"(r) : "v"(x), "v"(sa), "v"(ba), "v"(sb), "v"(bb));
-            return r;
-        };
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            u32x4 o;
-            o[0] = act2(v[p][0], c.s0[0], c.b0[0], c.s0[1], c.b0[1]);
-            o[1] = act2(v[p][1], c.s0[2], c.b0[2], c.s0[3], c.b0[3]);
-            o[2] = act2(v[p][2], c.s1[0], c.b1[0], c.s1[1], c.b1[1]);
-            o[3] = act2(v[p][3], c.s1[2], c.b1[2], c.s1[3], c.b1[3]);
-            *reinterpret_cast<u32x4*>(base + p * 1024) = o;
-        }
+    auto activated = [&](const u32x4& v, const ActRegs& c) {
+        u32x4 o;
+        o[0] = act2(v[0], c.s0[0], c.b0[0], c.s0[1], c.b0[1]);
+        o[1] = act2(v[1], c.s0[2], c.b0[2], c.s0[3], c.b0[3]);
+        o[2] = act2(v[2], c.s1[0], c.b1[0], c.s1[1], c.b1[1]);
+        o[3] = act2(v[3], c.s1[2], c.b1[2], c.s1[3], c.b1[3]);
+        return o;
     };
 
     // (Tried and dropped, measured: conv2 cut into jobs of 24 MFMAs run one per stage behind the NEXT step's conv1 stages, so
@@ -217,12 +199,26 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             if (s1) store(a1, O1);
     };
 
-    if (wave >= 4) {
-        // ================================================================= producers
-        const int pw = wave - 4;
-        f32x16 pa0, pa1;                                       // conv2 accumulators (S = 64: these waves take part)
+    f32x16 fa0, fa1;                                           // conv2 accumulators of the feeder waves (S = 64 only)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { pa0[r] = 0.f; pa1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { fa0[r] = 0.f; fa1[r] = 0.f; }
+    // the step after (u, j) in this workgroup's sequence (u >= n_units: none)
+    auto next_step = [&](int& u, int& j) {
+        if (++j == J) { j = 0; u += G; }
+    };
+
+    if (wave >= 4) {
+        // ================================================================= feeders (waves 4-7)
+        // The input strip of a step goes global -> REGISTERS -> (norm1 + relu1) -> LDS.  The first version of this kernel
+        // moved it by LDS-DMA into a ring of raw stages that was then activated in place: its stage loop ran at 8 KB per
+        // 0.52 us and CU whatever was done to the waves around it - ring depth 5 or 6, two or four issuing waves, the
+        // activation split over two stages or shared with the consumers - because the LDS-DMA path itself delivers ~25 GB/s
+        // per CU (0.35 us per stage, stamped as the issue time of the loader waves) and every wave of the workgroup then
+        // waited for the loaders at the stage's barrier.  Plain buffer loads do not block their wave, keep three stages in
+        // flight in 24 registers, and let the activation happen on the way - no LDS round trip, half the LDS traffic.
+        // Feeder f takes pixels 32 f .. 32 f + 31 of every stage (two 1-KB pieces: lane = pixel (lane & 15) of the piece,
+        // 16-B column lane >> 4), consumers only multiply.
+        const int fw = wave - 4;
         {
             const int pt = t - 256;                            // 0..255
             reinterpret_cast<f32x4*>(lds + DL_Z)[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -230,132 +226,108 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                 reinterpret_cast<float*>(lds + DL_OT)[pt] = sc2[pt];
                 reinterpret_cast<float*>(lds + DL_OT + 512)[pt] = sh2[pt];
             }
+            for (int k = pt; k < K; k += 256) {                // norm1's table: [stage][column][scale 8 | shift 8]
+                float* d = reinterpret_cast<float*>(lds + DL_CT) + (k >> 3) * 16 + (k & 7);
+                d[0] = sc1[k];
+                d[8] = sh1[k];
+            }
         }
         {
             const __amdgpu_buffer_rsrc_t rW2 =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(w2p), 0, DL_W2_BYTES, 0x00020000);
 #pragma unroll
             for (int p = 0; p < 18; ++p) {
-                const int piece = pw + 4 * p;
+                const int piece = fw + 4 * p;
                 dma16_buf(rW2, lane * 16, piece * 1024, lb + DL_W2 + piece * 1024);
             }
         }
-        // Waves 4, 5 are LOADERS, waves 6, 7 ACTIVATORS: the DMA issue of a stage (~100 cycles per 1-KB piece) and its
-        // norm1 + relu1 pass (an LDS round trip) then run side by side instead of one after the other in each wave - stamped,
-        // the serial form spent 250 + 540 cycles per stage and was what every wave of the workgroup waited for.
-        if (pw < 2) {
-            // ---- loaders.  A stage = four 1-KB pieces per loader (16 px x 32 channels each; loader l: pixels 64 l .. 64 l + 63)
-            // + the stage's norm1 constants (scale / shift of its 32 channels, 256 B into the slot's side area: 16 lanes, the two
-            // loaders take turns): the constants travel with the data.  Past this workgroup's last stage the cursor re-reads the
-            // workgroup's first unit into slots nobody will read: cheaper than a branch around every issue (and vmcnt stays
-            // countable).
-            int cu = bid, cj = 0, cs = 0, cslot = 0, cturn = 0;
-            const unsigned voffA = (unsigned)(((lane & 15) * ld + 8 * (lane >> 4)) * 2);
-            // constants piece, lane l < 16: 16-B column q = l >> 2 of the stage, {scale lo, scale hi, shift lo, shift hi}[l & 3]
-            const float* const csrc = ((lane & 2) ? sh1 : sc1) + 8 * ((lane >> 2) & 3) + 4 * (lane & 1);
-            const _Float16* pbase = X + ((long)bid * J * 128 + 64 * pw) * ld;             // this wave's rows of the cursor's step
-            const long step_stride = 128 * ld;
-            auto issue = [&]() {
-                if (DL_ABL(4) && cslot != 99) { cslot = cslot == DL_NS - 1 ? 0 : cslot + 1; return; }
-                if (cturn == pw && lane < 16) dma16_global(csrc + 32 * cs, lb + DL_CT + cslot * 256);
-                cturn ^= 1;
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                        const_cast<_Float16*>(pbase) + 16 * g4 * ld, 0, (unsigned)(16 * ld * 2), 0x00020000);
-                    dma16_buf(rs, voffA, cs * 64, lb + DL_AR + cslot * DL_SLOT + (4 * pw + g4) * 1024);
-                }
-                cslot = cslot == DL_NS - 1 ? 0 : cslot + 1;
-                if (++cs == nst) {
-                    cs = 0;
-                    pbase += step_stride;
-                    if (++cj == J) {
-                        cj = 0;
-                        cu += G;
-                        if (cu >= n_units) cu = bid;
-                        pbase = X + ((long)cu * J * 128 + 64 * pw) * ld;
-                    }
-                }
-            };
-#pragma unroll
-            for (int q = 0; q < DL_NS - 1; ++q) issue();       // stages 0..4
-            // W2, stages 0, 1 and 2 and their constants have landed (left in flight: the 8 pieces of stages 3 and 4, and a
-            // constants piece among them or none: then a piece more is waited for - never less than needed)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            lds_barrier();                                     // B_init
-            DL_T0();
-            for (int u = bid; u < n_units; u += G)
-                for (int j = 0; j < J; ++j) {
-                    for (int s = 0; s < nst; ++s) {
-                        lds_barrier();                         // B_t: stage t - 1 is consumed
-                        DL_LAP(0);
-                        issue();                               // stage t + 5 into the slot of stage t - 1
-                        DL_LAP(1);
-                        // stage t + 3 and its constants have landed: its raw pieces are requested after the next barrier
-                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                        DL_LAP(2);
-                    }
-                    lds_barrier();                             // E
-                    if constexpr (S == 64) conv2_step(u, j, pa0, pa1);
-                    DL_LAP(4);
-                }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (wave == 4) DL_OUT(8);
-            return;
-        }
-        // ---- activators: norm1 + relu1 on pixels 64..127 of a landed stage (activator a: the two pieces 64 + 32 a ..); the
-        // consumer waves, idle for most of a stage, take a piece each of pixels 0..63 behind their MFMAs: the pass is an LDS
-        // round trip (~200 cycles per piece, stamped), and the stage's barrier waits for its slowest wave.
-        const int aw = pw - 2;
-        int aslot = 0;                                         // slot whose pieces are held in registers (requested last stage)
-        f32x4 av2[2];
-        ActRegs ac;
-        const unsigned abase = lb + DL_AR + (4 + 2 * aw) * 1024 + lane * 16, actb = lb + DL_CT + 64 * (lane >> 4);
-        auto request = [&](int sl) {
-            act_request(std::integral_constant<int, 2>{}, abase + sl * DL_SLOT, actb + sl * 256, av2, ac);
+        const int voffA = (int)(((lane & 15) * ld + 8 * (lane >> 4)) * 2);
+        const int voffB = voffA + (int)(16 * ld * 2);          // the second piece: 16 pixel rows further
+        const unsigned nrec = (unsigned)(32 * ld * 2);
+        u32x4 rr[4][2];                                        // raw ring [stage & 3][piece]
+        // (a stage index past the step's last one makes the offset exceed the resource's extent: zeros, no memory traffic -
+        // no branch, so the compiler counts the loads in flight exactly)
+        auto load_raw = [&](u32x4(&dst)[2], const __amdgpu_buffer_rsrc_t& rs, int ss) {
+            const int inb = ss < nst ? ss * 64 : 0x7f000000;
+            dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voffA + inb, 0, 0);
+            dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voffB + inb, 0, 0);
         };
-        auto apply = [&]() {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av2[0]), "+v"(av2[1]), "+v"(ac.s0), "+v"(ac.s1), "+v"(ac.b0), "+v"(ac.b1));
-            act_apply(std::integral_constant<int, 2>{}, lds + DL_AR + aslot * DL_SLOT + (4 + 2 * aw) * 1024 + lane * 16, av2, ac);
+        auto strip = [&](int u, int j) {                       // this feeder's 32 pixel rows of step (u, j)
+            return __builtin_amdgcn_make_buffer_rsrc(X + (((long)u * J + j) * 128 + 32 * fw) * ld, 0, nrec, 0x00020000);
         };
-        // (Tried and dropped, measured: an L2 touch-prefetch from these waves - one dword per pixel row of the stage 7 or 13
-        // stages ahead of the loaders, never waited for - made every shape 5-15 % SLOWER; DMA pieces of 8 rows x 128 B instead
-        // of 16 rows x 64 B moved the DMA stream alone from 4.0 to 4.3 TB/s and the whole kernel not at all.)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of W2
-        lds_barrier();                                         // B_init: stages 0, 1 and 2 are in the LDS
-        request(0);
-        apply();                                               // stage 0 (the consumers: their pieces of it)
-        aslot = 1;
-        request(1);
-        DL_T0();
-        for (int u = bid; u < n_units; u += G)
-            for (int j = 0; j < J; ++j) {
-                for (int s = 0; s < nst; ++s) {
-                    lds_barrier();                             // B_t: stage t is visible to the consumers; stage t + 2 has landed
-                    DL_LAP(0);
-                    apply();                                   // stage t + 1, requested during the last stage
-                    aslot = aslot == DL_NS - 1 ? 0 : aslot + 1;
-                    request(aslot);                            // stage t + 2: arrives while the others work
-                    DL_LAP(3);
-                }
-                lds_barrier();                                 // E: the step's bottleneck tile is complete
-                if constexpr (S == 64) conv2_step(u, j, pa0, pa1);
-                DL_LAP(4);
+        ActRegs ac;                                            // constants of the stage applied next (requested a stage early)
+        const unsigned ctb = lb + DL_CT + 64 * (lane >> 4);
+        auto request_consts = [&](int ss) {
+            const unsigned a = ctb + (ss < nst ? ss : 0) * 256;
+            ac.s0 = lds_read4<0>(a);
+            ac.s1 = lds_read4<16>(a);
+            ac.b0 = lds_read4<32>(a);
+            ac.b1 = lds_read4<48>(a);
+        };
+        auto apply = [&](u32x4(&raw)[2], int sl) {             // -> LDS slot sl, pieces 2 fw and 2 fw + 1
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ac.s0), "+v"(ac.s1), "+v"(ac.b0), "+v"(ac.b1));
+            char* d = lds + DL_AR + sl * DL_SLOT + 2 * fw * 1024 + lane * 16;
+            if (!DL_ABL(1)) {
+                *reinterpret_cast<u32x4*>(d) = activated(raw[0], ac);
+                *reinterpret_cast<u32x4*>(d + 1024) = activated(raw[1], ac);
             }
-        if (wave == 6) DL_OUT(16);
+        };
+        auto fstage = [&](auto ph_c, int s, const __amdgpu_buffer_rsrc_t& rs) {
+            constexpr int P = decltype(ph_c)::value;
+            lds_barrier();                                     // B_s: stage s is visible, slot (s + 1) & 3 is free
+            if (s + 1 < nst) apply(rr[(P + 1) & 3], (P + 1) & 3);
+            request_consts(s + 2);
+            load_raw(rr[(P + 3) & 3], rs, s + 3);
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of W2
+        int u = bid, j = 0;
+        __amdgpu_buffer_rsrc_t rs = strip(u, j);
+        load_raw(rr[0], rs, 0);
+        load_raw(rr[1], rs, 1);
+        load_raw(rr[2], rs, 2);
+        lds_barrier();                                         // B_init: tables and W2 are in the LDS
+        request_consts(0);
+        apply(rr[0], 0);
+        request_consts(1);
+        while (u < n_units) {
+            for (int s = 0;; s += 4) {
+                fstage(std::integral_constant<int, 0>{}, s, rs);
+                if (s + 1 >= nst) break;
+                fstage(std::integral_constant<int, 1>{}, s + 1, rs);
+                if (s + 2 >= nst) break;
+                fstage(std::integral_constant<int, 2>{}, s + 2, rs);
+                if (s + 3 >= nst) break;
+                fstage(std::integral_constant<int, 3>{}, s + 3, rs);
+                if (s + 4 >= nst) break;
+            }
+            // the next step's first three stages: requested before the epilogue / conv2 phase, which hides their latency
+            const int cu = u, cj = j;
+            next_step(u, j);
+            if (u < n_units) {
+                rs = strip(u, j);
+                load_raw(rr[0], rs, 0);
+                load_raw(rr[1], rs, 1);
+                load_raw(rr[2], rs, 2);
+            }
+            lds_barrier();                                     // E: the step's bottleneck tile is complete
+            if constexpr (S == 64) conv2_step(cu, cj, fa0, fa1);
+            if (u < n_units) {                                 // the consumers are past every stage of step (cu, cj): slot 0 is free
+                request_consts(0);
+                apply(rr[0], 0);
+                request_consts(1);
+            }
+        }
         return;
     }
 
-    // ===================================================================== consumers
+    // ===================================================================== consumers (waves 0-3)
     const int nb = wave;                                       // conv1: output channels 32 nb .. 32 nb + 31
     const int KS = K >> 4;
     const __amdgpu_buffer_rsrc_t rW1 =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(w1p), 0, (unsigned)(128 * K * 2), 0x00020000);
-    // W1 fragment ring [stage % 4][k-step]: every step starts at ring phase 0 with its stages 0..2 already requested (before
+    // W1 fragment ring [stage & 3][k-step]: every step starts at ring phase 0 with its stages 0..2 already requested (before
     // the previous step's conv2 - their latency hides behind it), stage s + 3 is requested when stage s starts.
     u32x4 fr[4][2];
-    // (a stage index past the step's last one makes the per-lane offset exceed the resource's extent: the load returns zeros
-    // without touching memory - no branch, so the compiler can count the loads in flight exactly)
     auto load_w = [&](u32x4(&dst)[2], int ws) {
         const int vo = ws < nst ? (nb * KS + 2 * ws) * 1024 + lane * 16 : 0x7ffff000;
         dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rW1, vo, 0, 0);
@@ -368,44 +340,20 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
     };
     preload_w();
     lds_barrier();                                             // B_init
-    // this wave's share of the norm1 + relu1 pass: piece `wave` (pixels 16 wave .. 16 wave + 15) of the stage after next
-    f32x4 cv1[1];
-    ActRegs cc;
-    const unsigned cbase = lb + DL_AR + wave * 1024 + lane * 16, cctb = lb + DL_CT + 64 * (lane >> 4);
-    int hslot = 0;                                             // slot whose piece is held in registers
-    auto request_mine = [&](int sl) {
-        act_request(std::integral_constant<int, 1>{}, cbase + sl * DL_SLOT, cctb + sl * 256, cv1, cc);
-    };
-    auto apply_mine = [&]() {
-        act_apply(std::integral_constant<int, 1>{}, lds + DL_AR + hslot * DL_SLOT + wave * 1024 + lane * 16, cv1, cc);
-    };
-    request_mine(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cv1[0]), "+v"(cc.s0), "+v"(cc.s1), "+v"(cc.b0), "+v"(cc.b1));
-    apply_mine();
-    hslot = 1;
-    request_mine(1);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cv1[0]), "+v"(cc.s0), "+v"(cc.s1), "+v"(cc.b0), "+v"(cc.b1));
     f32x16 c1[4], a0, a1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
     const unsigned laneA = lb + DL_AR + (i >> 4) * 1024 + h * 256 + (i & 15) * 16;
-    int slot = 0;
-    DL_T0();
     // one stage: the 8 operand fragments (4 pixel blocks x 2 k-steps) are requested together, each MFMA waits for its own
     auto stage = [&](auto ph_c, int s) {
         constexpr int P = decltype(ph_c)::value;
-        lds_barrier();                                         // B_t
-        DL_LAP(0);
-        apply_mine();                                          // stage t + 1's piece, requested during the last stage
-        hslot = hslot == DL_NS - 1 ? 0 : hslot + 1;
+        lds_barrier();                                         // B_s
         load_w(fr[(P + DL_PF) & 3], s + DL_PF);
-        request_mine(hslot);                                   // stage t + 2's: older than the fragment reads below, so the
-        const unsigned ab = laneA + slot * DL_SLOT;            // counted waits there cover it
         f32x4 av[8];
         if (!DL_ABL(2)) {
         static_for<0, 8>([&](auto n_c) {
             constexpr int n = decltype(n_c)::value;            // n = 4 ks + rb
-            av[n] = lds_read4<(n & 3) * 2048 + (n >> 2) * 512>(ab);
+            av[n] = lds_read4<P * DL_SLOT + (n & 3) * 2048 + (n >> 2) * 512>(laneA);
         });
         static_for<0, 8>([&](auto n_c) {
             constexpr int n = decltype(n_c)::value;
@@ -414,9 +362,6 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                                                                __builtin_bit_cast(half8, av[n]), c1[n & 3], 0, 0, 0);
         });
         }
-        slot = slot == DL_NS - 1 ? 0 : slot + 1;
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cv1[0]), "+v"(cc.s0), "+v"(cc.s1), "+v"(cc.b0), "+v"(cc.b1));
-        DL_LAP(1);
     };
 
     for (int u = bid; u < n_units; u += G)
@@ -459,13 +404,9 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                         make_uint2(o[0], o[1]);
                 }
             }
-            DL_LAP(2);
             lds_barrier();                                     // E
-            DL_LAP(3);
             conv2_step(u, j, a0, a1);
-            DL_LAP(4);
         }
-    if (wave == 0) DL_OUT(0);
 }
 
 // W1 [128][K] fp32 -> fragment order halves: ((nb * K/16 + ks) * 64 + lane) * 8 + q = W[32 nb + (lane & 31)][16 ks + 8 (lane >> 5) + q]
