@@ -64,7 +64,7 @@ constexpr int DL_PF = 3;                       // W1 fragment stages in flight a
 #endif
 
 template <int S>
-__global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restrict__ X, long ld, int n_units, int K,
+__global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restrict__ X, long bstride, int n_units, int K,
                                                               const _Float16* __restrict__ w1p,
                                                               const _Float16* __restrict__ w2p,
                                                               const float* __restrict__ sc1, const float* __restrict__ sh1,
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
     const int G = gridDim.x, bid = blockIdx.x;
     const int nst = K >> 5;                                // stages per step
     const unsigned lb = lds_addr(lds);
+    DL_T0();
 
     // norm1 + relu1 on raw input pieces (16 px x 32 channels of fp16 each; a lane holds 16 B = 8 channels of one pixel): fp32
     // fma on the fp16 value, rounded once to fp16 (v_fma_mix), relu packed.
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                 });
             };
             auto store = [&](const f32x16& acc, int O_rel) {
-                _Float16* p = X + (R0 + O_rel + i) * ld + K + 4 * h;
+                _Float16* p = X + (K >> 5) * bstride + (R0 + O_rel + i) * 32 + 4 * h;   // the layer's new block [K / 32]
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     half4 o;
@@ -193,10 +194,14 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             if (DL_ABL(8)) { hi0 = lo0 - 1; hi1 = lo1 - 1; }
 #pragma unroll 1
             for (int dy = lo0; dy <= hi0; ++dy) tap3(a0, O0, dy);
-            if (s0) store(a0, O0);
+            DL_LAP(4);
+            if (s0 && !DL_ABL(64)) store(a0, O0);
+            DL_LAP(5);
 #pragma unroll 1
             for (int dy = lo1; dy <= hi1; ++dy) tap3(a1, O1, dy);
-            if (s1) store(a1, O1);
+            DL_LAP(4);
+            if (s1 && !DL_ABL(64)) store(a1, O1);
+            DL_LAP(5);
     };
 
     f32x16 fa0, fa1;                                           // conv2 accumulators of the feeder waves (S = 64 only)
@@ -241,19 +246,23 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                 dma16_buf(rW2, lane * 16, piece * 1024, lb + DL_W2 + piece * 1024);
             }
         }
-        const int voffA = (int)(((lane & 15) * ld + 8 * (lane >> 4)) * 2);
-        const int voffB = voffA + (int)(16 * ld * 2);          // the second piece: 16 pixel rows further
-        const unsigned nrec = (unsigned)(32 * ld * 2);
+        // X is channel-blocked, [channel / 32][pixel row][32]: the 32 channels a stage needs of this feeder's 32 consecutive
+        // pixel rows are ONE contiguous 2 KB of memory (in a row-major [row][channels] buffer they were 32 pieces of 64 B,
+        // 0.5-2 KB apart - whatever carried them, LDS-DMA or register loads, that stream stayed at ~4 TB/s)
+        const int voffA = ((lane & 15) * 32 + 8 * (lane >> 4)) * 2;
+        const int voffB = voffA + 1024;                        // the second piece: 16 pixel rows further
         u32x4 rr[4][2];                                        // raw ring [stage & 3][piece]
         // (a stage index past the step's last one makes the offset exceed the resource's extent: zeros, no memory traffic -
         // no branch, so the compiler counts the loads in flight exactly)
-        auto load_raw = [&](u32x4(&dst)[2], const __amdgpu_buffer_rsrc_t& rs, int ss) {
-            const int inb = ss < nst ? ss * 64 : 0x7f000000;
+        auto load_raw = [&](u32x4(&dst)[2], const _Float16* strip0, int ss) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<_Float16*>(strip0) + (ss < nst ? ss : 0) * bstride, 0, 2048, 0x00020000);
+            const int inb = (ss < nst && !DL_ABL(4)) ? 0 : 0x7f000000;
             dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voffA + inb, 0, 0);
             dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voffB + inb, 0, 0);
         };
-        auto strip = [&](int u, int j) {                       // this feeder's 32 pixel rows of step (u, j)
-            return __builtin_amdgcn_make_buffer_rsrc(X + (((long)u * J + j) * 128 + 32 * fw) * ld, 0, nrec, 0x00020000);
+        auto strip = [&](int u, int j) {                       // this feeder's 32 pixel rows of step (u, j), channel block 0
+            return static_cast<const _Float16*>(X) + (((long)u * J + j) * 128 + 32 * fw) * 32;
         };
         ActRegs ac;                                            // constants of the stage applied next (requested a stage early)
         const unsigned ctb = lb + DL_CT + 64 * (lane >> 4);
@@ -272,16 +281,19 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                 *reinterpret_cast<u32x4*>(d + 1024) = activated(raw[1], ac);
             }
         };
-        auto fstage = [&](auto ph_c, int s, const __amdgpu_buffer_rsrc_t& rs) {
+        auto fstage = [&](auto ph_c, int s, const _Float16* rs) {
             constexpr int P = decltype(ph_c)::value;
             lds_barrier();                                     // B_s: stage s is visible, slot (s + 1) & 3 is free
+            DL_LAP(0);
             if (s + 1 < nst) apply(rr[(P + 1) & 3], (P + 1) & 3);
+            DL_LAP(1);
             request_consts(s + 2);
             load_raw(rr[(P + 3) & 3], rs, s + 3);
+            DL_LAP(2);
         };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of W2
         int u = bid, j = 0;
-        __amdgpu_buffer_rsrc_t rs = strip(u, j);
+        const _Float16* rs = strip(u, j);
         load_raw(rr[0], rs, 0);
         load_raw(rr[1], rs, 1);
         load_raw(rr[2], rs, 2);
@@ -309,14 +321,18 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                 load_raw(rr[1], rs, 1);
                 load_raw(rr[2], rs, 2);
             }
+            DL_LAP(2);
             lds_barrier();                                     // E: the step's bottleneck tile is complete
+            DL_LAP(3);
             if constexpr (S == 64) conv2_step(cu, cj, fa0, fa1);
             if (u < n_units) {                                 // the consumers are past every stage of step (cu, cj): slot 0 is free
                 request_consts(0);
                 apply(rr[0], 0);
                 request_consts(1);
             }
+            DL_LAP(6);
         }
+        if (wave == 4) DL_OUT(8);
         return;
     }
 
@@ -329,7 +345,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
     // the previous step's conv2 - their latency hides behind it), stage s + 3 is requested when stage s starts.
     u32x4 fr[4][2];
     auto load_w = [&](u32x4(&dst)[2], int ws) {
-        const int vo = ws < nst ? (nb * KS + 2 * ws) * 1024 + lane * 16 : 0x7ffff000;
+        const int vo = (ws < nst && !DL_ABL(32)) ? (nb * KS + 2 * ws) * 1024 + lane * 16 : 0x7ffff000;
         dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rW1, vo, 0, 0);
         dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rW1, vo + 1024, 0, 0);
     };
@@ -348,6 +364,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
     auto stage = [&](auto ph_c, int s) {
         constexpr int P = decltype(ph_c)::value;
         lds_barrier();                                         // B_s
+        DL_LAP(0);
         load_w(fr[(P + DL_PF) & 3], s + DL_PF);
         f32x4 av[8];
         if (!DL_ABL(2)) {
@@ -362,6 +379,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                                                                __builtin_bit_cast(half8, av[n]), c1[n & 3], 0, 0, 0);
         });
         }
+        DL_LAP(1);
     };
 
     for (int u = bid; u < n_units; u += G)
@@ -404,9 +422,12 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                         make_uint2(o[0], o[1]);
                 }
             }
+            DL_LAP(2);
             lds_barrier();                                     // E
+            DL_LAP(3);
             conv2_step(u, j, a0, a1);
         }
+    if (wave == 0) DL_OUT(0);
 }
 
 // W1 [128][K] fp32 -> fragment order halves: ((nb * K/16 + ks) * 64 + lane) * 8 + q = W[32 nb + (lane & 31)][16 ks + 8 (lane >> 5) + q]
@@ -439,7 +460,8 @@ GNX_EXPORT int gnx_dense_layer_f16_pack(const float* w1, const float* w2, void* 
 }
 
 #ifdef GNX_DL_STAMP
-// ablation bits (diagnostic): 1 no norm1 pass, 2 no conv1 reads / MFMAs, 4 no DMA issue, 8 no conv2 taps, 16 no epilogue
+// ablation bits (diagnostic): 1 no norm1 arithmetic / LDS writes, 2 no conv1 reads / MFMAs, 4 no input loads, 8 no conv2 taps,
+// 16 no epilogue, 32 no W1 fragment loads, 64 no output stores, 128 / 256 no conv2 W / A fragment reads
 static unsigned long long* g_dl_stamps = nullptr;
 static int g_dl_abl = 0;
 GNX_EXPORT void gnx_dense_layer_f16_set_stamps(void* buf, int abl) {
@@ -448,16 +470,19 @@ GNX_EXPORT void gnx_dense_layer_f16_set_stamps(void* buf, int abl) {
 }
 #endif
 
-// The dense layer on an fp16 block buffer X16 [n_img * S * S][ld16]: reads columns [0, K), writes columns [K, K + 32).
-// bn_size * growth = 128 and growth = 32 are fixed; S in {4, 8, 16, 32, 64}; 32 | K; 8 | ld16, K + 32 <= ld16; X16 16-B
-// aligned; n_img * S * S a multiple of 128.  scale / shift: the folded running-statistics BatchNorms (norm1: K, norm2: 128).
-GNX_EXPORT int gnx_dense_layer_f16(void* X16, long ld16, long n_img, int S, int K, const void* w1p, const void* w2p,
+// The dense layer on a CHANNEL-BLOCKED fp16 block buffer X16 [channels / 32][rows_total][32] (element (row, c) at
+// (c >> 5) * rows_total * 32 + row * 32 + (c & 31); rows = n_img * S * S pixels, the first of rows_total): reads channel
+// blocks [0, K / 32), writes block K / 32.  bn_size * growth = 128 and growth = 32 are fixed; S in {4, 8, 16, 32, 64};
+// 32 | K <= 1024; X16 16-B aligned; n_img * S * S a multiple of 128.  scale / shift: the folded running-statistics
+// BatchNorms (norm1: K, norm2: 128).
+GNX_EXPORT int gnx_dense_layer_f16(void* X16, long rows_total, long n_img, int S, int K, const void* w1p, const void* w2p,
                                    const float* scale1, const float* shift1, const float* scale2, const float* shift2,
                                    hipStream_t stream) {
-    if (!X16 || !w1p || !w2p || !scale1 || !shift1 || !scale2 || !shift2 || n_img < 0 || K <= 0 || ld16 < K + 32)
+    if (!X16 || !w1p || !w2p || !scale1 || !shift1 || !scale2 || !shift2 || n_img < 0 || K <= 0 || S <= 0 ||
+        rows_total < n_img * (long)S * S)
         return GNX_ERR_BAD_ARG;
-    if (K % 32 != 0 || ld16 % 8 != 0 || !al16(X16) || !al16(w1p) || !al16(w2p) || (n_img * S * S) % 128 != 0 ||
-        ld16 > 32768 || n_img * (long)S * S / 128 >= (1L << 31))
+    if (K % 32 != 0 || K > 1024 || !al16(X16) || !al16(w1p) || !al16(w2p) || (n_img * S * S) % 128 != 0 ||
+        n_img * (long)S * S / 128 >= (1L << 31))
         return GNX_ERR_UNSUPPORTED;
     if (n_img == 0) return GNX_OK;
     const long units = S >= 16 ? n_img : n_img * S * S / 128;
@@ -478,7 +503,8 @@ GNX_EXPORT int gnx_dense_layer_f16(void* X16, long ld16, long n_img, int S, int 
 #define GNX_DL_STAMP_ARG
 #endif
 #define GNX_DL(SS)                                                                                                   \
-    dense_layer_f16_kernel<SS><<<grid, 512, 0, stream>>>(X, ld16, (int)units, K, w1, w2, scale1, shift1, scale2, shift2 \
+    dense_layer_f16_kernel<SS><<<grid, 512, 0, stream>>>(X, rows_total * 32, (int)units, K, w1, w2, scale1, shift1, scale2,  \
+                                                          shift2                                                      \
                                                           GNX_DL_STAMP_ARG);                                          \
     return gnx_launch_status()
     switch (S) {

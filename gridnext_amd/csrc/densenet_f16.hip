@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void conv1x1_h16_kernel(const _Float16* __rest
                                                           long ldc, long M, int N, int K,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const float* __restrict__ oscale,
-                                                          const float* __restrict__ oshift) {
+                                                          const float* __restrict__ oshift, long obs = 32) {
     __shared__ __attribute__((aligned(16))) _Float16 smem[2 * 128 * LDH2];
     _Float16* const As = smem;
     _Float16* const Bs = smem + 128 * LDH2;
@@ -330,8 +330,9 @@ __global__ __launch_bounds__(256) void conv1x1_h16_kernel(const _Float16* __rest
             const int piece = lane + 64 * p, rr = piece >> 3, c8 = piece & 7;
             const long row = m0 + 64 * wm + 32 * mt + rr;
             const int col = n0 + 64 * wn + 8 * c8;
-            if (row < M && col < N)
-                *reinterpret_cast<half8*>(out + row * ldc + col) = *reinterpret_cast<const half8*>(&Os[rr * LDH2 + 8 * c8]);
+            if (row < M && col < N)       // (obs = 32: row-major; ldc = 32, obs = rows * 32: channel-blocked [N / 32][rows][32])
+                *reinterpret_cast<half8*>(out + row * ldc + (col >> 5) * obs + (col & 31)) =
+                    *reinterpret_cast<const half8*>(&Os[rr * LDH2 + 8 * c8]);
         }
     }
 }
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h16_m256_kernel(const _Float16
                                                                   const float* __restrict__ scale,
                                                                   const float* __restrict__ shift,
                                                                   const float* __restrict__ oscale,
-                                                                  const float* __restrict__ oshift) {
+                                                                  const float* __restrict__ oshift, long obs = 32) {
     __shared__ __attribute__((aligned(16))) _Float16 smem[(256 + 128) * LDH2];
     _Float16* const As = smem;
     _Float16* const Bs = smem + 256 * LDH2;
@@ -451,7 +452,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h16_m256_kernel(const _Float16
             const long row = m0 + 128 * wm + 32 * mt + rr;
             const int col = n0 + 64 * wn + 8 * c8;
             if (row < M && col < N)
-                *reinterpret_cast<half8*>(out + row * ldc + col) = *reinterpret_cast<const half8*>(&Os[rr * LDH2 + 8 * c8]);
+                *reinterpret_cast<half8*>(out + row * ldc + (col >> 5) * obs + (col & 31)) =
+                    *reinterpret_cast<const half8*>(&Os[rr * LDH2 + 8 * c8]);
         }
     }
 }
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_h16_m256_kernel(const _Float16
 __global__ __launch_bounds__(256) void bnrelu_avgpool2_h16_kernel(const _Float16* __restrict__ in, long ldi,
                                                                   _Float16* __restrict__ out, long ldo, long Mout, int C8,
                                                                   int S, const float* __restrict__ scale,
-                                                                  const float* __restrict__ shift) {
+                                                                  const float* __restrict__ shift, long ibs = 32) {
     const long total = Mout * C8;
     const int So = S >> 1;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(256) void bnrelu_avgpool2_h16_kernel(const _Float16
         const long img = row / ((long)So * So);
         const int rem = (int)(row - img * So * So);
         const int oy = rem / So, ox = rem - oy * So;
-        const long src = ((img * S + 2 * oy) * S + 2 * ox) * ldi + c;
+        const long src = ((img * S + 2 * oy) * S + 2 * ox) * ldi + (c >> 5) * ibs + (c & 31);   // ibs = 32: row-major input
         const float4 sc0 = ld4(scale + c), sc1 = ld4(scale + c + 4), sh0 = ld4(shift + c), sh1 = ld4(shift + c + 4);
         const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
         const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
@@ -673,16 +675,32 @@ GNX_EXPORT int gnx_bnrelu_avgpool2_h16(const void* in16, long ldi, void* out16, 
                                                                 scale, shift);
     return gnx_launch_status();
 }
+// the same reading the channel-blocked buffer [C / 32][rows_total][32] halves of the fused dense layers (32 | C)
+GNX_EXPORT int gnx_bnrelu_avgpool2_h16_cb(const void* in16, long rows_total, void* out16, long ldo, long imgs, int C, int S,
+                                          const float* scale, const float* shift, hipStream_t stream) {
+    if (!in16 || !out16 || !scale || !shift || imgs < 0 || C <= 0 || S < 2 || rows_total < imgs * S * S || ldo < C)
+        return GNX_ERR_BAD_ARG;
+    if (C % 32 != 0 || S % 2 != 0 || ldo % 8 != 0 || !al16h(in16) || !al16h(out16) || !al16h(scale) || !al16h(shift))
+        return GNX_ERR_UNSUPPORTED;
+    const long Mout = imgs * (S / 2) * (S / 2);
+    if (Mout == 0) return GNX_OK;
+    long blocks = (Mout * (C / 8) + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    bnrelu_avgpool2_h16_kernel<<<(int)blocks, 256, 0, stream>>>(reinterpret_cast<const _Float16*>(in16), 32,
+                                                                reinterpret_cast<_Float16*>(out16), ldo, Mout, C / 8, S,
+                                                                scale, shift, rows_total * 32);
+    return gnx_launch_status();
+}
 
 // Dense-layer conv1 of config 5 on fp16 block buffers with fp16 weights (W16 = the weight rounded once, [N][K] halves):
 // gnx_conv1x1_bnrelu_f16_h (pool = 0) in chunks of 64 channels and 16-B loads.  32 | K, 8 | N.  scale / shift NULL: no
 // prologue (the operand is used as it is); out_scale / out_shift NULL: no consumer activation at the store - together the
 // second step of a transition (gnx_bnrelu_avgpool2_h16 first).
-GNX_EXPORT int gnx_conv1x1_bnrelu_h16(const void* A16, long lda16, const void* W16, void* out16, long ldc16, long M, int N,
-                                      int K, const float* scale, const float* shift, const float* out_scale,
-                                      const float* out_shift, hipStream_t stream) {
+static int conv1x1_h16_launch(const void* A16, long lda16, const void* W16, void* out16, long ldc16, long obs, long M, int N,
+                              int K, const float* scale, const float* shift, const float* out_scale, const float* out_shift,
+                              hipStream_t stream) {
     if (!A16 || !W16 || !out16 || (!scale) != (!shift) || (!out_scale) != (!out_shift) || M < 0 || N <= 0 || K <= 0 ||
-        lda16 < K || ldc16 < N)
+        lda16 < K || (obs == 32 ? ldc16 < N : (ldc16 != 32 || N % 32 != 0)))
         return GNX_ERR_BAD_ARG;
     if (!(al16h(A16) && al16h(W16) && al16h(out16) && al16h(scale) && al16h(shift) && lda16 % 8 == 0 && K % 8 == 0 &&
           N % 8 == 0 && ldc16 % 8 == 0))
@@ -694,12 +712,25 @@ GNX_EXPORT int gnx_conv1x1_bnrelu_h16(const void* A16, long lda16, const void* W
         conv1x1_h16_m256_kernel<<<grid, 256, 0, stream>>>(reinterpret_cast<const _Float16*>(A16), lda16,
                                                           reinterpret_cast<const _Float16*>(W16),
                                                           reinterpret_cast<_Float16*>(out16), ldc16, M, N, K, scale, shift,
-                                                          out_scale, out_shift);
+                                                          out_scale, out_shift, obs);
         return gnx_launch_status();
     }
     dim3 grid(gnx_cdiv(M, 128), gnx_cdiv(N, 128));
     conv1x1_h16_kernel<<<grid, 256, 0, stream>>>(reinterpret_cast<const _Float16*>(A16), lda16,
                                                  reinterpret_cast<const _Float16*>(W16), reinterpret_cast<_Float16*>(out16),
-                                                 ldc16, M, N, K, scale, shift, out_scale, out_shift);
+                                                 ldc16, M, N, K, scale, shift, out_scale, out_shift, obs);
     return gnx_launch_status();
+}
+GNX_EXPORT int gnx_conv1x1_bnrelu_h16(const void* A16, long lda16, const void* W16, void* out16, long ldc16, long M, int N,
+                                      int K, const float* scale, const float* shift, const float* out_scale,
+                                      const float* out_shift, hipStream_t stream) {
+    return conv1x1_h16_launch(A16, lda16, W16, out16, ldc16, 32, M, N, K, scale, shift, out_scale, out_shift, stream);
+}
+// the same storing into the channel-blocked buffer [.. / 32][rows_total][32] halves of the fused dense layers: the N output
+// channels become its first N / 32 blocks (a transition's output = the next dense block's first channels); 32 | N
+GNX_EXPORT int gnx_conv1x1_bnrelu_h16_cb(const void* A16, long lda16, const void* W16, void* out16, long rows_total, long M,
+                                         int N, int K, const float* scale, const float* shift, const float* out_scale,
+                                         const float* out_shift, hipStream_t stream) {
+    if (rows_total < M) return GNX_ERR_BAD_ARG;
+    return conv1x1_h16_launch(A16, lda16, W16, out16, 32, rows_total * 32, M, N, K, scale, shift, out_scale, out_shift, stream);
 }

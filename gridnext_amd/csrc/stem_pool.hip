@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
                                                                  _Float16* __restrict__ out, long ldo, int H, int Wd, int O,
                                                                  const float* __restrict__ scale,
                                                                  const float* __restrict__ shift, long imgs,
-                                                                 const float* __restrict__ nrm) {
+                                                                 const float* __restrict__ nrm, long obs = 32) {
     const float* __restrict__ x = reinterpret_cast<const float*>(xv);
     const uint8_t* __restrict__ x8 = reinterpret_cast<const uint8_t*>(xv);
     constexpr int CIN = 3, KH = 7, KW = 7, STRIDE = 2, PAD = 3;
@@ -655,7 +655,9 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
                     }
                     if (emit && ch < O) {
                         const sp_half4 hv = {(_Float16)o4.x, (_Float16)o4.y, (_Float16)o4.z, (_Float16)o4.w};
-                        *reinterpret_cast<sp_half4*>(out + orow * ldo + ch) = hv;
+                        // (element (row, c) lives at row * ldo + (c >> 5) * obs + (c & 31): obs = 32 is the row-major matrix,
+                        // ldo = 32 with obs = rows * 32 the channel-blocked buffer [c / 32][rows][32] of the fused dense layers)
+                        *reinterpret_cast<sp_half4*>(out + orow * ldo + (ch >> 5) * obs + (ch & 31)) = hv;
                     }
                 }
             }
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_vec4_kernel(const float* _
 template <bool IN16 = false>
 __global__ __launch_bounds__(256) void bnrelu_avgpool_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out,
                                                              long ldo, int C, int S2, const float* __restrict__ scale,
-                                                             const float* __restrict__ shift) {
+                                                             const float* __restrict__ shift, long ibs = 32) {
     __shared__ float red[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cl;
@@ -761,7 +763,7 @@ __global__ __launch_bounds__(256) void bnrelu_avgpool_kernel(const float* __rest
     if (c < C) {
         const float sc = scale[c], sh = shift[c];
         for (int r = rl; r < S2; r += 4) {
-            const long off = (img * S2 + r) * ldi + c;
+            const long off = (img * S2 + r) * ldi + (c >> 5) * ibs + (c & 31);     // ibs = 32: the row-major matrix
             const float v = IN16 ? (float)reinterpret_cast<const _Float16*>(in)[off] : in[off];
             acc += fmaxf(fmaf(v, sc, sh), 0.f);
         }
@@ -906,8 +908,9 @@ GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool_h16(const float* x, const float* w, 
 template <bool U8>
 static int stem_pool_f16_launch(const void* x, const float* w, void* out16, long ldo, long imgs, int Cin, int H, int W, int O,
                                 int KH, int KW, int stride, int pad, const float* scale, const float* shift,
-                                const float* nrm, hipStream_t stream) {
-    if (!x || !w || !out16 || !scale || !shift || imgs < 0 || Cin <= 0 || O <= 0 || H <= 0 || W <= 0 || ldo < O)
+                                const float* nrm, hipStream_t stream, long obs = 32) {
+    if (!x || !w || !out16 || !scale || !shift || imgs < 0 || Cin <= 0 || O <= 0 || H <= 0 || W <= 0 ||
+        (obs == 32 ? ldo < O : ldo != 32))
         return GNX_ERR_BAD_ARG;
     if (Cin != 3 || KH != 7 || KW != 7 || stride != 2 || pad != 3 || O > 64 || O % 4 != 0 || ldo % 4 != 0 ||
         (reinterpret_cast<uintptr_t>(out16) & 7) != 0)
@@ -923,9 +926,9 @@ static int stem_pool_f16_launch(const void* x, const float* w, void* out16, long
     const int grid = (int)(imgs < 256 * per_cu ? imgs : 256 * per_cu);
     _Float16* o = reinterpret_cast<_Float16*>(out16);
     if (Wo == 64)
-        conv_stem_pool_f16_kernel<64, U8><<<grid, 256, lds_bytes, stream>>>(x, w, o, ldo, H, W, O, scale, shift, imgs, nrm);
+        conv_stem_pool_f16_kernel<64, U8><<<grid, 256, lds_bytes, stream>>>(x, w, o, ldo, H, W, O, scale, shift, imgs, nrm, obs);
     else
-        conv_stem_pool_f16_kernel<128, U8><<<grid, 256, lds_bytes, stream>>>(x, w, o, ldo, H, W, O, scale, shift, imgs, nrm);
+        conv_stem_pool_f16_kernel<128, U8><<<grid, 256, lds_bytes, stream>>>(x, w, o, ldo, H, W, O, scale, shift, imgs, nrm, obs);
     return gnx_launch_status();
 }
 GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool_f16mul(const void* x, int x_is_u8, const float* w, void* out16, long ldo,
@@ -936,6 +939,21 @@ GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool_f16mul(const void* x, int x_is_u8, c
         return stem_pool_f16_launch<true>(x, w, out16, ldo, imgs, Cin, H, W, O, KH, KW, stride, pad, scale, shift, norm, stream);
     if (norm) return GNX_ERR_BAD_ARG;                      // float patches are taken as already transformed
     return stem_pool_f16_launch<false>(x, w, out16, ldo, imgs, Cin, H, W, O, KH, KW, stride, pad, scale, shift, nullptr, stream);
+}
+// The same storing into a CHANNEL-BLOCKED buffer [O / 32][rows_total][32] halves (the layout gnx_dense_layer_f16 streams:
+// a layer's 32-channel slice of consecutive pixels is contiguous memory): element (row, c) at (c >> 5) * rows_total * 32 +
+// row * 32 + (c & 31).  32 | O.
+GNX_EXPORT int gnx_conv_stem_bnrelu_maxpool_f16mul_cb(const void* x, int x_is_u8, const float* w, void* out16, long rows_total,
+                                                      long imgs, int Cin, int H, int W, int O, int KH, int KW, int stride,
+                                                      int pad, const float* scale, const float* shift, const float* norm,
+                                                      hipStream_t stream) {
+    if (rows_total <= 0 || O % 32 != 0) return GNX_ERR_BAD_ARG;
+    if (x_is_u8)
+        return stem_pool_f16_launch<true>(x, w, out16, 32, imgs, Cin, H, W, O, KH, KW, stride, pad, scale, shift, norm, stream,
+                                          rows_total * 32);
+    if (norm) return GNX_ERR_BAD_ARG;
+    return stem_pool_f16_launch<false>(x, w, out16, 32, imgs, Cin, H, W, O, KH, KW, stride, pad, scale, shift, nullptr, stream,
+                                       rows_total * 32);
 }
 
 // The fused stem on uint8 patches x8 [imgs][3][H][W] (image_datasets.py:102-105 does ToTensor on the host):
@@ -1027,5 +1045,17 @@ GNX_EXPORT int gnx_bnrelu_avgpool_h16(const void* in16, long ldi, float* out, lo
     dim3 grid((unsigned)imgs, gnx_cdiv(C, 64));
     bnrelu_avgpool_kernel<true><<<grid, 256, 0, stream>>>(reinterpret_cast<const float*>(in16), ldi, out, ldo, C, S2, scale,
                                                           shift);
+    return gnx_launch_status();
+}
+// the same reading the channel-blocked buffer [C / 32][rows_total][32] halves of the fused dense layers
+GNX_EXPORT int gnx_bnrelu_avgpool_h16_cb(const void* in16, long rows_total, float* out, long ldo, long imgs, int C, int S2,
+                                         const float* scale, const float* shift, hipStream_t stream) {
+    if (!in16 || !out || !scale || !shift || imgs < 0 || C <= 0 || S2 <= 0 || rows_total < imgs * S2 || ldo < C || C % 32 != 0)
+        return GNX_ERR_BAD_ARG;
+    if (imgs == 0) return GNX_OK;
+    if (imgs > 2147483647L) return GNX_ERR_UNSUPPORTED;
+    dim3 grid((unsigned)imgs, gnx_cdiv(C, 64));
+    bnrelu_avgpool_kernel<true><<<grid, 256, 0, stream>>>(reinterpret_cast<const float*>(in16), 32, out, ldo, C, S2, scale, shift,
+                                                          rows_total * 32);
     return gnx_launch_status();
 }

@@ -386,6 +386,37 @@ class DenseNet(nn.Module):
             raise RuntimeError("gnx_conv_stem_bnrelu_maxpool failed (%d)" % rc)
         return stem_out
 
+    def _block_fused(self, bi, buf, nxt, xs, n, s, P, fold, w0, dlp, st):
+        """One dense block of config 5 on its channel-blocked fp16 buffer `buf` [c_total / 32][rows][32] for the chunk's `n`
+        spots: the fp16 stem (block 0) or nothing (the previous transition already stored this block's first channels), every
+        dense layer as one kernel (gnx_dense_layer_f16), and the transition into `nxt` in two steps (pooling pass reading
+        the blocked buffer, 1x1 conv storing blocked)."""
+        c_in, layers, trans, c_total = self._blocks[bi]
+        H = torch.float16
+        rows_total = buf.shape[1]
+        if bi == 0:
+            sc, sh = fold[self.features.norm0]
+            u8 = xs.dtype == torch.uint8
+            c0 = self.features.conv0.out_channels
+            L.call('gnx_conv_stem_bnrelu_maxpool_f16mul_cb', xs.data_ptr(), 1 if u8 else 0, L.ptr(w0), buf.data_ptr(), rows_total, n,
+                   3, P, P, c0, 7, 7, 2, 3, L.ptr(sc), L.ptr(sh), L.ptr(self._norm_vector(xs.device)) if u8 else None, st)
+        for li, layer in enumerate(layers):
+            cin = c_in + li * self.growth_rate
+            sc1, sh1 = fold[layer.norm1]
+            sc2, sh2 = fold[layer.norm2]
+            t0 = self._probe_begin()
+            L.call('gnx_dense_layer_f16', L.ptr(buf, H), rows_total, n, s, cin, L.ptr(dlp[layer][0], H), L.ptr(dlp[layer][1], H),
+                   L.ptr(sc1), L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), st)
+            self._probe_mark('dense_layer', t0)
+        if trans is not None:
+            so = s // 2
+            sct, sht = fold[trans.norm]
+            pooled = torch.empty((n * so * so, c_total), device=buf.device, dtype=H)
+            L.call('gnx_bnrelu_avgpool2_h16_cb', L.ptr(buf, H), rows_total, L.ptr(pooled, H), c_total, n, c_total, s, L.ptr(sct),
+                   L.ptr(sht), st)
+            L.call('gnx_conv1x1_bnrelu_h16_cb', L.ptr(pooled, H), c_total, L.ptr(self._trans_f16()[trans], H), L.ptr(nxt, H),
+                   nxt.shape[1], n * so * so, trans.conv.out_channels, c_total, None, None, None, None, st)
+
     # ------------------------------------------------------------------ forward
     def forward(self, x):
         if not x.is_cuda:
@@ -421,7 +452,9 @@ class DenseNet(nn.Module):
         mid = self.bn_size * self.growth_rate
         # the fused dense-layer kernel (fp16 block buffers) takes: growth 32, bottleneck 128, maps of 4..64, 32 | channels
         fused_ok = bool(sfx) and self.f16_buffers and self.f16_fused and self.growth_rate == 32 and mid == 128 and \
-            all(s in (4, 8, 16, 32, 64) for s in sizes) and all(blk[0] % 32 == 0 for blk in self._blocks)
+            all(s in (4, 8, 16, 32, 64) for s in sizes) and all(blk[0] % 32 == 0 for blk in self._blocks) and \
+            self.num_features % 32 == 0 and not self.small_inputs and P in (128, 256) and \
+            all(blk[3] <= 1024 + 32 for blk in self._blocks)
         if sfx and self.atonce is None and chunk >= 8:
             if fused_ok:
                 chunk = chunk // 8 * 8                          # whole 128-row tiles; it indexes with 64 bits
@@ -448,8 +481,14 @@ class DenseNet(nn.Module):
         w1h = self._conv1_f16() if (use_h and not fused) else None
         dlp = self._dense_f16_packed() if fused else None
         # workspace for one chunk
-        bufs = [torch.empty((chunk * s * s, c_total), device=dev, dtype=torch.float16 if use_h else F32)
-                for (_, _, _, c_total), s in zip(self._blocks, sizes)]
+        if fused:
+            # channel-blocked block buffers [c_total / 32][rows][32] (include/gridnext_hip.h: gnx_dense_layer_f16): the 32
+            # channels a layer's K-loop stage needs of consecutive pixels are contiguous memory
+            bufs = [torch.empty((c_total // 32, chunk * s * s, 32), device=dev, dtype=torch.float16)
+                    for (_, _, _, c_total), s in zip(self._blocks, sizes)]
+        else:
+            bufs = [torch.empty((chunk * s * s, c_total), device=dev, dtype=torch.float16 if use_h else F32)
+                    for (_, _, _, c_total), s in zip(self._blocks, sizes)]
         bott = torch.empty((1 if fused else chunk * sizes[0] * sizes[0], mid), device=dev, dtype=F32)
         bott16 = bott.view(torch.float16)                       # the same memory as [rows][2 mid] halves (fp16 path)
         stem_out = None                                         # conv0 map: only the unfused stem needs it
@@ -464,8 +503,11 @@ class DenseNet(nn.Module):
                 sub = sub_range(bi, n)
                 for u0 in range(0, n, sub):
                     nu = min(sub, n - u0)
-                    rows = buf[u0 * s * s:(u0 + nu) * s * s]
                     M = nu * s * s
+                    if fused:
+                        self._block_fused(bi, buf, bufs[bi + 1] if trans is not None else None, xs, nu, s, P, fold, w0, dlp, st)
+                        continue
+                    rows = buf[u0 * s * s:(u0 + nu) * s * s]
                     if bi == 0:
                         stem_out = self._stem_eval(xs[u0:u0 + nu], rows, c_total, P, hs, use_h, fold, w0, stem_out, chunk, st)
                     for li, layer in enumerate(layers):
@@ -473,13 +515,6 @@ class DenseNet(nn.Module):
                         sc1, sh1 = fold[layer.norm1]
                         sc2, sh2 = fold[layer.norm2]
                         t0 = self._probe_begin()
-                        if fused:
-                            # norm1 .. conv2 in one kernel: K columns in, 32 columns out, the bottleneck never leaves the CU
-                            L.call('gnx_dense_layer_f16', L.ptr(rows, torch.float16), c_total, nu, s, cin,
-                                   L.ptr(dlp[layer][0], torch.float16), L.ptr(dlp[layer][1], torch.float16),
-                                   L.ptr(sc1), L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), st)
-                            self._probe_mark('dense_layer', t0)
-                            continue
                         if use_h:
                             L.call('gnx_conv1x1_bnrelu_h16', L.ptr(rows, torch.float16), c_total,
                                    L.ptr(w1h[layer], torch.float16), L.ptr(bott16, torch.float16), mid, M, mid, cin,
@@ -550,7 +585,10 @@ class DenseNet(nn.Module):
                                    c_total, L.ptr(sct), L.ptr(sht), 1, s, st)
             scf, shf = fold[self.features.norm_final]
             s_last = sizes[-1]
-            if use_h:
+            if fused:
+                L.call('gnx_bnrelu_avgpool_h16_cb', L.ptr(bufs[-1], torch.float16), bufs[-1].shape[1], L.ptr(feats[s0:]),
+                       self.num_features, n, self.num_features, s_last * s_last, L.ptr(scf), L.ptr(shf), st)
+            elif use_h:
                 L.call('gnx_bnrelu_avgpool_h16', L.ptr(bufs[-1], torch.float16), bufs[-1].shape[1], L.ptr(feats[s0:]),
                        self.num_features, n, self.num_features, s_last * s_last, L.ptr(scf), L.ptr(shf), st)
             else:

@@ -239,14 +239,27 @@ int gnx_conv3x3_f16_dma_h(const void* A16, long lda16, const void* Wr16, void* o
 int gnx_bnrelu_avgpool_h16(const void* in16, long ldi, float* out, long ldo, long imgs, int C, int S2, const float* scale,
                            const float* shift, gnx_stream_t stream);
 /* One whole dense layer of config 5 in ONE kernel (gridnext/densenet.py:35-44: cat -> norm1 -> relu1 -> conv1 -> norm2 ->
- * relu2 -> conv2) on the fp16 block buffer X16 [n_img * S * S][ld16]: reads columns [0, K), writes the layer's 32 new columns
- * [K, K + 32); the 128-channel bottleneck lives in LDS only.  gnx_dense_layer_f16_pack rounds conv1.weight [128][K] and
- * conv2.weight [32][128][3][3] (fp32, torch layouts) to fp16 ONCE into the MFMA-fragment order the kernel streams
- * (w1p: 128 * K halves, w2p: 36 864 halves).  bn_size * growth_rate = 128, growth_rate = 32; S in {4, 8, 16, 32, 64};
- * 32 | K; 8 | ld16; 128 | n_img * S * S; anything else: GNX_ERR_UNSUPPORTED (callers fall back to the two-kernel pair). */
+ * relu2 -> conv2) on a CHANNEL-BLOCKED fp16 block buffer X16 [channels / 32][rows_total][32] - element (row, c) at
+ * (c >> 5) * rows_total * 32 + row * 32 + (c & 31), so the 32 channels a K-loop stage needs of consecutive pixels are
+ * contiguous memory: reads channel blocks [0, K / 32), writes block K / 32; the 128-channel bottleneck lives in LDS only.
+ * gnx_dense_layer_f16_pack rounds conv1.weight [128][K] and conv2.weight [32][128][3][3] (fp32, torch layouts) to fp16 ONCE
+ * into the MFMA-fragment order the kernel streams (w1p: 128 * K halves, w2p: 36 864 halves).  bn_size * growth_rate = 128,
+ * growth_rate = 32; S in {4, 8, 16, 32, 64}; 32 | K <= 1024; 128 | n_img * S * S; anything else: GNX_ERR_UNSUPPORTED (callers
+ * fall back to the two-kernel pair on row-major buffers).  The `_cb` entry points are the neighbours of that layout: the
+ * fp16 stem and the transition's 1x1 conv STORE channel-blocked, the transition's pooling pass and the final pool READ it. */
 int gnx_dense_layer_f16_pack(const float* w1, const float* w2, void* w1p, void* w2p, int K, gnx_stream_t stream);
-int gnx_dense_layer_f16(void* X16, long ld16, long n_img, int S, int K, const void* w1p, const void* w2p, const float* scale1,
-                        const float* shift1, const float* scale2, const float* shift2, gnx_stream_t stream);
+int gnx_dense_layer_f16(void* X16, long rows_total, long n_img, int S, int K, const void* w1p, const void* w2p,
+                        const float* scale1, const float* shift1, const float* scale2, const float* shift2, gnx_stream_t stream);
+int gnx_conv_stem_bnrelu_maxpool_f16mul_cb(const void* x, int x_is_u8, const float* w, void* out16, long rows_total, long imgs,
+                                           int Cin, int H, int W, int O, int KH, int KW, int stride, int pad, const float* scale,
+                                           const float* shift, const float* norm, gnx_stream_t stream);
+int gnx_conv1x1_bnrelu_h16_cb(const void* A16, long lda16, const void* W16, void* out16, long rows_total, long M, int N, int K,
+                              const float* scale, const float* shift, const float* out_scale, const float* out_shift,
+                              gnx_stream_t stream);
+int gnx_bnrelu_avgpool2_h16_cb(const void* in16, long rows_total, void* out16, long ldo, long imgs, int C, int S,
+                               const float* scale, const float* shift, gnx_stream_t stream);
+int gnx_bnrelu_avgpool_h16_cb(const void* in16, long rows_total, float* out, long ldo, long imgs, int C, int S2,
+                              const float* scale, const float* shift, gnx_stream_t stream);
 
 /* ---- DenseNet-BC backward (the gradients torch.autograd derives for gridnext/densenet.py) -----------------------------
  * Data gradients reuse gnx_conv1x1_bnrelu / gnx_conv3x3_bnrelu with weights transformed by gnx_transpose_weight

@@ -593,9 +593,9 @@ def _dense_layer_ref(x16, W1, W2, sc1, sh1, sc2, sh2):
     return o.permute(0, 2, 3, 1)
 
 
-@pytest.mark.parametrize("S,n,K,ct", [(64, 2, 64, 104), (64, 3, 96, 136), (64, 260, 64, 104), (32, 4, 128, 168),
-                                      (32, 300, 224, 264), (16, 8, 256, 296), (16, 520, 96, 136), (8, 16, 512, 552),
-                                      (8, 1040, 64, 104), (4, 64, 992, 1032), (4, 4160, 64, 104)])
+@pytest.mark.parametrize("S,n,K,ct", [(64, 2, 64, 128), (64, 3, 96, 160), (64, 260, 64, 128), (32, 4, 128, 192),
+                                      (32, 300, 224, 288), (16, 8, 256, 320), (16, 520, 96, 160), (8, 16, 512, 576),
+                                      (8, 1040, 64, 128), (4, 64, 992, 1056), (4, 4160, 64, 128)])
 def test_dense_layer_f16_fused(L, S, n, K, ct):
     """gnx_dense_layer_f16 (one kernel per dense layer, bottleneck in LDS only) against the layer evaluated in double on the
     same fp16 values with the same rounding points.  Tolerance 3e-3 of the output range: the fp16 rounding of the output
@@ -612,16 +612,23 @@ def test_dense_layer_f16_fused(L, S, n, K, ct):
     sc2, sh2 = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.5
     st = L.stream()
     H = torch.float16
-    X = x.reshape(-1, ct).to(DEV)
+    # the kernel's buffer is channel-blocked: [ct / 32][rows][32]
+    def blocked(t):
+        return t.reshape(-1, ct // 32, 32).permute(1, 0, 2).contiguous()
+
+    def rowmajor(b):
+        return b.permute(1, 0, 2).reshape(-1, ct)
+    X = blocked(x).to(DEV)
+    rows = X.shape[1]
     W1d, W2d = W1.to(DEV), W2.to(DEV)
     w1p = torch.empty(128 * K, device=DEV, dtype=H)
     w2p = torch.empty(9 * 8 * 512, device=DEV, dtype=H)
     L.call('gnx_dense_layer_f16_pack', L.ptr(W1d), L.ptr(W2d), L.ptr(w1p, H), L.ptr(w2p, H), K, st)
     d = [v.to(DEV) for v in (sc1, sh1, sc2, sh2)]
-    L.call('gnx_dense_layer_f16', L.ptr(X, H), ct, n, S, K, L.ptr(w1p, H), L.ptr(w2p, H), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]),
+    L.call('gnx_dense_layer_f16', L.ptr(X, H), rows, n, S, K, L.ptr(w1p, H), L.ptr(w2p, H), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]),
            L.ptr(d[3]), st)
     torch.cuda.synchronize()
-    got = X.cpu().reshape(n, S, S, ct)
+    got = rowmajor(X.cpu()).reshape(n, S, S, ct)
     assert torch.equal(got[..., :K], x[..., :K]), "input columns changed"
     assert float(got[..., K + 32:].float().min()) == 7.0 and float(got[..., K + 32:].float().max()) == 7.0
     pick = sorted(set(i for i in (0, 1, 2, 3, 255, 256, 257, 511, 512, n // 2, n - 2, n - 1) if 0 <= i < n))
@@ -635,11 +642,11 @@ def test_dense_layer_f16_fused(L, S, n, K, ct):
     # batch (a work unit is an image or a tile of whole images: the result must not depend on which workgroup ran it)
     if n >= 16:
         perm = torch.randperm(n, generator=g)
-        X2 = x[perm].reshape(-1, ct).to(DEV)
-        L.call('gnx_dense_layer_f16', L.ptr(X2, H), ct, n, S, K, L.ptr(w1p, H), L.ptr(w2p, H), L.ptr(d[0]), L.ptr(d[1]),
+        X2 = blocked(x[perm]).to(DEV)
+        L.call('gnx_dense_layer_f16', L.ptr(X2, H), rows, n, S, K, L.ptr(w1p, H), L.ptr(w2p, H), L.ptr(d[0]), L.ptr(d[1]),
                L.ptr(d[2]), L.ptr(d[3]), st)
         torch.cuda.synchronize()
-        assert torch.equal(X2.cpu().reshape(n, S, S, ct), got[perm]), "result depends on the image's position in the batch"
+        assert torch.equal(rowmajor(X2.cpu()).reshape(n, S, S, ct), got[perm]), "result depends on the image's position in the batch"
 
 
 @pytest.mark.parametrize("n,O,P", [(3, 64, 128), (300, 64, 128), (2, 32, 128), (3, 64, 256), (270, 64, 256), (2, 32, 256)])

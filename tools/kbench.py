@@ -117,7 +117,7 @@ def main():
                    (16, 992, 1024), (8, 512, 1024), (8, 992, 1024)]
         for S, K, ct in fshapes:
             M = n * S * S
-            X = torch.randn(M, ct, device=DEV).to(H)
+            X = torch.randn(ct // 32, M, 32, device=DEV).to(H)          # channel-blocked [ct / 32][rows][32]
             W1 = torch.randn(128, K, device=DEV) * (1.0 / K ** 0.5)
             W2 = torch.randn(32, 128, 3, 3, device=DEV) * 0.05
             sc, sh = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
@@ -125,12 +125,13 @@ def main():
             w1p = torch.empty(128 * K, device=DEV, dtype=H)
             w2p = torch.empty(9 * 8 * 512, device=DEV, dtype=H)
             L.call('gnx_dense_layer_f16_pack', L.ptr(W1), L.ptr(W2), L.ptr(w1p, H), L.ptr(w2p, H), K, st)
-            ms = timeit(lambda: L.call('gnx_dense_layer_f16', L.ptr(X, H), ct, n, S, K, L.ptr(w1p, H), L.ptr(w2p, H), L.ptr(sc),
+            ms = timeit(lambda: L.call('gnx_dense_layer_f16', L.ptr(X, H), M, n, S, K, L.ptr(w1p, H), L.ptr(w2p, H), L.ptr(sc),
                                        L.ptr(sh), L.ptr(osc), L.ptr(osh), st), args.reps)
             byts = M * (2.0 * K + 64)
             fl = 2.0 * M * 128 * (K + 9 * 32)
             line = "fused S=%2d K=%4d M=%8d  %8.3f ms  %5.2f TB/s  %6.1f TFLOP/s" % (S, K, M, ms, byts / ms / 1e9, fl / ms / 1e9)
             if args.only == 'fusedcmp' and M * ct < 2 ** 31:
+                Xr = torch.randn(M, ct, device=DEV).to(H)                  # the pair works on a row-major buffer
                 bott = torch.empty(M, 128, device=DEV, dtype=H)
                 W16 = W1.to(H)
                 Wr = torch.empty(9, 32, 128, device=DEV)
@@ -138,12 +139,12 @@ def main():
                 Wr16 = Wr.to(H)
 
                 def pair():
-                    L.call('gnx_conv1x1_bnrelu_h16', L.ptr(X, H), ct, L.ptr(W16, H), L.ptr(bott, H), 128, M, 128, K, L.ptr(sc),
+                    L.call('gnx_conv1x1_bnrelu_h16', L.ptr(Xr, H), ct, L.ptr(W16, H), L.ptr(bott, H), 128, M, 128, K, L.ptr(sc),
                            L.ptr(sh), L.ptr(osc), L.ptr(osh), st)
-                    L.call('gnx_conv3x3_f16_dma_h', L.ptr(bott, H), 128, L.ptr(Wr16, H), X.data_ptr() + 2 * K, ct, M, 32, 128, S, st)
+                    L.call('gnx_conv3x3_f16_dma_h', L.ptr(bott, H), 128, L.ptr(Wr16, H), Xr.data_ptr() + 2 * K, ct, M, 32, 128, S, st)
                 ms2 = timeit(pair, args.reps)
                 line += "   | pair %8.3f ms (x%.2f)" % (ms2, ms2 / ms)
-                del bott
+                del bott, Xr
             print(line, flush=True)
             del X
     if args.only in ('', 'wgrad1'):
