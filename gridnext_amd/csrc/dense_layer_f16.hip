@@ -292,6 +292,103 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             DL_LAP(2);
         };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of W2
+        if constexpr (S < 64) {
+            // One continuous stream of stages over all the workgroup's steps: global stage g = n * nst + s sits in register
+            // ring entry g & 7 (compile-time in the 8-fold unrolled loop; the LDS slot is the step's stage & 3), so seven stages
+            // (56 KB per CU) are in flight whatever the step length - an HBM miss takes ~900 cycles on an idle chip and two
+            // to three times that under load, three stages in flight (the first form of this loop) left the stream
+            // latency-bound at ~1100 cycles per stage where the HBM rate allows ~650.
+            constexpr int RD = 8;
+            u32x4 rq[RD][2];
+            int lu = bid, lj = 0, ls = 0;                      // the next load: unit, step, stage
+            const _Float16* lrows = strip(lu, lj);
+            // (inline asm: the compiler's own vmcnt bookkeeping gives up on a ring this deep in a loop and drains it - it
+            // waited vmcnt(1) where 14 younger loads were in flight; these loads are therefore invisible to it and every use
+            // waits by hand: exactly RD stages are outstanding at each apply, the oldest is the one applied.  The feeders
+            // issue no other vector-memory operation after the prologue.)
+            auto load_next = [&](u32x4(&dst)[2]) {
+                const bool in = lu < n_units && !DL_ABL(4);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<_Float16*>(lrows) + (in ? ls : 0) * bstride, 0, 2048, 0x00020000);
+                const int vo = voffA + (in ? 0 : 0x7f000000);
+                if (!DL_ABL(512))
+                asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:1024"
+                             : "=&v"(dst[0]), "=&v"(dst[1]) : "v"(vo), "s"(rs) : "memory");
+                if (++ls == nst) {
+                    ls = 0;
+                    if (++lj == J) { lj = 0; lu += G; }
+                    lrows = strip(lu < n_units ? lu : bid, lj);
+                }
+            };
+            auto landed = [&](u32x4(&v)[2]) {                  // the oldest of the RD stages in flight
+                if (!DL_ABL(512))
+                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0]), "+v"(v[1]) : "n"(2 * RD - 2) : "memory");
+            };
+            const int Gt = (bid < n_units ? ((n_units - bid + G - 1) / G) * J : 0) * nst;   // this workgroup's stages
+            static_for<0, RD>([&](auto k_c) { load_next(rq[decltype(k_c)::value]); });
+            lds_barrier();                                     // B_init: tables and W2 are in the LDS
+            // The consumers take the step's stages in PAIRS (one barrier per 64 channels): pair p sits in slots (2p, 2p + 1) & 3
+            // and is read between the barriers B_p and B_p+1, the feeders write pair p + 1 meanwhile; the next step's first
+            // pair goes in after the E barrier.  norm1 constants: two register sets, requested two stages ahead.
+            ActRegs ak[2];
+            auto request_k = [&](ActRegs& c, int ss) {
+                if (DL_ABL(1024)) return;
+                const unsigned a = ctb + ss * 256;
+                c.s0 = lds_read4<0>(a);
+                c.s1 = lds_read4<16>(a);
+                c.b0 = lds_read4<32>(a);
+                c.b1 = lds_read4<48>(a);
+            };
+            auto wrap = [&](int x) {
+                while (x >= nst) x -= nst;
+                return x;
+            };
+            request_k(ak[0], 0);
+            request_k(ak[1], wrap(1));
+            int sa = 0;                                        // in-step index of the stage applied next
+            auto gapply = [&](auto ph_c, int g) {
+                constexpr int P = decltype(ph_c)::value;
+                if (sa == 0) {
+                    if (g > 0) {
+                        lds_barrier();                         // the previous step's last pair barrier
+                        DL_LAP(0);
+                        lds_barrier();                         // E: its bottleneck tile is complete, every slot is free
+                        DL_LAP(3);
+                    }
+                } else if ((sa & 1) == 0) {
+                    lds_barrier();                             // B_(sa / 2 - 1): pair sa / 2 - 2 has been read
+                    DL_LAP(0);
+                }
+                landed(rq[P]);
+                DL_LAP(7);
+                ActRegs& c = ak[P & 1];
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c.s0), "+v"(c.s1), "+v"(c.b0), "+v"(c.b1));
+                char* d = lds + DL_AR + (sa & 3) * DL_SLOT + 2 * fw * 1024 + lane * 16;
+                if (!DL_ABL(1)) {
+                    *reinterpret_cast<u32x4*>(d) = activated(rq[P][0], c);
+                    *reinterpret_cast<u32x4*>(d + 1024) = activated(rq[P][1], c);
+                }
+                DL_LAP(1);
+                load_next(rq[P]);
+                request_k(c, wrap(sa + 2));
+                sa = sa + 1 == nst ? 0 : sa + 1;
+                DL_LAP(2);
+            };
+#define DL_GS(k) gapply(std::integral_constant<int, k>{}, g + k); if (g + k + 1 >= Gt) break;
+            if (Gt > 0) {
+                for (int g = 0;; g += RD) { DL_GS(0) DL_GS(1) DL_GS(2) DL_GS(3) DL_GS(4) DL_GS(5) DL_GS(6) DL_GS(7) }
+                lds_barrier();                                 // the last step's last pair barrier and E
+                lds_barrier();
+            }
+#undef DL_GS
+            // the stages requested past the end of the stream: nothing may reuse their registers before they have landed
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[1][0]), "+v"(rq[1][1]), "+v"(rq[2][0]), "+v"(rq[2][1]),
+                           "+v"(rq[3][0]), "+v"(rq[3][1]), "+v"(rq[4][0]), "+v"(rq[4][1]), "+v"(rq[5][0]), "+v"(rq[5][1]),
+                           "+v"(rq[6][0]), "+v"(rq[6][1]), "+v"(rq[7][0]), "+v"(rq[7][1])::"memory");
+            if (wave == 4) DL_OUT(8);
+            return;
+        }
         int u = bid, j = 0;
         const _Float16* rs = strip(u, j);
         load_raw(rr[0], rs, 0);
@@ -350,9 +447,14 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
         dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rW1, vo + 1024, 0, 0);
     };
     auto preload_w = [&]() {
-        load_w(fr[0], 0);
-        load_w(fr[1], 1);
-        load_w(fr[2], 2);
+        if constexpr (S == 64) {
+            load_w(fr[0], 0);
+            load_w(fr[1], 1);
+            load_w(fr[2], 2);
+        } else {                                               // (a pair requests the next pair's fragments itself)
+            load_w(fr[0], 0);
+            load_w(fr[1], 1);
+        }
     };
     preload_w();
     lds_barrier();                                             // B_init
@@ -382,6 +484,51 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
         DL_LAP(1);
     };
 
+    // S < 64: two stages per barrier (the feeders' pair protocol): the second stage's fragments are requested while the first
+    // stage multiplies; its W1 fragments of the NEXT pair are requested at the pair's start (L2 hits: one pair ahead is enough)
+    auto pair = [&](auto ph_c, int s) {
+        constexpr int P = decltype(ph_c)::value;               // s & 3: 0 or 2
+        lds_barrier();                                         // B_(s / 2)
+        DL_LAP(0);
+        load_w(fr[(P + 2) & 3], s + 2);
+        load_w(fr[(P + 3) & 3], s + 3);
+        f32x4 av[16];
+        if (!DL_ABL(2)) {
+        static_for<0, 8>([&](auto n_c) {
+            constexpr int n = decltype(n_c)::value;            // n = 4 ks + rb
+            av[n] = lds_read4<P * DL_SLOT + (n & 3) * 2048 + (n >> 2) * 512>(laneA);
+        });
+        static_for<0, 8>([&](auto n_c) {
+            constexpr int n = decltype(n_c)::value;
+            av[8 + n] = lds_read4<(P + 1) * DL_SLOT + (n & 3) * 2048 + (n >> 2) * 512>(laneA);
+            asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(av[n]));
+            c1[n & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fr[P][n >> 2]),
+                                                               __builtin_bit_cast(half8, av[n]), c1[n & 3], 0, 0, 0);
+        });
+        if (s + 1 < nst)
+            static_for<0, 8>([&](auto n_c) {
+                constexpr int n = decltype(n_c)::value;
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(av[8 + n]) : "n"(7 - n));
+                c1[n & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fr[P + 1][n >> 2]),
+                                                                   __builtin_bit_cast(half8, av[8 + n]), c1[n & 3], 0, 0, 0);
+            });
+        else                                                   // an odd step's last pair: the reads still own their registers
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[8]), "+v"(av[9]), "+v"(av[10]), "+v"(av[11]), "+v"(av[12]), "+v"(av[13]),
+                                                  "+v"(av[14]), "+v"(av[15]));
+        }
+        DL_LAP(1);
+    };
+
+    auto pairs_from = [&](auto k_c) {
+        auto impl = [&](auto& self, auto kk_c) -> void {
+            constexpr int k = decltype(kk_c)::value;
+            pair(std::integral_constant<int, (2 * k) & 3>{}, 2 * k);
+            if constexpr (k + 1 < 16)
+                if (2 * k + 2 < nst) self(self, std::integral_constant<int, k + 1>{});
+        };
+        impl(impl, k_c);
+    };
+
     for (int u = bid; u < n_units; u += G)
         for (int j = 0; j < J; ++j) {
 #pragma unroll
@@ -389,15 +536,21 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c1[rb][r] = 0.f;
             // ---- conv1 over the step's K channels
-            for (int s = 0;; s += 4) {
-                stage(std::integral_constant<int, 0>{}, s);
-                if (s + 1 >= nst) break;
-                stage(std::integral_constant<int, 1>{}, s + 1);
-                if (s + 2 >= nst) break;
-                stage(std::integral_constant<int, 2>{}, s + 2);
-                if (s + 3 >= nst) break;
-                stage(std::integral_constant<int, 3>{}, s + 3);
-                if (s + 4 >= nst) break;
+            if constexpr (S < 64) {
+                // no loop: the (up to 16) pairs of a step are laid out one after the other with an exit after each, so that
+                // the compiler counts the W1 loads in flight exactly - around a loop it drained them (vmcnt(0)) at every trip
+                pairs_from(std::integral_constant<int, 0>{});
+            } else {
+                for (int s = 0;; s += 4) {
+                    stage(std::integral_constant<int, 0>{}, s);
+                    if (s + 1 >= nst) break;
+                    stage(std::integral_constant<int, 1>{}, s + 1);
+                    if (s + 2 >= nst) break;
+                    stage(std::integral_constant<int, 2>{}, s + 2);
+                    if (s + 3 >= nst) break;
+                    stage(std::integral_constant<int, 3>{}, s + 3);
+                    if (s + 4 >= nst) break;
+                }
             }
             preload_w();                                       // the next step's first stages (the same weights)
             // ---- norm2 + relu2, rounded to fp16, into the bottleneck tile

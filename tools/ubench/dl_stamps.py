@@ -54,11 +54,12 @@ def main():
         launch()
         torch.cuda.synchronize()
         v = stamps.view(grid, 24).double().mean(0) / steps
-        print("S=%2d K=%4d cycles/step: back wave 0 [wait %.0f | conv2 taps %.0f | stores %.0f | rest %.0f]  front wave 4 [conv1 %.0f |"
-              " epilogue %.0f | wait %.0f]" % (S, K, v[0], v[4], v[5], v[6], v[8], v[9], v[10]), flush=True)
+        print("S=%2d K=%4d cycles/step: consumer wave 0 [barrier wait %.0f | conv1 %.0f | epilogue %.0f | E wait %.0f | conv2 taps %.0f | stores %.0f]"
+              "  feeder wave 4 [barrier wait %.0f | data wait %.0f | apply %.0f | issue %.0f | E wait %.0f | conv2 %.0f | stores %.0f | first apply %.0f]"
+              % (S, K, v[0], v[1], v[2], v[3], v[4], v[5], v[8], v[15], v[9], v[10], v[11], v[12], v[13], v[14]), flush=True)
         # what the launch costs when a part is left out (wrong results, timing only)
-        names = {0: 'full', 4: '-x loads', 1: '-norm1', 2: '-conv1 mfma', 32: '-W1 loads', 16: '-epilogue', 8: '-conv2 taps',
-                 64: '-stores', 72: 'front only', 55: 'back only', 91: 'loads only', 95: 'W1 loads only', 123: 'x loads only'}
+        names = {0: 'full', 127: 'sync only', 127 + 512: 'sync, no x load issue', 127 + 1024: 'sync, no consts', 127 + 1536: 'sync, neither',
+                 512 + 4: 'full, no x load issue', 1024: 'full, no consts'}
         line = []
         for abl, nm in names.items():
             lib.gnx_dense_layer_f16_set_stamps(None, abl)
