@@ -345,6 +345,8 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             };
             request_k(ak[0], 0);
             request_k(ak[1], wrap(1));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ak[0].s0), "+v"(ak[0].s1), "+v"(ak[0].b0), "+v"(ak[0].b1), "+v"(ak[1].s0),
+                                                  "+v"(ak[1].s1), "+v"(ak[1].b0), "+v"(ak[1].b1));
             int sa = 0;                                        // in-step index of the stage applied next
             auto gapply = [&](auto ph_c, int g) {
                 constexpr int P = decltype(ph_c)::value;
@@ -362,7 +364,9 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                 landed(rq[P]);
                 DL_LAP(7);
                 ActRegs& c = ak[P & 1];
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c.s0), "+v"(c.s1), "+v"(c.b0), "+v"(c.b1));
+                // this stage's constants were requested two stages ago; younger LDS operations of this wave: the previous
+                // stage's two writes and its four constant reads - they stay in flight
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(c.s0), "+v"(c.s1), "+v"(c.b0), "+v"(c.b1));
                 char* d = lds + DL_AR + (sa & 3) * DL_SLOT + 2 * fw * 1024 + lane * 16;
                 if (!DL_ABL(1)) {
                     *reinterpret_cast<u32x4*>(d) = activated(rq[P][0], c);
