@@ -285,7 +285,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             constexpr int P = decltype(ph_c)::value;
             lds_barrier();                                     // B_s: stage s is visible, slot (s + 1) & 3 is free
             DL_LAP(0);
-            if (s + 1 < nst) apply(rr[(P + 1) & 3], (P + 1) & 3);
+            if (s + 1 < nst && s + 1 >= 3) apply(rr[(P + 1) & 3], (P + 1) & 3);   // (stages 0..2: pre_apply)
             DL_LAP(1);
             request_consts(s + 2);
             load_raw(rr[(P + 3) & 3], rs, s + 3);
@@ -398,10 +398,23 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
         load_raw(rr[0], rs, 0);
         load_raw(rr[1], rs, 1);
         load_raw(rr[2], rs, 2);
+        // A step's first three stages go into their slots right after the previous step's E barrier (every slot is free then),
+        // BEFORE this wave's share of conv2: the consumers come out of conv2 and find them there - applied after conv2, one
+        // per stage barrier, they were 2200 of a K = 64 step's 8100 consumer cycles.
+        auto pre_apply = [&]() {
+            request_consts(0);
+            apply(rr[0], 0);
+            if (nst > 1) {
+                request_consts(1);
+                apply(rr[1], 1);
+            }
+            if (nst > 2) {
+                request_consts(2);
+                apply(rr[2], 2);
+            }
+        };
         lds_barrier();                                         // B_init: tables and W2 are in the LDS
-        request_consts(0);
-        apply(rr[0], 0);
-        request_consts(1);
+        pre_apply();
         while (u < n_units) {
             for (int s = 0;; s += 4) {
                 fstage(std::integral_constant<int, 0>{}, s, rs);
@@ -425,13 +438,9 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             DL_LAP(2);
             lds_barrier();                                     // E: the step's bottleneck tile is complete
             DL_LAP(3);
-            if constexpr (S == 64) conv2_step(cu, cj, fa0, fa1);
-            if (u < n_units) {                                 // the consumers are past every stage of step (cu, cj): slot 0 is free
-                request_consts(0);
-                apply(rr[0], 0);
-                request_consts(1);
-            }
+            if (u < n_units) pre_apply();                      // the consumers are past every stage of step (cu, cj)
             DL_LAP(6);
+            if constexpr (S == 64) conv2_step(cu, cj, fa0, fa1);
         }
         if (wave == 4) DL_OUT(8);
         return;
@@ -556,7 +565,6 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                     if (s + 4 >= nst) break;
                 }
             }
-            preload_w();                                       // the next step's first stages (the same weights)
             // ---- norm2 + relu2, rounded to fp16, into the bottleneck tile
             if (!DL_ABL(16))
 #pragma unroll
@@ -582,6 +590,8 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             DL_LAP(2);
             lds_barrier();                                     // E
             DL_LAP(3);
+            preload_w();                                       // the next step's first stages (the same weights): behind E, not
+                                                               // in front of it - every wave of the workgroup waits for E
             conv2_step(u, j, a0, a1);
         }
     if (wave == 0) DL_OUT(0);
