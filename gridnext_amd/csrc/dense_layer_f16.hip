@@ -51,7 +51,11 @@ constexpr int DL_PF = 3;                       // W1 fragment stages in flight a
 // their own.  In the product build the macros are empty: no stamp executes.
 #ifdef GNX_DL_STAMP
 #define GNX_DL_STAMP_PARAM , unsigned long long* __restrict__ stamps, int abl
+#ifdef GNX_DL_NOABL                             // timers only: the ablation tests are run-time branches inside the MFMA streams
+#define DL_ABL(bit) false
+#else
 #define DL_ABL(bit) (abl & (bit))
+#endif
 #define DL_T0() unsigned long long dl_t = __builtin_readcyclecounter(), dl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define DL_LAP(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); dl_acc[k] += n_ - dl_t; dl_t = n_; } while (0)
 #define DL_OUT(base) do { if (stamps && lane == 0) for (int q_ = 0; q_ < 8; ++q_) stamps[(long)blockIdx.x * 24 + (base) + q_] = dl_acc[q_]; } while (0)
@@ -597,6 +601,346 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
     if (wave == 0) DL_OUT(0);
 }
 
+// ------------------------------------------------------------------------------------------------ S = 64 (block 1: K <= 224)
+// At 64 x 64 maps a step has only 2-7 stages of conv1 in front of 288 MFMAs of conv2: run one after the other (the kernel
+// above did: conv1 stages, epilogue, conv2 on all eight waves) a 128-pixel step took 6600-10100 cycles against 2800-4100 of
+// MFMA work.  Here the two halves of the layer OVERLAP: waves 4-7 ("front") compute conv1 + norm2/relu2 of step n into one
+// half of a double-buffered bottleneck tile while waves 0-3 ("back") run conv2 of step n - 1 from the other half; ONE
+// workgroup barrier per step.  The front waves take their operands straight from global memory in fragment order (no LDS
+// staging, no barrier inside a step): wave (pixel half, channel half) owns 64 pixels x 64 bottleneck channels; a pixel's 32
+// channels of a block are 64 contiguous bytes, so a lane's 8 channels are one 16-B load and a fragment one coalesced 2 KB.
+// That form pulls every input byte through the texture path twice and W1 twice (32 KB per stage and CU, ~740 cycles at the
+// ~43 B/clk the path sustains): affordable with few stages per step, not for S <= 32 (K up to 992), which stay above.
+// Timers-only stamps (no ablation branches in the MFMA streams): back 3900 cycles of conv2 + 370 of stores per step.
+__global__ __launch_bounds__(512) void dense_layer_f16_s64_kernel(_Float16* __restrict__ X, long bstride, int n_units, int K,
+                                                              const _Float16* __restrict__ w1p,
+                                                              const _Float16* __restrict__ w2p,
+                                                              const float* __restrict__ sc1, const float* __restrict__ sh1,
+                                                              const float* __restrict__ sc2, const float* __restrict__ sh2
+                                                              GNX_DL_STAMP_PARAM) {
+    constexpr int S = 64, J = S * S / 128, LOG2S = 6;      // 32 steps of two image rows per unit
+    __shared__ __attribute__((aligned(16))) char lds[DL_LDS];
+    const int t = threadIdx.x, lane = t & 63, h = lane >> 5, i = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int nst = K >> 5;                                // stages per step
+    const unsigned lb = lds_addr(lds);
+    DL_T0();
+
+    // norm1 + relu1 on raw input pieces (16 px x 32 channels of fp16 each; a lane holds 16 B = 8 channels of one pixel): fp32
+    // fma on the fp16 value, rounded once to fp16 (v_fma_mix), relu packed.
+    struct ActRegs { f32x4 s0, s1, b0, b1; };
+    auto act2 = [](unsigned x, float sa, float ba, float sb, float bb) {                  // two halves of one register
+        unsigned r;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %0, %1, %4, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_pk_max_f16 %0, %0, 0"
+            : "=&v"(r) : "v"(x), "v"(sa), "v"(ba), "v"(sb), "v"(bb));
+        return r;
+    };
+    auto activated = [&](const u32x4& v, const ActRegs& c) {
+        u32x4 o;
+        o[0] = act2(v[0], c.s0[0], c.b0[0], c.s0[1], c.b0[1]);
+        o[1] = act2(v[1], c.s0[2], c.b0[2], c.s0[3], c.b0[3]);
+        o[2] = act2(v[2], c.s1[0], c.b1[0], c.s1[1], c.b1[1]);
+        o[3] = act2(v[3], c.s1[2], c.b1[2], c.s1[3], c.b1[3]);
+        return o;
+    };
+
+    // this workgroup's steps: unit bid, bid + G, ... , each J steps; step n is (u, j) = (bid + (n / J) G, n % J)
+    const int N = bid < n_units ? ((n_units - bid + G - 1) / G) * J : 0;
+
+    // ---- conv2 of step n, scatter form: the step's bottleneck tile (LDS, parity n & 1) into every output block it touches.
+    auto conv2_step = [&](int n, f32x16& a0, f32x16& a1) {
+            const int u = bid + (n / J) * G, j = n & (J - 1);
+            const unsigned btb = lb + DL_BT + (n & 1) * DL_BT_BYTES;
+            const long R0 = ((long)u * J + j) * 128;
+            auto tap3 = [&](f32x16& acc, int O_rel, int dy) {  // the three dx taps of row offset dy into the block at O_rel
+                const int o = O_rel + i;
+                const int pin = 128 * j + o;
+                const int y = pin >> LOG2S, x = pin & (S - 1);
+                unsigned aA[3];
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int r = o + dy * S + dx;
+                    const bool ok = (unsigned)(y + dy) < (unsigned)S && (unsigned)(x + dx) < (unsigned)S && (unsigned)r < 128u;
+                    aA[dx + 1] = ok ? btb + (r >> 4) * 4096 + (r & 15) * 16 + h * 256 : lb + DL_Z + h * 256;
+                }
+                const unsigned aW = lb + DL_W2 + (dy + 1) * 3 * 8192 + lane * 16;
+                // 24 (dx, k-step) products; the fragment pairs of the next D are in flight while one multiplies (a ring of
+                // D + 2 register pairs: a pair is overwritten two MFMAs after the MFMA that read it)
+                constexpr int D = 6, NSL = D + 2, NE = 24;
+                f32x4 ra[NSL] = {}, rw[NSL] = {};
+                auto request = [&](auto e_c) {
+                    constexpr int e = decltype(e_c)::value, dxi = e / 8, ks = e % 8;
+                    if (!DL_ABL(256)) ra[e % NSL] = lds_read4<ks * 512>(aA[dxi]);
+                    if (!DL_ABL(128)) rw[e % NSL] = lds_read4<dxi * 8192 + ks * 1024>(aW);
+                };
+                static_for<0, D>(request);
+                static_for<0, NE>([&](auto e_c) {
+                    constexpr int e = decltype(e_c)::value;
+                    if constexpr (e + D < NE) request(std::integral_constant<int, e + D>{});
+                    constexpr int younger = 2 * (e + D < NE ? D : NE - 1 - e);
+                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ra[e % NSL]), "+v"(rw[e % NSL]) : "n"(younger));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, rw[e % NSL]),
+                                                                 __builtin_bit_cast(half8, ra[e % NSL]), acc, 0, 0, 0);
+                });
+            };
+            auto store = [&](const f32x16& acc, int O_rel) {
+                _Float16* p = X + (K >> 5) * bstride + (R0 + O_rel + i) * 32 + 4 * h;   // the layer's new block [K / 32]
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    half4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = (_Float16)acc[4 * g + q];
+                    *reinterpret_cast<half4*>(p + 8 * g) = o;
+                }
+            };
+            auto zero = [&](f32x16& acc) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            };
+            // Which blocks this wave works on in this step: accumulator a0 on the block at O0 with row offsets dy = lo0..hi0,
+            // a1 on the block at O1 with lo1..hi1 (an empty range: nothing); zN: the accumulator starts from zero in this
+            // step (else it is carried in from the previous one); sN: it is complete after this step and goes to HBM.
+            int O0, lo0, hi0, O1 = 0, lo1 = 0, hi1 = -1;
+            bool z0, z1 = false, s0, s1 = false;
+            // a step = image rows 2j, 2j + 1; a block = half a row; the step touches output rows 2j - 1 .. 2j + 2.  Wave (g, xh)
+            // works on x half xh and alternates between FINISHING rows 2j - 1 (its dy = +1 taps) and 2j (dy = 0, +1) and
+            // OPENING rows 2j + 1 (dy = -1, 0) and 2j + 2 (dy = -1): 72 MFMAs either way, and what a wave opens in one step
+            // is what it finishes in the next.
+            const int xh = wave & 1;
+            if ((((wave >> 1) + j) & 1) == 0) {
+                O0 = -64 + 32 * xh; lo0 = 1; hi0 = j == 0 ? 0 : 1; z0 = false; s0 = j != 0;
+                O1 = 32 * xh; lo1 = 0; hi1 = 1; z1 = j == 0; s1 = true;
+            } else {
+                O0 = 64 + 32 * xh; lo0 = -1; hi0 = 0; z0 = true; s0 = j == J - 1;
+                O1 = 128 + 32 * xh; lo1 = -1; hi1 = j == J - 1 ? -2 : -1; z1 = true;
+            }
+            if (z0) zero(a0);
+            if (z1) zero(a1);
+            if (DL_ABL(8)) { hi0 = lo0 - 1; hi1 = lo1 - 1; }
+#pragma unroll 1
+            for (int dy = lo0; dy <= hi0; ++dy) tap3(a0, O0, dy);
+            DL_LAP(4);
+            if (s0 && !DL_ABL(64)) store(a0, O0);
+            DL_LAP(5);
+#pragma unroll 1
+            for (int dy = lo1; dy <= hi1; ++dy) tap3(a1, O1, dy);
+            DL_LAP(4);
+            if (s1 && !DL_ABL(64)) store(a1, O1);
+            DL_LAP(5);
+    };
+
+    if (wave < 4) {
+        // ================================================================= back (waves 0-3): tables, W2, then conv2
+        {
+            reinterpret_cast<f32x4*>(lds + DL_Z)[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < 128) {
+                reinterpret_cast<float*>(lds + DL_OT)[t] = sc2[t];
+                reinterpret_cast<float*>(lds + DL_OT + 512)[t] = sh2[t];
+            }
+            for (int k = t; k < K; k += 256) {                 // norm1's table: [stage][column][scale 8 | shift 8]
+                float* d = reinterpret_cast<float*>(lds + DL_CT) + (k >> 3) * 16 + (k & 7);
+                d[0] = sc1[k];
+                d[8] = sh1[k];
+            }
+            const __amdgpu_buffer_rsrc_t rW2 =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(w2p), 0, DL_W2_BYTES, 0x00020000);
+#pragma unroll
+            for (int p = 0; p < 18; ++p) {
+                const int piece = wave + 4 * p;
+                dma16_buf(rW2, lane * 16, piece * 1024, lb + DL_W2 + piece * 1024);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of W2
+        lds_barrier();                                         // B_init: tables and W2 are in the LDS
+        f32x16 a0, a1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+        for (int n = 0; n <= N; ++n) {                         // barrier n: tile n is complete, tile n - 1 is free
+            if (n >= 1) conv2_step(n - 1, a0, a1);
+            DL_LAP(6);
+            if (n < N) lds_barrier();
+            DL_LAP(0);
+        }
+        if (wave == 0) DL_OUT(0);
+        return;
+    }
+
+    // ===================================================================== front (waves 4-7): conv1 of step n -> tile n & 1
+    const int fw = wave - 4, ph = fw & 1, ch = fw >> 1;         // pixels 64 ph .. + 63, bottleneck channels 64 ch .. + 63
+    const int KS = K >> 4;
+    const __amdgpu_buffer_rsrc_t rW1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(w1p), 0, (unsigned)(128 * K * 2), 0x00020000);
+    // Both operand streams run CONTINUOUSLY over all the workgroup's steps through register rings of four stages (a stage = 32
+    // input channels): the input fragments [pixel block][k-step] three stages ahead (raw: norm1 is applied when the stage is
+    // used; at K = 64 that is a step and a half ahead - an HBM miss under load takes 2-3 thousand cycles), the W1 fragments
+    // [channel block][k-step] two ahead (L2 hits, ~1000 cycles when every CU asks for the same lines).  Inline asm loads with
+    // hand-counted waits (the compiler drains its own loads at every trip of a loop like this one); per stage the wave issues
+    // x(g + 3) then W(g + 2), so behind x(g) there are 7 younger groups of four loads and behind W(g) four.  Every load is
+    // waited for before its registers die.  Past the end of the stream the offsets leave the resource: zeros, no traffic.
+    u32x4 rx[4][2][2], rw[4][2][2];
+    const int vX = i * 64 + h * 16;                            // lane (pixel i, k half h) in a [64 px][64 B] window
+    auto step_rows = [&](int n) {                              // this wave's 64 pixel rows of step n, channel block 0
+        const int u = bid + (n / J) * G, j = n & (J - 1);
+        return static_cast<const _Float16*>(X) + (((long)u * J + j) * 128 + 64 * ph) * 32;
+    };
+    int xn = 0, xs = 0;                                        // step / stage of the next input load
+    const _Float16* xrows = step_rows(0);
+    auto load_x = [&](u32x4(&dst)[2][2]) {
+        const bool in = xn < N && !DL_ABL(4);
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<_Float16*>(xrows) + (in ? xs : 0) * bstride, 0, 4096, 0x00020000);
+        const int vo = vX + (in ? 0 : 0x7f000000);
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst[0][0]) : "v"(vo), "s"(r) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:32" : "=v"(dst[0][1]) : "v"(vo), "s"(r) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:2048" : "=v"(dst[1][0]) : "v"(vo), "s"(r) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:2080" : "=v"(dst[1][1]) : "v"(vo), "s"(r) : "memory");
+        if (++xs == nst) {
+            xs = 0;
+            ++xn;
+            xrows = step_rows(xn < N ? xn : 0);
+        }
+    };
+    int wn = 0, ws = 0;                                        // step / stage of the next W1 load (the stage wraps with the step)
+    auto load_w = [&](u32x4(&dst)[2][2]) {
+        const bool in = wn < N && !DL_ABL(32);
+        const int vo = lane * 16 + (in ? 0 : 0x7f000000);
+        const int so0 = (2 * ch * KS + 2 * ws) * 1024, so1 = so0 + KS * 1024;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst[0][0]) : "v"(vo), "s"(rW1), "s"(so0) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(dst[0][1]) : "v"(vo), "s"(rW1), "s"(so0) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst[1][0]) : "v"(vo), "s"(rW1), "s"(so1) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(dst[1][1]) : "v"(vo), "s"(rW1), "s"(so1) : "memory");
+        if (++ws == nst) {
+            ws = 0;
+            ++wn;
+        }
+    };
+    ActRegs ac[2];                                             // norm1 constants of the stage used next, per k-step
+    const unsigned ctb = lb + DL_CT + 64 * h;
+    auto request_consts = [&](int ss) {
+        const unsigned a = ctb + ss * 256;
+        ac[0].s0 = lds_read4<0>(a);
+        ac[0].s1 = lds_read4<16>(a);
+        ac[0].b0 = lds_read4<32>(a);
+        ac[0].b1 = lds_read4<48>(a);
+        ac[1].s0 = lds_read4<128>(a);
+        ac[1].s1 = lds_read4<144>(a);
+        ac[1].b0 = lds_read4<160>(a);
+        ac[1].b1 = lds_read4<176>(a);
+    };
+    f32x16 c1[2][2];                                           // [channel block][pixel block]
+    auto zero_c1 = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c1[q >> 1][q & 1][r] = 0.f;
+    };
+    // ---- norm2 + relu2, rounded to fp16, into the bottleneck tile of the step's parity.  One base register per table and
+    // immediate offsets for everything static (written plainly, the compiler hoists 30-odd per-store addresses out of the stage
+    // loop and spills ring registers to make room for them)
+    const unsigned ot_base = lb + DL_OT + (64 * ch + 4 * h) * 4;
+    const unsigned bt_base = lb + DL_BT + ((64 * ph + i) >> 4) * 4096 + (i & 15) * 16 + 8 * h + 8 * ch * 256;
+    auto epilogue = [&](int parity) {
+        const unsigned bt = bt_base + parity * DL_BT_BYTES;
+        if (!DL_ABL(16))
+        static_for<0, 8>([&](auto q_c) {
+            constexpr int nbl = decltype(q_c)::value >> 2, g = decltype(q_c)::value & 3;
+            const f32x4 osc = lds_read4<(32 * nbl + 8 * g) * 4>(ot_base);
+            const f32x4 osh = lds_read4<512 + (32 * nbl + 8 * g) * 4>(ot_base);
+            f32x4 sc_ = osc, sh_ = osh;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sc_), "+v"(sh_));
+            static_for<0, 2>([&](auto r_c) {
+                constexpr int rbl = decltype(r_c)::value;
+                unsigned o0, o1;                               // fp32 fma rounded once to fp16 (v_fma_mix), relu packed
+                asm("v_fma_mixlo_f16 %0, %1, %2, %3\n\t"
+                    "v_fma_mixhi_f16 %0, %4, %5, %6\n\t"
+                    "v_pk_max_f16 %0, %0, 0"
+                    : "=&v"(o0)
+                    : "v"(c1[nbl][rbl][4 * g]), "v"(sc_[0]), "v"(sh_[0]), "v"(c1[nbl][rbl][4 * g + 1]), "v"(sc_[1]), "v"(sh_[1]));
+                asm("v_fma_mixlo_f16 %0, %1, %2, %3\n\t"
+                    "v_fma_mixhi_f16 %0, %4, %5, %6\n\t"
+                    "v_pk_max_f16 %0, %0, 0"
+                    : "=&v"(o1)
+                    : "v"(c1[nbl][rbl][4 * g + 2]), "v"(sc_[2]), "v"(sh_[2]), "v"(c1[nbl][rbl][4 * g + 3]), "v"(sc_[3]), "v"(sh_[3]));
+                const uint2 ov = make_uint2(o0, o1);
+                const unsigned btl = bt;                       // (an asm operand cannot name a capture of an enclosing lambda)
+                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(btl), "v"(ov), "n"(rbl * 8192 + (4 * nbl + g) * 256) : "memory");
+            });
+        });
+    };
+    auto stage = [&](auto ph_c, int s) {                       // (s: the stage's index in its step)
+        constexpr int P = decltype(ph_c)::value;
+        // (the stage's own norm1 constants, requested here and not a stage early: carried across the step's end they cost 60
+        // registers more than the file has; the eight load issues below cover most of the LDS latency)
+        request_consts(s);
+        load_x(rx[(P + 3) & 3]);
+        load_w(rw[(P + 2) & 3]);
+        asm volatile("s_waitcnt vmcnt(28)" : "+v"(rx[P][0][0]), "+v"(rx[P][0][1]), "+v"(rx[P][1][0]), "+v"(rx[P][1][1])::"memory");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ac[0].s0), "+v"(ac[0].s1), "+v"(ac[0].b0), "+v"(ac[0].b1), "+v"(ac[1].s0), "+v"(ac[1].s1),
+                       "+v"(ac[1].b0), "+v"(ac[1].b1));
+        u32x4 av[2][2];
+#pragma unroll
+        for (int rbl = 0; rbl < 2; ++rbl)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) av[rbl][ks] = DL_ABL(1) ? rx[P][rbl][ks] : activated(rx[P][rbl][ks], ac[ks]);
+        asm volatile("s_waitcnt vmcnt(16)" : "+v"(rw[P][0][0]), "+v"(rw[P][0][1]), "+v"(rw[P][1][0]), "+v"(rw[P][1][1])::"memory");
+        if (!DL_ABL(2))
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nbl = 0; nbl < 2; ++nbl)
+#pragma unroll
+                for (int rbl = 0; rbl < 2; ++rbl)
+                    c1[nbl][rbl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, rw[P][nbl][ks]),
+                                                                          __builtin_bit_cast(half8, av[rbl][ks]), c1[nbl][rbl],
+                                                                          0, 0, 0);
+    };
+
+    load_x(rx[0]);
+    load_x(rx[1]);
+    load_w(rw[0]);
+    load_x(rx[2]);
+    load_w(rw[1]);
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(rx[0][0][0]), "+v"(rx[0][0][1]), "+v"(rx[0][1][0]), "+v"(rx[0][1][1]), "+v"(rx[1][0][0]), "+v"(rx[1][0][1]),
+                   "+v"(rx[1][1][0]), "+v"(rx[1][1][1]), "+v"(rx[2][0][0]), "+v"(rx[2][0][1]), "+v"(rx[2][1][0]), "+v"(rx[2][1][1]),
+                   "+v"(rw[0][0][0]), "+v"(rw[0][0][1]), "+v"(rw[0][1][0]), "+v"(rw[0][1][1]), "+v"(rw[1][0][0]), "+v"(rw[1][0][1]),
+                   "+v"(rw[1][1][0]), "+v"(rw[1][1][1])::"memory");
+    lds_barrier();                                             // B_init
+    zero_c1();
+    const int Gt = N * nst;
+    // (the step / stage counters are plain locals of this scope, never captured: captured by the lambdas they ended up in
+    // scratch memory, i.e. per lane - divergent branches and scratch loads in the middle of the hand-counted stream)
+    int n = 0, s = 0;                                          // the step / stage being multiplied
+#define DL_ST(k)                                                                                     \
+    stage(std::integral_constant<int, k>{}, s);                                                       \
+    if (s + 1 == nst) {                                                                               \
+        DL_LAP(0);                                                                                    \
+        epilogue(n & 1);                                                                              \
+        DL_LAP(1);                                                                                    \
+        lds_barrier(); /* barrier n: tile n is complete, tile n - 1 is free */                        \
+        DL_LAP(2);                                                                                    \
+        zero_c1();                                                                                    \
+        s = 0;                                                                                        \
+        ++n;                                                                                          \
+    } else {                                                                                          \
+        ++s;                                                                                          \
+    }                                                                                                 \
+    if (g + k + 1 >= Gt) break;
+    if (Gt > 0)
+        for (int g = 0;; g += 4) { DL_ST(0) DL_ST(1) DL_ST(2) DL_ST(3) }
+#undef DL_ST
+    // the stages requested past the end of the stream (out of range: zeros) must land before anything reuses their registers;
+    // naming all 32 ring registers here would keep them live through the whole loop (253 spills): a bare wait that nothing
+    // may be scheduled across does the same
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave == 4) DL_OUT(8);
+}
+
 // W1 [128][K] fp32 -> fragment order halves: ((nb * K/16 + ks) * 64 + lane) * 8 + q = W[32 nb + (lane & 31)][16 ks + 8 (lane >> 5) + q]
 __global__ void dl_pack_w1_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int K) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -679,7 +1023,10 @@ GNX_EXPORT int gnx_dense_layer_f16(void* X16, long rows_total, long n_img, int S
         case 8: GNX_DL(8);
         case 16: GNX_DL(16);
         case 32: GNX_DL(32);
-        case 64: GNX_DL(64);
+        case 64:
+            dense_layer_f16_s64_kernel<<<grid, 512, 0, stream>>>(X, rows_total * 32, (int)units, K, w1, w2, scale1, shift1,
+                                                                 scale2, shift2 GNX_DL_STAMP_ARG);
+            return gnx_launch_status();
         default: break;
     }
 #undef GNX_DL

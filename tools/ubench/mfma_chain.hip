@@ -22,6 +22,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 // MODE bits: 1 = no A (activation) reads, 2 = no W reads, 4 = two accumulator chains (even / odd products),
+//            32 / 64 = the MFMA as inline asm with its accumulator in arch / acc VGPRs,
 //            8 = waves 4-7 stay resident and spin on s_sleep (a second, idle wave per SIMD), 16 = random-ish lane addresses for A
 template <int MODE, int D, int NTHR>
 __global__ __launch_bounds__(NTHR) void k(float* out, unsigned long long* cyc, int calls, float seed) {
@@ -62,7 +63,11 @@ __global__ __launch_bounds__(NTHR) void k(float* out, unsigned long long* cyc, i
             constexpr int per = ((MODE & 1) ? 0 : 1) + ((MODE & 2) ? 0 : 1);
             constexpr int younger = per * (e + D < NE ? D : NE - 1 - e);
             asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ra[e % NSL]), "+v"(rw[e % NSL]) : "n"(younger));
-            if ((MODE & 4) && (e & 1))
+            if (MODE & 32)                                      // accumulator pinned in ARCH VGPRs
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(rw[e % NSL]), "v"(ra[e % NSL]));
+            else if (MODE & 64)                                 // accumulator pinned in ACC VGPRs
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(rw[e % NSL]), "v"(ra[e % NSL]));
+            else if ((MODE & 4) && (e & 1))
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, rw[e % NSL]),
                                                               __builtin_bit_cast(half8, ra[e % NSL]), acc2, 0, 0, 0);
             else
@@ -115,5 +120,9 @@ int main() {
     run<0, 3, 256>("D=3, A+W", out, cyc, calls);
     run<0, 4, 256>("D=4, A+W", out, cyc, calls);
     run<16, 6, 256>("D=6, A rows spread over 16 pixel groups", out, cyc, calls);
+    run<32, 6, 256>("D=6, A+W, accumulator in arch VGPRs (asm)", out, cyc, calls);
+    run<64, 6, 256>("D=6, A+W, accumulator in acc VGPRs (asm)", out, cyc, calls);
+    run<32 | 3, 6, 256>("no reads, accumulator in arch VGPRs (asm)", out, cyc, calls);
+    run<64 | 3, 6, 256>("no reads, accumulator in acc VGPRs (asm)", out, cyc, calls);
     return 0;
 }
