@@ -5,15 +5,19 @@
 // this kernel moves 26.6 MB - the K input columns in, 32 columns out, nothing else.
 //
 // Work unit: an image (S x S map of one spot) for S >= 16, swept top to bottom in steps of 128 pixels; a tile of 128
-// pixels (whole images) for S <= 8.  One persistent workgroup per CU, 8 waves:
-//   waves 4-7 (producers): stream the step's [128 px][K] input strip global -> LDS by buffer DMA in stages of 32 channels
-//     (a ring of 6 x 8 KB, four stages in flight), apply norm1 + relu1 in place on the stage they fetched (fp32 fma on the
-//     fp16 value, one rounding: v_fma_mix), one stage ahead of the consumers;
+// pixels (whole images) for S <= 8.  One persistent workgroup per CU, 8 waves.  Two kernels:
+// * dense_layer_f16_kernel<S> (S <= 32, K up to 992 - HBM-side):
+//   waves 4-7 (feeders): the [128 px][K] input strip of every step, in stages of 32 channels, global -> registers ->
+//     norm1 + relu1 (fp32 fma on the fp16 value, one rounding: v_fma_mix) -> LDS slot; the stages of ALL the workgroup's
+//     steps are one stream through an 8-deep register ring (seven stages = 56 KB per CU in flight);
 //   waves 0-3 (consumers): conv1 as [128 ch] x [128 px] per step, wave w owning output channels 32w..32w+31 for all 128
 //     pixels (its W1 fragments come straight from global memory in a pre-packed fragment order: 1 KB coalesced per
-//     fragment, three stages ahead, no LDS); norm2 + relu2 on the accumulators; the activated bottleneck tile
-//     [128 px][128 ch] goes to LDS as fp16 - and never to HBM; conv2 reads it back with per-tap shifted fragment addresses
-//     (W2, 72 KB in fragment order, is LDS-resident for the workgroup's lifetime).
+//     fragment, no LDS), two stages per workgroup barrier; norm2 + relu2 on the accumulators; the activated bottleneck
+//     tile [128 px][128 ch] goes to LDS as fp16 - and never to HBM; conv2 reads it back with per-tap shifted fragment
+//     addresses (W2, 72 KB in fragment order, is LDS-resident for the workgroup's lifetime).
+// * dense_layer_f16_s64_kernel (64 x 64 maps, K <= 224 - few conv1 stages in front of 288 conv2 MFMAs per step): conv1 of
+//   step n (waves 4-7, operands straight from global memory) overlaps conv2 of step n - 1 (waves 0-3) through a
+//   double-buffered bottleneck tile; see there.
 // conv2 runs in SCATTER form so that the LDS holds only the step's own bottleneck rows (32 KB) instead of a ring with halo
 // rows: a step's bottleneck rows are multiplied into every output row they touch - the previous step's last row (its
 // dy = +1 taps), the step's own rows, the next step's first row (dy = -1) - and the accumulators of output rows that still
@@ -44,7 +48,6 @@ constexpr int DL_OT = DL_Z + 4096;             // norm2: scale[128], shift[128]
 constexpr int DL_CT = DL_OT + 1024;            // norm1 of the whole layer: [stage][16-B column 4][scale 8 | shift 8] floats (K <= 1024)
 constexpr int DL_LDS = DL_CT + 8192;
 static_assert(DL_LDS <= 160 * 1024, "LDS");
-constexpr int DL_PF = 3;                       // W1 fragment stages in flight ahead of their use
 
 // Diagnostic build only (tools/ubench/dl_stamps.py compiles this file with -DGNX_DL_STAMP into its own library): per
 // workgroup, wave 0 and wave 4 sum the shader cycles they spend in each segment of a step and leave them in a buffer of
@@ -75,7 +78,8 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                                                               const float* __restrict__ sc2, const float* __restrict__ sh2
                                                               GNX_DL_STAMP_PARAM) {
     constexpr int J = S >= 16 ? S * S / 128 : 1;           // steps per unit
-    constexpr int LOG2S = S == 64 ? 6 : S == 32 ? 5 : S == 16 ? 4 : S == 8 ? 3 : 2;
+    constexpr int LOG2S = S == 32 ? 5 : S == 16 ? 4 : S == 8 ? 3 : 2;
+    static_assert(S <= 32, "64 x 64 maps: dense_layer_f16_s64_kernel");
     __shared__ __attribute__((aligned(16))) char lds[DL_LDS];
     const int t = threadIdx.x, lane = t & 63, h = lane >> 5, i = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -163,18 +167,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             // step (else it is carried in from the previous one); sN: it is complete after this step and goes to HBM.
             int O0, lo0, hi0, O1 = 0, lo1 = 0, hi1 = -1;
             bool z0, z1 = false, s0, s1 = false;
-            if constexpr (S == 64) {
-                // a step = image rows 2j, 2j + 1; a block = half a row; the step touches output rows 2j - 1 .. 2j + 2, i.e. eight
-                // blocks, one per wave: wave (ph, xh) owns the rows congruent to ph mod 4 (x half xh), so a row that waits for the
-                // next step stays with its wave.  Rows 2j - 1 and 2j are finished here (their dy = -1 / 0 taps came last step),
-                // rows 2j + 1 and 2j + 2 are opened.
-                const int xh = wave & 1, m = ((wave >> 1) - 2 * j + 1) & 3;
-                O0 = (m == 0 ? -64 : m == 1 ? 0 : m == 2 ? 64 : 128) + 32 * xh;
-                lo0 = m == 0 ? 1 : m == 1 ? 0 : -1;
-                hi0 = m == 0 ? (j == 0 ? 0 : 1) : m == 1 ? 1 : m == 2 ? 0 : (j == J - 1 ? -2 : -1);
-                z0 = m >= 2 || (m == 1 && j == 0);
-                s0 = m == 0 ? j != 0 : m == 1 ? true : m == 2 ? j == J - 1 : false;
-            } else if constexpr (S >= 16) {
+            if constexpr (S >= 16) {
                 // S = 32: a block = one image row, a step = 4 rows; S = 16: a block = two rows, a step = 8 rows - there the
                 // head's own block still lacks the dy = -1 taps of its second row and the tail's block the dy = +1 taps of
                 // its first (their other lanes are outside the tile: zeros).
@@ -208,25 +201,13 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             DL_LAP(5);
     };
 
-    f32x16 fa0, fa1;                                           // conv2 accumulators of the feeder waves (S = 64 only)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { fa0[r] = 0.f; fa1[r] = 0.f; }
-    // the step after (u, j) in this workgroup's sequence (u >= n_units: none)
-    auto next_step = [&](int& u, int& j) {
-        if (++j == J) { j = 0; u += G; }
-    };
-
     if (wave >= 4) {
         // ================================================================= feeders (waves 4-7)
-        // The input strip of a step goes global -> REGISTERS -> (norm1 + relu1) -> LDS.  The first version of this kernel
-        // moved it by LDS-DMA into a ring of raw stages that was then activated in place: its stage loop ran at 8 KB per
-        // 0.52 us and CU whatever was done to the waves around it - ring depth 5 or 6, two or four issuing waves, the
-        // activation split over two stages or shared with the consumers - because the LDS-DMA path itself delivers ~25 GB/s
-        // per CU (0.35 us per stage, stamped as the issue time of the loader waves) and every wave of the workgroup then
-        // waited for the loaders at the stage's barrier.  Plain buffer loads do not block their wave, keep three stages in
-        // flight in 24 registers, and let the activation happen on the way - no LDS round trip, half the LDS traffic.
-        // Feeder f takes pixels 32 f .. 32 f + 31 of every stage (two 1-KB pieces: lane = pixel (lane & 15) of the piece,
-        // 16-B column lane >> 4), consumers only multiply.
+        // The input strip of a step goes global -> REGISTERS -> (norm1 + relu1) -> LDS.  (The first version moved it by LDS-DMA
+        // into a ring of raw stages that was then activated in place: 8 KB per 0.52 us and CU whatever the ring depth or the
+        // number of issuing waves - the LDS-DMA path itself delivers ~25 GB/s per CU.)  Feeder f takes pixels 32 f .. 32 f + 31
+        // of every stage (two 1-KB pieces: lane = pixel (lane & 15) of the piece, 16-B column lane >> 4), consumers only
+        // multiply.
         const int fw = wave - 4;
         {
             const int pt = t - 256;                            // 0..255
@@ -254,198 +235,108 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
         // pixel rows are ONE contiguous 2 KB of memory (in a row-major [row][channels] buffer they were 32 pieces of 64 B,
         // 0.5-2 KB apart - whatever carried them, LDS-DMA or register loads, that stream stayed at ~4 TB/s)
         const int voffA = ((lane & 15) * 32 + 8 * (lane >> 4)) * 2;
-        const int voffB = voffA + 1024;                        // the second piece: 16 pixel rows further
-        u32x4 rr[4][2];                                        // raw ring [stage & 3][piece]
-        // (a stage index past the step's last one makes the offset exceed the resource's extent: zeros, no memory traffic -
-        // no branch, so the compiler counts the loads in flight exactly)
-        auto load_raw = [&](u32x4(&dst)[2], const _Float16* strip0, int ss) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<_Float16*>(strip0) + (ss < nst ? ss : 0) * bstride, 0, 2048, 0x00020000);
-            const int inb = (ss < nst && !DL_ABL(4)) ? 0 : 0x7f000000;
-            dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voffA + inb, 0, 0);
-            dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voffB + inb, 0, 0);
-        };
         auto strip = [&](int u, int j) {                       // this feeder's 32 pixel rows of step (u, j), channel block 0
             return static_cast<const _Float16*>(X) + (((long)u * J + j) * 128 + 32 * fw) * 32;
         };
-        ActRegs ac;                                            // constants of the stage applied next (requested a stage early)
         const unsigned ctb = lb + DL_CT + 64 * (lane >> 4);
-        auto request_consts = [&](int ss) {
-            const unsigned a = ctb + (ss < nst ? ss : 0) * 256;
-            ac.s0 = lds_read4<0>(a);
-            ac.s1 = lds_read4<16>(a);
-            ac.b0 = lds_read4<32>(a);
-            ac.b1 = lds_read4<48>(a);
-        };
-        auto apply = [&](u32x4(&raw)[2], int sl) {             // -> LDS slot sl, pieces 2 fw and 2 fw + 1
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ac.s0), "+v"(ac.s1), "+v"(ac.b0), "+v"(ac.b1));
-            char* d = lds + DL_AR + sl * DL_SLOT + 2 * fw * 1024 + lane * 16;
-            if (!DL_ABL(1)) {
-                *reinterpret_cast<u32x4*>(d) = activated(raw[0], ac);
-                *reinterpret_cast<u32x4*>(d + 1024) = activated(raw[1], ac);
-            }
-        };
-        auto fstage = [&](auto ph_c, int s, const _Float16* rs) {
-            constexpr int P = decltype(ph_c)::value;
-            lds_barrier();                                     // B_s: stage s is visible, slot (s + 1) & 3 is free
-            DL_LAP(0);
-            if (s + 1 < nst && s + 1 >= 3) apply(rr[(P + 1) & 3], (P + 1) & 3);   // (stages 0..2: pre_apply)
-            DL_LAP(1);
-            request_consts(s + 2);
-            load_raw(rr[(P + 3) & 3], rs, s + 3);
-            DL_LAP(2);
-        };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of W2
-        if constexpr (S < 64) {
-            // One continuous stream of stages over all the workgroup's steps: global stage g = n * nst + s sits in register
-            // ring entry g & 7 (compile-time in the 8-fold unrolled loop; the LDS slot is the step's stage & 3), so seven stages
-            // (56 KB per CU) are in flight whatever the step length - an HBM miss takes ~900 cycles on an idle chip and two
-            // to three times that under load, three stages in flight (the first form of this loop) left the stream
-            // latency-bound at ~1100 cycles per stage where the HBM rate allows ~650.
-            constexpr int RD = 8;
-            u32x4 rq[RD][2];
-            int lu = bid, lj = 0, ls = 0;                      // the next load: unit, step, stage
-            const _Float16* lrows = strip(lu, lj);
-            // (inline asm: the compiler's own vmcnt bookkeeping gives up on a ring this deep in a loop and drains it - it
-            // waited vmcnt(1) where 14 younger loads were in flight; these loads are therefore invisible to it and every use
-            // waits by hand: exactly RD stages are outstanding at each apply, the oldest is the one applied.  The feeders
-            // issue no other vector-memory operation after the prologue.)
-            auto load_next = [&](u32x4(&dst)[2]) {
-                const bool in = lu < n_units && !DL_ABL(4);
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<_Float16*>(lrows) + (in ? ls : 0) * bstride, 0, 2048, 0x00020000);
-                const int vo = voffA + (in ? 0 : 0x7f000000);
-                if (!DL_ABL(512))
-                asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:1024"
-                             : "=&v"(dst[0]), "=&v"(dst[1]) : "v"(vo), "s"(rs) : "memory");
-                if (++ls == nst) {
-                    ls = 0;
-                    if (++lj == J) { lj = 0; lu += G; }
-                    lrows = strip(lu < n_units ? lu : bid, lj);
-                }
-            };
-            auto landed = [&](u32x4(&v)[2]) {                  // the oldest of the RD stages in flight
-                if (!DL_ABL(512))
-                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0]), "+v"(v[1]) : "n"(2 * RD - 2) : "memory");
-            };
-            const int Gt = (bid < n_units ? ((n_units - bid + G - 1) / G) * J : 0) * nst;   // this workgroup's stages
-            static_for<0, RD>([&](auto k_c) { load_next(rq[decltype(k_c)::value]); });
-            lds_barrier();                                     // B_init: tables and W2 are in the LDS
-            // The consumers take the step's stages in PAIRS (one barrier per 64 channels): pair p sits in slots (2p, 2p + 1) & 3
-            // and is read between the barriers B_p and B_p+1, the feeders write pair p + 1 meanwhile; the next step's first
-            // pair goes in after the E barrier.  norm1 constants: two register sets, requested two stages ahead.
-            ActRegs ak[2];
-            auto request_k = [&](ActRegs& c, int ss) {
-                if (DL_ABL(1024)) return;
-                const unsigned a = ctb + ss * 256;
-                c.s0 = lds_read4<0>(a);
-                c.s1 = lds_read4<16>(a);
-                c.b0 = lds_read4<32>(a);
-                c.b1 = lds_read4<48>(a);
-            };
-            auto wrap = [&](int x) {
-                while (x >= nst) x -= nst;
-                return x;
-            };
-            request_k(ak[0], 0);
-            request_k(ak[1], wrap(1));
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ak[0].s0), "+v"(ak[0].s1), "+v"(ak[0].b0), "+v"(ak[0].b1), "+v"(ak[1].s0),
-                                                  "+v"(ak[1].s1), "+v"(ak[1].b0), "+v"(ak[1].b1));
-            int sa = 0;                                        // in-step index of the stage applied next
-            auto gapply = [&](auto ph_c, int g) {
-                constexpr int P = decltype(ph_c)::value;
-                if (sa == 0) {
-                    if (g > 0) {
-                        lds_barrier();                         // the previous step's last pair barrier
-                        DL_LAP(0);
-                        lds_barrier();                         // E: its bottleneck tile is complete, every slot is free
-                        DL_LAP(3);
-                    }
-                } else if ((sa & 1) == 0) {
-                    lds_barrier();                             // B_(sa / 2 - 1): pair sa / 2 - 2 has been read
-                    DL_LAP(0);
-                }
-                landed(rq[P]);
-                DL_LAP(7);
-                ActRegs& c = ak[P & 1];
-                // this stage's constants were requested two stages ago; younger LDS operations of this wave: the previous
-                // stage's two writes and its four constant reads - they stay in flight
-                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(c.s0), "+v"(c.s1), "+v"(c.b0), "+v"(c.b1));
-                char* d = lds + DL_AR + (sa & 3) * DL_SLOT + 2 * fw * 1024 + lane * 16;
-                if (!DL_ABL(1)) {
-                    *reinterpret_cast<u32x4*>(d) = activated(rq[P][0], c);
-                    *reinterpret_cast<u32x4*>(d + 1024) = activated(rq[P][1], c);
-                }
-                DL_LAP(1);
-                load_next(rq[P]);
-                request_k(c, wrap(sa + 2));
-                sa = sa + 1 == nst ? 0 : sa + 1;
-                DL_LAP(2);
-            };
-#define DL_GS(k) gapply(std::integral_constant<int, k>{}, g + k); if (g + k + 1 >= Gt) break;
-            if (Gt > 0) {
-                for (int g = 0;; g += RD) { DL_GS(0) DL_GS(1) DL_GS(2) DL_GS(3) DL_GS(4) DL_GS(5) DL_GS(6) DL_GS(7) }
-                lds_barrier();                                 // the last step's last pair barrier and E
-                lds_barrier();
-            }
-#undef DL_GS
-            // the stages requested past the end of the stream: nothing may reuse their registers before they have landed
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[1][0]), "+v"(rq[1][1]), "+v"(rq[2][0]), "+v"(rq[2][1]),
-                           "+v"(rq[3][0]), "+v"(rq[3][1]), "+v"(rq[4][0]), "+v"(rq[4][1]), "+v"(rq[5][0]), "+v"(rq[5][1]),
-                           "+v"(rq[6][0]), "+v"(rq[6][1]), "+v"(rq[7][0]), "+v"(rq[7][1])::"memory");
-            if (wave == 4) DL_OUT(8);
-            return;
-        }
-        int u = bid, j = 0;
-        const _Float16* rs = strip(u, j);
-        load_raw(rr[0], rs, 0);
-        load_raw(rr[1], rs, 1);
-        load_raw(rr[2], rs, 2);
-        // A step's first three stages go into their slots right after the previous step's E barrier (every slot is free then),
-        // BEFORE this wave's share of conv2: the consumers come out of conv2 and find them there - applied after conv2, one
-        // per stage barrier, they were 2200 of a K = 64 step's 8100 consumer cycles.
-        auto pre_apply = [&]() {
-            request_consts(0);
-            apply(rr[0], 0);
-            if (nst > 1) {
-                request_consts(1);
-                apply(rr[1], 1);
-            }
-            if (nst > 2) {
-                request_consts(2);
-                apply(rr[2], 2);
+        // One continuous stream of stages over all the workgroup's steps: global stage g = n * nst + s sits in register
+        // ring entry g & 7 (compile-time in the 8-fold unrolled loop; the LDS slot is the step's stage & 3), so seven stages
+        // (56 KB per CU) are in flight whatever the step length - an HBM miss takes ~900 cycles on an idle chip and two
+        // to three times that under load, three stages in flight (the first form of this loop) left the stream
+        // latency-bound at ~1100 cycles per stage where the HBM rate allows ~650.
+        constexpr int RD = 8;
+        u32x4 rq[RD][2];
+        int lu = bid, lj = 0, ls = 0;                      // the next load: unit, step, stage
+        const _Float16* lrows = strip(lu, lj);
+        // (inline asm: the compiler's own vmcnt bookkeeping gives up on a ring this deep in a loop and drains it - it
+        // waited vmcnt(1) where 14 younger loads were in flight; these loads are therefore invisible to it and every use
+        // waits by hand: exactly RD stages are outstanding at each apply, the oldest is the one applied.  The feeders
+        // issue no other vector-memory operation after the prologue.)
+        auto load_next = [&](u32x4(&dst)[2]) {
+            const bool in = lu < n_units && !DL_ABL(4);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<_Float16*>(lrows) + (in ? ls : 0) * bstride, 0, 2048, 0x00020000);
+            const int vo = voffA + (in ? 0 : 0x7f000000);
+            if (!DL_ABL(512))
+            asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:1024"
+                         : "=&v"(dst[0]), "=&v"(dst[1]) : "v"(vo), "s"(rs) : "memory");
+            if (++ls == nst) {
+                ls = 0;
+                if (++lj == J) { lj = 0; lu += G; }
+                lrows = strip(lu < n_units ? lu : bid, lj);
             }
         };
-        lds_barrier();                                         // B_init: tables and W2 are in the LDS
-        pre_apply();
-        while (u < n_units) {
-            for (int s = 0;; s += 4) {
-                fstage(std::integral_constant<int, 0>{}, s, rs);
-                if (s + 1 >= nst) break;
-                fstage(std::integral_constant<int, 1>{}, s + 1, rs);
-                if (s + 2 >= nst) break;
-                fstage(std::integral_constant<int, 2>{}, s + 2, rs);
-                if (s + 3 >= nst) break;
-                fstage(std::integral_constant<int, 3>{}, s + 3, rs);
-                if (s + 4 >= nst) break;
+        auto landed = [&](u32x4(&v)[2]) {                  // the oldest of the RD stages in flight
+            if (!DL_ABL(512))
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0]), "+v"(v[1]) : "n"(2 * RD - 2) : "memory");
+        };
+        const int Gt = (bid < n_units ? ((n_units - bid + G - 1) / G) * J : 0) * nst;   // this workgroup's stages
+        static_for<0, RD>([&](auto k_c) { load_next(rq[decltype(k_c)::value]); });
+        lds_barrier();                                     // B_init: tables and W2 are in the LDS
+        // The consumers take the step's stages in PAIRS (one barrier per 64 channels): pair p sits in slots (2p, 2p + 1) & 3
+        // and is read between the barriers B_p and B_p+1, the feeders write pair p + 1 meanwhile; the next step's first
+        // pair goes in after the E barrier.  norm1 constants: two register sets, requested two stages ahead.
+        ActRegs ak[2];
+        auto request_k = [&](ActRegs& c, int ss) {
+            if (DL_ABL(1024)) return;
+            const unsigned a = ctb + ss * 256;
+            c.s0 = lds_read4<0>(a);
+            c.s1 = lds_read4<16>(a);
+            c.b0 = lds_read4<32>(a);
+            c.b1 = lds_read4<48>(a);
+        };
+        auto wrap = [&](int x) {
+            while (x >= nst) x -= nst;
+            return x;
+        };
+        request_k(ak[0], 0);
+        request_k(ak[1], wrap(1));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ak[0].s0), "+v"(ak[0].s1), "+v"(ak[0].b0), "+v"(ak[0].b1), "+v"(ak[1].s0),
+                                              "+v"(ak[1].s1), "+v"(ak[1].b0), "+v"(ak[1].b1));
+        int sa = 0;                                        // in-step index of the stage applied next
+        auto gapply = [&](auto ph_c, int g) {
+            constexpr int P = decltype(ph_c)::value;
+            if (sa == 0) {
+                if (g > 0) {
+                    lds_barrier();                         // the previous step's last pair barrier
+                    DL_LAP(0);
+                    lds_barrier();                         // E: its bottleneck tile is complete, every slot is free
+                    DL_LAP(3);
+                }
+            } else if ((sa & 1) == 0) {
+                lds_barrier();                             // B_(sa / 2 - 1): pair sa / 2 - 2 has been read
+                DL_LAP(0);
             }
-            // the next step's first three stages: requested before the epilogue / conv2 phase, which hides their latency
-            const int cu = u, cj = j;
-            next_step(u, j);
-            if (u < n_units) {
-                rs = strip(u, j);
-                load_raw(rr[0], rs, 0);
-                load_raw(rr[1], rs, 1);
-                load_raw(rr[2], rs, 2);
+            landed(rq[P]);
+            DL_LAP(7);
+            ActRegs& c = ak[P & 1];
+            // this stage's constants were requested two stages ago; younger LDS operations of this wave: the previous
+            // stage's two writes and its four constant reads - they stay in flight
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(c.s0), "+v"(c.s1), "+v"(c.b0), "+v"(c.b1));
+            char* d = lds + DL_AR + (sa & 3) * DL_SLOT + 2 * fw * 1024 + lane * 16;
+            if (!DL_ABL(1)) {
+                *reinterpret_cast<u32x4*>(d) = activated(rq[P][0], c);
+                *reinterpret_cast<u32x4*>(d + 1024) = activated(rq[P][1], c);
             }
+            DL_LAP(1);
+            load_next(rq[P]);
+            request_k(c, wrap(sa + 2));
+            sa = sa + 1 == nst ? 0 : sa + 1;
             DL_LAP(2);
-            lds_barrier();                                     // E: the step's bottleneck tile is complete
-            DL_LAP(3);
-            if (u < n_units) pre_apply();                      // the consumers are past every stage of step (cu, cj)
-            DL_LAP(6);
-            if constexpr (S == 64) conv2_step(cu, cj, fa0, fa1);
+        };
+#define DL_GS(k) gapply(std::integral_constant<int, k>{}, g + k); if (g + k + 1 >= Gt) break;
+        if (Gt > 0) {
+            for (int g = 0;; g += RD) { DL_GS(0) DL_GS(1) DL_GS(2) DL_GS(3) DL_GS(4) DL_GS(5) DL_GS(6) DL_GS(7) }
+            lds_barrier();                                 // the last step's last pair barrier and E
+            lds_barrier();
         }
+#undef DL_GS
+        // the stages requested past the end of the stream: nothing may reuse their registers before they have landed
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[1][0]), "+v"(rq[1][1]), "+v"(rq[2][0]), "+v"(rq[2][1]),
+                       "+v"(rq[3][0]), "+v"(rq[3][1]), "+v"(rq[4][0]), "+v"(rq[4][1]), "+v"(rq[5][0]), "+v"(rq[5][1]),
+                       "+v"(rq[6][0]), "+v"(rq[6][1]), "+v"(rq[7][0]), "+v"(rq[7][1])::"memory");
         if (wave == 4) DL_OUT(8);
         return;
     }
@@ -463,15 +354,9 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
         dst[0] = __builtin_amdgcn_raw_buffer_load_b128(rW1, vo, 0, 0);
         dst[1] = __builtin_amdgcn_raw_buffer_load_b128(rW1, vo + 1024, 0, 0);
     };
-    auto preload_w = [&]() {
-        if constexpr (S == 64) {
-            load_w(fr[0], 0);
-            load_w(fr[1], 1);
-            load_w(fr[2], 2);
-        } else {                                               // (a pair requests the next pair's fragments itself)
-            load_w(fr[0], 0);
-            load_w(fr[1], 1);
-        }
+    auto preload_w = [&]() {                                   // (a pair requests the next pair's fragments itself)
+        load_w(fr[0], 0);
+        load_w(fr[1], 1);
     };
     preload_w();
     lds_barrier();                                             // B_init
@@ -479,29 +364,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
     const unsigned laneA = lb + DL_AR + (i >> 4) * 1024 + h * 256 + (i & 15) * 16;
-    // one stage: the 8 operand fragments (4 pixel blocks x 2 k-steps) are requested together, each MFMA waits for its own
-    auto stage = [&](auto ph_c, int s) {
-        constexpr int P = decltype(ph_c)::value;
-        lds_barrier();                                         // B_s
-        DL_LAP(0);
-        load_w(fr[(P + DL_PF) & 3], s + DL_PF);
-        f32x4 av[8];
-        if (!DL_ABL(2)) {
-        static_for<0, 8>([&](auto n_c) {
-            constexpr int n = decltype(n_c)::value;            // n = 4 ks + rb
-            av[n] = lds_read4<P * DL_SLOT + (n & 3) * 2048 + (n >> 2) * 512>(laneA);
-        });
-        static_for<0, 8>([&](auto n_c) {
-            constexpr int n = decltype(n_c)::value;
-            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(av[n]) : "n"(7 - n));
-            c1[n & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fr[P][n >> 2]),
-                                                               __builtin_bit_cast(half8, av[n]), c1[n & 3], 0, 0, 0);
-        });
-        }
-        DL_LAP(1);
-    };
-
-    // S < 64: two stages per barrier (the feeders' pair protocol): the second stage's fragments are requested while the first
+    // two stages per barrier (the feeders' pair protocol): the second stage's fragments are requested while the first
     // stage multiplies; its W1 fragments of the NEXT pair are requested at the pair's start (L2 hits: one pair ahead is enough)
     auto pair = [&](auto ph_c, int s) {
         constexpr int P = decltype(ph_c)::value;               // s & 3: 0 or 2
@@ -553,22 +416,9 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c1[rb][r] = 0.f;
             // ---- conv1 over the step's K channels
-            if constexpr (S < 64) {
-                // no loop: the (up to 16) pairs of a step are laid out one after the other with an exit after each, so that
-                // the compiler counts the W1 loads in flight exactly - around a loop it drained them (vmcnt(0)) at every trip
-                pairs_from(std::integral_constant<int, 0>{});
-            } else {
-                for (int s = 0;; s += 4) {
-                    stage(std::integral_constant<int, 0>{}, s);
-                    if (s + 1 >= nst) break;
-                    stage(std::integral_constant<int, 1>{}, s + 1);
-                    if (s + 2 >= nst) break;
-                    stage(std::integral_constant<int, 2>{}, s + 2);
-                    if (s + 3 >= nst) break;
-                    stage(std::integral_constant<int, 3>{}, s + 3);
-                    if (s + 4 >= nst) break;
-                }
-            }
+            // no loop: the (up to 16) pairs of a step are laid out one after the other with an exit after each, so that the
+            // compiler counts the W1 loads in flight exactly - around a loop it drained them (vmcnt(0)) at every trip
+            pairs_from(std::integral_constant<int, 0>{});
             // ---- norm2 + relu2, rounded to fp16, into the bottleneck tile
             if (!DL_ABL(16))
 #pragma unroll
