@@ -366,8 +366,9 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
     const unsigned laneA = lb + DL_AR + (i >> 4) * 1024 + h * 256 + (i & 15) * 16;
     // two stages per barrier (the feeders' pair protocol): the second stage's fragments are requested while the first
     // stage multiplies; its W1 fragments of the NEXT pair are requested at the pair's start (L2 hits: one pair ahead is enough)
-    auto pair = [&](auto ph_c, int s) {
+    auto pair = [&](auto ph_c, int s, auto first_c) {          // first: the step's first pair starts from srcC = 0
         constexpr int P = decltype(ph_c)::value;               // s & 3: 0 or 2
+        constexpr bool FIRST = decltype(first_c)::value;
         lds_barrier();                                         // B_(s / 2)
         DL_LAP(0);
         load_w(fr[(P + 2) & 3], s + 2);
@@ -382,8 +383,10 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             constexpr int n = decltype(n_c)::value;
             av[8 + n] = lds_read4<(P + 1) * DL_SLOT + (n & 3) * 2048 + (n >> 2) * 512>(laneA);
             asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(av[n]));
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             c1[n & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fr[P][n >> 2]),
-                                                               __builtin_bit_cast(half8, av[n]), c1[n & 3], 0, 0, 0);
+                                                               __builtin_bit_cast(half8, av[n]),
+                                                               FIRST && n < 4 ? zero16 : c1[n & 3], 0, 0, 0);
         });
         if (s + 1 < nst)
             static_for<0, 8>([&](auto n_c) {
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
     auto pairs_from = [&](auto k_c) {
         auto impl = [&](auto& self, auto kk_c) -> void {
             constexpr int k = decltype(kk_c)::value;
-            pair(std::integral_constant<int, (2 * k) & 3>{}, 2 * k);
+            pair(std::integral_constant<int, (2 * k) & 3>{}, 2 * k, std::integral_constant<bool, k == 0>{});
             if constexpr (k + 1 < 16)
                 if (2 * k + 2 < nst) self(self, std::integral_constant<int, k + 1>{});
         };
@@ -411,11 +414,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
 
     for (int u = bid; u < n_units; u += G)
         for (int j = 0; j < J; ++j) {
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) c1[rb][r] = 0.f;
-            // ---- conv1 over the step's K channels
+            // ---- conv1 over the step's K channels (the first pair starts the accumulators from the constant zero)
             // no loop: the (up to 16) pairs of a step are laid out one after the other with an exit after each, so that the
             // compiler counts the W1 loads in flight exactly - around a loop it drained them (vmcnt(0)) at every trip
             pairs_from(std::integral_constant<int, 0>{});
@@ -681,12 +680,6 @@ __global__ __launch_bounds__(512) void dense_layer_f16_s64_kernel(_Float16* __re
         ac[1].b1 = lds_read4<176>(a);
     };
     f32x16 c1[2][2];                                           // [channel block][pixel block]
-    auto zero_c1 = [&]() {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) c1[q >> 1][q & 1][r] = 0.f;
-    };
     // ---- norm2 + relu2, rounded to fp16, into the bottleneck tile of the step's parity.  One base register per table and
     // immediate offsets for everything static (written plainly, the compiler hoists 30-odd per-store addresses out of the stage
     // loop and spills ring registers to make room for them)
@@ -694,13 +687,21 @@ __global__ __launch_bounds__(512) void dense_layer_f16_s64_kernel(_Float16* __re
     const unsigned bt_base = lb + DL_BT + ((64 * ph + i) >> 4) * 4096 + (i & 15) * 16 + 8 * h + 8 * ch * 256;
     auto epilogue = [&](int parity) {
         const unsigned bt = bt_base + parity * DL_BT_BYTES;
-        if (!DL_ABL(16))
+        if (!DL_ABL(16)) {
+        // all sixteen constant reads first, ONE wait (a wait per channel group exposed the LDS latency eight times: 1980
+        // cycles per step); the ring registers of the stages in flight leave room for the 64 registers at this point
+        f32x4 osc[8], osh[8];
         static_for<0, 8>([&](auto q_c) {
-            constexpr int nbl = decltype(q_c)::value >> 2, g = decltype(q_c)::value & 3;
-            const f32x4 osc = lds_read4<(32 * nbl + 8 * g) * 4>(ot_base);
-            const f32x4 osh = lds_read4<512 + (32 * nbl + 8 * g) * 4>(ot_base);
-            f32x4 sc_ = osc, sh_ = osh;
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sc_), "+v"(sh_));
+            constexpr int q8 = decltype(q_c)::value, nbl = q8 >> 2, g = q8 & 3;
+            osc[q8] = lds_read4<(32 * nbl + 8 * g) * 4>(ot_base);
+            osh[q8] = lds_read4<512 + (32 * nbl + 8 * g) * 4>(ot_base);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(osc[0]), "+v"(osc[1]), "+v"(osc[2]), "+v"(osc[3]), "+v"(osc[4]), "+v"(osc[5]), "+v"(osc[6]), "+v"(osc[7]),
+                       "+v"(osh[0]), "+v"(osh[1]), "+v"(osh[2]), "+v"(osh[3]), "+v"(osh[4]), "+v"(osh[5]), "+v"(osh[6]), "+v"(osh[7]));
+        static_for<0, 8>([&](auto q_c) {
+            constexpr int q8 = decltype(q_c)::value, nbl = q8 >> 2, g = q8 & 3;
+            const f32x4 sc_ = osc[q8], sh_ = osh[q8];
             static_for<0, 2>([&](auto r_c) {
                 constexpr int rbl = decltype(r_c)::value;
                 unsigned o0, o1;                               // fp32 fma rounded once to fp16 (v_fma_mix), relu packed
@@ -719,6 +720,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_s64_kernel(_Float16* __re
                 asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(btl), "v"(ov), "n"(rbl * 8192 + (4 * nbl + g) * 256) : "memory");
             });
         });
+        }
     };
     auto stage = [&](auto ph_c, int s) {                       // (s: the stage's index in its step)
         constexpr int P = decltype(ph_c)::value;
@@ -737,16 +739,33 @@ __global__ __launch_bounds__(512) void dense_layer_f16_s64_kernel(_Float16* __re
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) av[rbl][ks] = DL_ABL(1) ? rx[P][rbl][ks] : activated(rx[P][rbl][ks], ac[ks]);
         asm volatile("s_waitcnt vmcnt(16)" : "+v"(rw[P][0][0]), "+v"(rw[P][0][1]), "+v"(rw[P][1][0]), "+v"(rw[P][1][1])::"memory");
-        if (!DL_ABL(2))
+        if (!DL_ABL(2)) {
+            // a step's first k-step starts its accumulators from the constant zero (srcC = 0): no 64 moves per step
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (s == 0) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+                for (int nbl = 0; nbl < 2; ++nbl)
+#pragma unroll
+                    for (int rbl = 0; rbl < 2; ++rbl)
+                        c1[nbl][rbl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, rw[P][nbl][0]),
+                                                                              __builtin_bit_cast(half8, av[rbl][0]), zero16, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int nbl = 0; nbl < 2; ++nbl)
+#pragma unroll
+                    for (int rbl = 0; rbl < 2; ++rbl)
+                        c1[nbl][rbl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, rw[P][nbl][0]),
+                                                                              __builtin_bit_cast(half8, av[rbl][0]), c1[nbl][rbl],
+                                                                              0, 0, 0);
+            }
 #pragma unroll
             for (int nbl = 0; nbl < 2; ++nbl)
 #pragma unroll
                 for (int rbl = 0; rbl < 2; ++rbl)
-                    c1[nbl][rbl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, rw[P][nbl][ks]),
-                                                                          __builtin_bit_cast(half8, av[rbl][ks]), c1[nbl][rbl],
+                    c1[nbl][rbl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, rw[P][nbl][1]),
+                                                                          __builtin_bit_cast(half8, av[rbl][1]), c1[nbl][rbl],
                                                                           0, 0, 0);
+        }
     };
 
     load_x(rx[0]);
@@ -760,7 +779,6 @@ __global__ __launch_bounds__(512) void dense_layer_f16_s64_kernel(_Float16* __re
                    "+v"(rw[0][0][0]), "+v"(rw[0][0][1]), "+v"(rw[0][1][0]), "+v"(rw[0][1][1]), "+v"(rw[1][0][0]), "+v"(rw[1][0][1]),
                    "+v"(rw[1][1][0]), "+v"(rw[1][1][1])::"memory");
     lds_barrier();                                             // B_init
-    zero_c1();
     const int Gt = N * nst;
     // (the step / stage counters are plain locals of this scope, never captured: captured by the lambdas they ended up in
     // scratch memory, i.e. per lane - divergent branches and scratch loads in the middle of the hand-counted stream)
@@ -773,7 +791,6 @@ __global__ __launch_bounds__(512) void dense_layer_f16_s64_kernel(_Float16* __re
         DL_LAP(1);                                                                                    \
         lds_barrier(); /* barrier n: tile n is complete, tile n - 1 is free */                        \
         DL_LAP(2);                                                                                    \
-        zero_c1();                                                                                    \
         s = 0;                                                                                        \
         ++n;                                                                                          \
     } else {                                                                                          \
