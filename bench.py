@@ -121,7 +121,7 @@ def dense_layer_bytes_per_spot(patch):
 
 # kind -> (kernel name, FLOPs per spot, algorithmic bytes per spot)           (backward kinds: the f-trained series)
 KINDS = {
-    'dense_layer': ('dense_layer_f16_kernel', lambda patch: conv1x1_flops_per_spot(patch) + conv3x3_flops_per_spot(patch),
+    'dense_layer': ('dense_layer_f16_kernel / dense_layer_f16_s64_kernel', lambda patch: conv1x1_flops_per_spot(patch) + conv3x3_flops_per_spot(patch),
                     dense_layer_bytes_per_spot),
     'conv1x1': ('conv1x1_ws_kernel', conv1x1_flops_per_spot, conv1x1_bytes_per_spot),
     'conv3x3': ('conv3x3_dma_kernel', conv3x3_flops_per_spot, conv3x3_bytes_per_spot),
@@ -596,7 +596,7 @@ def config5_series(args, device, rank, world, steps=4, warmup=2):
         gbs = kk["algorithmic_bytes_per_launch_avg"] / (kk["avg_launch_ms"] * 1e-3) / 1e9
         kk.update({"bound": "hbm", "matrix_tflops": kk["achieved"], "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "frac": gbs / PEAK_HBM_GBS, "kernel": {"conv1x1": "conv1x1_h16_kernel", "conv3x3": "conv3x3_dma_kernel<H16, O16>",
-                                                          "dense_layer": "dense_layer_f16_kernel"}.get(kind, kk["kernel"])})
+                                                          "dense_layer": "dense_layer_f16_kernel / dense_layer_f16_s64_kernel"}.get(kind, kk["kernel"])})
         kk.pop("algorithmic_gbs", None)
     attach_traffic(kt, '_f16_256')
     if kt:
@@ -868,7 +868,7 @@ def worker_main(args):
             # config 5's kernels multiply 16x faster than they can be fed: they are priced against HBM (algorithmic bytes
             # per launch / launch time); the fp32-FLOP figure stays in `matrix_tflops` for reference
             h16 = bool(getattr(f_img, '_used_f16_buffers', False))     # block buffers in fp16: every operand is 2 B
-            for kind, name in (('dense_layer', 'dense_layer_f16_kernel (norm1 .. conv2 in one kernel, bottleneck in LDS)'),
+            for kind, name in (('dense_layer', 'dense_layer_f16_kernel / dense_layer_f16_s64_kernel (norm1 .. conv2 in one kernel, bottleneck in LDS)'),
                                ('conv1x1', 'conv1x1_h16_kernel' if h16 else 'conv1x1_f16_kernel'),
                                ('conv3x3', 'conv3x3_dma_kernel<H16, O16>' if h16 else 'conv3x3_dma_kernel<H16> / conv3x3_f16_kernel')):
                 if kind not in kern:

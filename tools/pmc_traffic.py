@@ -24,7 +24,7 @@ def _targs(n, kernel):
 
 
 GROUPS = [                                   # first match wins; names as bench.py's kernel kinds
-    ('dense_layer', lambda n: 'dense_layer_f16_kernel' in n),
+    ('dense_layer', lambda n: 'dense_layer_f16_kernel' in n or 'dense_layer_f16_s64_kernel' in n),
     ('dgrad1x1_bn1', lambda n: 'conv1x1_ws_kernel<false, false, 4, true>' in n),
     ('dgrad3x3_bn2', lambda n: len(_targs(n, 'conv3x3_dma_kernel')) >= 7 and _targs(n, 'conv3x3_dma_kernel')[6] == 'true'),
     ('wgrad1x1', lambda n: 'wgrad1_t_kernel' in n),
