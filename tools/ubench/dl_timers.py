@@ -1,3 +1,13 @@
+#!/usr/bin/env python3
+"""Timers-only stamps of gnx_dense_layer_f16 (diagnostic; runs on the GPU box): builds of csrc/dense_layer_f16.hip with
+-DGNX_DL_STAMP -DGNX_DL_NOABL (no run-time ablation branches inside the MFMA streams - with them conv2 reads 6100 cycles per
+step instead of 3900) are loaded by name from tools/ubench/build/ and, per shape, the launch time and the cycles per step
+wave 0 and wave 4 spent in each stamped segment are printed.
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DGNX_DL_STAMP -DGNX_DL_NOABL -I gridnext_amd/csrc \
+          gridnext_amd/csrc/dense_layer_f16.hip -o tools/ubench/build/libdl_noabl.so
+    python tools/ubench/dl_timers.py libdl_noabl.so
+"""
 import ctypes, sys, os, torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 P, I, Lg = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
@@ -9,7 +19,7 @@ for name in sys.argv[1:]:
     lib.gnx_dense_layer_f16_pack.argtypes = [P, P, P, P, I, P]
     lib.gnx_dense_layer_f16.argtypes = [P, Lg, Lg, I, I, P, P, P, P, P, P, P]
     lib.gnx_dense_layer_f16_set_stamps.argtypes = [P, I]
-    for S, K, ct in [(64, 64, 256), (64, 128, 256), (64, 224, 256)]:
+    for S, K, ct in [(64, 64, 256), (64, 224, 256), (32, 128, 512), (32, 480, 512), (16, 992, 1024)]:
         M = n * S * S
         X = torch.randn(ct // 32, M, 32, device=dev).to(H)
         W1 = torch.randn(128, K, device=dev) / K ** 0.5
