@@ -112,6 +112,9 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
     // the consumers doing conv1 + epilogue only (extra barrier F before the epilogue): 8-22 % SLOWER - a wave's share is 3-4
     // dependent chains of ~1500 cycles whatever wave runs them, and behind the feeders' own chain they lengthen the pair
     // period; the step stays bound by one group's serial work.)
+    // (Tried and dropped, measured: every tap's eight k-steps split between consumer w (0-3) and feeder w (4-7), the feeder's
+    // half of a finished block handed over through the LDS between two more barriers: 3-15 % SLOWER - a 12-MFMA stream is
+    // half pipeline fill, and the address set-up per tap does not shrink.)
     // (Tried and dropped, measured: conv2 cut into jobs of 24 MFMAs run one per stage behind the NEXT step's conv1 stages, so
     // that stage barriers - and with them the loaders' refills - keep passing during conv2: S = 32 / 16 layers got 12-37 %
     // SLOWER, S = 64 / 8 unchanged.  A stage's period is set by its slowest wave, and the consumer waves are no faster per stage
