@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void conv_stem_patch_kernel(const float* __res
 // tile's second row: every thread owns the same (px, 4 channels) items in every tile, so that carry lives in registers.
 // relu >= 0, so "outside the map" contributes 0 exactly as in gnx_bnrelu_maxpool.
 constexpr int SP_LDT = 40;         // floats per position of the activated 32-channel half tile in LDS: 4 * 40 = 32 (mod 64)
+constexpr int SP_LDTH = 72;        // the fp16 stem's tile: halves per position (36 dwords: lane halves 4 positions apart land 16 banks apart)
                                    // banks, so the two lane halves of an accumulator store (positions p, p + 4) hit disjoint banks
 // WO = width of the conv0 map: 64 (128-px patches: tiles of 2 rows, one pooled row each, one carried row) or 128
 // (256-px patches: tiles of 1 row; a pooled row is emitted on every odd conv row from the two carried rows and the new one).
@@ -507,7 +508,9 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
     extern __shared__ __attribute__((aligned(16))) float lds[];
     _Float16* Bs = reinterpret_cast<_Float16*>(lds);      // [64][LDBH]
     _Float16* Ps = Bs + 64 * LDBH;                        // [CIN][PH][PW]
-    float* Ts = reinterpret_cast<float*>(Ps + CIN * PH * PW);       // [128 positions][SP_LDT] activated conv tile
+    // The activated conv tile is kept as fp16: rounding is monotonic, so the maximum of the rounded values IS the rounded
+    // maximum the fp32 tile gave - bit-identical output, half the tile (20 -> 9 KB: three workgroups per CU instead of two)
+    _Float16* Ts = Ps + CIN * PH * PW;                    // [128 positions][SP_LDTH]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
     for (int idx = t; idx < 64 * LDBH; idx += 256) {
         const int n = idx / LDBH, rem = idx - n * LDBH;
@@ -575,10 +578,10 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
     fetch_patch(blockIdx.x, 0);
 
     for (long img = blockIdx.x; img < imgs; img += gridDim.x) {
-        float4 carry[2][NIT], carry2[2][NIT];
+        sp_half4 carry[2][NIT], carry2[2][NIT];
+        const sp_half4 hz = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
 #pragma unroll
-        for (int q = 0; q < NIT; ++q)
-            carry[0][q] = carry[1][q] = carry2[0][q] = carry2[1][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < NIT; ++q) carry[0][q] = carry[1][q] = carry2[0][q] = carry2[1][q] = hz;
         for (int tt = 0; tt < ntt; ++tt) {
             __syncthreads();
             stash_patch();
@@ -615,49 +618,42 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rr = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    Ts[rr * SP_LDT + i] = pass == 0 ? fmaxf(fmaf(acc0[r], sc0, sh0), 0.f) : fmaxf(fmaf(acc1[r], sc1, sh1), 0.f);
+                    Ts[rr * SP_LDTH + i] =
+                        (_Float16)(pass == 0 ? fmaxf(fmaf(acc0[r], sc0, sh0), 0.f) : fmaxf(fmaf(acc1[r], sc1, sh1), 0.f));
                 }
                 __syncthreads();
                 const int ch = 32 * pass + 4 * c4;
 #pragma unroll
                 for (int q = 0; q < NIT; ++q) {
                     const int px = pxa + 32 * q;
-                    float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
+                    sp_half4 m0 = hz, m1 = hz;
 #pragma unroll
                     for (int dx = -1; dx <= 1; ++dx) {
                         const int ox = 2 * px + dx;
                         if (ox < 0) continue;
-                        const float4 v0 = ld4(&Ts[ox * SP_LDT + 4 * c4]);
-                        m0 = make_float4(fmaxf(m0.x, v0.x), fmaxf(m0.y, v0.y), fmaxf(m0.z, v0.z), fmaxf(m0.w, v0.w));
-                        if (RT == 2) {
-                            const float4 v1 = ld4(&Ts[(WO + ox) * SP_LDT + 4 * c4]);
-                            m1 = make_float4(fmaxf(m1.x, v1.x), fmaxf(m1.y, v1.y), fmaxf(m1.z, v1.z), fmaxf(m1.w, v1.w));
-                        }
+                        m0 = __builtin_elementwise_max(m0, *reinterpret_cast<const sp_half4*>(&Ts[ox * SP_LDTH + 4 * c4]));
+                        if (RT == 2)
+                            m1 = __builtin_elementwise_max(m1, *reinterpret_cast<const sp_half4*>(&Ts[(WO + ox) * SP_LDTH + 4 * c4]));
                     }
-                    float4 o4;
+                    sp_half4 o4;
                     bool emit;
                     long orow;
                     if (RT == 2) {
-                        const float4 cv = carry[pass][q];
-                        o4 = make_float4(fmaxf(fmaxf(cv.x, m0.x), m1.x), fmaxf(fmaxf(cv.y, m0.y), m1.y),
-                                         fmaxf(fmaxf(cv.z, m0.z), m1.z), fmaxf(fmaxf(cv.w, m0.w), m1.w));
+                        o4 = __builtin_elementwise_max(__builtin_elementwise_max(carry[pass][q], m0), m1);
                         carry[pass][q] = m1;
                         emit = true;
                         orow = (img * (Ho2 / 2) + tt) * (long)(WO / 2) + px;
                     } else {
-                        const float4 c2 = carry2[pass][q], c1 = carry[pass][q];
-                        o4 = make_float4(fmaxf(fmaxf(c2.x, c1.x), m0.x), fmaxf(fmaxf(c2.y, c1.y), m0.y),
-                                         fmaxf(fmaxf(c2.z, c1.z), m0.z), fmaxf(fmaxf(c2.w, c1.w), m0.w));
+                        o4 = __builtin_elementwise_max(__builtin_elementwise_max(carry2[pass][q], carry[pass][q]), m0);
                         emit = (tt & 1) != 0;
                         orow = (img * (Ho2 / 2) + (tt >> 1)) * (long)(WO / 2) + px;
                         carry2[pass][q] = carry[pass][q];
                         carry[pass][q] = m0;
                     }
                     if (emit && ch < O) {
-                        const sp_half4 hv = {(_Float16)o4.x, (_Float16)o4.y, (_Float16)o4.z, (_Float16)o4.w};
                         // (element (row, c) lives at row * ldo + (c >> 5) * obs + (c & 31): obs = 32 is the row-major matrix,
                         // ldo = 32 with obs = rows * 32 the channel-blocked buffer [c / 32][rows][32] of the fused dense layers)
-                        *reinterpret_cast<sp_half4*>(out + orow * ldo + (ch >> 5) * obs + (ch & 31)) = hv;
+                        *reinterpret_cast<sp_half4*>(out + orow * ldo + (ch >> 5) * obs + (ch & 31)) = o4;
                     }
                 }
             }
@@ -921,8 +917,8 @@ static int stem_pool_f16_launch(const void* x, const float* w, void* out16, long
         return GNX_ERR_UNSUPPORTED;
     if (imgs == 0) return GNX_OK;
     const int RT = 128 / Wo, PH = 2 * (RT - 1) + 7, PW = ((Wo - 1) * 2 + 8 + 2 + 7) & ~7;
-    const size_t lds_bytes = ((size_t)64 * (11 * 16 + 8) + (size_t)3 * PH * PW) * 2 + (size_t)128 * SP_LDT * sizeof(float);
-    const int per_cu = lds_bytes <= 53 * 1024 ? 3 : 2;
+    const size_t lds_bytes = ((size_t)64 * (11 * 16 + 8) + (size_t)3 * PH * PW + (size_t)128 * SP_LDTH) * 2;
+    const int per_cu = lds_bytes <= 53 * 1024 ? 3 : 2;     // 256-px geometry: 52.2 KB, three workgroups per CU
     const int grid = (int)(imgs < 256 * per_cu ? imgs : 256 * per_cu);
     _Float16* o = reinterpret_cast<_Float16*>(out16);
     if (Wo == 64)
