@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
     constexpr int PH = STRIDE * (RT - 1) + KH, PW = ((WO - 1) * STRIDE + 8 + 1 + 1 + 7) & ~7;   // patch per channel (halves)
     constexpr int F4R = WO * STRIDE / 4;                  // 4-pixel pieces per input row (row width 2 WO)
     constexpr int NPC = CIN * PH * F4R, NPRE = (NPC + 255) / 256;
-    constexpr int NIT = (WO / 2) * 8 / 256;
+    constexpr int NIT = (WO / 2) * 16 / 256;             // pooled (position, 4-channel group) items per thread: all 64 channels at once
     constexpr int NG = CIN * KH, NSTEP = (NG + 1) / 2;    // 21 (c, ky) groups of 8 kx, two per MFMA
     constexpr int LDBH = NSTEP * 16 + 8;                  // halves per weight row (184: 23 sixteen-byte slots)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
     const _Float16* pb = Bs + i * LDBH + 8 * h;
     const float sc0 = i < O ? scale[i] : 0.f, sh0 = i < O ? shift[i] : 0.f;
     const float sc1 = 32 + i < O ? scale[32 + i] : 0.f, sh1 = 32 + i < O ? shift[32 + i] : 0.f;
-    const int c4 = t & 7, pxa = t >> 3;
+    const int c4 = t & 15, pxa = t >> 4;
     const int Ho2 = (H + 2 * PAD - KH) / STRIDE + 1;
     const int ntt = Ho2 / RT;
 
@@ -578,10 +578,10 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
     fetch_patch(blockIdx.x, 0);
 
     for (long img = blockIdx.x; img < imgs; img += gridDim.x) {
-        sp_half4 carry[2][NIT], carry2[2][NIT];
+        sp_half4 carry[NIT], carry2[NIT];
         const sp_half4 hz = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
 #pragma unroll
-        for (int q = 0; q < NIT; ++q) carry[0][q] = carry[1][q] = carry2[0][q] = carry2[1][q] = hz;
+        for (int q = 0; q < NIT; ++q) carry[q] = carry2[q] = hz;
         for (int tt = 0; tt < ntt; ++tt) {
             __syncthreads();
             stash_patch();
@@ -612,20 +612,20 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b0, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b1, acc1, 0, 0, 0);
             }
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-                if (pass == 1) __syncthreads();
+            // both 32-channel halves of the tile go to the LDS together (a position's row holds all 64 channels), ONE barrier,
+            // one pooling sweep - three barriers per tile instead of five
+            {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rr = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    Ts[rr * SP_LDTH + i] =
-                        (_Float16)(pass == 0 ? fmaxf(fmaf(acc0[r], sc0, sh0), 0.f) : fmaxf(fmaf(acc1[r], sc1, sh1), 0.f));
+                    Ts[rr * SP_LDTH + i] = (_Float16)fmaxf(fmaf(acc0[r], sc0, sh0), 0.f);
+                    Ts[rr * SP_LDTH + 32 + i] = (_Float16)fmaxf(fmaf(acc1[r], sc1, sh1), 0.f);
                 }
                 __syncthreads();
-                const int ch = 32 * pass + 4 * c4;
+                const int ch = 4 * c4;
 #pragma unroll
                 for (int q = 0; q < NIT; ++q) {
-                    const int px = pxa + 32 * q;
+                    const int px = pxa + 16 * q;
                     sp_half4 m0 = hz, m1 = hz;
 #pragma unroll
                     for (int dx = -1; dx <= 1; ++dx) {
@@ -639,16 +639,16 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
                     bool emit;
                     long orow;
                     if (RT == 2) {
-                        o4 = __builtin_elementwise_max(__builtin_elementwise_max(carry[pass][q], m0), m1);
-                        carry[pass][q] = m1;
+                        o4 = __builtin_elementwise_max(__builtin_elementwise_max(carry[q], m0), m1);
+                        carry[q] = m1;
                         emit = true;
                         orow = (img * (Ho2 / 2) + tt) * (long)(WO / 2) + px;
                     } else {
-                        o4 = __builtin_elementwise_max(__builtin_elementwise_max(carry2[pass][q], carry[pass][q]), m0);
+                        o4 = __builtin_elementwise_max(__builtin_elementwise_max(carry2[q], carry[q]), m0);
                         emit = (tt & 1) != 0;
                         orow = (img * (Ho2 / 2) + (tt >> 1)) * (long)(WO / 2) + px;
-                        carry2[pass][q] = carry[pass][q];
-                        carry[pass][q] = m0;
+                        carry2[q] = carry[q];
+                        carry[q] = m0;
                     }
                     if (emit && ch < O) {
                         // (element (row, c) lives at row * ldo + (c >> 5) * obs + (c & 31): obs = 32 is the row-major matrix,
