@@ -238,112 +238,107 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                 dma16_buf(rW2, lane * 16, piece * 1024, lb + DL_W2 + piece * 1024);
             }
         }
-        // X is channel-blocked, [channel / 32][pixel row][32]: the 32 channels a stage needs of this feeder's 32 consecutive
-        // pixel rows are ONE contiguous 2 KB of memory (in a row-major [row][channels] buffer they were 32 pieces of 64 B,
-        // 0.5-2 KB apart - whatever carried them, LDS-DMA or register loads, that stream stayed at ~4 TB/s)
+        // X is channel-blocked, [channel / 32][pixel row][32]: the 32 channels a stage needs of 64 consecutive pixel rows are
+        // ONE contiguous 4 KB of memory (in a row-major [row][channels] buffer they were 64 pieces of 64 B, 0.5-2 KB apart)
+        // Feeder (par, hw) = (fw >> 1, fw & 1) takes the stages of parity par of every step and of each of them the pixel rows
+        // 64 hw .. 64 hw + 63: 4 KB per stage and wave (four 1-KB pieces: lane = pixel (lane & 15) of the piece, 16-B column
+        // lane >> 4), ONE chain of [wait for the data -> norm1 + relu1 -> four LDS writes -> four loads] per pair of stages and
+        // wave.  (With every feeder on a quarter of every stage the chain ran twice per pair: the pair period was the feeders'.)
+        const int par = fw >> 1, hw = fw & 1;
         const int voffA = ((lane & 15) * 32 + 8 * (lane >> 4)) * 2;
-        auto strip = [&](int u, int j) {                       // this feeder's 32 pixel rows of step (u, j), channel block 0
-            return static_cast<const _Float16*>(X) + (((long)u * J + j) * 128 + 32 * fw) * 32;
+        auto strip = [&](int u, int j) {                       // this feeder's 64 pixel rows of step (u, j), channel block 0
+            return static_cast<const _Float16*>(X) + (((long)u * J + j) * 128 + 64 * hw) * 32;
         };
         const unsigned ctb = lb + DL_CT + 64 * (lane >> 4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of W2
-        // One continuous stream of stages over all the workgroup's steps: global stage g = n * nst + s sits in register
-        // ring entry g & 7 (compile-time in the 8-fold unrolled loop; the LDS slot is the step's stage & 3), so seven stages
-        // (56 KB per CU) are in flight whatever the step length - an HBM miss takes ~900 cycles on an idle chip and two
-        // to three times that under load, three stages in flight (the first form of this loop) left the stream
-        // latency-bound at ~1100 cycles per stage where the HBM rate allows ~650.
-        constexpr int RD = 8;
-        u32x4 rq[RD][2];
-        int lu = bid, lj = 0, ls = 0;                      // the next load: unit, step, stage
+        // The wave's stages of ALL the workgroup's steps are one stream through a 4-deep register ring (its own stage k sits
+        // in entry k & 3: three of its stages = six of the step's = 48 KB per CU in flight whatever the step length - an HBM
+        // miss takes ~900 cycles on an idle chip and two to three times that under load).  Inline asm loads: the compiler's
+        // own vmcnt bookkeeping drains a ring like this at every loop trip; these loads are invisible to it and every use
+        // waits by hand - exactly RD stages of four loads are outstanding at each apply, the oldest is the one applied.  The
+        // feeders issue no other vector-memory operation after the prologue.
+        constexpr int RD = 4;
+        u32x4 rq[RD][4];
+        const int own = (nst + 1 - par) >> 1;              // this wave's stages per step (nst >= 2: at least one)
+        int lu = bid, lj = 0, ls = par;                    // the next load: unit, step, stage
         const _Float16* lrows = strip(lu, lj);
-        // (inline asm: the compiler's own vmcnt bookkeeping gives up on a ring this deep in a loop and drains it - it
-        // waited vmcnt(1) where 14 younger loads were in flight; these loads are therefore invisible to it and every use
-        // waits by hand: exactly RD stages are outstanding at each apply, the oldest is the one applied.  The feeders
-        // issue no other vector-memory operation after the prologue.)
-        auto load_next = [&](u32x4(&dst)[2]) {
+        auto load_next = [&](u32x4(&dst)[4]) {
             const bool in = lu < n_units && !DL_ABL(4);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<_Float16*>(lrows) + (in ? ls : 0) * bstride, 0, 2048, 0x00020000);
+                const_cast<_Float16*>(lrows) + (in ? ls : 0) * bstride, 0, 4096, 0x00020000);
             const int vo = voffA + (in ? 0 : 0x7f000000);
-            if (!DL_ABL(512))
-            asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:1024"
-                         : "=&v"(dst[0]), "=&v"(dst[1]) : "v"(vo), "s"(rs) : "memory");
-            if (++ls == nst) {
-                ls = 0;
+            asm volatile("buffer_load_dwordx4 %0, %4, %5, 0 offen\n\tbuffer_load_dwordx4 %1, %4, %5, 0 offen offset:1024\n\t"
+                         "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:2048\n\tbuffer_load_dwordx4 %3, %4, %5, 0 offen offset:3072"
+                         : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]) : "v"(vo), "s"(rs) : "memory");
+            ls += 2;
+            if (ls >= nst) {
+                ls = par;
                 if (++lj == J) { lj = 0; lu += G; }
                 lrows = strip(lu < n_units ? lu : bid, lj);
             }
         };
-        auto landed = [&](u32x4(&v)[2]) {                  // the oldest of the RD stages in flight
-            if (!DL_ABL(512))
-            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(v[0]), "+v"(v[1]) : "n"(2 * RD - 2) : "memory");
+        auto landed = [&](u32x4(&v)[4]) {                  // the oldest of the RD stages in flight
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(4 * RD - 4) : "memory");
         };
-        const int Gt = (bid < n_units ? ((n_units - bid + G - 1) / G) * J : 0) * nst;   // this workgroup's stages
+        const int nsteps = bid < n_units ? ((n_units - bid + G - 1) / G) * J : 0;
+        const int Gt = nsteps * own;                       // this wave's stages
         static_for<0, RD>([&](auto k_c) { load_next(rq[decltype(k_c)::value]); });
         lds_barrier();                                     // B_init: tables and W2 are in the LDS
-        // The consumers take the step's stages in PAIRS (one barrier per 64 channels): pair p sits in slots (2p, 2p + 1) & 3
-        // and is read between the barriers B_p and B_p+1, the feeders write pair p + 1 meanwhile; the next step's first
-        // pair goes in after the E barrier.  norm1 constants: two register sets, requested two stages ahead.
-        ActRegs ak[2];
-        auto request_k = [&](ActRegs& c, int ss) {
-            if (DL_ABL(1024)) return;
+        // The consumers take the step's stages in PAIRS (one barrier per 64 channels): pair p sits in slots (2p, 2p + 1) & 3 and
+        // is read between the barriers B_p and B_p+1; its slots are pair p - 2's, free once B_p-1 has passed; a step's first
+        // pair goes in after the previous step's E barrier.  Every feeder executes every barrier, whether or not the pair has
+        // a stage of its parity (an odd step's last pair has none of parity 1).
+        const int np = (nst + 1) >> 1;                     // pairs (= pair barriers) per step
+        ActRegs ak;                                        // norm1 constants of the wave's next stage
+        auto request_k = [&](int ss) {
             const unsigned a = ctb + ss * 256;
-            c.s0 = lds_read4<0>(a);
-            c.s1 = lds_read4<16>(a);
-            c.b0 = lds_read4<32>(a);
-            c.b1 = lds_read4<48>(a);
+            ak.s0 = lds_read4<0>(a);
+            ak.s1 = lds_read4<16>(a);
+            ak.b0 = lds_read4<32>(a);
+            ak.b1 = lds_read4<48>(a);
         };
-        auto wrap = [&](int x) {
-            while (x >= nst) x -= nst;
-            return x;
-        };
-        request_k(ak[0], 0);
-        request_k(ak[1], wrap(1));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ak[0].s0), "+v"(ak[0].s1), "+v"(ak[0].b0), "+v"(ak[0].b1), "+v"(ak[1].s0),
-                                              "+v"(ak[1].s1), "+v"(ak[1].b0), "+v"(ak[1].b1));
-        int sa = 0;                                        // in-step index of the stage applied next
+        request_k(par);
+        int sa = par, bdone = 0;                           // in-step index of the stage applied next; pair barriers passed in its step
         auto gapply = [&](auto ph_c, int g) {
             constexpr int P = decltype(ph_c)::value;
-            if (sa == 0) {
-                if (g > 0) {
-                    lds_barrier();                         // the previous step's last pair barrier
-                    DL_LAP(0);
-                    lds_barrier();                         // E: its bottleneck tile is complete, every slot is free
-                    DL_LAP(3);
-                }
-            } else if ((sa & 1) == 0) {
-                lds_barrier();                             // B_(sa / 2 - 1): pair sa / 2 - 2 has been read
+            if (sa == par && g > 0) {                      // a new step: what is left of the previous one's barriers, then E
+                for (; bdone < np; ++bdone) lds_barrier();
                 DL_LAP(0);
+                lds_barrier();                             // E: its bottleneck tile is complete, every slot is free
+                DL_LAP(3);
+                bdone = 0;
             }
+            for (; bdone < (sa >> 1); ++bdone) lds_barrier();  // ... B_(pair - 1): the pair's slots have been read
+            DL_LAP(0);
             landed(rq[P]);
             DL_LAP(7);
-            ActRegs& c = ak[P & 1];
-            // this stage's constants were requested two stages ago; younger LDS operations of this wave: the previous
-            // stage's two writes and its four constant reads - they stay in flight
-            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(c.s0), "+v"(c.s1), "+v"(c.b0), "+v"(c.b1));
-            char* d = lds + DL_AR + (sa & 3) * DL_SLOT + 2 * fw * 1024 + lane * 16;
+            // (younger LDS operations of this wave than the constants: none but a barrier's drain - they were requested
+            // after the previous stage's writes)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ak.s0), "+v"(ak.s1), "+v"(ak.b0), "+v"(ak.b1));
+            char* d = lds + DL_AR + (sa & 3) * DL_SLOT + 4 * hw * 1024 + lane * 16;
             if (!DL_ABL(1)) {
-                *reinterpret_cast<u32x4*>(d) = activated(rq[P][0], c);
-                *reinterpret_cast<u32x4*>(d + 1024) = activated(rq[P][1], c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(d + q * 1024) = activated(rq[P][q], ak);
             }
             DL_LAP(1);
             load_next(rq[P]);
-            request_k(c, wrap(sa + 2));
-            sa = sa + 1 == nst ? 0 : sa + 1;
+            sa += 2;
+            if (sa >= nst) sa = par;
+            request_k(sa);
             DL_LAP(2);
         };
 #define DL_GS(k) gapply(std::integral_constant<int, k>{}, g + k); if (g + k + 1 >= Gt) break;
         if (Gt > 0) {
-            for (int g = 0;; g += RD) { DL_GS(0) DL_GS(1) DL_GS(2) DL_GS(3) DL_GS(4) DL_GS(5) DL_GS(6) DL_GS(7) }
-            lds_barrier();                                 // the last step's last pair barrier and E
+            for (int g = 0;; g += RD) { DL_GS(0) DL_GS(1) DL_GS(2) DL_GS(3) }
+            for (; bdone < np; ++bdone) lds_barrier();     // the last step's remaining pair barriers, and E
             lds_barrier();
         }
 #undef DL_GS
         // the stages requested past the end of the stream: nothing may reuse their registers before they have landed
         asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[1][0]), "+v"(rq[1][1]), "+v"(rq[2][0]), "+v"(rq[2][1]),
-                       "+v"(rq[3][0]), "+v"(rq[3][1]), "+v"(rq[4][0]), "+v"(rq[4][1]), "+v"(rq[5][0]), "+v"(rq[5][1]),
-                       "+v"(rq[6][0]), "+v"(rq[6][1]), "+v"(rq[7][0]), "+v"(rq[7][1])::"memory");
+                     : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[0][2]), "+v"(rq[0][3]), "+v"(rq[1][0]), "+v"(rq[1][1]),
+                       "+v"(rq[1][2]), "+v"(rq[1][3]), "+v"(rq[2][0]), "+v"(rq[2][1]), "+v"(rq[2][2]), "+v"(rq[2][3]),
+                       "+v"(rq[3][0]), "+v"(rq[3][1]), "+v"(rq[3][2]), "+v"(rq[3][3])::"memory");
         if (wave == 4) DL_OUT(8);
         return;
     }
@@ -858,7 +853,7 @@ GNX_EXPORT void gnx_dense_layer_f16_set_stamps(void* buf, int abl) {
 // The dense layer on a CHANNEL-BLOCKED fp16 block buffer X16 [channels / 32][rows_total][32] (element (row, c) at
 // (c >> 5) * rows_total * 32 + row * 32 + (c & 31); rows = n_img * S * S pixels, the first of rows_total): reads channel
 // blocks [0, K / 32), writes block K / 32.  bn_size * growth = 128 and growth = 32 are fixed; S in {4, 8, 16, 32, 64};
-// 32 | K <= 1024; X16 16-B aligned; n_img * S * S a multiple of 128.  scale / shift: the folded running-statistics
+// 32 | K, 64 <= K <= 1024; X16 16-B aligned; n_img * S * S a multiple of 128.  scale / shift: the folded running-statistics
 // BatchNorms (norm1: K, norm2: 128).
 GNX_EXPORT int gnx_dense_layer_f16(void* X16, long rows_total, long n_img, int S, int K, const void* w1p, const void* w2p,
                                    const float* scale1, const float* shift1, const float* scale2, const float* shift2,
@@ -866,7 +861,7 @@ GNX_EXPORT int gnx_dense_layer_f16(void* X16, long rows_total, long n_img, int S
     if (!X16 || !w1p || !w2p || !scale1 || !shift1 || !scale2 || !shift2 || n_img < 0 || K <= 0 || S <= 0 ||
         rows_total < n_img * (long)S * S)
         return GNX_ERR_BAD_ARG;
-    if (K % 32 != 0 || K > 1024 || !al16(X16) || !al16(w1p) || !al16(w2p) || (n_img * S * S) % 128 != 0 ||
+    if (K % 32 != 0 || K < 64 || K > 1024 || !al16(X16) || !al16(w1p) || !al16(w2p) || (n_img * S * S) % 128 != 0 ||
         n_img * (long)S * S / 128 >= (1L << 31))
         return GNX_ERR_UNSUPPORTED;
     if (n_img == 0) return GNX_OK;

@@ -450,9 +450,9 @@ class DenseNet(nn.Module):
         # (fp16 block buffers hold twice the spots in the same bytes: a whole 256-px array - 34 GB - is then one chunk)
         chunk = self._auto_chunk(P, N, 2 if (self.mfma == 'f16' and self.f16_buffers) else 4)
         mid = self.bn_size * self.growth_rate
-        # the fused dense-layer kernel (fp16 block buffers) takes: growth 32, bottleneck 128, maps of 4..64, 32 | channels
+        # the fused dense-layer kernel (fp16 block buffers) takes: growth 32, bottleneck 128, maps of 4..64, 32 | channels >= 64
         fused_ok = bool(sfx) and self.f16_buffers and self.f16_fused and self.growth_rate == 32 and mid == 128 and \
-            all(s in (4, 8, 16, 32, 64) for s in sizes) and all(blk[0] % 32 == 0 for blk in self._blocks) and \
+            all(s in (4, 8, 16, 32, 64) for s in sizes) and all(blk[0] % 32 == 0 and blk[0] >= 64 for blk in self._blocks) and \
             self.num_features % 32 == 0 and not self.small_inputs and P in (128, 256) and \
             all(blk[3] <= 1024 + 32 for blk in self._blocks)
         if sfx and self.atonce is None and chunk >= 8:

@@ -244,7 +244,7 @@ int gnx_bnrelu_avgpool_h16(const void* in16, long ldi, float* out, long ldo, lon
  * contiguous memory: reads channel blocks [0, K / 32), writes block K / 32; the 128-channel bottleneck lives in LDS only.
  * gnx_dense_layer_f16_pack rounds conv1.weight [128][K] and conv2.weight [32][128][3][3] (fp32, torch layouts) to fp16 ONCE
  * into the MFMA-fragment order the kernel streams (w1p: 128 * K halves, w2p: 36 864 halves).  bn_size * growth_rate = 128,
- * growth_rate = 32; S in {4, 8, 16, 32, 64}; 32 | K <= 1024; 128 | n_img * S * S; anything else: GNX_ERR_UNSUPPORTED (callers
+ * growth_rate = 32; S in {4, 8, 16, 32, 64}; 32 | K, 64 <= K <= 1024; 128 | n_img * S * S; anything else: GNX_ERR_UNSUPPORTED (callers
  * fall back to the two-kernel pair on row-major buffers).  The `_cb` entry points are the neighbours of that layout: the
  * fp16 stem and the transition's 1x1 conv STORE channel-blocked, the transition's pooling pass and the final pool READ it. */
 int gnx_dense_layer_f16_pack(const float* w1, const float* w2, void* w1p, void* w2p, int K, gnx_stream_t stream);
