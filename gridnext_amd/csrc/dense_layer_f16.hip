@@ -112,6 +112,9 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
     // the consumers doing conv1 + epilogue only (extra barrier F before the epilogue): 8-22 % SLOWER - a wave's share is 3-4
     // dependent chains of ~1500 cycles whatever wave runs them, and behind the feeders' own chain they lengthen the pair
     // period; the step stays bound by one group's serial work.)
+    // (Tried and dropped, measured: four slot pairs - two of them the bottleneck tile's own bytes, dead outside epilogue .. conv2 -
+    // with the feeders up to three pairs ahead of the consumers: no faster (S = 32 K = 480 1.42 -> 1.49 ms).  The consumers do
+    // not wait for data: a pair costs them ~900 cycles for 512 of MFMA - barrier, first-fragment latency, W1 issue.)
     // (Tried and dropped, measured: every tap's eight k-steps split between consumer w (0-3) and feeder w (4-7), the feeder's
     // half of a finished block handed over through the LDS between two more barriers: 3-15 % SLOWER - a 12-MFMA stream is
     // half pipeline fill, and the address set-up per tap does not shrink.)
