@@ -594,7 +594,7 @@ def _dense_layer_ref(x16, W1, W2, sc1, sh1, sc2, sh2):
 
 
 @pytest.mark.parametrize("S,n,K,ct", [(64, 2, 64, 128), (64, 3, 96, 160), (64, 260, 64, 128), (64, 5, 224, 288),
-                                      (64, 258, 160, 224), (32, 4, 128, 192),
+                                      (64, 258, 160, 224), (64, 2, 480, 544), (32, 9, 992, 1056), (32, 4, 128, 192),
                                       (32, 300, 224, 288), (16, 8, 256, 320), (16, 520, 96, 160), (8, 16, 512, 576),
                                       (8, 1040, 64, 128), (4, 64, 992, 1056), (4, 4160, 64, 128)])
 def test_dense_layer_f16_fused(L, S, n, K, ct):
