@@ -179,7 +179,7 @@ def pmc_traffic_table(suffix=''):
 KIND_SOURCES = {
     'dense_layer': ('dense_layer_f16.hip', 'fwd_common.h', 'common.h'),
     'conv1x1': ('conv1x1.hip', 'densenet_f16.hip', 'fwd_common.h', 'common.h'),
-    'transition': ('conv1x1.hip', 'densenet_f16.hip', 'fwd_common.h', 'common.h'),
+    'transition': ('conv1x1.hip', 'densenet_f16.hip', 'transition_f16.hip', 'fwd_common.h', 'common.h'),
     'conv3x3': ('conv3x3.hip', 'fwd_common.h', 'common.h'),
     'stem': ('stem_pool.hip', 'fwd_common.h', 'common.h'),
     'dgrad1x1_bn1': ('conv1x1.hip', 'fwd_common.h', 'common.h'),

@@ -70,6 +70,7 @@ class DenseNet(nn.Module):
         self.f16_buffers = True     # mfma = 'f16' only: the block buffers themselves in fp16 where the shapes allow
         self.f16_stem = True        # ... and, with fp16 block buffers, conv0's matrix operands in fp16 too
         self.f16_fused = True       # ... and every dense layer as ONE kernel, the bottleneck in LDS only (gnx_dense_layer_f16)
+        self.f16_fused_transitions = True   # ... and every transition as ONE kernel, the pooled operand in LDS only (gnx_transition_f16)
         self.input_norm = None      # (mean[3], std[3]) of a torchvision Normalize to apply to UINT8 input patches after the
                                     # u8 / 255 of ToTensor (fused into the stem's operand load); float inputs are taken as
                                     # already transformed by the dataset, as in the reference
@@ -242,6 +243,24 @@ class DenseNet(nn.Module):
         self._cache['wth'] = (key, table)
         return table
 
+    def _trans_f16_packed(self):
+        """{transition: conv weight in gnx_transition_f16's fragment order (fp16)} - the fused transitions of config 5 -,
+        refreshed with the weights."""
+        trs = [t for _, _, t, _ in self._blocks if t is not None]
+        key = self._key([t.conv.weight for t in trs])
+        hit = self._cache.get('wtp')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        st = L.stream()
+        table = {}
+        for t in trs:
+            w = t.conv.weight.detach().reshape(t.conv.weight.shape[0], -1).contiguous()
+            wp = torch.empty(w.numel(), device=w.device, dtype=torch.float16)
+            L.call('gnx_transition_f16_pack', L.ptr(w), L.ptr(wp, torch.float16), w.shape[0], w.shape[1], st)
+            table[t] = wp
+        self._cache['wtp'] = (key, table)
+        return table
+
     def _f16_dma_ok(self, M, s, mid, c_total):
         """Shapes gnx_conv3x3_f16_dma takes (conv3x3.hip): growth 32, 128 | mid, power-of-two maps 4..64, whole 128-row
         tiles, 32-bit element offsets."""
@@ -411,11 +430,18 @@ class DenseNet(nn.Module):
         if trans is not None:
             so = s // 2
             sct, sht = fold[trans.norm]
+            cout = trans.conv.out_channels
+            if (self.f16_fused_transitions and s in (8, 16, 32, 64) and 64 <= c_total <= 1024 and cout % 128 == 0 and
+                    cout <= 512 and (n * so * so) % 128 == 0 and rows_total * 64 < 2 ** 32 - 2 ** 25):
+                # one kernel: the pooled activated operand exists in the LDS only (bit-identical to the pooling pass's output)
+                L.call('gnx_transition_f16', L.ptr(buf, H), rows_total, n, s, c_total, cout, L.ptr(self._trans_f16_packed()[trans], H),
+                       L.ptr(sct), L.ptr(sht), L.ptr(nxt, H), nxt.shape[1], st)
+                return
             pooled = torch.empty((n * so * so, c_total), device=buf.device, dtype=H)
             L.call('gnx_bnrelu_avgpool2_h16_cb', L.ptr(buf, H), rows_total, L.ptr(pooled, H), c_total, n, c_total, s, L.ptr(sct),
                    L.ptr(sht), st)
             L.call('gnx_conv1x1_bnrelu_h16_cb', L.ptr(pooled, H), c_total, L.ptr(self._trans_f16()[trans], H), L.ptr(nxt, H),
-                   nxt.shape[1], n * so * so, trans.conv.out_channels, c_total, None, None, None, None, st)
+                   nxt.shape[1], n * so * so, cout, c_total, None, None, None, None, st)
 
     # ------------------------------------------------------------------ forward
     def forward(self, x):

@@ -238,6 +238,16 @@ int gnx_conv3x3_f16_dma_h(const void* A16, long lda16, const void* Wr16, void* o
                           gnx_stream_t stream);
 int gnx_bnrelu_avgpool_h16(const void* in16, long ldi, float* out, long ldo, long imgs, int C, int S2, const float* scale,
                            const float* shift, gnx_stream_t stream);
+/* A DenseNet transition of the fp16 path as ONE kernel on channel-blocked fp16 buffers (transition_f16.hip):
+ * norm -> relu -> conv 1x1 (K -> N) -> avgpool 2x2 (/root/reference/gridnext/densenet.py:47-53), evaluated pool-first; the
+ * pooled activated operand exists in the LDS only (bit-identical to gnx_bnrelu_avgpool2_h16_cb's output).
+ * gnx_transition_f16_pack: conv.weight [N][K] fp32 -> wp (N * K halves, MFMA fragment order).
+ * gnx_transition_f16: X16 [K / 32][rows_in][32] -> channel blocks [0, N / 32) of Y16 [..][rows_out][32]; S in {8, 16, 32, 64};
+ * 32 | K, 64 <= K <= 1024; 128 | N <= 512; 128 | n_img * (S / 2)^2; anything else: GNX_ERR_UNSUPPORTED (callers take the
+ * two-kernel form). */
+int gnx_transition_f16_pack(const float* w, void* wp, int N, int K, hipStream_t stream);
+int gnx_transition_f16(const void* X16, long rows_in, long n_img, int S, int K, int N, const void* wp, const float* scale,
+                       const float* shift, void* Y16, long rows_out, hipStream_t stream);
 /* One whole dense layer of config 5 in ONE kernel (gridnext/densenet.py:35-44: cat -> norm1 -> relu1 -> conv1 -> norm2 ->
  * relu2 -> conv2) on a CHANNEL-BLOCKED fp16 block buffer X16 [channels / 32][rows_total][32] - element (row, c) at
  * (c >> 5) * rows_total * 32 + row * 32 + (c & 31), so the 32 channels a K-loop stage needs of consecutive pixels are

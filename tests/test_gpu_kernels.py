@@ -593,6 +593,42 @@ def _dense_layer_ref(x16, W1, W2, sc1, sh1, sc2, sh2):
     return o.permute(0, 2, 3, 1)
 
 
+@pytest.mark.parametrize("S,n,K,N", [(64, 2, 256, 128), (32, 3, 512, 256), (16, 6, 1024, 512), (8, 8, 64, 128),
+                                     (16, 1040, 96, 128), (32, 5, 160, 384)])
+def test_transition_f16_fused(L, S, n, K, N):
+    """gnx_transition_f16 (norm -> relu -> 1x1 conv -> avgpool 2x2 as one kernel, evaluated pool-first on channel-blocked fp16
+    buffers) against the transition evaluated in double on the same fp16 values with the kernel's rounding points: the pooled
+    activated operand rounded to fp16 (fp32 arithmetic in the order of gnx_bnrelu_avgpool2_h16), fp16 weights, exact sums,
+    fp16 output.  Shapes: every map size, one and two channel blocks per wave, two output passes, more steps than CUs."""
+    g = torch.Generator().manual_seed(S * 1000 + K + n)
+    x = torch.randn(n, S, S, K, generator=g).half()
+    W = torch.randn(N, K, generator=g) * (1.0 / K ** 0.5)
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+    sc[::5] *= -1.0
+    H = torch.float16
+    st = L.stream()
+    X = x.reshape(-1, K // 32, 32).permute(1, 0, 2).contiguous().to(DEV)       # channel-blocked [K / 32][rows][32]
+    so = S // 2
+    rows_out = n * so * so
+    cy = N + 64                                                                 # the output buffer is wider than the N columns
+    Y = torch.full((cy // 32, rows_out, 32), 7.0, dtype=H, device=DEV)
+    wp = torch.empty(N * K, device=DEV, dtype=H)
+    Wd, scd, shd = W.to(DEV), sc.to(DEV), sh.to(DEV)
+    L.call('gnx_transition_f16_pack', L.ptr(Wd), L.ptr(wp, H), N, K, st)
+    L.call('gnx_transition_f16', L.ptr(X, H), X.shape[1], n, S, K, N, L.ptr(wp, H), L.ptr(scd), L.ptr(shd), L.ptr(Y, H), rows_out, st)
+    torch.cuda.synchronize()
+    got = Y.cpu().permute(1, 0, 2).reshape(n, so, so, cy)
+    assert float(got[..., N:].float().min()) == 7.0 and float(got[..., N:].float().max()) == 7.0
+    a = torch.relu(torch.addcmul(sh, x.float(), sc))                            # fp32, as the kernel
+    p = (0.25 * (((a[:, 0::2, 0::2] + a[:, 0::2, 1::2]) + a[:, 1::2, 0::2]) + a[:, 1::2, 1::2])).half()
+    ref = torch.einsum('nyxk,ok->nyxo', p.double(), W.half().double())
+    out = got[..., :N].double()
+    assert torch.isfinite(out).all()
+    err = (out - ref).abs().max().item()
+    tol = 2e-3 * ref.abs().max().item()
+    assert err <= tol, "S=%d n=%d K=%d N=%d: max abs err %.3e > %.3e" % (S, n, K, N, err, tol)
+
+
 @pytest.mark.parametrize("S,n,K,ct", [(64, 2, 64, 128), (64, 3, 96, 160), (64, 260, 64, 128), (64, 5, 224, 288),
                                       (64, 258, 160, 224), (64, 2, 480, 544), (32, 9, 992, 1056), (32, 4, 128, 192),
                                       (32, 300, 224, 288), (16, 8, 256, 320), (16, 520, 96, 160), (8, 16, 512, 576),

@@ -31,7 +31,7 @@ GROUPS = [                                   # first match wins; names as bench.
     ('wgrad3x3', lambda n: 'wgrad9_t_kernel' in n),
     ('conv1x1', lambda n: 'conv1x1_ws_kernel<true, false' in n or 'conv1x1_ws_kernel<false, false' in n
         or 'conv1x1_kernel<false' in n or 'conv1x1_h16' in n),
-    ('transition', lambda n: 'conv1x1_ws_kernel<true, true' in n or 'conv1x1_kernel<true' in n),
+    ('transition', lambda n: 'conv1x1_ws_kernel<true, true' in n or 'conv1x1_kernel<true' in n or 'transition_f16_kernel' in n),
     ('conv3x3', lambda n: 'conv3x3_' in n),
     ('stem', lambda n: 'conv_stem' in n),
     ('maxpool', lambda n: 'maxpool' in n),
