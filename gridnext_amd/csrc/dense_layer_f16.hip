@@ -625,6 +625,9 @@ __global__ __launch_bounds__(512) void dense_layer_f16_s64_kernel(_Float16* __re
     // ===================================================================== front (waves 4-7): conv1 of step n -> tile n & 1
     const int fw = wave - 4, ph = fw & 1, ch = fw >> 1;         // pixels 64 ph .. + 63, bottleneck channels 64 ch .. + 63
     const int KS = K >> 4;
+    // from four stages on the front bounds the step: its instructions go first on the SIMD it shares with a conv2 wave
+    // (K = 224: 3.75 -> 3.55 ms; below that the two halves are balanced and any priority, either way, costs 3-5 %)
+    if (nst >= 4) __builtin_amdgcn_s_setprio(3);
     const __amdgpu_buffer_rsrc_t rW1 =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(w1p), 0, (unsigned)(128 * K * 2), 0x00020000);
     // Both operand streams run CONTINUOUSLY over all the workgroup's steps through register rings of four stages (a stage = 32
