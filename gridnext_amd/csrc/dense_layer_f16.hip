@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                 const unsigned aW = lb + DL_W2 + (dy + 1) * 3 * 8192 + lane * 16;
                 // 24 (dx, k-step) products; the fragment pairs of the next D are in flight while one multiplies (a ring of
                 // D + 2 register pairs: a pair is overwritten two MFMAs after the MFMA that read it)
-                constexpr int D = 6, NSL = D + 2, NE = 24;
+                constexpr int D = 7, NSL = D + 2, NE = 24;
                 f32x4 ra[NSL] = {}, rw[NSL] = {};
                 auto request = [&](auto e_c) {
                     constexpr int e = decltype(e_c)::value, dxi = e / 8, ks = e % 8;
@@ -348,6 +348,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
 
     // ===================================================================== consumers (waves 0-3)
     const int nb = wave;                                       // conv1: output channels 32 nb .. 32 nb + 31
+    __builtin_amdgcn_s_setprio(3);                             // (the consumers bound the step: their instructions first)
     const int KS = K >> 4;
     const __amdgpu_buffer_rsrc_t rW1 =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(w1p), 0, (unsigned)(128 * K * 2), 0x00020000);
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(512) void dense_layer_f16_s64_kernel(_Float16* __re
                 const unsigned aW = lb + DL_W2 + (dy + 1) * 3 * 8192 + lane * 16;
                 // 24 (dx, k-step) products; the fragment pairs of the next D are in flight while one multiplies (a ring of
                 // D + 2 register pairs: a pair is overwritten two MFMAs after the MFMA that read it)
-                constexpr int D = 6, NSL = D + 2, NE = 24;
+                constexpr int D = 7, NSL = D + 2, NE = 24;
                 f32x4 ra[NSL] = {}, rw[NSL] = {};
                 auto request = [&](auto e_c) {
                     constexpr int e = decltype(e_c)::value, dxi = e / 8, ks = e % 8;
