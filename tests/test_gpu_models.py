@@ -572,6 +572,9 @@ def test_fp16_block_buffers_config5_128px():
         out16h_pair = m(x).cpu()                                  # the two-kernel pair it replaces, same fp16 buffers
         assert m._used_f16_buffers and not m._used_f16_fused
         m.f16_fused = True
+        m.f16_fused_transitions = False
+        out16h_tr2 = m(x).cpu()                                   # transitions as pooling pass + conv instead of one kernel
+        m.f16_fused_transitions = True
         out16h_odd = m(x[:23]).cpu()                              # 23 spots: not whole tiles -> fp32 buffers
         assert not m._used_f16_buffers
     scale = out32.abs().max().item()
@@ -582,6 +585,9 @@ def test_fp16_block_buffers_config5_128px():
     e_pair = (out16h - out16h_pair).abs().max().item() / scale    # same operands, other summation order / rounding points
     print("fused dense layers vs the two-kernel pair: %.2e" % e_pair)
     assert e_pair < 5e-3
+    e_tr = (out16h - out16h_tr2).abs().max().item() / scale       # the same pooled fp16 operand, another k order in the conv
+    print("fused transitions vs pooling pass + conv: %.2e" % e_tr)
+    assert e_tr < 2e-3
     assert (out16h_odd - out16[:23]).abs().max().item() / scale < 1e-3     # other kernels for ragged tiles: rounding only
     top = out32.topk(2, dim=1).values
     decided = (top[:, 0] - top[:, 1]) > 5e-2
