@@ -140,22 +140,30 @@ KINDS = {
 
 
 def kernel_table(probe, patch, steps):
-    """{kind: roofline dict} from the (kind, start_event, end_event) records of `steps` timed steps."""
+    """{kind: roofline dict} from the (kind, start_event, end_event, flops, bytes) records of `steps` timed steps.  Every
+    kind is credited with the ALGORITHMIC work of exactly the launches that were timed under its name (the launch sites in
+    gridnext_amd/densenet.py / densenet_train.py state each launch's FLOPs and bytes from its own M, K, N): a series that
+    launches a kernel twice per step (recompute) or splits a role over two kinds is priced launch by launch.  The closed
+    forms above (`*_per_spot`) are the same sums over one pass of the network and serve DESIGN.md's tables and the tests."""
     kern = {}
-    for kind in sorted({k for k, _, _ in probe}):
+    for kind in sorted({r[0] for r in probe}):
         if kind not in KINDS:
             continue
         name, flops_per_spot, bytes_per_spot = KINDS[kind]
-        ms = sum(s.elapsed_time(e) for k, s, e in probe if k == kind)
-        n_launch = sum(1 for k, _, _ in probe if k == kind)
-        flops = flops_per_spot(patch) * H * W * steps
+        recs = [r for r in probe if r[0] == kind]
+        ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+        n_launch = len(recs)
+        if all(len(r) >= 5 and r[3] is not None for r in recs):
+            flops, nbytes = sum(r[3] for r in recs), sum(r[4] for r in recs)
+        else:                                                   # records without their own work: one pass of the network
+            flops, nbytes = flops_per_spot(patch) * H * W * steps, bytes_per_spot(patch) * H * W * steps
         achieved = flops / (ms * 1e-3) / 1e12
         kern[kind] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
                       "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
                       "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
                       "flops_per_launch_avg": flops / max(n_launch, 1),
-                      "algorithmic_bytes_per_launch_avg": bytes_per_spot(patch) * H * W * steps / max(n_launch, 1),
-                      "algorithmic_gbs": bytes_per_spot(patch) * H * W * steps / (ms * 1e-3) / 1e9,
+                      "algorithmic_bytes_per_launch_avg": nbytes / max(n_launch, 1),
+                      "algorithmic_gbs": nbytes / (ms * 1e-3) / 1e9,
                       "ms_per_step": ms / steps}
     return kern
 
@@ -222,7 +230,8 @@ def winograd_credit(k3, patch, steps):
     """The Winograd launches execute 2/3 of the direct-convolution multiply-adds: `achieved` / `frac` become the EXECUTED
     matrix FLOPs against the matrix peak; the direct-convolution credit (SURVEY 8d's algorithmic figure) moves to
     `direct_conv_*`."""
-    ex = conv3x3_executed_flops_per_spot(patch) * H * W * steps
+    # (whole passes of the network were timed, so the executed : direct ratio of one pass applies to the recorded total)
+    ex = k3["flops_per_launch_avg"] * k3["launches"] * conv3x3_executed_flops_per_spot(patch) / conv3x3_flops_per_spot(patch)
     k3["kernel"] = "conv3x3_wino_kernel (S >= 8) + conv3x3_dma_kernel (S = 4)"
     k3["algorithm"] = ("Winograd F(2,3) along x for maps of 8 x 8 and up: 2/3 of the direct multiply-adds. "
                        "`achieved`/`frac` = executed matrix FLOPs; `direct_conv_*` = the same time credited with "
@@ -590,9 +599,8 @@ def config5_series(args, device, rank, world, steps=4, warmup=2):
         _, out["ce_vs_ref"] = cpu_leg(model, P, 'f16', device, timed_steps=0, sub_hw=(13, 8), u8=True)
         out["fused_dense_layers"] = bool(getattr(f_img, '_used_f16_fused', False))
     kt = kernel_table(probe, P, steps)
-    for kind in kt:                                              # fp16 operands: half the bytes; priced against HBM
+    for kind in kt:                                              # fp16 operands (2 B, stated per launch); priced against HBM
         kk = kt[kind]
-        kk["algorithmic_bytes_per_launch_avg"] *= 0.5
         gbs = kk["algorithmic_bytes_per_launch_avg"] / (kk["avg_launch_ms"] * 1e-3) / 1e9
         kk.update({"bound": "hbm", "matrix_tflops": kk["achieved"], "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "frac": gbs / PEAK_HBM_GBS, "kernel": {"conv1x1": "conv1x1_h16_kernel", "conv3x3": "conv3x3_dma_kernel<H16, O16>",
@@ -678,13 +686,11 @@ def config5_trained_series(args, device, rank, world, steps=2, warmup=1):
                        "HBM; f in recomputed chunks (bounded tape)"}
     kt = kernel_table(probe, P, steps)
     if kt:
-        # every forward kernel ran twice (tape-free pass + recompute): kernel_table credited one pass of FLOPs to two passes of time
         for kind in ('conv1x1', 'conv3x3'):
             if kind in kt:
-                kt[kind]["note"] = "launched twice per step (forward without tape + recompute in backward)"
-                kt[kind]["achieved"] *= 2
-                kt[kind]["frac"] *= 2
-                kt[kind]["flops_per_launch_avg"] *= 2
+                kt[kind]["note"] = "launched twice per step (forward without tape + recompute in backward), each launch credited"
+        if getattr(f_img, 'winograd', False) and f_img.mfma == 'f32' and 'conv3x3' in kt:
+            winograd_credit(kt['conv3x3'], P, steps)
         order = sorted(kt, key=lambda k: -kt[k]["ms_per_step"])
         out["roofline"] = dict(kt[order[0]])
         out["roofline"]["other_kernels"] = {k: {f: kt[k][f] for f in ("kernel", "achieved", "frac", "ms_per_step", "launches")}
@@ -722,6 +728,9 @@ def worker_main(args):
     from gridnext_amd import distributed as gdist
     from gridnext_amd import training as gtrain
     from gridnext_amd.synthetic import visium_array
+    threads = _pin_to_rank_cpus()                                 # N > 1: this rank's slice of the host cores
+    if threads:
+        torch.set_num_threads(max(1, threads))
     rank, world, device = gdist.init_from_env(args.backend)
     assert torch.cuda.is_available(), "bench.py measures the HIP path; no HIP device visible"
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
@@ -849,6 +858,10 @@ def worker_main(args):
                    "final_loss": last_loss},
         "rccl_ranks": world, "backend": (torch.distributed.get_backend() if gdist.is_active() else "none (1 process)"),
         "devices": names, "ranks": run_series.last_ranks,
+        "threads_per_rank": threads or torch.get_num_threads(),
+        # f-trained steps: the DenseNet's gradients are all-reduced bucket by bucket from inside its backward
+        # (distributed.BackwardReducer); frozen-f steps have one 108 KB flat call into a persistent buffer
+        "allreduce_overlapped": bool(gdist.BackwardReducer.wanted()),
     }
     if probe:
         kern = kernel_table(probe, args.patch, args.steps)
@@ -874,8 +887,6 @@ def worker_main(args):
                 if kind not in kern:
                     continue
                 kk = kern[kind]
-                if h16:
-                    kk["algorithmic_bytes_per_launch_avg"] *= 0.5
                 kk["fp16_block_buffers"] = h16
                 gbs = kk["algorithmic_bytes_per_launch_avg"] / (kk["avg_launch_ms"] * 1e-3) / 1e9
                 kk.update({"bound": "hbm", "kernel": name, "matrix_tflops": kk["achieved"], "achieved": gbs,
@@ -909,15 +920,18 @@ def worker_main(args):
         optional("from_host", lambda: from_host_series(args, model, optimizer, criterion, device, rank, world))
 
     # ---- BASELINE config 5's geometry in the same run: 256-px patches, fp16 MFMA conv path (fp16 block buffers, fp16 stem)
-    if not args.no_series and not args.train_f and args.mfma == 'f32' and args.patch == 128:
+    # (a SCALE run - N > 1 - carries the headline and the host-fed series only, unless --all-series: the other series are
+    #  single-GPU characterisations and would lengthen every N for numbers nobody reads there)
+    more = not args.no_series and (world == 1 or args.all_series)
+    if more and not args.train_f and args.mfma == 'f32' and args.patch == 128:
         optional("config5_f16_256px", lambda: config5_series(args, device, rank, world))
 
     # ---- and its "everything trained" column: 256 px, fp32, f in recomputed chunks (bounded tape)
-    if not args.no_series and not args.train_f and args.mfma == 'f32' and args.patch == 128:
+    if more and not args.train_f and args.mfma == 'f32' and args.patch == 128:
         optional("config5_everything_trained_256px", lambda: config5_trained_series(args, device, rank, world))
 
     # ---- second series of SURVEY 8d in the same run: f trained (DenseNet forward + backward)
-    if not args.train_f and not args.no_series and args.mfma == 'f32' and args.patch == 128:
+    if not args.train_f and more and args.mfma == 'f32' and args.patch == 128:
         free, _ = torch.cuda.mem_get_info(device)
         if tape_bytes(args.patch, H * W) < free:
             def train_f_series():
@@ -960,6 +974,35 @@ def _free_port():
     return port
 
 
+def _rank_cpus(rank, world):
+    """The host cores rank `rank` of `world` pins itself to: a contiguous slice of the cores this process may use - with
+    the usual enumeration (socket 0's cores first) contiguous slices are NUMA-local, and GPUs 0-3 / 4-7 hang off sockets
+    0 / 1 on an 8-GPU MI355X node.  Hyper-thread siblings (the second half of the enumeration) go with their cores."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return []
+    if world <= 1 or len(allowed) < world:
+        return []
+    per = len(allowed) // world
+    return allowed[rank * per:(rank + 1) * per]
+
+
+def _pin_to_rank_cpus():
+    """Apply GNX_BENCH_CPUS (set by launch(); under torchrun: derived from LOCAL_RANK / LOCAL_WORLD_SIZE) - affinity and the
+    intra-op thread count.  Returns the number of threads per rank (None: untouched)."""
+    spec = os.environ.get('GNX_BENCH_CPUS')
+    cpus = [int(c) for c in spec.split(',')] if spec else \
+        _rank_cpus(int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1'))))
+    if not cpus:
+        return None
+    try:
+        os.sched_setaffinity(0, cpus)
+    except (AttributeError, OSError):
+        return None
+    return len(cpus)
+
+
 def launch(n, argv):
     """Start `n` worker processes (one per GPU) and wait for them.  This process never initialises the GPU: it imports
     neither torch nor the package; children are fresh interpreters (never exec'd over a process that touched the card)."""
@@ -968,6 +1011,13 @@ def launch(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        # every rank gets its own slice of the host cores: 8 ranks with torch's default intra-op pool (all cores each)
+        # contend in the host-fed series' collate / staging (worker_main pins itself to GNX_BENCH_CPUS)
+        cpus = _rank_cpus(r, n)
+        if cpus:
+            env['GNX_BENCH_CPUS'] = ','.join(str(c) for c in cpus)
+            env.setdefault('OMP_NUM_THREADS', str(len(cpus)))
+            env.setdefault('MKL_NUM_THREADS', str(len(cpus)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), '--worker'] + argv, env=env))
     failed = 0
     pending = dict(enumerate(procs))
@@ -1002,6 +1052,8 @@ def parse(argv):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-series', action='store_true', help='skip the extra series appended to the default run')
+    ap.add_argument('--all-series', action='store_true',
+                    help='with --gpus N > 1: also run the single-GPU characterisation series on every rank')
     ap.add_argument('--from-host', action='store_true',
                     help='(with --no-series) still run the fed-from-host-memory series: uint8 patches through the prefetcher')
     ap.add_argument('--series-steps', type=int, default=3)

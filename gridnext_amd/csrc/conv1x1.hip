@@ -1022,8 +1022,8 @@ __global__ __launch_bounds__(256) void conv1x1_fold_kernel(const float* __restri
 
 // out[M][N] (ldc) = act(A[M][K] (lda)) . W[N][K]^T ; pool != 0: A is on an S_in x S_in grid per image and M counts the
 // (S_in/2)^2 pooled positions.  scale/shift may both be NULL (no activation).
-// conv1's fused data gradient: workgroups take contiguous runs of the column-fastest tile list (GNX_C1_RUNS=0: the XCD
-// placement the forward transitions keep).  Same box, same run: 52.5 -> 50.0 ms per f-trained step; the forward transitions
+// conv1's fused data gradient: workgroups take contiguous runs of the column-fastest tile list (the forward transitions
+// keep their XCD placement instead).  Same box, same run: 52.5 -> 50.0 ms per f-trained step; the forward transitions
 // measured no better with runs (2.97 ms either way within noise), so they keep their order.
 static int c1_tile_runs() { return 1; }
 

@@ -341,7 +341,9 @@ class DenseNet(nn.Module):
         return max(1, min(n, max(32, budget // max(per_spot, 1))))
 
     # ------------------------------------------------------------------ optional per-kernel timing (bench.py)
-    _probe = None      # when a list: (kind, start_event, end_event) per dense-layer launch, on the launch stream
+    _probe = None      # when a list: (kind, start_event, end_event, flops, bytes) per dense-layer launch, on the launch stream
+                       # (flops / bytes: the ALGORITHMIC work of that launch - bench.py credits a kernel kind with exactly the
+                       # launches it timed)
 
     def _probe_begin(self):
         if self._probe is None:
@@ -350,12 +352,12 @@ class DenseNet(nn.Module):
         ev.record()
         return ev
 
-    def _probe_mark(self, kind, start):
+    def _probe_mark(self, kind, start, flops=None, nbytes=None):
         if self._probe is None:
             return None
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
-        self._probe.append((kind, start, ev))
+        self._probe.append((kind, start, ev, flops, nbytes))
         return ev
 
     # ------------------------------------------------------------------ stem of the eval forward
@@ -426,7 +428,8 @@ class DenseNet(nn.Module):
             t0 = self._probe_begin()
             L.call('gnx_dense_layer_f16', L.ptr(buf, H), rows_total, n, s, cin, L.ptr(dlp[layer][0], H), L.ptr(dlp[layer][1], H),
                    L.ptr(sc1), L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), st)
-            self._probe_mark('dense_layer', t0)
+            Ml = n * s * s
+            self._probe_mark('dense_layer', t0, 2 * Ml * (cin * 128 + 9 * 128 * 32), 2 * Ml * (cin + 32))
         if trans is not None:
             so = s // 2
             sct, sht = fold[trans.norm]
@@ -473,16 +476,23 @@ class DenseNet(nn.Module):
             raise ValueError("DenseNet.mfma must be 'f32' or 'f16'")
         sfx = '_f16' if self.mfma == 'f16' else ''
         hs, sizes = self._geometry(P)
-        # (fp16 block buffers hold twice the spots in the same bytes: a whole 256-px array - 34 GB - is then one chunk)
-        chunk = self._auto_chunk(P, N, 2 if (self.mfma == 'f16' and self.f16_buffers) else 4)
         mid = self.bn_size * self.growth_rate
-        # the fused dense-layer kernel (fp16 block buffers) takes: growth 32, bottleneck 128, maps of 4..64, 32 | channels >= 64
+        conv0 = self.features.conv0
+        c0 = conv0.out_channels
+        # the fused dense-layer kernel (fp16 block buffers) takes: growth 32, bottleneck 128, maps of 4..64, 32 | channels >= 64;
+        # its stem (gnx_conv_stem_bnrelu_maxpool_f16mul_cb) 32 | c0 <= 64 and always multiplies fp16 operands (f16_stem)
         fused_ok = bool(sfx) and self.f16_buffers and self.f16_fused and self.growth_rate == 32 and mid == 128 and \
             all(s in (4, 8, 16, 32, 64) for s in sizes) and all(blk[0] % 32 == 0 and blk[0] >= 64 for blk in self._blocks) and \
             self.num_features % 32 == 0 and not self.small_inputs and P in (128, 256) and \
-            all(blk[3] <= 1024 + 32 for blk in self._blocks)
+            all(blk[3] <= 1024 + 32 for blk in self._blocks) and c0 in (32, 64) and self.f16_stem
+        # fp16 BLOCK BUFFERS (decided for the whole call: the buffers cannot change type half-way) hold twice the spots in
+        # the same bytes - a whole 256-px array, 34 GB, is then one chunk; the chunk is sized for the element type that is
+        # actually taken
+        h_shapes = bool(sfx) and self.f16_buffers and not self.small_inputs and P in (128, 256) and c0 % 4 == 0 and \
+            self.growth_rate == 32 and mid % 128 == 0 and N % 8 == 0 and all(s in (4, 8, 16, 32, 64) for s in sizes)
+        chunk = self._auto_chunk(P, N, 2 if h_shapes else 4)
         if sfx and self.atonce is None and chunk >= 8:
-            if fused_ok:
+            if fused_ok and h_shapes:
                 chunk = chunk // 8 * 8                          # whole 128-row tiles; it indexes with 64 bits
             else:
                 # two-kernel fp16 path: chunks of whole 128-row tiles whose element offsets fit 32 bits (its DMA kernels)
@@ -496,9 +506,7 @@ class DenseNet(nn.Module):
         # config 5 with fp16 BLOCK BUFFERS: the concatenated features live in HBM as fp16 (as under the reference's autocast),
         # every kernel of the chain reads / writes halves.  Taken when every launch of the call has a shape those kernels
         # take (decided here, for the whole call: the buffers cannot change type half-way).
-        use_h = bool(sfx) and self.f16_buffers and not self.small_inputs and P in (128, 256) and c0 % 4 == 0 and \
-            self.growth_rate == 32 and mid % 128 == 0 and N % 8 == 0 and chunk % 8 == 0 and \
-            all(s in (4, 8, 16, 32, 64) for s in sizes) and \
+        use_h = h_shapes and chunk % 8 == 0 and \
             (fused_ok or all(sub_range(bi, min(chunk, N)) * sizes[bi] ** 2 * max(mid, self._blocks[bi][3]) < 2 ** 31
                              for bi in range(len(sizes))))
         fused = use_h and fused_ok
@@ -541,11 +549,15 @@ class DenseNet(nn.Module):
                         sc1, sh1 = fold[layer.norm1]
                         sc2, sh2 = fold[layer.norm2]
                         t0 = self._probe_begin()
+                        eb = 2 if use_h else 4                                        # bytes per block-buffer element
+                        em = 2 if (use_h or (sfx and self._f16_dma_ok(M, s, mid, c_total))) else 4   # ... per bottleneck element
+                        work1 = (2 * M * cin * mid, M * (cin * eb + mid * em))
+                        work2 = (2 * M * 9 * mid * self.growth_rate, M * (mid * em + self.growth_rate * eb))
                         if use_h:
                             L.call('gnx_conv1x1_bnrelu_h16', L.ptr(rows, torch.float16), c_total,
                                    L.ptr(w1h[layer], torch.float16), L.ptr(bott16, torch.float16), mid, M, mid, cin,
                                    L.ptr(sc1), L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), st)
-                            t1 = self._probe_mark('conv1x1', t0)
+                            t1 = self._probe_mark('conv1x1', t0, *work1)
                             L.call('gnx_conv3x3_f16_dma_h', L.ptr(bott16, torch.float16), mid,
                                    L.ptr(w2h[layer], torch.float16), rows.data_ptr() + 2 * cin, c_total, M,
                                    self.growth_rate, mid, s, st)
@@ -554,13 +566,13 @@ class DenseNet(nn.Module):
                             # depends on the map size and channel counts only (128 | M holds for every whole spot)
                             L.call('gnx_conv1x1_bnrelu_f16_act16', L.ptr(rows), c_total, L.ptr(layer.conv1.weight),
                                    L.ptr(bott16, torch.float16), mid, M, mid, cin, L.ptr(sc1), L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), st)
-                            t1 = self._probe_mark('conv1x1', t0)
+                            t1 = self._probe_mark('conv1x1', t0, *work1)
                             L.call('gnx_conv3x3_f16_dma', L.ptr(bott16, torch.float16), mid, L.ptr(w2h[layer], torch.float16),
                                    rows.data_ptr() + 4 * cin, c_total, M, self.growth_rate, mid, s, st)
                         elif sfx:
                             L.call('gnx_conv1x1_bnrelu_f16', L.ptr(rows), c_total, L.ptr(layer.conv1.weight),
                                    L.ptr(bott), mid, M, mid, cin, L.ptr(sc1), L.ptr(sh1), 0, 0, st)
-                            t1 = self._probe_mark('conv1x1', t0)
+                            t1 = self._probe_mark('conv1x1', t0, *work1)
                             L.call('gnx_conv3x3_bnrelu_f16', L.ptr(bott), mid, L.ptr(w2[layer]),
                                    rows.data_ptr() + 4 * cin, c_total, M, self.growth_rate, mid, s, L.ptr(sc2),
                                    L.ptr(sh2), st)
@@ -569,7 +581,7 @@ class DenseNet(nn.Module):
                             # (global -> LDS DMA, no prologue)
                             L.call('gnx_conv1x1_bnrelu_act', L.ptr(rows), c_total, L.ptr(layer.conv1.weight),
                                    L.ptr(bott), mid, M, mid, cin, L.ptr(sc1), L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), st)
-                            t1 = self._probe_mark('conv1x1', t0)
+                            t1 = self._probe_mark('conv1x1', t0, *work1)
                             # conv2 on the ready operand: Winograd F(2,3) along x (1.5x fewer matrix operations, rounding-
                             # level differences) for maps of 8 x 8 and up (4 x 4 measured faster direct).  The choice
                             # depends on the map size only - never on how many spots a call or a chunk holds - so chunked
@@ -583,7 +595,7 @@ class DenseNet(nn.Module):
                             if rc == L.ERR_UNSUPPORTED:
                                 L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2[layer]),
                                        rows.data_ptr() + 4 * cin, c_total, M, self.growth_rate, mid, s, None, None, st)
-                        self._probe_mark('conv3x3', t1)
+                        self._probe_mark('conv3x3', t1, *work2)
                     if trans is not None:
                         nxt = bufs[bi + 1]
                         so = s // 2

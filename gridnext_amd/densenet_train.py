@@ -4,11 +4,14 @@ Used by `DenseNet.forward` whenever the module is in training mode or a gradient
 `train_spotwise` on an image classifier (BatchNorm batch statistics, /root/reference/gridnext/training.py:60-67)
 and `train_gridwise` with `f_opt` (f kept in eval mode by training.py:126, but its parameters trained).
 
-MI355X-first: nothing is recomputed and nothing is checkpointed (the reference's `efficient=True` and
-`atonce_patch_limit` recompute paths exist to save memory; a 128-px array's full tape is ~42 GB of the 288 GB
-HBM).  The tape holds the raw (pre-BN) tensors only: stem output, the dense-block buffers and each layer's
-1x1-conv output; every BN+ReLU is re-evaluated inside the consuming kernel's operand load, forward and backward.
-One autograd node covers the whole network; gradients are returned for every parameter that requires one.
+MI355X-first: a 128-px array's full tape is ~55 GB of the 288 GB HBM, so by default one tape covers the whole batch and
+nothing is recomputed.  Where the reference saves memory (`efficient=True`, densenet.py:36-40; `atonce_patch_limit` chunks
+under `cp.checkpoint`, gridnet_models.py:88-104) or where the tape would exceed `DenseNet.tape_budget` (256-px arrays), the
+batch goes through in chunks whose forward keeps no tape and whose backward rebuilds it (`_RecomputeFn`).
+The tape holds the raw (pre-BN) tensors only: stem output, the dense-block buffers and each layer's 1x1-conv output (stored
+activated under running statistics); every other BN+ReLU is re-evaluated inside the consuming kernel's operand load, forward
+and backward.  One autograd node covers the whole network; gradients are returned for every parameter that requires one.
+`DenseNet.mfma = 'f16'` under running statistics takes the fp16 tape and the fp16-MFMA backward of densenet_train_f16.
 """
 import os
 import struct
@@ -185,7 +188,7 @@ class _DenseNetFn(Function):
                     t0 = model._probe_begin()
                     L.call('gnx_conv1x1_bnrelu_act', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid, M,
                            mid, cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s2[0]), L.ptr(s2[1]), st)
-                    model._probe_mark('conv1x1', t0)
+                    model._probe_mark('conv1x1', t0, 2 * M * cin * mid, 4 * M * (cin + mid))
                     # conv2 on the ready operand as in the eval forward: Winograd F(2,3) along x for maps of 8 x 8 and up
                     # (`model.winograd`), the direct form otherwise.  The backward is the adjoint of whichever ran (masks
                     # and x_hat come from the stored activations).  Against a direct-form reference the outputs differ at
@@ -201,7 +204,7 @@ class _DenseNetFn(Function):
                     if rc == L.ERR_UNSUPPORTED:
                         L.call('gnx_conv3x3_bnrelu', L.ptr(bott), mid, L.ptr(w2r[layer.conv2.weight]), _cols(buf, cin), c_total,
                                M, g, mid, s, None, None, st)
-                    model._probe_mark('conv3x3', t0)
+                    model._probe_mark('conv3x3', t0, 2 * M * 9 * mid * g, 4 * M * (mid + g))
                 else:
                     nws = L.query('gnx_conv1x1_workspace', M, mid, cin)       # small batches: K split over workgroups
                     ws1 = torch.empty(nws, device=dev, dtype=F32) if nws else None
@@ -297,7 +300,8 @@ class _DenseNetFn(Function):
             t0 = model._probe_begin()
             L.call('gnx_wgrad_bnrelu', dy_ptr, lddy, x_ptr, ldx, sc, sh, L.ptr(dw), L.ptr(ws), M, Nn, K, S, taps, pool, 0,
                    L.stream())
-            model._probe_mark('wgrad3x3' if taps == 9 else ('wgrad_trans' if pool else 'wgrad1x1'), t0)
+            model._probe_mark('wgrad3x3' if taps == 9 else ('wgrad_trans' if pool else 'wgrad1x1'), t0, 2 * M * taps * Nn * K,
+                              4 * M * (Nn + K * (4 if pool else 1)))
 
         # Under hipGraph capture (the spot loop's small-batch steps, graphs.py) a dense block's weight gradients are DEFERRED to
         # the end of the block and launched on a side stream as ONE parallel branch of the step graph: they are off the critical
@@ -326,6 +330,19 @@ class _DenseNetFn(Function):
             done = torch.cuda.Event()
             done.record(side)
             side_done.append(done)
+
+        # data-parallel runs: this node's gradients leave block by block, each bucket's all-reduce overlapping the rest of the
+        # backward (distributed.BackwardReducer); what autograd receives is already the average over ranks
+        from . import distributed as gdist
+        reducer = gdist.BackwardReducer() if gdist.BackwardReducer.wanted() else None
+        sent = set()
+
+        def send_bucket():
+            if reducer is None:
+                return
+            ps = [p for p in grads if id(p) not in sent]
+            sent.update(id(p) for p in ps)
+            reducer.bucket([grads[p] for p in ps], ps)
 
         w2b = relayout_weights(model, 1, dev, st)            # conv2 weights for the data gradient, all layers, one launch
         w1ts = relayout_weights(model, 2, dev, st)           # conv1 / transition weights transposed, one launch
@@ -404,15 +421,15 @@ class _DenseNetFn(Function):
                     if rc not in (0, L.ERR_UNSUPPORTED):
                         raise RuntimeError("gnx_conv3x3_dgrad_bnrelu_bwd failed (%d)" % rc)
                     if rc == 0:
-                        model._probe_mark('dgrad3x3_bn2', t0)
+                        model._probe_mark('dgrad3x3_bn2', t0, 2 * M * 9 * mid * g, 4 * M * (g + 2 * mid))
                 if rc == L.ERR_UNSUPPORTED:
                     t0 = model._probe_begin()
                     L.call('gnx_conv3x3_bnrelu', dy2, c_total, L.ptr(wb), L.ptr(tA), mid, M, mid, g, s, None, None, st)
-                    t0 = model._probe_mark('dgrad3x3', t0)
+                    t0 = model._probe_mark('dgrad3x3', t0, 2 * M * 9 * mid * g, 4 * M * (g + mid))
                     # norm2 + relu2
                     bn_bwd(layer.norm2, s2, L.ptr(tA), mid, L.ptr(bott), mid, L.ptr(tB), mid, M, mid, 0,
                            relu=2 if activated else 1)
-                    model._probe_mark('bn2_bwd', t0)
+                    model._probe_mark('bn2_bwd', t0, 0, 4 * M * 3 * mid)
                 # conv1
                 w1_call = (lambda layer=layer, tB=tB, s1=s1, cin=cin:
                            wgrad(layer.conv1.weight, L.ptr(tB), mid, L.ptr(buf), c_total, s1, M, mid, cin, s, 1, 0))
@@ -436,7 +453,7 @@ class _DenseNetFn(Function):
                     if rc not in (0, L.ERR_UNSUPPORTED):
                         raise RuntimeError("gnx_conv1x1_dgrad_bnrelu_bwd failed (%d)" % rc)
                     if rc == 0:
-                        model._probe_mark('dgrad1x1_bn1', t0)
+                        model._probe_mark('dgrad1x1_bn1', t0, 2 * M * cin * mid, 4 * M * (mid + 3 * cin))
                 if rc == L.ERR_UNSUPPORTED:
                     L.call('gnx_conv1x1_bnrelu', L.ptr(tB), mid, L.ptr(w1t), L.ptr(tC), c_total, M, cin, mid, None, None,
                            0, 0, st)
@@ -494,6 +511,7 @@ class _DenseNetFn(Function):
                 del dPool
                 dbufs[bi] = None
                 bufs[bi] = None
+            send_bucket()                                          # this block (+ the transition below it): final
 
         # ---- stem
         conv0 = model.features.conv0
@@ -542,6 +560,9 @@ class _DenseNetFn(Function):
         for ev in side_done:
             cur.wait_event(ev)                                     # join the weight-gradient branches
         held.clear()
+        if reducer is not None:
+            send_bucket()                                          # the stem's
+            reducer.finish()
         ctx.tape = None
         out = [None, None]
         for p in model.parameters():
@@ -561,7 +582,10 @@ class _RecomputeFn(Function):
 
     @staticmethod
     def forward(ctx, model, x, *params):
+        if x.requires_grad:
+            raise NotImplementedError("gradient with respect to the input patches is not part of the GridNext path")
         ctx.model, ctx.x = model, x
+        ctx.versions = [(p, p._version, p.data_ptr()) for p in params]
         ctx.bn_state = None
         # train-mode dropout: the recompute must draw the masks the first forward drew
         ctx.rng = torch.cuda.get_rng_state(x.device) if (model.training and model.drop_rate > 0) else None
@@ -575,6 +599,11 @@ class _RecomputeFn(Function):
     @staticmethod
     def backward(ctx, dout):
         model, x = ctx.model, ctx.x
+        for p, ver, addr in ctx.versions:
+            if p._version != ver or p.data_ptr() != addr:
+                raise RuntimeError("gridnext_amd.DenseNet: a parameter was modified between forward and backward "
+                                   "(optimizer.step() or load_state_dict before loss.backward()); the recomputed forward "
+                                   "would differ from the one whose output the loss was computed from")
         after = None
         if ctx.bn_state is not None:
             after = [(m, m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone())

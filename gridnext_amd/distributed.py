@@ -4,8 +4,10 @@ One process per GPU (torchrun / torch.distributed.run); Visium arrays (grid loop
 sharded round-robin over ranks; each rank runs f, g and the masked CE on its own arrays and the parameter
 gradients are summed with ONE flat all-reduce (RCCL over xGMI when the backend is "nccl") just before
 `optimizer.step()`, then divided by the world size.  With the corrector-only recipe of the tutorials the
-message is 27 144 floats (108.6 KB): a single latency-bound call; with f trainable it is 32 MB, still
-<1 ms against >=100 ms of compute per array, so no bucketing/overlap machinery is needed at this size.
+message is 27 144 floats (108.6 KB): a single latency-bound call into a persistent flat buffer (`.grad` becomes a view of
+it; no `cat`, no copy-back).  With f trainable it is 32 MB: the DenseNet's backward hands its gradients over block by block
+(`BackwardReducer`: one asynchronous bucket per dense block, block 4 first, overlapped with the rest of the backward), the
+remaining parameters (count MLP, corrector) go in the one flat call before the step.
 
 Semantics: per-rank batch = the reference's batch (1 array); averaging gradients over ranks equals the
 reference's gradient accumulation over `world` arrays with each array's foreground-mean weighted equally.
@@ -83,26 +85,105 @@ def optimizer_params(*optimizers):
     return out
 
 
+_FLAT = {}            # (device, dtype, numel-signature) -> persistent flat gradient buffer
+_EARLY = set()        # id(p) of parameters whose CURRENT gradient contributions were already averaged inside backward
+
+
+def _flat_buffer(params):
+    """One persistent flat tensor holding the gradients of `params` back to back (allocated once per parameter set, reused
+    by every step: no `cat` allocation, no copy-back)."""
+    key = (params[0].device, params[0].dtype, tuple(p.numel() for p in params))
+    flat = _FLAT.get(key)
+    if flat is None:
+        flat = _FLAT[key] = torch.zeros(sum(key[2]), device=key[0], dtype=key[1])
+    return flat
+
+
 def allreduce_gradients(params):
-    """Average .grad over ranks with one flat all-reduce. Parameters without a gradient contribute zeros
-    (every rank must issue the same collective)."""
+    """Average .grad over ranks with one flat all-reduce per dtype.  Parameters without a gradient contribute zeros (every
+    rank must issue the same collective).  The flat buffer is persistent and `.grad` becomes a VIEW of it: one multi-tensor
+    copy in (gradients autograd has just created live elsewhere), the collective, one in-place divide - nothing is copied
+    back.  Parameters whose gradients were already averaged bucket by bucket inside backward (`BackwardReducer`: a trained
+    DenseNet's dense blocks) are skipped."""
     if not is_active():
+        _EARLY.clear()
         return
-    params = [p for p in params if p.requires_grad]
-    if not params:
-        return
-    grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat.div_(world_size())
-    off = 0
-    for p, g in zip(params, grads):
-        n = g.numel()
-        if p.grad is None:
-            p.grad = flat[off:off + n].view_as(p).clone()
-        else:
-            p.grad.copy_(flat[off:off + n].view_as(p))
-        off += n
+    params = [p for p in params if p.requires_grad and id(p) not in _EARLY]
+    _EARLY.clear()
+    by = {}
+    for p in params:
+        by.setdefault((p.device, p.dtype), []).append(p)
+    for group in by.values():
+        flat = _flat_buffer(group)
+        views, off = [], 0
+        for p in group:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        src_d, src_s, zero = [], [], []
+        for p, v in zip(group, views):
+            if p.grad is None:
+                zero.append(v)
+            elif p.grad.data_ptr() != v.data_ptr():
+                src_d.append(v)
+                src_s.append(p.grad)
+        with torch.no_grad():
+            if src_d:
+                torch._foreach_copy_(src_d, src_s)
+            if zero:
+                torch._foreach_zero_(zero)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.div_(world_size())
+        for p, v in zip(group, views):
+            p.grad = v
+
+
+class BackwardReducer:
+    """Bucketed gradient all-reduce issued FROM INSIDE a backward, overlapped with the rest of it ("bucketed in
+    reverse-backward order and overlapped").  A backward that produces its parameter gradients in stages - the DenseNet's one
+    autograd node finishes block 4's gradients ~200 ms before block 1's at 128 px - calls `bucket(tensors, params)` after
+    each stage: the tensors are packed into a persistent flat bucket and an ASYNCHRONOUS all-reduce starts (RCCL runs it on
+    its own stream beside the remaining backward kernels).  `finish()`, called before the backward returns, makes the launch
+    stream wait for every bucket, divides by the world size and rewrites each gradient tensor with the averaged values: the
+    gradients handed to autograd are already the data-parallel averages, so accumulation (`accum_iters`) stays linear.  The
+    parameters are remembered in `_EARLY` and skipped by the step's `allreduce_gradients`.  Every rank runs the same model and
+    so issues the same buckets in the same order."""
+
+    def __init__(self):
+        self.pending = []
+
+    @staticmethod
+    def wanted():
+        return is_active() and os.environ.get('GNX_DP_OVERLAP', '1') != '0' and not sync_active() and \
+            not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+
+    def bucket(self, tensors, params):
+        if not tensors:
+            return
+        key = ('bucket', len(self.pending)) + tuple(t.numel() for t in tensors)
+        flat = _FLAT.get((tensors[0].device, tensors[0].dtype, key))
+        if flat is None:
+            flat = _FLAT[(tensors[0].device, tensors[0].dtype, key)] = torch.empty(
+                sum(t.numel() for t in tensors), device=tensors[0].device, dtype=tensors[0].dtype)
+        views, off = [], 0
+        for t in tensors:
+            views.append(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        with torch.no_grad():
+            torch._foreach_copy_(views, list(tensors))
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        self.pending.append((work, flat, views, list(tensors)))
+        for p in params:
+            _EARLY.add(id(p))
+
+    def finish(self):
+        with torch.no_grad():
+            for work, flat, views, tensors in self.pending:
+                work.wait()                       # the launch stream waits for the collective; the host does not (RCCL)
+                flat.div_(world_size())
+                torch._foreach_copy_(tensors, views)
+        n = len(self.pending)
+        self.pending = []
+        return n
 
 
 def allreduce_sums(values, device):

@@ -81,7 +81,12 @@ def wanted_spotwise(model, device):
         return False
     from . import functional as GF
     from .densenet import DenseNet
-    return GF.is_hip_sequential(model) or (isinstance(model, DenseNet) and model.mfma == 'f32')
+    if isinstance(model, DenseNet):
+        # the recompute path (efficient=True) and train-mode dropout keep host-side state a capture cannot hold: the former
+        # saves / restores BatchNorm buffers and the device RNG state around its second forward, which is illegal while
+        # capturing - those models step eagerly
+        return model.mfma == 'f32' and not model.efficient and not model.drop_rate > 0
+    return GF.is_hip_sequential(model)
 
 
 class GridStepGraph:
@@ -161,14 +166,24 @@ class GridStepGraph:
 class GridStepGraphs:
     """The per-loop-call collection: `run(phase_is_train, inputs, labels, eager_fn)`."""
 
-    def __init__(self, step_fn, params, drop_derived=None):
+    def __init__(self, step_fn, params, drop_derived=None, models=()):
         """drop_derived: called right before a capture and after every replay - for a model that caches tensors derived from
         its weights (DenseNet: folded BatchNorm vectors, re-laid-out weights).  Before a capture, so that they are recomputed
         INSIDE it from the live parameters (a replay after an optimizer step must not multiply with capture-time copies);
         after a replay, so that nothing outside the graph keeps using tensors that live in its memory pool."""
         self.step_fn, self.params = step_fn, list(params)
         self.drop_derived = drop_derived
+        self.models = tuple(models)     # modules whose DenseNets' derived caches are dropped when a capture aborts
         self.table = {}
+
+    def _drop_after_failed_capture(self):
+        if self.drop_derived is not None:
+            self.drop_derived()
+        from .densenet import DenseNet
+        for obj in self.models:                                # steppers without a drop_derived hook (the grid loop)
+            for m in obj.modules():
+                if isinstance(m, DenseNet):
+                    m.invalidate_cache()
 
     def run(self, train, inputs, labels):
         """(loss, correct, n_fg, did_backward): graph replay when one exists for this phase and these shapes, else None."""
@@ -191,6 +206,9 @@ class GridStepGraphs:
             except Exception as exc:                           # e.g. a host synchronisation inside the step: stay eager
                 import warnings
                 warnings.warn("gridnext_amd.graphs: step capture failed (%s); this step shape runs eagerly" % (exc,))
+                # tensors derived inside the aborted capture (folded BatchNorm vectors, re-laid-out weights) were recorded,
+                # never executed: the eager step must not find them in the model's cache under still-valid keys
+                self._drop_after_failed_capture()
                 return None
         out = st.replay(inputs, labels)
         if self.drop_derived is not None:

@@ -226,7 +226,7 @@ def train_gridwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
     stepper = None
     if graphs.wanted(model, fused_ok, device) and not gdist.sync_active():    # (collectives inside the step: not capturable)
         stepper = graphs.GridStepGraphs(lambda i, l: _grid_loss(model, i, l, criterion, accum_iters, fused_ok),
-                                        model.parameters())
+                                        model.parameters(), models=(model,))
 
     for epoch in range(num_epochs):
         _banner(epoch, num_epochs)

@@ -62,6 +62,42 @@ def _worker(rank, world, port, out_dir):
     gdist.allreduce_gradients([lin.weight, lin.bias])
     assert torch.allclose(lin.weight.grad, torch.full((2, 3), 1.5))
     assert lin.bias.grad is not None and float(lin.bias.grad.abs().max()) == 0.0
+    # ... through ONE persistent flat buffer: .grad is a view of it (no cat, no copy-back), reused by the next step
+    flat_ptr = lin.weight.grad.data_ptr()
+    assert lin.bias.grad.data_ptr() == flat_ptr + 4 * lin.weight.numel()
+    lin.weight.grad = None
+    lin.bias.grad = torch.full((2,), float(10 * (rank + 1)))
+    gdist.allreduce_gradients([lin.weight, lin.bias])
+    assert lin.weight.grad.data_ptr() == flat_ptr and float(lin.weight.grad.abs().max()) == 0.0
+    assert torch.allclose(lin.bias.grad, torch.full((2,), 15.0))
+    # bucketed all-reduce from inside a backward (BackwardReducer): an autograd node that finishes its parameter gradients
+    # in two stages hands over averaged gradients; the step's flat all-reduce then skips those parameters
+    a, b, c = (nn.Parameter(torch.ones(3)), nn.Parameter(torch.ones(2)), nn.Parameter(torch.ones(4)))
+
+    class Staged(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, a, b):
+            return x.sum() + a.sum() + b.sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            red = gdist.BackwardReducer()
+            assert gdist.BackwardReducer.wanted()
+            ga, gb = torch.full((3,), float(rank + 1)), torch.full((2,), float(4 * (rank + 1)))
+            red.bucket([gb], [b])                                  # "block 4" first ...
+            red.bucket([ga], [a])                                  # ... "block 1" last
+            assert red.finish() == 2
+            return None, ga, gb
+
+    for _ in range(2):                                             # two micro-batches accumulate (accum_iters semantics)
+        (Staged.apply(torch.ones(2), a, b) + (c * float(rank + 1)).sum()).backward()
+    assert torch.allclose(a.grad, torch.full((3,), 3.0)) and torch.allclose(b.grad, torch.full((2,), 12.0))
+    assert torch.allclose(c.grad, torch.full((4,), 2.0 * (rank + 1)))          # not reduced yet
+    gdist.allreduce_gradients([a, b, c])
+    assert torch.allclose(a.grad, torch.full((3,), 3.0)) and torch.allclose(b.grad, torch.full((2,), 12.0))   # skipped
+    assert torch.allclose(c.grad, torch.full((4,), 3.0))
+    gdist.allreduce_gradients([a])                                 # the skip list does not outlive the step
+    assert torch.allclose(a.grad, torch.full((3,), 3.0))
     # sampler
     ds = TensorDataset(torch.arange(7))
     mine = list(gdist.ShardedSampler(ds))

@@ -93,7 +93,7 @@ def main():
             print("conv3x3 S=%2d M=%8d  %8.3f ms  %6.1f TFLOP/s (direct-conv FLOPs)" % (S, M, ms, fl / ms / 1e9))
             del A, out
     if args.only in ('', 'conv1x1h'):
-        # config 5: conv1 on fp16 block buffers (GNX_H16_M128=1 keeps the 128-row tiles)
+        # config 5: conv1 on fp16 block buffers
         H = torch.float16
         for S, K, ct in shapes:
             M = n * S * S
