@@ -617,85 +617,135 @@ def config5_series(args, device, rank, world, steps=4, warmup=2):
     return out
 
 
-def config5_trained_series(args, device, rank, world, steps=2, warmup=1):
+def config5_trained_series(args, device, rank, world, steps=3, warmup=1):
     """SURVEY 8d's "everything trained" column at config 5's geometry (22.21 GFLOP per spot): the multimodal step on one
-    256-px array with both classifiers trained through f_opt, fp32 arithmetic (an fp16 backward is not built).  The tape of a
-    256-px array (~190 GB) exceeds `DenseNet.tape_budget`: the image f goes through in recomputed chunks
-    (densenet_train._RecomputeFn - forward without tape, tape rebuilt inside backward, /root/reference/gridnext/
-    gridnet_models.py:88-104 + densenet.py:36-40), so the step executes 4/3 of the algorithmic FLOPs."""
+    256-px array with both classifiers trained through f_opt on the fp16-MFMA path - `DenseNet.mfma = 'f16'` on the gradient
+    path: fp16 tape (block buffers + activated bottlenecks, one chunk: ~110 GB), fp16-MFMA backward with fp32 accumulation
+    and fp32 parameter gradients, power-of-two loss scale per backward (gridnext_amd/densenet_train_f16.py).  Running
+    statistics calibrated on one batch as in `config5_series`.  The SAME steps (same initial state, same inputs) then run on
+    the fp32 HIP gradient path (recomputed chunks): `ce_vs_fp32_path` is BASELINE's "CE vs ref" for this series - the loss
+    after every optimizer step on both paths."""
     import torch
     import torch.nn as nn
     from gridnext_amd import distributed as gdist
     from gridnext_amd import training as gtrain
     from gridnext_amd import densenet_train as dt
     P = 256
-    model = build_model(device, P)
-    gdist.broadcast_module(model)
-    f_img = model.image_classifier
-    free, _ = torch.cuda.mem_get_info(device)
-    f_img.tape_budget = min(f_img.tape_budget, int(0.55 * free))
-    opt = torch.optim.Adam(model.corrector.parameters(), lr=1e-3)
-    f_opt = torch.optim.Adam(list(model.image_classifier.parameters()) + list(model.count_classifier.parameters()), lr=1e-4)
     crit = nn.CrossEntropyLoss()
     gen = torch.Generator(device=device).manual_seed(950 + rank)
     y = torch.randint(0, CLASSES + 1, (1, H, W), device=device, generator=gen)
     x8 = torch.randint(0, 256, (1, H, W, 3, P, P), device=device, generator=gen, dtype=torch.uint8)
     xc = torch.randint(0, 10, (1, GENES, H, W), device=device, generator=gen).float()
-    model.train()
-    model.patch_classifier.eval()
-    stepped = gdist.optimizer_params(opt, f_opt)
 
-    def step():
-        loss, _, _ = gtrain._grid_loss(model, [x8, xc], y, crit, 1, True)
-        loss.backward()
-        gdist.allreduce_gradients(stepped)
-        opt.step()
-        opt.zero_grad()
-        f_opt.step()
-        f_opt.zero_grad()
-        return loss
+    def run(mfma, n_warm, n_timed, probe_on):
+        model = build_model(device, P)
+        gdist.broadcast_module(model)
+        f_img = model.image_classifier
+        bns = [m for m in f_img.modules() if isinstance(m, nn.BatchNorm2d)]
+        moms = [m.momentum for m in bns]
+        for m in bns:
+            m.momentum = 1.0
+        f_img.train()
+        with torch.no_grad():
+            f_img(x8.reshape(-1, 3, P, P)[:32])
+        for m, mo in zip(bns, moms):
+            m.momentum = mo
+        f_img.mfma = mfma
+        free, _ = torch.cuda.mem_get_info(device)
+        f_img.tape_budget = min(f_img.tape_budget, int(0.55 * free))
+        opt = torch.optim.Adam(model.corrector.parameters(), lr=1e-3)
+        f_opt = torch.optim.Adam(list(model.image_classifier.parameters()) + list(model.count_classifier.parameters()), lr=1e-4)
+        model.train()
+        model.patch_classifier.eval()
+        stepped = gdist.optimizer_params(opt, f_opt)
+        losses = []
 
-    torch.cuda.reset_peak_memory_stats(device)
-    for _ in range(warmup):
-        step()
-    f_img._probe = []
-    if gdist.is_active():
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        last = step()
-    torch.cuda.synchronize()
-    if gdist.is_active():
-        torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
-    if gdist.is_active():
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    probe, f_img._probe = f_img._probe, None
-    per = dt.tape_bytes_per_spot(f_img, P)
-    chunk = max(8, int(f_img.tape_budget // per) // 8 * 8)
+        def step():
+            loss, _, _ = gtrain._grid_loss(model, [x8, xc], y, crit, 1, True)
+            loss.backward()
+            gdist.allreduce_gradients(stepped)
+            opt.step()
+            opt.zero_grad()
+            f_opt.step()
+            f_opt.zero_grad()
+            losses.append(loss.detach())
+            return loss
+
+        torch.cuda.reset_peak_memory_stats(device)
+        for _ in range(n_warm):
+            step()
+        if probe_on:
+            f_img._probe = []
+        if gdist.is_active():
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_timed):
+            step()
+        torch.cuda.synchronize()
+        if gdist.is_active():
+            torch.distributed.barrier()
+        elapsed = time.perf_counter() - t0
+        if gdist.is_active():
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        probe, f_img._probe = f_img._probe, None
+        if mfma == 'f16':
+            from gridnext_amd import densenet_train_f16 as dt16
+            per = dt16.tape_bytes_per_spot(f_img, P)
+        else:
+            per = dt.tape_bytes_per_spot(f_img, P)
+        chunk = H * W if per * H * W <= f_img.tape_budget else max(8, int(f_img.tape_budget // per) // 8 * 8)
+        info = {"elapsed": elapsed, "losses": [float(v.item()) for v in losses], "probe": probe,
+                "peak_hbm_gb": torch.cuda.max_memory_allocated(device) / 1e9, "chunks": -(-H * W // chunk), "chunk_spots": chunk,
+                "overflow": int(f_img.f16_grad_overflow.item()) if 'f16_grad_overflow' in f_img.__dict__ else None,
+                "loss_scale": float(f_img.f16_grad_scale[0].item()) if 'f16_grad_scale' in f_img.__dict__ else None}
+        del model, opt, f_opt, f_img
+        torch.cuda.empty_cache()
+        return info
+
+    r16 = run('f16', warmup, steps, True)
+    elapsed = r16["elapsed"]
     out = {"value": H * W * world * steps / elapsed, "unit": "spots/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
-           "warmup": warmup, "dtype": "f32", "final_loss": float(last.item()),
-           "peak_hbm_gb": torch.cuda.max_memory_allocated(device) / 1e9,
-           "recomputed_chunks": -(-H * W // chunk), "chunk_spots": chunk,
+           "warmup": warmup, "dtype": "f16", "final_loss": r16["losses"][-1], "peak_hbm_gb": r16["peak_hbm_gb"],
+           "recomputed_chunks": 0 if r16["chunks"] == 1 else r16["chunks"], "chunk_spots": r16["chunk_spots"],
+           "loss_scale": r16["loss_scale"], "grad_overflow_flag": r16["overflow"],
            "algorithmic_tflops": 22.21e9 * H * W * world * steps / elapsed / 1e12,
-           "workload": "BASELINE config 5's geometry, everything trained: multimodal f (DenseNet-121 @256 px, fp32) + count MLP + "
-                       "hex g, 1 array (4992 spots) per step, f and g trained (f_opt), eval-mode BN, uint8 patches resident in "
-                       "HBM; f in recomputed chunks (bounded tape)"}
-    kt = kernel_table(probe, P, steps)
+           "workload": "BASELINE config 5's geometry, everything trained: multimodal f (DenseNet-121 @256 px, fp16-MFMA forward AND "
+                       "backward, fp32 accumulate / parameter gradients) + count MLP + hex g, 1 array (4992 spots) per step, f and "
+                       "g trained (f_opt), eval-mode BN (calibrated statistics), uint8 patches resident in HBM"}
+    if world == 1:
+        r32 = run('f32', 0, warmup + steps, False)
+        out["ce_vs_fp32_path"] = {"f16": r16["losses"], "f32": r32["losses"],
+                                  "abs_diff": [abs(a - b) for a, b in zip(r16["losses"], r32["losses"])],
+                                  "what": "masked CE of the array before optimizer step k = 0, 1, ... on the fp16-MFMA path and on "
+                                          "the fp32 HIP gradient path; same initial state_dict, inputs and optimizers",
+                                  "fp32_path_ms_per_step": 1e3 * r32["elapsed"] / (warmup + steps),
+                                  "fp32_path_recomputed_chunks": r32["chunks"], "fp32_path_peak_hbm_gb": r32["peak_hbm_gb"]}
+    probe = r16["probe"]
+    KINDS16 = {'conv1x1': 'conv1x1_h16_kernel (taped forward: stores the activated bottleneck, fp16)',
+               'conv3x3': 'conv3x3_dma_kernel<H16, O16> (taped forward)',
+               'wgrad3x3_f16': 'wgrad3x3_f16_kernel', 'dgrad3x3_bn2_f16': 'dgrad3x3_bn_f16_kernel',
+               'wgrad1x1_f16': 'wgrad1x1_f16_kernel', 'dgrad1x1_bn1_f16': 'dgrad1x1_bn_f16_kernel'}
+    kt = {}
+    for kind, name in KINDS16.items():
+        recs = [r for r in (probe or []) if r[0] == kind]
+        if not recs:
+            continue
+        ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+        flops, nbytes = sum(r[3] for r in recs), sum(r[4] for r in recs)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        kt[kind] = {"bound": "hbm", "kernel": name, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                    "traffic": None, "launches": len(recs), "avg_launch_ms": ms / len(recs),
+                    "algorithmic_bytes_per_launch_avg": nbytes / len(recs), "matrix_tflops": flops / (ms * 1e-3) / 1e12,
+                    "ms_per_step": ms / steps}
     if kt:
-        for kind in ('conv1x1', 'conv3x3'):
-            if kind in kt:
-                kt[kind]["note"] = "launched twice per step (forward without tape + recompute in backward), each launch credited"
-        if getattr(f_img, 'winograd', False) and f_img.mfma == 'f32' and 'conv3x3' in kt:
-            winograd_credit(kt['conv3x3'], P, steps)
         order = sorted(kt, key=lambda k: -kt[k]["ms_per_step"])
         out["roofline"] = dict(kt[order[0]])
         out["roofline"]["other_kernels"] = {k: {f: kt[k][f] for f in ("kernel", "achieved", "frac", "ms_per_step", "launches")}
                                             for k in order[1:]}
-    del model, x8, xc, opt, f_opt
+    del x8, xc
     torch.cuda.empty_cache()
     return out
 

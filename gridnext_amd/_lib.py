@@ -55,6 +55,19 @@ SIGNATURES = {
     'gnx_bnrelu_avgpool2_h16': (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _P]),
     'gnx_conv3x3_f16_dma_h': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _P]),
     'gnx_bnrelu_avgpool_h16': (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _P]),
+    'gnx_wgrad1x1_f16_workspace': (_L, [_L, _I, _I]),
+    'gnx_wgrad1x1_f16': (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P, _P]),
+    'gnx_wgrad3x3_f16_workspace': (_L, [_L]),
+    'gnx_wgrad3x3_f16': (_I, [_P, _L, _P, _P, _P, _L, _I, _P, _I, _P, _P]),
+    'gnx_conv3x3_dgrad_bnrelu_bwd_f16_workspace': (_L, [_L]),
+    'gnx_conv3x3_dgrad_bnrelu_bwd_f16': (_I, [_P, _L, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'gnx_conv1x1_dgrad_bnrelu_bwd_f16_workspace': (_L, [_L, _I]),
+    'gnx_conv1x1_dgrad_bnrelu_bwd_f16': (_I, [_P, _P, _P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'gnx_tail_bwd_f16_workspace': (_L, [_L, _I]),
+    'gnx_tail_bwd_f16': (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'gnx_trans_bwd_f16_workspace': (_L, [_L, _I, _I]),
+    'gnx_trans_bwd_f16': (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'gnx_h16_cols_to_f32': (_I, [_P, _L, _P, _L, _L, _I, _P, _P, _P]),
     'gnx_dense_layer_f16_pack': (_I, [_P, _P, _P, _P, _I, _P]),
     'gnx_dense_layer_f16': (_I, [_P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     'gnx_conv_stem_bnrelu_maxpool_f16mul_cb': (_I, [_P, _I, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),

@@ -1,0 +1,841 @@
+// fp16-MFMA backward of the DenseNet dense layers (BASELINE config 5 with f trained: /root/reference/gridnext/densenet.py:35-44
+// differentiated by torch.autograd, driven by training.py:164-171 with f_opt; BatchNorm on running statistics, training.py:126).
+//
+// Everything a dense layer's backward touches lives in HBM as fp16, row-major: the block buffer X16 [M][c_total] (the tape of
+// the taped fp16 forward), the block GRADIENT buffer G16 of the same shape, the activated bottleneck A16 [M][128] (the tape:
+// conv1's output after norm2 + relu2, as gnx_conv1x1_bnrelu_h16 stores it) and its gradient dB16 [M][128].  Matrix work runs
+// on v_mfma_f32_32x32x16_f16 with fp32 accumulation; parameter gradients and BatchNorm sums are fp32.  Gradients carry a
+// power-of-two LOSS SCALE `ls` = {s, 1/s} (device floats, chosen per backward by the caller so that the largest gradient
+// entering the network sits at 2^12): every fp16 gradient tensor holds s x the true value, every fp32 result is multiplied
+// by 1/s when its slabs are reduced.  `flag` (device int) is OR-ed with 1 when a reduced result is not finite (overflow).
+//
+// Per layer, last to first, with cin = the layer's input channels and dY = G16[:, cin : cin + 32]:
+//   gnx_wgrad3x3_f16                    dW2[n][k][ky][kx] = sum_q dY[q][n] A[q + (ky-1, kx-1)][k]
+//   gnx_conv3x3_dgrad_bnrelu_bwd_f16    dB = scale2 * conv3x3^T(dY) * [A > 0]; dgamma2, dbeta2 (x_hat recovered from A)
+//   gnx_wgrad1x1_f16                    dW1[n][k] = sum_m dB[m][n] relu(bn1(X))[m][k]
+//   gnx_conv1x1_dgrad_bnrelu_bwd_f16    G[:, :cin] += scale1 * (dB . W1) * [bn1(X) > 0]; dgamma1, dbeta1
+// All four are bound by HBM (8 to 10 bytes per block-buffer element and layer against 2 x 128 flops): a tile's operands go
+// global -> registers -> LDS with 16-B accesses, the next tile's loads are in flight while the current one multiplies, two to
+// three workgroups share a CU.  Contractions over PIXELS (the weight gradients) read both operands out of row-major
+// [pixel][channel] LDS tiles with the transposing read ds_read_b64_tr_b16 (a 4-pixel x 16-channel block per 16 lanes, each
+// lane receiving one channel's 4 pixels); contractions over channels read rows (ds_read_b128).  Weights stay in registers as
+// MFMA fragments for a workgroup's lifetime (conv2's nine taps: 72 registers; a 128-channel slice of conv1: 32).
+// Sums over pixels (weight gradients, BatchNorm adjoint sums) are per-workgroup slabs reduced in a fixed order: deterministic,
+// no float atomics.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(8)));
+typedef __fp16 fp16x8 __attribute__((__vector_size__(16)));
+
+constexpr int T_RS = 320;   // bytes per row of a [pixel][128 ch] LDS tile read by TRANSPOSING reads: the 64-B segments of 4
+                            // consecutive rows that a 32-lane half touches fall on distinct banks (256 + 64)
+constexpr int R_RS = 272;   // ... of a tile read by ROWS (ds_read_b128 of 16 consecutive rows: 16 distinct bank quads)
+constexpr int Y_RS = 80;    // a 32-channel dY strip row read by rows (64 B + 16)
+
+__device__ __forceinline__ h8 ldg8(const _Float16* p) { return *reinterpret_cast<const h8*>(p); }
+__device__ __forceinline__ h8 zero8() {
+    h8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
+    return z;
+}
+__device__ __forceinline__ void lds_barrier() {     // orders LDS traffic only: global loads stay in flight across it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// The 8 contraction elements (pixels 8h .. 8h + 7 of a 16-pixel step) of one channel for a 32x32x16 MFMA operand, out of a
+// row-major [pixel][channel] tile: two transposing reads of a 4-row x 16-column block each.  `lo` / `hi`: this lane's address
+// for rows 0-3 / 4-7 of its half's 8 pixels = &tile[row 8h + (lane & 15) / 4 (+ 4)][channel base + 16 ((lane >> 4) & 1) +
+// 4 (lane & 3)]; the lane receives channel base + (lane & 31).  EXEC must be all ones.
+__device__ __forceinline__ h8 tr8(const char* lo, const char* hi) {
+    const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)lo);
+    const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)hi);
+    const fp16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(h8, v);
+}
+__device__ __forceinline__ void zero_acc(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------ 1x1 weight gradient
+// ws[slab][n][k] = sum over the slab's pixels of dY[m][n] act(X[m][k]); 64-pixel tiles; a workgroup owns a 128 x 128 block of
+// (n, k) - a wave 64 x 64 - and a contiguous range of tiles.
+template <bool PRO>
+__global__ __launch_bounds__(256, 2) void wgrad1x1_f16_kernel(const _Float16* __restrict__ dY, long lddy,
+                                                              const _Float16* __restrict__ X, long ldx,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              float* __restrict__ ws, long M, int N, int K, long tiles_per_slab,
+                                                              int n_kb, int n_nb) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * T_RS];
+    char* const Pt = smem;
+    char* const Qt = smem + 64 * T_RS;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int bx = blockIdx.x, kb = bx % n_kb, nb = (bx / n_kb) % n_nb;
+    const long slab = bx / (n_kb * n_nb);
+    const int chunk = t & 15, row0 = t >> 4;
+    const int ncol = nb * 128 + chunk * 8, kcol = kb * 128 + chunk * 8;
+    const bool nok = ncol < N, kok = kcol < K;
+    float sc[8], sh[8];
+    if (PRO) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc[j] = kok ? scale[kcol + j] : 0.f;
+            sh[j] = kok ? shift[kcol + j] : 0.f;
+        }
+    }
+    const long ntiles = (M + 63) / 64;
+    const long tile0 = slab * tiles_per_slab;
+    const long tile1 = tile0 + tiles_per_slab < ntiles ? tile0 + tiles_per_slab : ntiles;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) zero_acc(acc[a][b]);
+    const int trow = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    h8 p[4], q[4];
+    auto fetch = [&](long tile) {
+        const long m0 = tile * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long row = m0 + row0 + 16 * i;
+            const bool ok = row < M;
+            p[i] = (ok && nok) ? ldg8(dY + row * lddy + ncol) : zero8();
+            q[i] = (ok && kok) ? ldg8(X + row * ldx + kcol) : zero8();
+        }
+    };
+    if (tile0 < tile1) fetch(tile0);
+    for (long tile = tile0; tile < tile1; ++tile) {
+        lds_barrier();                                              // the previous tile's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (PRO) {      // (rows past M hold zeros in P: whatever the activation makes of a zero there multiplies a zero)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) q[i][j] = (_Float16)fmaxf(fmaf((float)q[i][j], sc[j], sh[j]), 0.f);
+            }
+            *reinterpret_cast<h8*>(Pt + (row0 + 16 * i) * T_RS + chunk * 16) = p[i];
+            *reinterpret_cast<h8*>(Qt + (row0 + 16 * i) * T_RS + chunk * 16) = q[i];
+        }
+        lds_barrier();
+        if (tile + 1 < tile1) fetch(tile + 1);                      // in flight while this tile multiplies
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            h8 a[2], b[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const char* pa = Pt + (16 * ks + trow) * T_RS + (64 * wm + 32 * j + tcol) * 2;
+                const char* pb = Qt + (16 * ks + trow) * T_RS + (64 * wn + 32 * j + tcol) * 2;
+                a[j] = tr8(pa, pa + 4 * T_RS);
+                b[j] = tr8(pb, pb + 4 * T_RS);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* const out = ws + slab * (long)N * K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = kb * 128 + 64 * wn + 32 * j + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = nb * 128 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n < N && k < K) out[(long)n * K + k] = acc[i][j][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ 3x3 weight gradient
+// ws[slab][tap][n][k] = sum over the slab's pixels p of dY[p - (dy, dx)][n] A[p][k], tap = 3 (dy + 1) + (dx + 1), where the
+// output pixel p - (dy, dx) lies in p's image.  64-pixel tiles of A [64][128]; the dY strip of the tile [P0 - S - 1,
+// P0 + 64 + S + 1) is staged once and read at nine row offsets; rows a tap may not read are redirected - by the lane that
+// supplies that row's address - to a row of zeros.  Wave w owns channels k = 32 w .. 32 w + 31 for all nine taps.
+__global__ __launch_bounds__(256, 2) void wgrad3x3_f16_kernel(const _Float16* __restrict__ dY, long lddy,
+                                                              const _Float16* __restrict__ A, float* __restrict__ ws, long M,
+                                                              int S, long tiles_per_slab) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    const int nrows = 66 + 2 * S;
+    char* const At = dyn;
+    char* const strip = dyn + 64 * T_RS;
+    char* const zrow = strip + nrows * 64;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long slab = blockIdx.x;
+    const long ntiles = (M + 63) / 64;
+    const long tile0 = slab * tiles_per_slab;
+    const long tile1 = tile0 + tiles_per_slab < ntiles ? tile0 + tiles_per_slab : ntiles;
+    const int chunk = t & 15, row0 = t >> 4;
+    const int trow = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    if (t < 4) *reinterpret_cast<h8*>(zrow + 16 * t) = zero8();
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) zero_acc(acc[k]);
+    const int S2 = S * S;
+    for (long tile = tile0; tile < tile1; ++tile) {
+        const long P0 = tile * 64;
+        h8 av[4], sv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long row = P0 + row0 + 16 * i;
+            av[i] = row < M ? ldg8(A + row * 128 + chunk * 8) : zero8();
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int item = t + 256 * i;                           // (strip row, 16-B piece)
+            const long u = P0 - S - 1 + (item >> 2);
+            sv[i] = ((item >> 2) < nrows && u >= 0 && u < M) ? ldg8(dY + u * lddy + (item & 3) * 8) : zero8();
+        }
+        lds_barrier();                                              // the previous tile's reads are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<h8*>(At + (row0 + 16 * i) * T_RS + chunk * 16) = av[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int item = t + 256 * i;
+            if ((item >> 2) < nrows) *reinterpret_cast<h8*>(strip + (item >> 2) * 64 + (item & 3) * 16) = sv[i];
+        }
+        lds_barrier();
+#pragma unroll 1
+        for (int ks = 0; ks < 4; ++ks) {
+            const char* pb = At + (16 * ks + trow) * T_RS + (32 * wave + tcol) * 2;
+            const h8 b = tr8(pb, pb + 4 * T_RS);
+            // which taps may read the rows this lane supplies (pixel p of A; its partner is the output pixel p - (dy, dx))
+            unsigned vlo = 0, vhi = 0;
+            {
+                const int rem_lo = (int)((P0 + 16 * ks + trow) % S2), rem_hi = (int)((P0 + 16 * ks + trow + 4) % S2);
+                const int ylo = rem_lo / S, xlo = rem_lo - ylo * S, yhi = rem_hi / S, xhi = rem_hi - yhi * S;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                    if (ylo - dy >= 0 && ylo - dy < S && xlo - dx >= 0 && xlo - dx < S) vlo |= 1u << tap;
+                    if (yhi - dy >= 0 && yhi - dy < S && xhi - dx >= 0 && xhi - dx < S) vhi |= 1u << tap;
+                }
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int off = (tap / 3 - 1) * S + (tap % 3 - 1);
+                const char* lo = ((vlo >> tap) & 1) ? strip + (16 * ks + trow - off + S + 1) * 64 + tcol * 2 : zrow + tcol * 2;
+                const char* hi = ((vhi >> tap) & 1) ? strip + (16 * ks + trow + 4 - off + S + 1) * 64 + tcol * 2 : zrow + tcol * 2;
+                const h8 a = tr8(lo, hi);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[tap], 0, 0, 0);
+            }
+        }
+    }
+    float* const out = ws + slab * (9L * 32 * 128);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            out[(tap * 32 + n) * 128 + 32 * wave + (lane & 31)] = acc[tap][r];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ conv2 data gradient + norm2/relu2 adjoint
+// dB[p][m] = scale2[m] [A[p][m] > 0] sum_{tap, n} dY[p - (dy, dx)][n] W2[n][m][tap]; S0[m] = sum_p d, S1[m] = sum_p d A[p][m]
+// with d the masked gradient.  D = [m][pixel]: wave w owns bottleneck channels 32 w .. 32 w + 31 (its weights, nine taps x two
+// 16-channel steps, are register fragments), all 128 pixels of the tile; lanes are pixels, so a pixel whose tap leaves the
+// image reads the zero row instead (address select, never a data select).
+__global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16* __restrict__ dY, long lddy,
+                                                                 const _Float16* __restrict__ W2b,
+                                                                 const _Float16* __restrict__ A, _Float16* __restrict__ dB,
+                                                                 const float* __restrict__ scale2, float* __restrict__ ws, long M,
+                                                                 int S, long tiles_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    const int nrows = 130 + 2 * S;
+    char* const At = dyn;
+    char* const strip = dyn + 128 * R_RS;
+    char* const zrow = strip + nrows * Y_RS;
+    float* const sc2 = reinterpret_cast<float*>(zrow + Y_RS);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const long ntiles = (M + 127) / 128;
+    const long tile0 = blockIdx.x * tiles_per_wg;
+    const long tile1 = tile0 + tiles_per_wg < ntiles ? tile0 + tiles_per_wg : ntiles;
+    const int chunk = t & 15, row0 = t >> 4;
+    if (t < 5) *reinterpret_cast<h8*>(zrow + 16 * t) = zero8();
+    if (t < 128) sc2[t] = scale2[t];
+    h8 wf[9][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) wf[tap][s] = ldg8(W2b + ((tap * 128 + 32 * wave + r) * 32 + 16 * s + 8 * h));
+    float S0[16], S1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S0[i] = S1[i] = 0.f;
+    const int S2 = S * S;
+    const int strip_items = nrows * 4;
+    for (long tile = tile0; tile < tile1; ++tile) {
+        const long P0 = tile * 128;
+        lds_barrier();                                              // the previous tile's store-out reads are done
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long row = P0 + row0 + 16 * i;
+            const h8 v = row < M ? ldg8(A + row * 128 + chunk * 8) : zero8();
+            *reinterpret_cast<h8*>(At + (row0 + 16 * i) * R_RS + chunk * 16) = v;
+        }
+        for (int item = t; item < strip_items; item += 256) {
+            const long u = P0 - S - 1 + (item >> 2);
+            const h8 v = (u >= 0 && u < M) ? ldg8(dY + u * lddy + (item & 3) * 8) : zero8();
+            *reinterpret_cast<h8*>(strip + (item >> 2) * Y_RS + (item & 3) * 16) = v;
+        }
+        lds_barrier();
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            f32x16 acc;
+            zero_acc(acc);
+            const int px = 32 * c + r;
+            const int rem = (int)((P0 + px) % S2);
+            const int y = rem / S, x = rem - y * S;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                const bool ok = y - dy >= 0 && y - dy < S && x - dx >= 0 && x - dx < S;
+                const char* src = ok ? strip + (px - dy * S - dx + S + 1) * Y_RS : zrow;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const h8 b = *reinterpret_cast<const h8*>(src + (16 * s + 8 * h) * 2);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap][s], b, acc, 0, 0, 0);
+                }
+            }
+            // adjoint of norm2 -> relu2 on the accumulators; the tile is rewritten in place (each element by the lane that
+            // read it; the matrix operands above come from the strip, never from this tile)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int m0 = 32 * wave + 8 * g + 4 * h;
+                h4* const cell = reinterpret_cast<h4*>(At + px * R_RS + m0 * 2);
+                const h4 av = *cell;
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(sc2 + m0);
+                h4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float af = (float)av[e];
+                    const float d = af > 0.f ? acc[4 * g + e] : 0.f;
+                    S0[4 * g + e] += d;
+                    S1[4 * g + e] += d * af;
+                    o[e] = (_Float16)(d * s4[e]);
+                }
+                *cell = o;
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const long row = P0 + row0 + 16 * i;
+            if (row < M) *reinterpret_cast<h8*>(dB + row * 128 + chunk * 8) = *reinterpret_cast<const h8*>(At + (row0 + 16 * i) * R_RS + chunk * 16);
+        }
+    }
+    // sums over the workgroup's pixels: lanes of one half are 32 pixels of the same 16 channels
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            S0[i] += __shfl_xor(S0[i], o, 64);
+            S1[i] += __shfl_xor(S1[i], o, 64);
+        }
+    }
+    if (r == 0) {
+        float* const out = ws + (long)blockIdx.x * 256;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = 32 * wave + 8 * (i >> 2) + 4 * h + (i & 3);
+            out[m] = S0[i];
+            out[128 + m] = S1[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ conv1 data gradient + norm1/relu1 adjoint
+// G[p][c] += scale1[c] d,  d = [scale1[c] X[p][c] + shift1[c] > 0] sum_m dB[p][m] W1[m][c];  S0[c] = sum_p d,
+// S1[c] = sum_p d (X[p][c] - mean[c]).  A workgroup owns 128 input channels (a wave 32, its weight slice in registers) and a
+// contiguous range of 64-pixel tiles; D = [channel][pixel].
+__global__ __launch_bounds__(256, 3) void dgrad1x1_bn_f16_kernel(const _Float16* __restrict__ dB, const _Float16* __restrict__ W1t,
+                                                                 const _Float16* __restrict__ X, long ldx,
+                                                                 _Float16* __restrict__ G, long ldg,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean, float* __restrict__ ws, long M,
+                                                                 int cin, int n_cb, long tiles_per_slab) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * 64 * R_RS + 3 * 128 * 4];
+    char* const Bt = smem;
+    char* const Xt = smem + 64 * R_RS;
+    char* const Gt = smem + 2 * 64 * R_RS;
+    float* const cst = reinterpret_cast<float*>(smem + 3 * 64 * R_RS);     // [scale | shift | mean][128]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const int cb = blockIdx.x % n_cb;
+    const long slab = blockIdx.x / n_cb;
+    const int cbase = cb * 128;
+    const bool active = cbase + 32 * wave < cin;                           // 32 | cin: a wave's channels are all in or all out
+    const long ntiles = (M + 63) / 64;
+    const long tile0 = slab * tiles_per_slab;
+    const long tile1 = tile0 + tiles_per_slab < ntiles ? tile0 + tiles_per_slab : ntiles;
+    const int chunk = t & 15, row0 = t >> 4;
+    const bool cok = cbase + chunk * 8 < cin;
+    if (t < 128) {
+        const bool ok = cbase + t < cin;
+        cst[t] = ok ? scale[cbase + t] : 0.f;
+        cst[128 + t] = ok ? shift[cbase + t] : 0.f;
+        cst[256 + t] = ok ? mean[cbase + t] : 0.f;
+    }
+    h8 wf[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) wf[s] = active ? ldg8(W1t + ((long)(cbase + 32 * wave + r) * 128 + 16 * s + 8 * h)) : zero8();
+    float S0[16], S1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) S0[i] = S1[i] = 0.f;
+    h8 bv[4], xv[4], gv[4];
+    auto fetch = [&](long tile) {
+        const long m0 = tile * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long row = m0 + row0 + 16 * i;
+            const bool ok = row < M;
+            bv[i] = ok ? ldg8(dB + row * 128 + chunk * 8) : zero8();
+            xv[i] = (ok && cok) ? ldg8(X + row * ldx + cbase + chunk * 8) : zero8();
+            gv[i] = (ok && cok) ? ldg8(G + row * ldg + cbase + chunk * 8) : zero8();
+        }
+    };
+    if (tile0 < tile1) fetch(tile0);
+    for (long tile = tile0; tile < tile1; ++tile) {
+        const long m0 = tile * 64;
+        lds_barrier();                                              // the previous tile's store-out reads are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<h8*>(Bt + (row0 + 16 * i) * R_RS + chunk * 16) = bv[i];
+            *reinterpret_cast<h8*>(Xt + (row0 + 16 * i) * R_RS + chunk * 16) = xv[i];
+            *reinterpret_cast<h8*>(Gt + (row0 + 16 * i) * R_RS + chunk * 16) = gv[i];
+        }
+        lds_barrier();
+        if (tile + 1 < tile1) fetch(tile + 1);                      // (G rows of the next tile: written by nobody else)
+        if (active) {
+#pragma unroll 1
+            for (int c = 0; c < 2; ++c) {
+                f32x16 acc;
+                zero_acc(acc);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const h8 b = *reinterpret_cast<const h8*>(Bt + (32 * c + r) * R_RS + (16 * s + 8 * h) * 2);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], b, acc, 0, 0, 0);
+                }
+                const int px = 32 * c + r;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = 32 * wave + 8 * g + 4 * h;
+                    const h4 x4 = *reinterpret_cast<const h4*>(Xt + px * R_RS + c0 * 2);
+                    h4* const cell = reinterpret_cast<h4*>(Gt + px * R_RS + c0 * 2);
+                    const h4 g4 = *cell;
+                    const f32x4 sc4 = *reinterpret_cast<const f32x4*>(cst + c0);
+                    const f32x4 sh4 = *reinterpret_cast<const f32x4*>(cst + 128 + c0);
+                    const f32x4 mu4 = *reinterpret_cast<const f32x4*>(cst + 256 + c0);
+                    h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xf = (float)x4[e];
+                        const float d = fmaf(xf, sc4[e], sh4[e]) > 0.f ? acc[4 * g + e] : 0.f;
+                        S0[4 * g + e] += d;
+                        S1[4 * g + e] += d * (xf - mu4[e]);
+                        o[e] = (_Float16)fmaf(d, sc4[e], (float)g4[e]);
+                    }
+                    *cell = o;
+                }
+            }
+        }
+        lds_barrier();
+        if (cok) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long row = m0 + row0 + 16 * i;
+                if (row < M)
+                    *reinterpret_cast<h8*>(G + row * ldg + cbase + chunk * 8) =
+                        *reinterpret_cast<const h8*>(Gt + (row0 + 16 * i) * R_RS + chunk * 16);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            S0[i] += __shfl_xor(S0[i], o, 64);
+            S1[i] += __shfl_xor(S1[i], o, 64);
+        }
+    }
+    if (r == 0 && active) {
+        const long cw = (long)n_cb * 128;
+        float* const out = ws + slab * 2 * cw;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = cbase + 32 * wave + 8 * (i >> 2) + 4 * h + (i & 3);
+            out[c] = S0[i];
+            out[cw + c] = S1[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise adjoints (HBM passes)
+// norm_final -> relu -> global average (densenet.py:153-156): G[p][c] = s * scale[c] [bn(X[p][c]) > 0] dfeats[img][c] / S2 and the
+// BatchNorm sums (true scale: computed from the fp32 gradient).  One thread = 8 channels of one image slot.
+__global__ __launch_bounds__(256) void tail_bwd_f16_kernel(const float* __restrict__ dfeats, long ldf,
+                                                           const _Float16* __restrict__ X, long ldx, _Float16* __restrict__ G,
+                                                           long ldg, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ mean,
+                                                           const float* __restrict__ ls, float* __restrict__ ws, long imgs, int C,
+                                                           int S2, int slots) {
+    const int nch = C / 8;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int chunk = (int)(gid % nch);
+    const long slot = gid / nch;
+    if (slot >= slots) return;
+    const int c0 = chunk * 8;
+    float sc[8], sh[8], mu[8], S0[8], S1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = scale[c0 + j];
+        sh[j] = shift[c0 + j];
+        mu[j] = mean[c0 + j];
+        S0[j] = S1[j] = 0.f;
+    }
+    const float s = ls[0], inv = 1.f / (float)S2;
+    for (long img = slot; img < imgs; img += slots) {
+        float d[8];
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(dfeats + img * ldf + c0);
+        const f32x4 d1 = *reinterpret_cast<const f32x4*>(dfeats + img * ldf + c0 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            d[j] = d0[j] * inv;
+            d[4 + j] = d1[j] * inv;
+        }
+        for (int p = 0; p < S2; ++p) {
+            const long row = img * S2 + p;
+            const h8 x = ldg8(X + row * ldx + c0);
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xf = (float)x[j];
+                const float v = fmaf(xf, sc[j], sh[j]) > 0.f ? d[j] : 0.f;
+                S0[j] += v;
+                S1[j] += v * (xf - mu[j]);
+                o[j] = (_Float16)(v * sc[j] * s);
+            }
+            *reinterpret_cast<h8*>(G + row * ldg + c0) = o;
+        }
+    }
+    float* const out = ws + slot * 2L * C;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        out[c0 + j] = S0[j];
+        out[C + c0 + j] = S1[j];
+    }
+}
+
+// Transition norm -> relu -> (conv) -> avgpool 2x2 (densenet.py:47-54, evaluated pool-first): given the gradient of the POOLED
+// activated map dP [imgs (S/2)^2][C], G[p][c] = scale[c] [bn(X[p][c]) > 0] dP[pool(p)][c] / 4 for all four source pixels (this
+// INITIALISES the block gradient) and the BatchNorm sums (scaled by s like dP).  One thread = 8 channels of one pooled pixel.
+__global__ __launch_bounds__(256) void trans_bwd_f16_kernel(const _Float16* __restrict__ dP, long ldp,
+                                                            const _Float16* __restrict__ X, long ldx, _Float16* __restrict__ G,
+                                                            long ldg, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ mean,
+                                                            float* __restrict__ ws, long imgs, int C, int S, int slots) {
+    const int nch = C / 8;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int chunk = (int)(gid % nch);
+    const long slot = gid / nch;
+    if (slot >= slots) return;
+    const int c0 = chunk * 8;
+    float sc[8], sh[8], mu[8], S0[8], S1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = scale[c0 + j];
+        sh[j] = shift[c0 + j];
+        mu[j] = mean[c0 + j];
+        S0[j] = S1[j] = 0.f;
+    }
+    const int So = S / 2;
+    const long Mp = imgs * So * So;
+    for (long q = slot; q < Mp; q += slots) {
+        const long img = q / (So * So);
+        const int rem = (int)(q - img * So * So);
+        const int oy = rem / So, ox = rem - oy * So;
+        const h8 dp = ldg8(dP + q * ldp + c0);
+        float d[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = 0.25f * (float)dp[j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long row = (img * S + 2 * oy + (k >> 1)) * S + 2 * ox + (k & 1);
+            const h8 x = ldg8(X + row * ldx + c0);
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xf = (float)x[j];
+                const float v = fmaf(xf, sc[j], sh[j]) > 0.f ? d[j] : 0.f;
+                S0[j] += v;
+                S1[j] += v * (xf - mu[j]);
+                o[j] = (_Float16)(v * sc[j]);
+            }
+            *reinterpret_cast<h8*>(G + row * ldg + c0) = o;
+        }
+    }
+    float* const out = ws + slot * 2L * C;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        out[c0 + j] = S0[j];
+        out[C + c0 + j] = S1[j];
+    }
+}
+
+// out[m][c] = G16[m][c] / s for c < C (the gradient of block 1's first channels = of the pooled stem map, back in fp32)
+__global__ __launch_bounds__(256) void h16_cols_to_f32_kernel(const _Float16* __restrict__ G, long ldg, float* __restrict__ out,
+                                                              long ldo, long M, int C, const float* __restrict__ ls,
+                                                              int* __restrict__ flag) {
+    const int nch = C / 8;
+    const long total = M * nch;
+    const float inv = ls[1];
+    bool bad = false;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / nch;
+        const int c0 = (int)(i - m * nch) * 8;
+        const h8 v = ldg8(G + m * ldg + c0);
+        f32x4 a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = (float)v[j] * inv;
+            b[j] = (float)v[4 + j] * inv;
+            bad = bad || !(fabsf(a[j]) <= 3.0e38f) || !(fabsf(b[j]) <= 3.0e38f);
+        }
+        *reinterpret_cast<f32x4*>(out + m * ldo + c0) = a;
+        *reinterpret_cast<f32x4*>(out + m * ldo + c0 + 4) = b;
+    }
+    if (bad && flag) atomicOr(flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------ fixed-order slab reductions
+// out[map(i)] (+)= inv * sum_s ws[s * n + i].  mode 0: map = identity; mode 1: i = (tap, n, k) of [9][32][128] -> torch's
+// conv2.weight order [n][k][tap].
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ ws, long nslab, long n, float* __restrict__ out,
+                                                           const float* __restrict__ ls, int accumulate, int mode,
+                                                           int* __restrict__ flag) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (long k = 0; k < nslab; ++k) s += ws[k * n + i];
+    s *= ls ? ls[1] : 1.f;
+    long o = i;
+    if (mode == 1) {
+        const int tap = (int)(i / (32 * 128)), rem = (int)(i % (32 * 128));
+        o = (long)rem * 9 + tap;
+    }
+    if (accumulate) s += out[o];
+    out[o] = s;
+    if (flag && !(fabsf(s) <= 3.0e38f)) atomicOr(flag, 1);
+}
+// BatchNorm sums: slabs [s][2][cw] of (S0, S1) -> dbeta[c] = inv S0, dgamma[c] = inv f(S0, S1):
+// mode 0: dgamma = S1 p0[c] (S1 = sum d (x - mean), p0 = invstd);  mode 1: dgamma = (S1 - p1[c] S0) / p0[c] (S1 = sum d a with
+// a = relu(gamma x_hat + beta) the stored activation, p0 = gamma, p1 = beta: x_hat = (a - beta) / gamma where d != 0).
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ ws, long nslab, int C, long cw,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                        const float* __restrict__ p0, const float* __restrict__ p1, int mode,
+                                                        const float* __restrict__ ls, int accumulate, int* __restrict__ flag) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (long k = 0; k < nslab; ++k) {
+        s0 += ws[(2 * k) * cw + c];
+        s1 += ws[(2 * k + 1) * cw + c];
+    }
+    const float inv = ls ? ls[1] : 1.f;
+    float dg = mode == 0 ? s1 * p0[c] : (s1 - p1[c] * s0) / p0[c];
+    dg *= inv;
+    float db = s0 * inv;
+    if (dgamma) {
+        if (accumulate) dg += dgamma[c];
+        dgamma[c] = dg;
+    }
+    if (dbeta) {
+        if (accumulate) db += dbeta[c];
+        dbeta[c] = db;
+    }
+    if (flag && (!(fabsf(dg) <= 3.0e38f) || !(fabsf(db) <= 3.0e38f))) atomicOr(flag, 1);
+}
+
+bool al16b(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+struct SlabPlan {
+    long tiles, slabs, per;
+};
+SlabPlan plan_slabs(long M, int tile, long want) {
+    SlabPlan p;
+    p.tiles = (M + tile - 1) / tile;
+    long slabs = want < 1 ? 1 : want;
+    if (slabs > p.tiles) slabs = p.tiles;
+    if (slabs < 1) slabs = 1;
+    p.per = (p.tiles + slabs - 1) / slabs;
+    p.slabs = p.per > 0 ? (p.tiles + p.per - 1) / p.per : 1;
+    if (p.slabs < 1) p.slabs = 1;
+    return p;
+}
+SlabPlan plan_wgrad1(long M, int N, int K) {
+    const long blocks = (long)((K + 127) / 128) * ((N + 127) / 128);
+    return plan_slabs(M, 64, (512 + blocks - 1) / blocks);
+}
+SlabPlan plan_dgrad1(long M, int K) {
+    const long n_cb = (K + 127) / 128;
+    return plan_slabs(M, 64, (768 + n_cb - 1) / n_cb);
+}
+
+}  // namespace
+
+// dW[N][K] (fp32, (+)=) = 1/s sum_m dY16[m][n] act(X16[m][k]), act = relu(scale[k] x + shift[k]) or the identity when scale is
+// NULL.  8 | N, 8 | K, 16-B aligned rows.
+GNX_EXPORT long gnx_wgrad1x1_f16_workspace(long M, int N, int K) { return plan_wgrad1(M, N, K).slabs * (long)N * K; }
+GNX_EXPORT int gnx_wgrad1x1_f16(const void* dY16, long lddy, const void* X16, long ldx, const float* scale, const float* shift,
+                                float* dW, float* workspace, long M, int N, int K, const float* ls, int accumulate, int* flag,
+                                hipStream_t stream) {
+    if (!dY16 || !X16 || !dW || !workspace || !ls || M <= 0 || N <= 0 || K <= 0 || lddy < N || ldx < K || (!scale) != (!shift))
+        return GNX_ERR_BAD_ARG;
+    if (N % 8 || K % 8 || lddy % 8 || ldx % 8 || !al16b(dY16) || !al16b(X16)) return GNX_ERR_UNSUPPORTED;
+    const SlabPlan p = plan_wgrad1(M, N, K);
+    const int n_kb = (K + 127) / 128, n_nb = (N + 127) / 128;
+    const long grid = p.slabs * n_kb * n_nb;
+    const _Float16* dY = reinterpret_cast<const _Float16*>(dY16);
+    const _Float16* X = reinterpret_cast<const _Float16*>(X16);
+    if (scale)
+        wgrad1x1_f16_kernel<true><<<(int)grid, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, N, K, p.per, n_kb, n_nb);
+    else
+        wgrad1x1_f16_kernel<false><<<(int)grid, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, N, K, p.per, n_kb, n_nb);
+    const long n = (long)N * K;
+    reduce_slabs_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(workspace, p.slabs, n, dW, ls, accumulate, 0, flag);
+    return gnx_launch_status();
+}
+
+// dW2[32][128][3][3] (fp32, torch layout, (+)=) = 1/s sum_p dY16[p - (dy, dx)][n] A16[p][k] over S x S images.
+GNX_EXPORT long gnx_wgrad3x3_f16_workspace(long M) { return plan_slabs(M, 64, 512).slabs * 9L * 32 * 128; }
+GNX_EXPORT int gnx_wgrad3x3_f16(const void* dY16, long lddy, const void* A16, float* dW, float* workspace, long M, int S,
+                                const float* ls, int accumulate, int* flag, hipStream_t stream) {
+    if (!dY16 || !A16 || !dW || !workspace || !ls || M <= 0 || S <= 0 || lddy < 32 || M % ((long)S * S) != 0) return GNX_ERR_BAD_ARG;
+    if (lddy % 8 || !al16b(dY16) || !al16b(A16) || S > 64) return GNX_ERR_UNSUPPORTED;
+    const SlabPlan p = plan_slabs(M, 64, 512);
+    const size_t lds = (size_t)64 * T_RS + (size_t)(66 + 2 * S) * 64 + 64;
+    wgrad3x3_f16_kernel<<<(int)p.slabs, 256, lds, stream>>>(reinterpret_cast<const _Float16*>(dY16), lddy,
+                                                           reinterpret_cast<const _Float16*>(A16), workspace, M, S, p.per);
+    const long n = 9L * 32 * 128;
+    reduce_slabs_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(workspace, p.slabs, n, dW, ls, accumulate, 1, flag);
+    return gnx_launch_status();
+}
+
+// dB16[M][128] = scale2 * conv3x3^T(dY16, W2) * [A16 > 0]; dgamma2 / dbeta2 (fp32, (+)=) with x_hat recovered from the stored
+// activation (gamma2 != 0 everywhere).  W2b16: conv2.weight as [tap][128][32] halves (W2b[tap][m][n] = W[n][m][tap]).
+GNX_EXPORT long gnx_conv3x3_dgrad_bnrelu_bwd_f16_workspace(long M) { return plan_slabs(M, 128, 512).slabs * 256L; }
+GNX_EXPORT int gnx_conv3x3_dgrad_bnrelu_bwd_f16(const void* dY16, long lddy, const void* W2b16, const void* A16, void* dB16, long M,
+                                                int S, const float* scale2, const float* gamma2, const float* beta2,
+                                                float* dgamma, float* dbeta, float* workspace, const float* ls, int accumulate,
+                                                int* flag, hipStream_t stream) {
+    if (!dY16 || !W2b16 || !A16 || !dB16 || !scale2 || !gamma2 || !beta2 || !workspace || !ls || M <= 0 || S <= 0 || lddy < 32 ||
+        M % ((long)S * S) != 0)
+        return GNX_ERR_BAD_ARG;
+    if (lddy % 8 || !al16b(dY16) || !al16b(A16) || !al16b(dB16) || !al16b(W2b16) || S > 64) return GNX_ERR_UNSUPPORTED;
+    const SlabPlan p = plan_slabs(M, 128, 512);
+    const size_t lds = (size_t)128 * R_RS + (size_t)(130 + 2 * S) * Y_RS + Y_RS + 512;
+    dgrad3x3_bn_f16_kernel<<<(int)p.slabs, 256, lds, stream>>>(reinterpret_cast<const _Float16*>(dY16), lddy,
+                                                              reinterpret_cast<const _Float16*>(W2b16),
+                                                              reinterpret_cast<const _Float16*>(A16),
+                                                              reinterpret_cast<_Float16*>(dB16), scale2, workspace, M, S, p.per);
+    if (dgamma || dbeta)
+        bn_reduce_kernel<<<1, 256, 0, stream>>>(workspace, p.slabs, 128, 128, dgamma, dbeta, gamma2, beta2, 1, ls, accumulate, flag);
+    return gnx_launch_status();
+}
+
+// G16[:, :K] += scale1 * (dB16 . W1) * [bn1(X16) > 0]; dgamma1 / dbeta1 (fp32, (+)=).  W1t16: conv1.weight transposed to
+// [K][128] halves.  32 | K.
+GNX_EXPORT long gnx_conv1x1_dgrad_bnrelu_bwd_f16_workspace(long M, int K) {
+    return plan_dgrad1(M, K).slabs * 2L * ((K + 127) / 128) * 128;
+}
+GNX_EXPORT int gnx_conv1x1_dgrad_bnrelu_bwd_f16(const void* dB16, const void* W1t16, const void* X16, long ldx, void* G16, long ldg,
+                                                long M, int K, const float* scale, const float* shift, const float* mean,
+                                                const float* invstd, float* dgamma, float* dbeta, float* workspace,
+                                                const float* ls, int accumulate, int* flag, hipStream_t stream) {
+    if (!dB16 || !W1t16 || !X16 || !G16 || !scale || !shift || !mean || !invstd || !workspace || !ls || M <= 0 || K <= 0 ||
+        ldx < K || ldg < K)
+        return GNX_ERR_BAD_ARG;
+    if (K % 32 || ldx % 8 || ldg % 8 || !al16b(dB16) || !al16b(W1t16) || !al16b(X16) || !al16b(G16)) return GNX_ERR_UNSUPPORTED;
+    const SlabPlan p = plan_dgrad1(M, K);
+    const int n_cb = (K + 127) / 128;
+    dgrad1x1_bn_f16_kernel<<<(int)(p.slabs * n_cb), 256, 0, stream>>>(reinterpret_cast<const _Float16*>(dB16),
+                                                                     reinterpret_cast<const _Float16*>(W1t16),
+                                                                     reinterpret_cast<const _Float16*>(X16), ldx,
+                                                                     reinterpret_cast<_Float16*>(G16), ldg, scale, shift, mean,
+                                                                     workspace, M, K, n_cb, p.per);
+    if (dgamma || dbeta)
+        bn_reduce_kernel<<<(K + 255) / 256, 256, 0, stream>>>(workspace, p.slabs, K, (long)n_cb * 128, dgamma, dbeta, invstd, nullptr, 0,
+                                                             ls, accumulate, flag);
+    return gnx_launch_status();
+}
+
+// norm_final -> relu -> global average pool, backward: G16[M][C] = s * ..., dgamma / dbeta (fp32).  8 | C.
+static long tail_slots(long imgs, int C) {
+    long slots = 256L * 512 / (C / 8);
+    if (slots > imgs) slots = imgs;
+    return slots < 1 ? 1 : slots;
+}
+GNX_EXPORT long gnx_tail_bwd_f16_workspace(long imgs, int C) { return tail_slots(imgs, C) * 2L * C; }
+GNX_EXPORT int gnx_tail_bwd_f16(const float* dfeats, long ldf, const void* X16, long ldx, void* G16, long ldg, long imgs, int C,
+                                int S2, const float* scale, const float* shift, const float* mean, const float* invstd,
+                                float* dgamma, float* dbeta, float* workspace, const float* ls, int accumulate, int* flag,
+                                hipStream_t stream) {
+    if (!dfeats || !X16 || !G16 || !scale || !shift || !mean || !invstd || !workspace || !ls || imgs <= 0 || C <= 0 || S2 <= 0 ||
+        ldf < C || ldx < C || ldg < C)
+        return GNX_ERR_BAD_ARG;
+    if (C % 8 || ldf % 4 || ldx % 8 || ldg % 8 || !al16b(dfeats) || !al16b(X16) || !al16b(G16)) return GNX_ERR_UNSUPPORTED;
+    const long slots = tail_slots(imgs, C);
+    const long threads = slots * (C / 8);
+    tail_bwd_f16_kernel<<<(int)((threads + 255) / 256), 256, 0, stream>>>(dfeats, ldf, reinterpret_cast<const _Float16*>(X16), ldx,
+                                                                         reinterpret_cast<_Float16*>(G16), ldg, scale, shift, mean,
+                                                                         ls, workspace, imgs, C, S2, (int)slots);
+    if (dgamma || dbeta)
+        bn_reduce_kernel<<<(C + 255) / 256, 256, 0, stream>>>(workspace, slots, C, C, dgamma, dbeta, invstd, nullptr, 0, nullptr,
+                                                             accumulate, flag);
+    return gnx_launch_status();
+}
+
+// transition norm -> relu -> avgpool 2x2, backward from the pooled gradient dP16 [imgs (S/2)^2][C]: G16[imgs S^2][C] (written),
+// dgamma / dbeta (fp32).  8 | C, even S.
+static long trans_slots(long Mp, int C) {
+    long slots = 256L * 2048 / (C / 8);
+    if (slots > Mp) slots = Mp;
+    return slots < 1 ? 1 : slots;
+}
+GNX_EXPORT long gnx_trans_bwd_f16_workspace(long imgs, int C, int S) { return trans_slots(imgs * (S / 2) * (S / 2), C) * 2L * C; }
+GNX_EXPORT int gnx_trans_bwd_f16(const void* dP16, long ldp, const void* X16, long ldx, void* G16, long ldg, long imgs, int C, int S,
+                                 const float* scale, const float* shift, const float* mean, const float* invstd, float* dgamma,
+                                 float* dbeta, float* workspace, const float* ls, int accumulate, int* flag, hipStream_t stream) {
+    if (!dP16 || !X16 || !G16 || !scale || !shift || !mean || !invstd || !workspace || !ls || imgs <= 0 || C <= 0 || S < 2 ||
+        ldp < C || ldx < C || ldg < C)
+        return GNX_ERR_BAD_ARG;
+    if (C % 8 || S % 2 || ldp % 8 || ldx % 8 || ldg % 8 || !al16b(dP16) || !al16b(X16) || !al16b(G16)) return GNX_ERR_UNSUPPORTED;
+    const long slots = trans_slots(imgs * (S / 2) * (S / 2), C);
+    const long threads = slots * (C / 8);
+    trans_bwd_f16_kernel<<<(int)((threads + 255) / 256), 256, 0, stream>>>(reinterpret_cast<const _Float16*>(dP16), ldp,
+                                                                          reinterpret_cast<const _Float16*>(X16), ldx,
+                                                                          reinterpret_cast<_Float16*>(G16), ldg, scale, shift, mean,
+                                                                          workspace, imgs, C, S, (int)slots);
+    if (dgamma || dbeta)
+        bn_reduce_kernel<<<(C + 255) / 256, 256, 0, stream>>>(workspace, slots, C, C, dgamma, dbeta, invstd, nullptr, 0, ls, accumulate,
+                                                             flag);
+    return gnx_launch_status();
+}
+
+// out[M][C] (fp32, ldo) = G16[:, :C] / s.  8 | C.
+GNX_EXPORT int gnx_h16_cols_to_f32(const void* G16, long ldg, float* out, long ldo, long M, int C, const float* ls, int* flag,
+                                   hipStream_t stream) {
+    if (!G16 || !out || !ls || M <= 0 || C <= 0 || ldg < C || ldo < C) return GNX_ERR_BAD_ARG;
+    if (C % 8 || ldg % 8 || ldo % 4 || !al16b(G16) || !al16b(out)) return GNX_ERR_UNSUPPORTED;
+    long blocks = (M * (C / 8) + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    h16_cols_to_f32_kernel<<<(int)blocks, 256, 0, stream>>>(reinterpret_cast<const _Float16*>(G16), ldg, out, ldo, M, C, ls, flag);
+    return gnx_launch_status();
+}

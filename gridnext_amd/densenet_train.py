@@ -570,6 +570,16 @@ class _DenseNetFn(Function):
         return tuple(out)
 
 
+def _taped(model, x):
+    """The autograd node that runs this call: the fp16-MFMA tape + backward (densenet_train_f16) where `DenseNet.mfma = 'f16'`
+    and the shapes / mode are the ones it takes, the fp32 one otherwise."""
+    if model.mfma == 'f16':
+        from . import densenet_train_f16 as f16
+        if f16.eligible(model, x):
+            return f16._DenseNetF16Fn
+    return _DenseNetFn
+
+
 class _RecomputeFn(Function):
     """The same forward WITHOUT a tape; the backward runs the taped forward again on the saved input chunk and then its
     backward - what `cp.checkpoint` around a chunk (/root/reference/gridnext/gridnet_models.py:88-104) and `efficient=True`
@@ -593,7 +603,7 @@ class _RecomputeFn(Function):
             ctx.bn_state = [(m, m.running_mean.clone(), m.running_var.clone(), m.num_batches_tracked.clone())
                             for m in model._bn_modules()]
         with torch.no_grad():
-            out = _DenseNetFn.apply(model, x, *params)          # its tape dies with this call
+            out = _taped(model, x).apply(model, x, *params)     # its tape dies with this call
         return out
 
     @staticmethod
@@ -618,7 +628,7 @@ class _RecomputeFn(Function):
             rng_now = torch.cuda.get_rng_state(x.device)
             torch.cuda.set_rng_state(ctx.rng, x.device)
         with torch.enable_grad():
-            out = _DenseNetFn.apply(model, x.detach(), *list(model.parameters()))
+            out = _taped(model, x).apply(model, x.detach(), *list(model.parameters()))
         if rng_now is not None:
             torch.cuda.set_rng_state(rng_now, x.device)
         if after is not None:                                    # later chunks may have moved the statistics on: keep theirs
@@ -652,7 +662,12 @@ def densenet_autograd(model, x):
     batch goes through in chunks whose forward keeps no tape and whose backward recomputes it (`_RecomputeFn`)."""
     params = list(model.parameters())
     n = x.shape[0]
-    per = tape_bytes_per_spot(model, x.shape[2])
+    fn = _taped(model, x)
+    if fn is _DenseNetFn:
+        per = tape_bytes_per_spot(model, x.shape[2])
+    else:
+        from .densenet_train_f16 import tape_bytes_per_spot as per_f16
+        per = per_f16(model, x.shape[2])
     chunk = n
     budget = getattr(model, 'tape_budget', None)
     if not model.training and budget and per * n > budget:
@@ -660,7 +675,7 @@ def densenet_autograd(model, x):
     if chunk >= n:
         if getattr(model, 'efficient', False):
             return _RecomputeFn.apply(model, x, *params)
-        return _DenseNetFn.apply(model, x, *params)
+        return fn.apply(model, x, *params)
     return torch.cat([_RecomputeFn.apply(model, x.narrow(0, s0, min(chunk, n - s0)), *params) for s0 in range(0, n, chunk)], 0)
 
 

@@ -1,0 +1,336 @@
+"""DenseNet-BC gradient path on the fp16-MFMA kernels (BASELINE config 5 with f trained).
+
+`DenseNet.mfma = 'f16'` on the gradient path under running statistics - `train_gridwise` with `f_opt`
+(/root/reference/gridnext/training.py:126 keeps f in eval mode, :164-171 steps it) - runs here: the taped forward of
+/root/reference/gridnext/densenet.py:35-54 on fp16 block buffers (row-major [rows][c_total] halves; every dense layer's
+bottleneck is stored activated, fp16 [rows][128]) and the backward of csrc/dense_bwd_f16.hip - fp16 matrix operands and
+fp16 gradient tensors, fp32 accumulation, fp32 parameter gradients.
+
+Scaling policy for the fp16 gradients: ONE power-of-two loss scale `s` per backward, chosen on the device from the gradient
+that enters the network (no host synchronisation): s = 2^floor(12 - log2(max |dfeats| * max |scale_final| / S^2)), i.e. the
+largest element of the last block's gradient lands in [2^11, 2^12) - a factor 16 of headroom before fp16 overflows and 26
+binades down to the smallest normal.  Every fp16 gradient tensor holds s x the true gradient; every fp32 result is multiplied
+by 1/s (exact) where its partial sums are reduced.  `model.f16_grad_overflow` (device int32) is OR-ed with 1 by any kernel
+that reduces a non-finite value; `model.f16_grad_scale` holds {s, 1/s} of the last backward.
+
+The stem (conv0 .. pool0) and the classifier keep their fp32 kernels (4 % of the step): the pooled stem map is computed in
+fp32 with its window indices (densenet_train's running-statistics stem), copied into block 1's first columns as fp16, and
+the gradient of those columns is converted back (gnx_h16_cols_to_f32) for the fp32 stem adjoints.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from .densenet_train import _Tape, _bn, gammas_nonzero
+
+F32, H16 = torch.float32, torch.float16
+
+
+def eligible(model, x):
+    """Shapes / modes the fp16 gradient path takes; anything else runs the fp32 path (densenet_train._DenseNetFn)."""
+    if model.mfma != 'f16' or model.training or model.small_inputs or x.requires_grad:
+        return False
+    if model.growth_rate != 32 or model.bn_size * model.growth_rate != 128 or model.drop_rate > 0:
+        return False
+    N, _, P, _ = x.shape
+    if P not in (128, 256) or N % 8 != 0 or N == 0:
+        return False
+    c0 = model.features.conv0.out_channels
+    if c0 % 32 != 0 or any(blk[0] % 32 != 0 for blk in model._blocks) or model.num_features % 8 != 0:
+        return False
+    hs, sizes = model._geometry(P)
+    if any(s not in (4, 8, 16, 32, 64) for s in sizes):
+        return False
+    if any(t is not None and (t.conv.out_channels % 8 != 0) for _, _, t, _ in model._blocks):
+        return False
+    return gammas_nonzero(model)
+
+
+def tape_bytes_per_spot(model, P):
+    """HBM one spot holds on the fp16 tape plus its share of the backward's scratch: block buffers and their gradients (2 B),
+    one activated bottleneck per layer (2 B), the pooled transition operands, the float patch and the fp32 pooled stem map."""
+    hs, sizes = model._geometry(P)
+    total, biggest = 0, 0
+    for (c_in, layers, trans, c_total), s in zip(model._blocks, sizes):
+        block = s * s * c_total
+        total += block + len(layers) * s * s * 128 + (block // 4 if trans is not None else 0)
+        biggest = max(biggest, 2 * block + 2 * s * s * 128)
+    c0 = model.features.conv0.out_channels
+    return 2 * (total + biggest) + 4 * 3 * P * P + 4 * 3 * sizes[0] * sizes[0] * c0
+
+
+def _conv2_rows(c_total, S):
+    """Rows one gnx_conv3x3_f16_dma_h launch may take (32-bit element offsets inside that kernel), in whole groups of 8 images."""
+    lim = (2 ** 31 - 1) // max(c_total, 128)
+    return max(8, lim // (S * S) // 8 * 8) * S * S
+
+
+def _f32(n, dev):
+    return torch.empty(max(int(n), 1), device=dev, dtype=F32)
+
+
+class _DenseNetF16Fn(Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        x = model._float_patches(x)
+        N, _, P, _ = x.shape
+        dev = x.device
+        st = L.stream()
+        hs, sizes = model._geometry(P)
+        g, mid = model.growth_rate, model.bn_size * model.growth_rate
+        conv0 = model.features.conv0
+        c0 = conv0.out_channels
+        tape = _Tape()
+        tape.x, tape.N, tape.P, tape.hs, tape.sizes = x, N, P, hs, sizes
+        bufs = [torch.empty((N * s * s, c_total), device=dev, dtype=H16) for (_, _, _, c_total), s in zip(model._blocks, sizes)]
+        tape.bufs = bufs
+        # ---- stem in fp32 with window indices (running statistics), then into block 1's first columns as fp16
+        w0 = conv0.weight.detach().contiguous()
+        hp = (hs + 2 - 3) // 2 + 1
+        s0 = _bn(model.features.norm0, None, c0, N * hs * hs, False, dev, st)
+        stem32 = torch.empty((N * hp * hp, c0), device=dev, dtype=F32)
+        tape.pool_idx = torch.empty((N * hp * hp, c0), device=dev, dtype=torch.uint8)
+        L.call('gnx_conv_stem_bnrelu_maxpool_argmax', L.ptr(x), L.ptr(w0), L.ptr(stem32), c0, tape.pool_idx.data_ptr(), N, 3, P, P,
+               c0, 7, 7, 2, 3, L.ptr(s0[0]), L.ptr(s0[1]), st)
+        bufs[0][:, :c0].copy_(stem32)
+        tape.stem32, tape.stats0 = stem32, s0
+        w1h = model._conv1_f16()                 # {layer: conv1.weight [128][cin] halves}
+        w2h = model._repacked_conv2_f16()        # {layer: conv2.weight tap-major [9][32][128] halves}
+        wth = model._trans_f16()                 # {transition: conv.weight [c_out][c_total] halves}
+        tape.layers, tape.trans = [], []
+        for bi, ((c_in, layers, trans, c_total), s) in enumerate(zip(model._blocks, sizes)):
+            buf = bufs[bi]
+            M = N * s * s
+            step = _conv2_rows(c_total, s)
+            recs = []
+            for li, layer in enumerate(layers):
+                cin = c_in + li * g
+                s1 = _bn(layer.norm1, None, cin, M, False, dev, st)
+                s2 = _bn(layer.norm2, None, mid, M, False, dev, st)
+                a = torch.empty((M, mid), device=dev, dtype=H16)
+                t0 = model._probe_begin()
+                L.call('gnx_conv1x1_bnrelu_h16', buf.data_ptr(), c_total, w1h[layer].data_ptr(), a.data_ptr(), mid, M, mid, cin,
+                       L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s2[0]), L.ptr(s2[1]), st)
+                t0 = model._probe_mark('conv1x1', t0, 2 * M * cin * mid, 2 * M * (cin + mid))
+                for r0 in range(0, M, step):
+                    rows = min(step, M - r0)
+                    L.call('gnx_conv3x3_f16_dma_h', a.data_ptr() + 2 * r0 * mid, mid, w2h[layer].data_ptr(),
+                           buf.data_ptr() + 2 * (r0 * c_total + cin), c_total, rows, g, mid, s, st)
+                model._probe_mark('conv3x3', t0, 2 * M * 9 * mid * g, 2 * M * (mid + g))
+                recs.append((a, s1, s2))
+            tape.layers.append(recs)
+            if trans is not None:
+                nxt = bufs[bi + 1]
+                so = s // 2
+                stt = _bn(trans.norm, None, c_total, M, False, dev, st)
+                pooled = torch.empty((N * so * so, c_total), device=dev, dtype=H16)
+                L.call('gnx_bnrelu_avgpool2_h16', buf.data_ptr(), c_total, pooled.data_ptr(), c_total, N, c_total, s, L.ptr(stt[0]),
+                       L.ptr(stt[1]), st)
+                L.call('gnx_conv1x1_bnrelu_h16', pooled.data_ptr(), c_total, wth[trans].data_ptr(), nxt.data_ptr(), nxt.shape[1],
+                       N * so * so, trans.conv.out_channels, c_total, None, None, None, None, st)
+                tape.trans.append((stt, pooled))
+            else:
+                tape.trans.append(None)
+        s_last, c_last = sizes[-1], model.num_features
+        sf = _bn(model.features.norm_final, None, c_last, N * s_last * s_last, False, dev, st)
+        tape.statsf = sf
+        feats = torch.empty((N, c_last), device=dev, dtype=F32)
+        L.call('gnx_bnrelu_avgpool_h16', bufs[-1].data_ptr(), bufs[-1].shape[1], L.ptr(feats), c_last, N, c_last, s_last * s_last,
+               L.ptr(sf[0]), L.ptr(sf[1]), st)
+        tape.feats = feats
+        tape.versions = [(p, p._version, p.data_ptr()) for p in params]
+        ctx.tape, ctx.model = tape, model
+        if not model.classify:
+            return feats.clone()
+        nc = model.classifier.out_features
+        out = torch.empty((N, nc), device=dev, dtype=F32)
+        L.call('gnx_gemm_f32', L.ptr(feats), c_last, 0, L.ptr(model.classifier.weight), c_last, 0, L.ptr(model.classifier.bias),
+               L.ptr(out), nc, N, nc, c_last, 0, st)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, tape = ctx.model, ctx.tape
+        if tape is None:
+            raise RuntimeError("gridnext_amd.DenseNet: the tape of this forward was already consumed (a second backward / "
+                               "retain_graph=True is not supported: run the forward again)")
+        for p, ver, addr in tape.versions:
+            if p._version != ver or p.data_ptr() != addr:
+                raise RuntimeError("gridnext_amd.DenseNet: a parameter was modified between forward and backward "
+                                   "(optimizer.step() or load_state_dict before loss.backward()); its gradient would be "
+                                   "computed from the new value")
+        dout = dout.contiguous()
+        dev = dout.device
+        st = L.stream()
+        N, P, hs, sizes = tape.N, tape.P, tape.hs, tape.sizes
+        g, mid = model.growth_rate, model.bn_size * model.growth_rate
+        grads = {}
+
+        def want(p):
+            return p is not None and p.requires_grad
+
+        def new_like(p):
+            t = torch.empty_like(p, memory_format=torch.contiguous_format)
+            grads[p] = t
+            return t
+
+        def bn_out(bn):
+            return (new_like(bn.weight) if want(bn.weight) else None, new_like(bn.bias) if want(bn.bias) else None)
+
+        from . import distributed as gdist
+        reducer = gdist.BackwardReducer() if gdist.BackwardReducer.wanted() else None
+        sent = set()
+
+        def send_bucket():
+            if reducer is None:
+                return
+            ps = [p for p in grads if id(p) not in sent]
+            sent.update(id(p) for p in ps)
+            reducer.bucket([grads[p] for p in ps], ps)
+
+        flag = model.__dict__.get('f16_grad_overflow')
+        if flag is None or flag.device != dev:
+            flag = model.__dict__['f16_grad_overflow'] = torch.zeros(1, device=dev, dtype=torch.int32)
+        fp = flag.data_ptr()
+
+        # ---- classifier (fp32)
+        c_last = model.num_features
+        if model.classify:
+            cls = model.classifier
+            nc = cls.out_features
+            dfeats = torch.empty((N, c_last), device=dev, dtype=F32)
+            L.call('gnx_gemm_f32', L.ptr(dout), nc, 0, L.ptr(cls.weight), c_last, 1, None, L.ptr(dfeats), c_last, N, c_last, nc, 0, st)
+            if want(cls.weight):
+                L.call('gnx_gemm_f32', L.ptr(dout), nc, 1, L.ptr(tape.feats), c_last, 1, None, L.ptr(new_like(cls.weight)), c_last,
+                       nc, c_last, N, 0, st)
+            if want(cls.bias):
+                ws = _f32(L.query('gnx_bn_workspace', N, nc), dev)
+                L.call('gnx_colsum', L.ptr(dout), nc, N, nc, L.ptr(new_like(cls.bias)), 0, L.ptr(ws), st)
+        else:
+            dfeats = dout
+
+        # ---- the loss scale of this backward, on the device
+        sf = tape.statsf
+        s_last = sizes[-1]
+        S2 = s_last * s_last
+        top = dfeats.abs().max() * sf[0][:c_last].abs().max() / S2
+        e = torch.where(top > 0, torch.floor(12.0 - torch.log2(top.clamp_min(1e-38))), torch.zeros_like(top)).clamp(-24.0, 60.0)
+        s_val = torch.exp2(e)
+        ls = torch.stack([s_val, 1.0 / s_val]).to(F32).contiguous()
+        model.__dict__['f16_grad_scale'] = ls
+        lp = L.ptr(ls)
+
+        # ---- tail: norm_final -> relu -> global average
+        bufs = tape.bufs
+        dbufs = [None] * len(bufs)
+        dbufs[-1] = torch.empty_like(bufs[-1])
+        ldl = bufs[-1].shape[1]
+        dgf, dbf = bn_out(model.features.norm_final)
+        ws = _f32(L.query('gnx_tail_bwd_f16_workspace', N, c_last), dev)
+        L.call('gnx_tail_bwd_f16', L.ptr(dfeats), c_last, bufs[-1].data_ptr(), ldl, dbufs[-1].data_ptr(), ldl, N, c_last, S2,
+               L.ptr(sf[0]), L.ptr(sf[1]), L.ptr(sf[2]), L.ptr(sf[3]), L.ptr(dgf), L.ptr(dbf), L.ptr(ws), lp, 0, fp, st)
+
+        # ---- dense blocks, last to first
+        for bi in range(len(model._blocks) - 1, -1, -1):
+            c_in, layers, trans, c_total = model._blocks[bi]
+            s = sizes[bi]
+            M = N * s * s
+            X, G = bufs[bi], dbufs[bi]
+            dB = torch.empty((M, mid), device=dev, dtype=H16)
+            ws3 = _f32(L.query('gnx_wgrad3x3_f16_workspace', M), dev)
+            wsd3 = _f32(L.query('gnx_conv3x3_dgrad_bnrelu_bwd_f16_workspace', M), dev)
+            for li in range(len(layers) - 1, -1, -1):
+                layer = layers[li]
+                a, s1, s2 = tape.layers[bi][li]
+                cin = c_in + li * g
+                dy = G.data_ptr() + 2 * cin
+                w2 = layer.conv2.weight
+                if want(w2):
+                    t0 = model._probe_begin()
+                    L.call('gnx_wgrad3x3_f16', dy, c_total, a.data_ptr(), L.ptr(new_like(w2)), L.ptr(ws3), M, s, lp, 0, fp, st)
+                    model._probe_mark('wgrad3x3_f16', t0, 2 * M * 9 * mid * g, 2 * M * (mid + g))
+                w2b = w2.detach().permute(2, 3, 1, 0).reshape(9, mid, g).to(H16).contiguous()      # [tap][m][n]
+                dg2, db2 = bn_out(layer.norm2)
+                t0 = model._probe_begin()
+                L.call('gnx_conv3x3_dgrad_bnrelu_bwd_f16', dy, c_total, w2b.data_ptr(), a.data_ptr(), dB.data_ptr(), M, s,
+                       L.ptr(s2[0]), L.ptr(layer.norm2.weight), L.ptr(layer.norm2.bias), L.ptr(dg2), L.ptr(db2), L.ptr(wsd3), lp, 0,
+                       fp, st)
+                model._probe_mark('dgrad3x3_bn2_f16', t0, 2 * M * 9 * mid * g, 2 * M * (g + 2 * mid))
+                w1 = layer.conv1.weight
+                if want(w1):
+                    ws1 = _f32(L.query('gnx_wgrad1x1_f16_workspace', M, mid, cin), dev)
+                    t0 = model._probe_begin()
+                    L.call('gnx_wgrad1x1_f16', dB.data_ptr(), mid, X.data_ptr(), c_total, L.ptr(s1[0]), L.ptr(s1[1]),
+                           L.ptr(new_like(w1)), L.ptr(ws1), M, mid, cin, lp, 0, fp, st)
+                    model._probe_mark('wgrad1x1_f16', t0, 2 * M * cin * mid, 2 * M * (cin + mid))
+                w1t = w1.detach().reshape(mid, cin).t().to(H16).contiguous()                         # [cin][128]
+                dg1, db1 = bn_out(layer.norm1)
+                wsd1 = _f32(L.query('gnx_conv1x1_dgrad_bnrelu_bwd_f16_workspace', M, cin), dev)
+                t0 = model._probe_begin()
+                L.call('gnx_conv1x1_dgrad_bnrelu_bwd_f16', dB.data_ptr(), w1t.data_ptr(), X.data_ptr(), c_total, G.data_ptr(), c_total,
+                       M, cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s1[2]), L.ptr(s1[3]), L.ptr(dg1), L.ptr(db1), L.ptr(wsd1), lp, 0, fp,
+                       st)
+                model._probe_mark('dgrad1x1_bn1_f16', t0, 2 * M * cin * mid, 2 * M * (mid + 3 * cin))
+                tape.layers[bi][li] = None
+                del a
+            del dB, ws3, wsd3
+            if bi > 0:
+                # transition bi-1 -> bi: its output gradient is columns [0, c_in) of this block's gradient
+                p_c_in, p_layers, p_trans, p_total = model._blocks[bi - 1]
+                ps = sizes[bi - 1]
+                stt, pooled = tape.trans[bi - 1]
+                c_out = p_trans.conv.out_channels
+                wt = p_trans.conv.weight
+                if want(wt):
+                    wsw = _f32(L.query('gnx_wgrad1x1_f16_workspace', M, c_out, p_total), dev)
+                    L.call('gnx_wgrad1x1_f16', G.data_ptr(), c_total, pooled.data_ptr(), p_total, None, None, L.ptr(new_like(wt)),
+                           L.ptr(wsw), M, c_out, p_total, lp, 0, fp, st)
+                    del wsw
+                tape.trans[bi - 1] = None
+                del pooled
+                wtt = wt.detach().reshape(c_out, p_total).t().to(H16).contiguous()                    # [p_total][c_out]
+                dPool = torch.empty((M, p_total), device=dev, dtype=H16)
+                L.call('gnx_conv1x1_bnrelu_h16', G.data_ptr(), c_total, wtt.data_ptr(), dPool.data_ptr(), p_total, M, p_total, c_out,
+                       None, None, None, None, st)
+                dbufs[bi - 1] = torch.empty_like(bufs[bi - 1])
+                dgt, dbt = bn_out(p_trans.norm)
+                wst = _f32(L.query('gnx_trans_bwd_f16_workspace', N, p_total, ps), dev)
+                L.call('gnx_trans_bwd_f16', dPool.data_ptr(), p_total, bufs[bi - 1].data_ptr(), p_total, dbufs[bi - 1].data_ptr(),
+                       p_total, N, p_total, ps, L.ptr(stt[0]), L.ptr(stt[1]), L.ptr(stt[2]), L.ptr(stt[3]), L.ptr(dgt), L.ptr(dbt),
+                       L.ptr(wst), lp, 0, fp, st)
+                del dPool, wst
+                dbufs[bi] = None
+                bufs[bi] = None
+            send_bucket()
+
+        # ---- stem (fp32): the gradient of the pooled map back in fp32, then densenet_train's running-statistics adjoints
+        conv0 = model.features.conv0
+        norm0 = model.features.norm0
+        c0 = conv0.out_channels
+        if want(conv0.weight) or want(norm0.weight) or want(norm0.bias):
+            hp = (hs + 2 - 3) // 2 + 1
+            M1, M0 = N * hp * hp, N * hs * hs
+            c_total1 = bufs[0].shape[1]
+            dO = torch.empty((M1, c0), device=dev, dtype=F32)
+            L.call('gnx_h16_cols_to_f32', dbufs[0].data_ptr(), c_total1, L.ptr(dO), c0, M1, c0, lp, fp, st)
+            dbufs[0] = None
+            s0 = tape.stats0
+            dS = torch.empty((M0, c0), device=dev, dtype=F32)
+            L.call('gnx_maxpool_bwd_argmax_bnrelu', tape.pool_idx.data_ptr(), L.ptr(dO), c0, L.ptr(tape.stem32), c0, L.ptr(s0[0]),
+                   L.ptr(dS), c0, N, c0, hs, hs, st)
+            dg0, db0 = bn_out(norm0)
+            ws = _f32(L.query('gnx_bn_workspace', M1, c0), dev)
+            L.call('gnx_bn_relu_bwd', L.ptr(dO), c0, L.ptr(tape.stem32), c0, None, c0, M1, c0, L.ptr(s0[0]), L.ptr(s0[1]),
+                   L.ptr(s0[2]), L.ptr(s0[3]), L.ptr(dg0), L.ptr(db0), 2, 0, 0, 0, L.ptr(ws), st)
+            if want(conv0.weight):
+                ws = _f32(L.query('gnx_conv0_wgrad_workspace', N, P, P, c0, 7, 7, 2, 3), dev)
+                L.call('gnx_conv0_wgrad', L.ptr(tape.x), L.ptr(dS), c0, L.ptr(new_like(conv0.weight)), L.ptr(ws), N, P, P, c0, 7, 7,
+                       2, 3, 0, st)
+        if reducer is not None:
+            send_bucket()
+            reducer.finish()
+        ctx.tape = None
+        out = [None, None]
+        for p in model.parameters():
+            out.append(grads.get(p))
+        return tuple(out)

@@ -311,6 +311,49 @@ long gnx_conv0_wgrad_workspace(long imgs, int H, int W, int O, int KH, int KW, i
 int gnx_conv0_wgrad(const float* x, const float* dS, long ldd, float* dW, float* workspace, long imgs, int H, int W,
                     int O, int KH, int KW, int stride, int pad, int accumulate, gnx_stream_t stream);
 
+/* ---- DenseNet-BC backward on the fp16-MFMA path (BASELINE config 5 with f trained: what torch.autograd derives for
+ * gridnext/densenet.py:35-54 when training.py:164-171 steps f_opt; BatchNorm on running statistics, training.py:126) --------
+ * Tape and gradients are fp16, row-major: block buffer X16 [M][c_total], block gradient G16 (same shape), activated bottleneck
+ * A16 [M][128] (conv1's output after norm2 -> relu2, as gnx_conv1x1_bnrelu_h16 stores it), its gradient dB16 [M][128].
+ * v_mfma_f32_32x32x16_f16, fp32 accumulation, fp32 parameter gradients.  `ls`: device floats {s, 1/s}, a power-of-two loss
+ * scale - every fp16 gradient tensor holds s x the true gradient, every fp32 result is multiplied by 1/s; `flag` (device int,
+ * may be NULL) is OR-ed with 1 when a result is not finite.  Workspaces in floats; `accumulate` != 0 adds to the outputs.
+ *   gnx_wgrad1x1_f16: dW[N][K] = sum_m dY16[m][n] act(X16[m][k]), act = relu(scale x + shift) or identity (scale NULL)
+ *                     - conv1 (:37) and the transition conv (:51, X16 = the pooled activated map of gnx_bnrelu_avgpool2_h16)
+ *   gnx_wgrad3x3_f16: dW[32][128][3][3] of conv2 (:40) from dY16 (the layer's 32 gradient columns) and A16, S x S maps
+ *   gnx_conv3x3_dgrad_bnrelu_bwd_f16: dB16 = scale2 * conv3x3^T(dY16, W2) * [A16 > 0] (+ dgamma2, dbeta2; gamma2 != 0);
+ *                     W2b16 = conv2.weight as [tap][128][32] halves
+ *   gnx_conv1x1_dgrad_bnrelu_bwd_f16: G16[:, :K] += scale1 * (dB16 . W1) * [bn1(X16) > 0] (+ dgamma1, dbeta1); W1t16 =
+ *                     conv1.weight transposed to [K][128] halves; 32 | K
+ *   gnx_tail_bwd_f16: norm_final -> relu -> adaptive_avg_pool (:153-156): G16 [imgs S2][C] = s * scale [bn(X16) > 0] dfeats / S2
+ *   gnx_trans_bwd_f16: transition norm -> relu -> avgpool 2x2 (:48-53, pool-first) from the pooled gradient dP16: writes G16
+ *   gnx_h16_cols_to_f32: out[M][C] = G16[:, :C] / s (the gradient of the pooled stem map, handed to the fp32 stem adjoints) */
+long gnx_wgrad1x1_f16_workspace(long M, int N, int K);
+int gnx_wgrad1x1_f16(const void* dY16, long lddy, const void* X16, long ldx, const float* scale, const float* shift, float* dW,
+                     float* workspace, long M, int N, int K, const float* ls, int accumulate, int* flag, gnx_stream_t stream);
+long gnx_wgrad3x3_f16_workspace(long M);
+int gnx_wgrad3x3_f16(const void* dY16, long lddy, const void* A16, float* dW, float* workspace, long M, int S, const float* ls,
+                     int accumulate, int* flag, gnx_stream_t stream);
+long gnx_conv3x3_dgrad_bnrelu_bwd_f16_workspace(long M);
+int gnx_conv3x3_dgrad_bnrelu_bwd_f16(const void* dY16, long lddy, const void* W2b16, const void* A16, void* dB16, long M, int S,
+                                     const float* scale2, const float* gamma2, const float* beta2, float* dgamma, float* dbeta,
+                                     float* workspace, const float* ls, int accumulate, int* flag, gnx_stream_t stream);
+long gnx_conv1x1_dgrad_bnrelu_bwd_f16_workspace(long M, int K);
+int gnx_conv1x1_dgrad_bnrelu_bwd_f16(const void* dB16, const void* W1t16, const void* X16, long ldx, void* G16, long ldg, long M,
+                                     int K, const float* scale, const float* shift, const float* mean, const float* invstd,
+                                     float* dgamma, float* dbeta, float* workspace, const float* ls, int accumulate, int* flag,
+                                     gnx_stream_t stream);
+long gnx_tail_bwd_f16_workspace(long imgs, int C);
+int gnx_tail_bwd_f16(const float* dfeats, long ldf, const void* X16, long ldx, void* G16, long ldg, long imgs, int C, int S2,
+                     const float* scale, const float* shift, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                     float* workspace, const float* ls, int accumulate, int* flag, gnx_stream_t stream);
+long gnx_trans_bwd_f16_workspace(long imgs, int C, int S);
+int gnx_trans_bwd_f16(const void* dP16, long ldp, const void* X16, long ldx, void* G16, long ldg, long imgs, int C, int S,
+                      const float* scale, const float* shift, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                      float* workspace, const float* ls, int accumulate, int* flag, gnx_stream_t stream);
+int gnx_h16_cols_to_f32(const void* G16, long ldg, float* out, long ldo, long M, int C, const float* ls, int* flag,
+                        gnx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,350 @@
+"""GPU parity of the fp16-MFMA backward kernels (csrc/dense_bwd_f16.hip) against fp64 torch arithmetic on the SAME fp16 inputs:
+what torch.autograd derives for /root/reference/gridnext/densenet.py:35-54 (dense layer, transition, tail) on running
+statistics.  Tolerances: the operands are exact fp16 values on both sides, sums are fp32 (MFMA accumulate + fixed-order slab
+reduce) - parameter gradients agree to 2e-4 of their scale; fp16 OUTPUTS (dB, G) to one fp16 rounding (1e-3 of their scale)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+H = torch.float16
+
+
+@pytest.fixture(scope='module')
+def L():
+    from gridnext_amd import _lib
+    return _lib
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def ls_tensor(s):
+    return torch.tensor([s, 1.0 / s], device=DEV, dtype=torch.float32)
+
+
+def flag_tensor():
+    return torch.zeros(1, device=DEV, dtype=torch.int32)
+
+
+def f32(n):
+    return torch.empty(max(int(n), 1), device=DEV, dtype=torch.float32)
+
+
+@pytest.mark.parametrize("M,N,K,lddy,ldx,pro,s", [(1000, 128, 96, 128, 160, True, 1.0), (4096, 128, 992, 128, 1024, True, 8.0),
+                                                  (777, 256, 160, 320, 160, False, 4.0), (64, 128, 64, 128, 64, True, 1.0)])
+def test_wgrad1x1_f16(L, M, N, K, lddy, ldx, pro, s):
+    g = torch.Generator().manual_seed(M + K)
+    dY = (torch.randn(M, lddy, generator=g) * s).to(H).to(DEV)
+    X = torch.randn(M, ldx, generator=g).to(H).to(DEV)
+    sc = (torch.rand(K, generator=g) + 0.5).to(DEV)
+    sh = (torch.randn(K, generator=g) * 0.3).to(DEV)
+    dW = torch.full((N, K), 7.0, device=DEV)
+    ws = f32(L.query('gnx_wgrad1x1_f16_workspace', M, N, K))
+    flag = flag_tensor()
+    L.call('gnx_wgrad1x1_f16', dY.data_ptr(), lddy, X.data_ptr(), ldx, L.ptr(sc) if pro else None, L.ptr(sh) if pro else None,
+           L.ptr(dW), L.ptr(ws), M, N, K, L.ptr(ls_tensor(s)), 0, flag.data_ptr(), L.stream())
+    xa = X[:, :K].double()
+    if pro:
+        xa = torch.relu(xa.float() * sc + sh).to(H).double()          # the operand is rounded to fp16 after the activation
+    ref = dY[:, :N].double().t() @ xa / s
+    assert rel(dW, ref) < 2e-4 and int(flag.item()) == 0
+    # accumulate
+    L.call('gnx_wgrad1x1_f16', dY.data_ptr(), lddy, X.data_ptr(), ldx, L.ptr(sc) if pro else None, L.ptr(sh) if pro else None,
+           L.ptr(dW), L.ptr(ws), M, N, K, L.ptr(ls_tensor(s)), 1, flag.data_ptr(), L.stream())
+    assert rel(dW, 2 * ref) < 2e-4
+
+
+def _conv_case(imgs, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    M = imgs * S * S
+    ld = 96
+    Gbuf = torch.randn(M, ld, generator=g).to(H).to(DEV)               # dY = columns [32, 64) of a wider gradient buffer
+    A = torch.relu(torch.randn(M, 128, generator=g)).to(H).to(DEV)     # activated bottleneck: about half zeros
+    W = (torch.randn(32, 128, 3, 3, generator=g) * 0.1).to(DEV)
+    return M, ld, Gbuf, A, W
+
+
+@pytest.mark.parametrize("imgs,S", [(8, 4), (3, 8), (2, 16), (1, 32), (2, 7), (1, 64)])
+def test_wgrad3x3_f16(L, imgs, S):
+    M, ld, Gbuf, A, W = _conv_case(imgs, S, 11 * S + imgs)
+    dY = Gbuf[:, 32:64]
+    dW = torch.zeros(32, 128, 3, 3, device=DEV)
+    ws = f32(L.query('gnx_wgrad3x3_f16_workspace', M))
+    flag = flag_tensor()
+    L.call('gnx_wgrad3x3_f16', dY.data_ptr(), ld, A.data_ptr(), L.ptr(dW), L.ptr(ws), M, S, L.ptr(ls_tensor(2.0)), 0,
+           flag.data_ptr(), L.stream())
+    a = A.double().reshape(imgs, S, S, 128).permute(0, 3, 1, 2)
+    dy = dY.double().reshape(imgs, S, S, 32).permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(a, (32, 128, 3, 3), dy, padding=1) / 2.0
+    assert rel(dW, ref) < 2e-4 and int(flag.item()) == 0
+
+
+@pytest.mark.parametrize("imgs,S", [(8, 4), (3, 8), (2, 16), (1, 32), (2, 7), (1, 64), (5, 8)])
+def test_conv3x3_dgrad_bnrelu_bwd_f16(L, imgs, S):
+    M, ld, Gbuf, A, W = _conv_case(imgs, S, 13 * S + imgs)
+    dY = Gbuf[:, 32:64]
+    g = torch.Generator().manual_seed(5)
+    gamma = (torch.rand(128, generator=g) + 0.5).to(DEV) * torch.where(torch.rand(128, generator=g) < 0.2, -1.0, 1.0).to(DEV)
+    beta = (torch.randn(128, generator=g) * 0.2).to(DEV)
+    scale2 = (gamma * (torch.rand(128, generator=g) + 0.5).to(DEV)).contiguous()
+    W2b = W.permute(2, 3, 1, 0).reshape(9, 128, 32).to(H).contiguous()        # [tap][m][n]
+    dB = torch.empty(M, 128, device=DEV, dtype=H)
+    dg, db = torch.zeros(128, device=DEV), torch.zeros(128, device=DEV)
+    ws = f32(L.query('gnx_conv3x3_dgrad_bnrelu_bwd_f16_workspace', M))
+    flag = flag_tensor()
+    L.call('gnx_conv3x3_dgrad_bnrelu_bwd_f16', dY.data_ptr(), ld, W2b.data_ptr(), A.data_ptr(), dB.data_ptr(), M, S, L.ptr(scale2),
+           L.ptr(gamma), L.ptr(beta), L.ptr(dg), L.ptr(db), L.ptr(ws), L.ptr(ls_tensor(4.0)), 0, flag.data_ptr(), L.stream())
+    dy = dY.double().reshape(imgs, S, S, 32).permute(0, 3, 1, 2)
+    w = W.to(H).double()
+    dA = torch.nn.grad.conv2d_input((imgs, 128, S, S), w, dy, padding=1).permute(0, 2, 3, 1).reshape(M, 128)
+    d = dA * (A.double() > 0)
+    assert rel(dB, d * scale2.double()) < 1.5e-3
+    assert rel(db, d.sum(0) / 4.0) < 2e-4
+    assert rel(dg, (d * (A.double() - beta.double()) / gamma.double()).sum(0) / 4.0) < 2e-4
+    assert int(flag.item()) == 0
+
+
+@pytest.mark.parametrize("M,K,ld", [(1000, 96, 160), (4096, 992, 1024), (640, 64, 64), (130, 224, 256)])
+def test_conv1x1_dgrad_bnrelu_bwd_f16(L, M, K, ld):
+    g = torch.Generator().manual_seed(M + K)
+    dB = torch.randn(M, 128, generator=g).to(H).to(DEV)
+    X = torch.randn(M, ld, generator=g).to(H).to(DEV)
+    G0 = torch.randn(M, ld, generator=g).to(H).to(DEV)
+    W1 = (torch.randn(128, K, generator=g) * 0.1).to(DEV)
+    W1t = W1.t().contiguous().to(H)
+    sc = ((torch.rand(K, generator=g) + 0.5) * torch.where(torch.rand(K, generator=g) < 0.2, -1.0, 1.0)).to(DEV)
+    sh = (torch.randn(K, generator=g) * 0.3).to(DEV)
+    mean = (torch.randn(K, generator=g) * 0.5).to(DEV)
+    invstd = (torch.rand(K, generator=g) + 0.5).to(DEV)
+    G = G0.clone()
+    dg, db = torch.zeros(K, device=DEV), torch.zeros(K, device=DEV)
+    ws = f32(L.query('gnx_conv1x1_dgrad_bnrelu_bwd_f16_workspace', M, K))
+    flag = flag_tensor()
+    L.call('gnx_conv1x1_dgrad_bnrelu_bwd_f16', dB.data_ptr(), W1t.data_ptr(), X.data_ptr(), ld, G.data_ptr(), ld, M, K, L.ptr(sc),
+           L.ptr(sh), L.ptr(mean), L.ptr(invstd), L.ptr(dg), L.ptr(db), L.ptr(ws), L.ptr(ls_tensor(2.0)), 0, flag.data_ptr(),
+           L.stream())
+    x = X[:, :K].double()
+    acc = dB.double() @ W1t.double().t()
+    mask = torch.addcmul(sh, X[:, :K].float(), sc) > 0                 # the kernel's fp32 fma decides the mask
+    d = acc * mask
+    ref = G0[:, :K].double() + d * sc.double()
+    assert rel(G[:, :K], ref) < 1.5e-3
+    assert torch.equal(G[:, K:], G0[:, K:]), "columns past K (later layers' gradients) must not be touched"
+    assert rel(db, d.sum(0) / 2.0) < 2e-4
+    assert rel(dg, (d * (x - mean.double())).sum(0) * invstd.double() / 2.0) < 2e-4
+    assert int(flag.item()) == 0
+
+
+def test_tail_trans_and_conversion_f16(L):
+    g = torch.Generator().manual_seed(3)
+    imgs, S, C, ld = 24, 4, 64, 96
+    S2 = S * S
+    M = imgs * S2
+    X = torch.randn(M, ld, generator=g).to(H).to(DEV)
+    sc = ((torch.rand(C, generator=g) + 0.5) * torch.where(torch.rand(C, generator=g) < 0.2, -1.0, 1.0)).to(DEV)
+    sh = (torch.randn(C, generator=g) * 0.3).to(DEV)
+    mean = (torch.randn(C, generator=g) * 0.5).to(DEV)
+    invstd = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    dfe = torch.randn(imgs, C, generator=g).to(DEV)
+    s = 64.0
+    ls = ls_tensor(s)
+    flag = flag_tensor()
+    # tail
+    G = torch.zeros(M, ld, device=DEV, dtype=H)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ws = f32(L.query('gnx_tail_bwd_f16_workspace', imgs, C))
+    L.call('gnx_tail_bwd_f16', L.ptr(dfe), C, X.data_ptr(), ld, G.data_ptr(), ld, imgs, C, S2, L.ptr(sc), L.ptr(sh), L.ptr(mean),
+           L.ptr(invstd), L.ptr(dg), L.ptr(db), L.ptr(ws), L.ptr(ls), 0, flag.data_ptr(), L.stream())
+    x = X[:, :C].double()
+    mask = torch.addcmul(sh, X[:, :C].float(), sc) > 0
+    d = (dfe.double() / S2).repeat_interleave(S2, 0) * mask
+    assert rel(G[:, :C], d * sc.double() * s) < 1.5e-3
+    assert rel(db, d.sum(0)) < 2e-4 and rel(dg, (d * (x - mean.double())).sum(0) * invstd.double()) < 2e-4
+    # transition adjoint from a pooled gradient
+    So = S // 2
+    dP = torch.randn(imgs * So * So, ld, generator=g).to(H).to(DEV)
+    G2 = torch.zeros(M, ld, device=DEV, dtype=H)
+    ws = f32(L.query('gnx_trans_bwd_f16_workspace', imgs, C, S))
+    L.call('gnx_trans_bwd_f16', dP.data_ptr(), ld, X.data_ptr(), ld, G2.data_ptr(), ld, imgs, C, S, L.ptr(sc), L.ptr(sh), L.ptr(mean),
+           L.ptr(invstd), L.ptr(dg), L.ptr(db), L.ptr(ws), L.ptr(ls), 0, flag.data_ptr(), L.stream())
+    up = dP[:, :C].double().reshape(imgs, So, So, C).repeat_interleave(2, 1).repeat_interleave(2, 2).reshape(M, C) * 0.25
+    d = up * mask
+    assert rel(G2[:, :C], d * sc.double()) < 1.5e-3
+    assert rel(db, d.sum(0) / s) < 2e-4 and rel(dg, (d * (x - mean.double())).sum(0) * invstd.double() / s) < 2e-4
+    # conversion of the first columns
+    out = torch.empty(M, 32, device=DEV)
+    L.call('gnx_h16_cols_to_f32', G2.data_ptr(), ld, L.ptr(out), 32, M, 32, L.ptr(ls), flag.data_ptr(), L.stream())
+    assert torch.equal(out, G2[:, :32].float() / s) and int(flag.item()) == 0
+    G2[5, 3] = float('inf')
+    L.call('gnx_h16_cols_to_f32', G2.data_ptr(), ld, L.ptr(out), 32, M, 32, L.ptr(ls), flag.data_ptr(), L.stream())
+    assert int(flag.item()) == 1, "an overflowed fp16 gradient must raise the flag"
+
+
+def _calibrated_densenet121(seed, x):
+    """DenseNet-121 with random weights and running statistics calibrated on `x` (one train-mode forward, momentum 1): the
+    state any network that has seen data is in; with untouched statistics the activations of a fresh network reach 1e6 and
+    overflow fp16."""
+    import torch.nn as nn
+    import gridnext_amd as ga
+    from oracle import densenet as odn
+    torch.manual_seed(seed)
+    m = ga.DenseNet(num_classes=8, **odn.DENSENET121).to(DEV)
+    bns = [b for b in m.modules() if isinstance(b, nn.BatchNorm2d)]
+    for b in bns:
+        b.momentum = 1.0
+    m.train()
+    with torch.no_grad():
+        m(x)
+    for b in bns:
+        b.momentum = 0.1
+    m.eval()
+    return m
+
+
+def _fp32_backward_on_f16_tape(m, x, dout):
+    """The fp32 HIP backward (densenet_train._DenseNetFn.backward) run on the fp16 path's OWN tape converted to fp32: the same
+    activations, hence the same ReLU masks and the same operands up to the fp16 rounding of weights and gradient tensors."""
+    from gridnext_amd import densenet_train as dt, densenet_train_f16 as dt16
+
+    class Ctx:
+        pass
+    ctx = Ctx()
+    params = list(m.parameters())
+    with torch.no_grad():
+        out = dt16._DenseNetF16Fn.forward(ctx, m, x, *params)
+    t16 = ctx.tape
+    tape = dt._Tape()
+    tape.x, tape.N, tape.P, tape.hs, tape.sizes, tape.training = t16.x, t16.N, t16.P, t16.hs, t16.sizes, False
+    tape.bufs = [b.float() for b in t16.bufs]
+    tape.stem_out, tape.pool_idx, tape.stats0 = None, t16.pool_idx, t16.stats0
+    tape.layers = [[(a.float(), s1, s2, True, None) for (a, s1, s2) in recs] for recs in t16.layers]
+    tape.trans = [None if t is None else t[0] for t in t16.trans]
+    tape.statsf, tape.feats, tape.versions = t16.statsf, t16.feats, t16.versions
+    ctx2 = Ctx()
+    ctx2.tape, ctx2.model, ctx2.x_needs_grad = tape, m, False
+    grads = dt._DenseNetFn.backward(ctx2, dout)
+    return out, list(grads[2:])
+
+
+def test_f16_backward_equals_fp32_backward_on_the_same_tape(capsys):
+    """The fp16-MFMA backward against the fp32 HIP backward GIVEN THE SAME TAPE (the fp16 forward's activations, converted):
+    what is left is the fp16 rounding of the gradient tensors (G, dB: 2^-11 per element and accumulation) and of the weights in
+    the data-gradient products.  All 364 gradients of DenseNet-121 on 16 patches of 128 px: cosine >= 0.9999, every parameter
+    within 2 % of its scale.  (Against a forward in higher precision the comparison is dominated by the FORWARD's fp16 noise
+    moving single ReLU masks - next test.)"""
+    import numpy as np
+    import torch.nn as nn
+    gen = torch.Generator().manual_seed(79)
+    x = torch.rand(16, 3, 128, 128, generator=gen).to(DEV)
+    labels = (torch.arange(16) % 8).to(DEV)
+    m = _calibrated_densenet121(23, x)
+    m.mfma = 'f16'
+    out = m(x)
+    nn.functional.cross_entropy(out, labels).backward()
+    assert int(m.f16_grad_overflow.item()) == 0
+    dout = (torch.softmax(out.detach(), 1) - nn.functional.one_hot(labels, 8).float()) / 16
+    out2, ref = _fp32_backward_on_f16_tape(m, x, dout)
+    assert torch.equal(out2, out.detach())
+    errs, a, b = [], [], []
+    for (k, p), r in zip(m.named_parameters(), ref):
+        errs.append(((p.grad - r).abs().max() / (r.abs().max() + 1e-30)).item())
+        a.append(p.grad.double().reshape(-1))
+        b.append(r.double().reshape(-1))
+    a, b = torch.cat(a), torch.cat(b)
+    cos = (a @ b / (a.norm() * b.norm())).item()
+    errs = np.array(errs)
+    with capsys.disabled():
+        print("\n[f16 backward vs fp32 backward on the same tape] cosine %.7f, per-parameter max-abs error / scale: median %.2e, "
+              "p90 %.2e, max %.2e" % (cos, np.median(errs), np.percentile(errs, 90), errs.max()))
+    assert len(errs) == 364 and cos >= 0.9999 and errs.max() < 2e-2, (cos, errs.max())
+
+
+def test_densenet121_f16_gradients_vs_fp64_oracle(capsys):
+    """`DenseNet.mfma = 'f16'` on the gradient path (running statistics, as train_gridwise with f_opt runs f): logits, loss and
+    all 364 parameter gradients of DenseNet-121 on 16 patches of 128 px against the fp64 oracle with the same state_dict.
+    The oracle evaluates config 5's arithmetic model (oracle.densenet.forward(quant=fp16_straight_through): fp16 storage and
+    operand points, everything else exact) - the function the fp16 path differentiates; bar: cosine >= 0.999 over all 6.96 M
+    gradient entries, per-parameter error distribution reported, no overflow.
+    Also reported, not gated: the cosine against the UNQUANTISED fp64 oracle.  On this untrained network it is ~0.97 whatever
+    the batch size: the fp16 forward moves activations by ~0.5 % of their spread, which flips ~0.4 % of the ReLU masks, and a
+    gradient that is a random-sign sum over positions changes by sqrt(that fraction) per layer - a property of evaluating the
+    FORWARD in fp16 (torch.autocast would show the same), not of the backward kernels (previous test: 0.999998 on one tape)."""
+    import numpy as np
+    import torch.nn as nn
+    from oracle import densenet as odn
+    gen = torch.Generator().manual_seed(77)
+    x = torch.rand(16, 3, 128, 128, generator=gen)
+    labels = torch.arange(16) % 8
+    m = _calibrated_densenet121(21, x.to(DEV))
+    m.mfma = 'f16'
+    out = m(x.to(DEV))
+    loss = nn.functional.cross_entropy(out, labels.to(DEV))
+    loss.backward()
+    assert 'f16_grad_scale' in m.__dict__, "the fp16 gradient path did not run"
+    assert int(m.f16_grad_overflow.item()) == 0
+    s = float(m.f16_grad_scale[0].item())
+    assert s == 2.0 ** round(np.log2(s)), "the loss scale is a power of two"
+    cfg = odn.DenseNetCfg(num_classes=8, **odn.DENSENET121)
+    sd = {k: v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu() for k, v in m.state_dict().items()}
+    hip = {k: p.grad.double().cpu() for k, p in m.named_parameters()}
+    report = {}
+    for name, quant in (('config-5 arithmetic model', odn.fp16_straight_through), ('unquantised', None)):
+        ref_sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
+                  for k, v in sd.items()}
+        out64 = odn.forward(ref_sd, x.double(), cfg, training=False, quant=quant)
+        loss64 = nn.functional.cross_entropy(out64, labels)
+        loss64.backward()
+        errs, a, b = [], [], []
+        for k in hip:
+            ref = ref_sd[k].grad
+            errs.append(((hip[k] - ref).abs().max() / (ref.abs().max() + 1e-30)).item())
+            a.append(hip[k].reshape(-1))
+            b.append(ref.reshape(-1))
+        a, b = torch.cat(a), torch.cat(b)
+        cos = (a @ b / (a.norm() * b.norm())).item()
+        errs = np.array(errs)
+        report[name] = (cos, errs, (out.detach().double().cpu() - out64.detach()).abs().max().item() / out64.abs().max().item(),
+                        abs(loss.item() - loss64.item()))
+        with capsys.disabled():
+            print("\n[f16 gradient path vs fp64 oracle, %s] loss scale 2^%d, |dlogits|/max %.1e, |dloss| %.1e, cosine %.6f, "
+                  "per-parameter max-abs error / scale: median %.2e, p90 %.2e, max %.2e (%d parameters)"
+                  % (name, round(np.log2(s)), report[name][2], report[name][3], cos, np.median(errs), np.percentile(errs, 90),
+                     errs.max(), len(errs)))
+    cos, errs, dlog, dloss = report['config-5 arithmetic model']
+    assert len(errs) == 364
+    assert dlog <= 2e-3 and dloss <= 1e-4, (dlog, dloss)
+    assert cos >= 0.999, cos
+    assert np.median(errs) < 2e-2 and errs.max() < 0.25, (np.median(errs), errs.max())
+    assert report['unquantised'][2] <= 2e-2 and report['unquantised'][3] <= 5e-3
+
+
+def test_f16_gradient_path_matches_fp32_hip_path_and_recompute():
+    """The same network through the fp32 HIP gradient path: losses agree to 1e-3 and the gradients point the same way (cosine
+    >= 0.95: the fp16 FORWARD's mask flips, see the previous test); recomputed chunks (tape_budget) give the single-tape fp16
+    gradients up to the order of the pixel sums."""
+    import torch.nn as nn
+    gen = torch.Generator().manual_seed(78)
+    x = torch.rand(16, 3, 128, 128, generator=gen).to(DEV)
+    labels = (torch.arange(16) % 8).to(DEV)
+    m = _calibrated_densenet121(22, x)
+    res = {}
+    for mode in ('f32', 'f16', 'f16_chunks'):
+        m.mfma = 'f32' if mode == 'f32' else 'f16'
+        m.tape_budget = 150 * 1024 ** 3
+        if mode == 'f16_chunks':
+            from gridnext_amd.densenet_train_f16 import tape_bytes_per_spot
+            m.tape_budget = 8 * tape_bytes_per_spot(m, 128) + 1            # two chunks of 8 patches
+        m.zero_grad()
+        loss = nn.functional.cross_entropy(m(x), labels)
+        loss.backward()
+        res[mode] = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).double()
+    cos = (res['f32'] @ res['f16'] / (res['f32'].norm() * res['f16'].norm())).item()
+    assert cos >= 0.95, cos
+    # chunks: every kernel's per-row arithmetic is independent of the batch; the pixel sums differ in their slab order only
+    cos2 = (res['f16'] @ res['f16_chunks'] / (res['f16'].norm() * res['f16_chunks'].norm())).item()
+    assert cos2 >= 0.99999, cos2
