@@ -164,7 +164,7 @@ def fp16_straight_through(t):
     return t + (t.detach().to(torch.float16).to(t.dtype) - t.detach())
 
 
-def forward(sd, x, cfg, training=False, return_features=False, dropout_masks=None, quant=None):
+def forward(sd, x, cfg, training=False, return_features=False, dropout_masks=None, quant=None, tap=None):
     """DenseNet.forward (densenet.py:152-159). `sd` BN buffers are updated in place when training.
     dropout_masks: optional iterator of keep-masks (N, growth, S, S), one per dense layer in order, used INSTEAD of
     F.dropout's own random mask (densenet.py:42-43: new_features * mask / (1 - p)) so a test can give both sides the same one.
@@ -173,9 +173,18 @@ def forward(sd, x, cfg, training=False, return_features=False, dropout_masks=Non
     same tensors would be halves): the concatenated features, every conv's two matrix operands (activated input, weight) and
     the transition's pooled operand are rounded to fp16 where the HIP path stores / stages them; BatchNorm + ReLU, every
     accumulation, the stem, the final pool and the classifier stay in the working precision; transitions pool first (the
-    HIP path's order; equal in exact arithmetic).  Gradients pass the rounding points unchanged."""
+    HIP path's order; equal in exact arithmetic).  Gradients pass the rounding points unchanged.
+    tap: optional callable (name, tensor) -> tensor applied to every STORED tensor of that model ('stem', '<layer>.a' = the
+    activated bottleneck, '<layer>.out' = the layer's new features, '<transition>.pooled', '<transition>.out'): a test can
+    record them, or substitute another implementation's values (straight-through) so that both sides differentiate at the
+    same activations."""
     feats = None
-    q = quant if quant is not None else (lambda t: t)
+    if quant is not None and tap is not None:
+        q = lambda t, name=None: tap(name, quant(t)) if name else quant(t)       # noqa: E731
+    elif quant is not None:
+        q = lambda t, name=None: quant(t)                                        # noqa: E731
+    else:
+        q = lambda t, name=None: t                                               # noqa: E731
     masks = iter(dropout_masks) if dropout_masks is not None else None
     for kind, p, ci, co in stages(cfg):
         if kind == 'stem':
@@ -184,20 +193,20 @@ def forward(sd, x, cfg, training=False, return_features=False, dropout_masks=Non
             else:
                 h = F.conv2d(x, sd[p + '.conv0.weight'], None, stride=2, padding=3)
                 h = F.relu(_bn(sd, p + '.norm0', h, training))
-                feats = q(F.max_pool2d(h, kernel_size=3, stride=2, padding=1))
+                feats = q(F.max_pool2d(h, kernel_size=3, stride=2, padding=1), 'stem')
         elif kind == 'dense':
             h = q(F.relu(_bn(sd, p + '.norm1', feats, training)))
             h = F.conv2d(h, q(sd[p + '.conv1.weight']))
-            h = q(F.relu(_bn(sd, p + '.norm2', h, training)))
-            h = q(F.conv2d(h, q(sd[p + '.conv2.weight']), None, padding=1))
+            h = q(F.relu(_bn(sd, p + '.norm2', h, training)), p + '.a')
+            h = q(F.conv2d(h, q(sd[p + '.conv2.weight']), None, padding=1), p + '.out')
             if cfg.drop_rate > 0 and training and masks is not None:
                 h = h * next(masks).to(h.dtype) / (1.0 - cfg.drop_rate)
             elif cfg.drop_rate > 0:
                 h = F.dropout(h, p=cfg.drop_rate, training=training)
             feats = torch.cat([feats, h], dim=1)
         elif kind == 'transition' and quant is not None:
-            h = q(F.avg_pool2d(F.relu(_bn(sd, p + '.norm', feats, training)), kernel_size=2, stride=2))
-            feats = q(F.conv2d(h, q(sd[p + '.conv.weight'])))
+            h = q(F.avg_pool2d(F.relu(_bn(sd, p + '.norm', feats, training)), kernel_size=2, stride=2), p + '.pooled')
+            feats = q(F.conv2d(h, q(sd[p + '.conv.weight'])), p + '.out')
         elif kind == 'transition':
             h = F.relu(_bn(sd, p + '.norm', feats, training))
             h = F.conv2d(h, sd[p + '.conv.weight'])

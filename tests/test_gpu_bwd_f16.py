@@ -265,38 +265,68 @@ def test_f16_backward_equals_fp32_backward_on_the_same_tape(capsys):
 
 
 def test_densenet121_f16_gradients_vs_fp64_oracle(capsys):
-    """`DenseNet.mfma = 'f16'` on the gradient path (running statistics, as train_gridwise with f_opt runs f): logits, loss and
-    all 364 parameter gradients of DenseNet-121 on 16 patches of 128 px against the fp64 oracle with the same state_dict.
-    The oracle evaluates config 5's arithmetic model (oracle.densenet.forward(quant=fp16_straight_through): fp16 storage and
-    operand points, everything else exact) - the function the fp16 path differentiates; bar: cosine >= 0.999 over all 6.96 M
-    gradient entries, per-parameter error distribution reported, no overflow.
-    Also reported, not gated: the cosine against the UNQUANTISED fp64 oracle.  On this untrained network it is ~0.97 whatever
-    the batch size: the fp16 forward moves activations by ~0.5 % of their spread, which flips ~0.4 % of the ReLU masks, and a
-    gradient that is a random-sign sum over positions changes by sqrt(that fraction) per layer - a property of evaluating the
-    FORWARD in fp16 (torch.autocast would show the same), not of the backward kernels (previous test: 0.999998 on one tape)."""
+    """`DenseNet.mfma = 'f16'` on the gradient path (running statistics, as train_gridwise with f_opt runs f): all 364 parameter
+    gradients of DenseNet-121 on 16 patches of 128 px against the fp64 oracle (torch.autograd in fp64 over oracle.densenet.forward)
+    with the same state_dict.
+    GATED: the oracle differentiates config 5's arithmetic model (fp16 storage / operand points, straight-through) AT THE
+    ACTIVATIONS THE HIP FORWARD PRODUCED (its stored tensors substituted through `tap`): cosine >= 0.999 over all 6.96 M gradient
+    entries, per-parameter error distribution reported, no overflow, loss within 1e-5.
+    REPORTED, not gated: the same oracle running its own forward - (a) with the fp16 rounding points, (b) without.  Two forwards
+    that round to fp16 after every layer cannot agree better than ~0.5 % at the end of 121 layers whatever their accumulation
+    order (a rounding that flips is a 5e-4 error which the next layers' roundings compound: tools/diag/f16_fwd_diag.py shows
+    99.96 % bit-equal elements after the stem, 97 % after one dense layer, 3 % in block 4), ~0.4 % of the ReLU masks then
+    differ, and on an UNTRAINED network - whose gradients are random-sign sums over positions - that is a relative change of
+    sqrt(fraction) per layer: cosine 0.97-0.98 for ANY batch size (measured 16 ... 1024 patches).  It is a property of evaluating
+    the forward in fp16 (torch.autocast would show the same), not of the backward."""
     import numpy as np
     import torch.nn as nn
+    from gridnext_amd import densenet_train_f16 as dt16
     from oracle import densenet as odn
     gen = torch.Generator().manual_seed(77)
-    x = torch.rand(16, 3, 128, 128, generator=gen)
-    labels = torch.arange(16) % 8
+    n = 16
+    x = torch.rand(n, 3, 128, 128, generator=gen)
+    labels = torch.arange(n) % 8
     m = _calibrated_densenet121(21, x.to(DEV))
     m.mfma = 'f16'
-    out = m(x.to(DEV))
-    loss = nn.functional.cross_entropy(out, labels.to(DEV))
-    loss.backward()
-    assert 'f16_grad_scale' in m.__dict__, "the fp16 gradient path did not run"
+    assert dt16.eligible(m, x.to(DEV))
+
+    class Ctx:
+        pass
+    ctx = Ctx()
+    with torch.no_grad():
+        out = dt16._DenseNetF16Fn.forward(ctx, m, x.to(DEV), *list(m.parameters()))
+    tape = ctx.tape
+
+    def nchw(rows, s):
+        return rows.double().cpu().reshape(n, s, s, rows.shape[1]).permute(0, 3, 1, 2).contiguous()
+
+    stored = {'stem': nchw(tape.bufs[0][:, :m.features.conv0.out_channels], tape.sizes[0])}
+    for bi, ((c_in, layers, trans, c_total), s) in enumerate(zip(m._blocks, tape.sizes)):
+        for li in range(len(layers)):
+            p = 'features.denseblock%d.denselayer%d' % (bi + 1, li + 1)
+            cin = c_in + 32 * li
+            stored[p + '.a'] = nchw(tape.layers[bi][li][0], s)
+            stored[p + '.out'] = nchw(tape.bufs[bi][:, cin:cin + 32], s)
+        if trans is not None:
+            p = 'features.transition%d' % (bi + 1)
+            stored[p + '.pooled'] = nchw(tape.trans[bi][1], s // 2)
+            stored[p + '.out'] = nchw(tape.bufs[bi + 1][:, :trans.conv.out_channels], s // 2)
+    dout = (torch.softmax(out, 1) - nn.functional.one_hot(labels, 8).float().to(DEV)) / n
+    loss = nn.functional.cross_entropy(out, labels.to(DEV)).item()
+    grads = dt16._DenseNetF16Fn.backward(ctx, dout)[2:]
     assert int(m.f16_grad_overflow.item()) == 0
     s = float(m.f16_grad_scale[0].item())
     assert s == 2.0 ** round(np.log2(s)), "the loss scale is a power of two"
+    hip = {k: g.double().cpu() for (k, _), g in zip(m.named_parameters(), grads)}
     cfg = odn.DenseNetCfg(num_classes=8, **odn.DENSENET121)
     sd = {k: v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu() for k, v in m.state_dict().items()}
-    hip = {k: p.grad.double().cpu() for k, p in m.named_parameters()}
     report = {}
-    for name, quant in (('config-5 arithmetic model', odn.fp16_straight_through), ('unquantised', None)):
+    cases = (('at the HIP activations (gated)', odn.fp16_straight_through, lambda name, t: t + (stored[name] - t).detach()),
+             ('own forward, fp16 rounding points', odn.fp16_straight_through, None), ('own forward, unquantised', None, None))
+    for name, quant, tap in cases:
         ref_sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
                   for k, v in sd.items()}
-        out64 = odn.forward(ref_sd, x.double(), cfg, training=False, quant=quant)
+        out64 = odn.forward(ref_sd, x.double(), cfg, training=False, quant=quant, tap=tap)
         loss64 = nn.functional.cross_entropy(out64, labels)
         loss64.backward()
         errs, a, b = [], [], []
@@ -308,19 +338,20 @@ def test_densenet121_f16_gradients_vs_fp64_oracle(capsys):
         a, b = torch.cat(a), torch.cat(b)
         cos = (a @ b / (a.norm() * b.norm())).item()
         errs = np.array(errs)
-        report[name] = (cos, errs, (out.detach().double().cpu() - out64.detach()).abs().max().item() / out64.abs().max().item(),
-                        abs(loss.item() - loss64.item()))
+        report[name] = (cos, errs, (out.double().cpu() - out64.detach()).abs().max().item() / out64.abs().max().item(),
+                        abs(loss - loss64.item()))
         with capsys.disabled():
-            print("\n[f16 gradient path vs fp64 oracle, %s] loss scale 2^%d, |dlogits|/max %.1e, |dloss| %.1e, cosine %.6f, "
+            print("\n[f16 gradient path vs fp64 oracle %s] loss scale 2^%d, |dlogits|/max %.1e, |dloss| %.1e, cosine %.6f, "
                   "per-parameter max-abs error / scale: median %.2e, p90 %.2e, max %.2e (%d parameters)"
                   % (name, round(np.log2(s)), report[name][2], report[name][3], cos, np.median(errs), np.percentile(errs, 90),
                      errs.max(), len(errs)))
-    cos, errs, dlog, dloss = report['config-5 arithmetic model']
+    cos, errs, dlog, dloss = report['at the HIP activations (gated)']
     assert len(errs) == 364
-    assert dlog <= 2e-3 and dloss <= 1e-4, (dlog, dloss)
+    assert dlog <= 1e-4 and dloss <= 1e-5, (dlog, dloss)
     assert cos >= 0.999, cos
-    assert np.median(errs) < 2e-2 and errs.max() < 0.25, (np.median(errs), errs.max())
-    assert report['unquantised'][2] <= 2e-2 and report['unquantised'][3] <= 5e-3
+    assert np.median(errs) < 1e-2 and errs.max() < 0.1, (np.median(errs), errs.max())
+    assert report['own forward, unquantised'][2] <= 2e-2 and report['own forward, unquantised'][3] <= 5e-3
+    assert report['own forward, unquantised'][0] >= 0.95
 
 
 def test_f16_gradient_path_matches_fp32_hip_path_and_recompute():
