@@ -617,6 +617,76 @@ def config5_series(args, device, rank, world, steps=4, warmup=2):
     return out
 
 
+def patch224_series(args, device, rank, world, steps=3, warmup=1, P=224):
+    """The headline tutorial-mode step at the REFERENCE's own patch geometry, (3, 224, 224) (/root/reference/scripts/
+    multimodal_model_test.py:32-36, notebooks/Tutorial_visium_image.ipynb; maps 56 / 28 / 14 / 7; 5.666 GFLOP per spot): fp32,
+    f frozen / eval, g trained, uint8 patches resident in HBM, one 78 x 64 array per step."""
+    import torch
+    import torch.nn as nn
+    from gridnext_amd import distributed as gdist
+    from gridnext_amd import training as gtrain
+    model = build_model(device, P)
+    gdist.broadcast_module(model)
+    for p in model.patch_classifier.parameters():
+        p.requires_grad = False
+    opt = torch.optim.Adam(model.corrector.parameters(), lr=1e-3)
+    crit = nn.CrossEntropyLoss()
+    gen = torch.Generator(device=device).manual_seed(700 + rank)
+    y = torch.randint(0, CLASSES + 1, (1, H, W), device=device, generator=gen)
+    x8 = torch.randint(0, 256, (1, H, W, 3, P, P), device=device, generator=gen, dtype=torch.uint8)
+    xc = torch.randint(0, 10, (1, GENES, H, W), device=device, generator=gen).float()
+    f_img = model.image_classifier
+    model.train()
+    model.patch_classifier.eval()
+    stepped = gdist.optimizer_params(opt)
+
+    def step():
+        loss, _, _ = gtrain._grid_loss(model, [x8, xc], y, crit, 1, True)
+        loss.backward()
+        gdist.allreduce_gradients(stepped)
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    f_img._probe = []
+    if gdist.is_active():
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    if gdist.is_active():
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if gdist.is_active():
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    probe, f_img._probe = f_img._probe, None
+    flops_per_spot = 5.666e9 if P == 224 else None
+    out = {"value": H * W * world * steps / elapsed, "unit": "spots/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+           "warmup": warmup, "dtype": "f32", "patch": P, "final_loss": float(last.item()),
+           "workload": "the headline step at the reference's own patch size: multimodal f (DenseNet-121 @%d px, fp32, frozen/eval) + "
+                       "count MLP + hex g, 1 array (4992 spots) per step, uint8 patches resident in HBM" % P}
+    if flops_per_spot:
+        out["algorithmic_tflops"] = flops_per_spot * H * W * world * steps / elapsed / 1e12
+        out["frac_of_fp32_matrix_peak"] = out["algorithmic_tflops"] / PEAK_F32_MATRIX_TFLOPS
+    kt = kernel_table(probe, P, steps)
+    if getattr(f_img, 'winograd', False) and 'conv3x3' in kt:
+        kt['conv3x3']["kernel"] = "conv3x3 (Winograd F(2,3) where the map allows, direct otherwise)"
+    if kt:
+        order = sorted(kt, key=lambda k: -kt[k]["ms_per_step"])
+        out["roofline"] = dict(kt[order[0]])
+        if len(order) > 1:
+            out["roofline"]["second_kernel"] = kt[order[1]]
+    del model, x8, xc
+    torch.cuda.empty_cache()
+    return out
+
+
 def config5_trained_series(args, device, rank, world, steps=3, warmup=1):
     """SURVEY 8d's "everything trained" column at config 5's geometry (22.21 GFLOP per spot): the multimodal step on one
     256-px array with both classifiers trained through f_opt on the fp16-MFMA path - `DenseNet.mfma = 'f16'` on the gradient
@@ -975,6 +1045,10 @@ def worker_main(args):
     more = not args.no_series and (world == 1 or args.all_series)
     if more and not args.train_f and args.mfma == 'f32' and args.patch == 128:
         optional("config5_f16_256px", lambda: config5_series(args, device, rank, world))
+
+    # ---- the reference's own patch size (224 px)
+    if more and not args.train_f and args.mfma == 'f32' and args.patch == 128:
+        optional("patch224_f32", lambda: patch224_series(args, device, rank, world))
 
     # ---- and its "everything trained" column: 256 px, fp32, f in recomputed chunks (bounded tape)
     if more and not args.train_f and args.mfma == 'f32' and args.patch == 128:

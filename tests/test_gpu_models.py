@@ -649,6 +649,151 @@ def test_full_size_multimodal_array_config4():
     assert m.count_classifier[0].weight.grad is not None          # GridNetHexMM quirk: the count f still gets gradients
 
 
+def test_full_size_multimodal_array_config5_fp16():
+    """BASELINE config 5 at FULL size through the product: ONE synthetic 78x64 array of 4 992 uint8 patches of 256 px + 2000-gene
+    counts through GridNetHexMM with the image f on the fp16-MFMA path (fp16 block buffers, every dense layer and transition
+    as one fused kernel - incl. the S = 64 kernel's many-images-per-CU schedule).  As config 4's full-size test: 24 sampled
+    spots against the fp32 CPU oracle (fp16 tolerance: 2e-2 of the logit range, same argmax where the top-2 margin exceeds
+    5e-2), chunked == unchunked bit for bit, permutation equivariance, CE-gradient properties of one tutorial-mode step."""
+    import gridnext_amd as ga
+    from gridnext_amd import functional as GF
+    from gridnext_amd.synthetic import count_mlp
+    from oracle import densenet as odn
+    torch.manual_seed(0)
+    C, G, P, H, W = 8, 2000, 256, 78, 64
+    f_img = ga.DenseNet(num_classes=C, **odn.DENSENET121)
+    m = ga.GridNetHexMM(f_img, count_mlp(G, C), (3, P, P), (G,), (H, W), C).to(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(31)
+    y = torch.randint(0, C + 1, (H, W), device=DEV, generator=gen)
+    x8 = torch.randint(0, 256, (H, W, 3, P, P), device=DEV, generator=gen, dtype=torch.uint8)
+    x8 *= (y > 0).to(torch.uint8).view(H, W, 1, 1, 1)
+    xc = torch.randint(0, 10, (G, H, W), device=DEV, generator=gen).float() * (y > 0).float().unsqueeze(0)
+    spots = x8.reshape(-1, 3, P, P)
+    # running statistics of a network that has seen data (untouched ones overflow fp16, bench.py does the same)
+    bns = [b for b in f_img.modules() if isinstance(b, nn.BatchNorm2d)]
+    for b in bns:
+        b.momentum = 1.0
+    f_img.train()
+    with torch.no_grad():
+        f_img(spots[y.reshape(-1) > 0][:32])
+    for b in bns:
+        b.momentum = 0.1
+    f_img.eval()
+    f_img.mfma = 'f16'
+    with torch.no_grad():
+        full = f_img(spots)                                   # 4992 spots of 256 px in one pass
+        assert f_img._used_f16_buffers and f_img._used_f16_fused
+        f_img.atonce = 1000
+        chunked = f_img(spots)
+        f_img.atonce = None
+        assert torch.equal(full, chunked)
+        perm = torch.randperm(spots.shape[0], device=DEV)[:512]
+        sub_out = f_img(spots[perm])
+        assert torch.equal(sub_out, full[perm])
+        idx = torch.randperm(spots.shape[0], generator=torch.Generator().manual_seed(5))[:24]
+        sd = {k: v.detach().cpu() for k, v in f_img.state_dict().items()}
+        cfg = odn.DenseNetCfg(num_classes=C, **odn.DENSENET121)
+        ref = odn.forward(sd, spots[idx.to(DEV)].cpu().float() / 255, cfg)
+    got = full[idx.to(DEV)].cpu()
+    assert torch.isfinite(full).all()
+    rng = (ref.max() - ref.min()).item()
+    assert (got - ref).abs().max().item() <= 2e-2 * rng, ((got - ref).abs().max().item(), rng)
+    top = ref.topk(2, dim=1).values
+    decided = (top[:, 0] - top[:, 1]) > 5e-2 * rng
+    assert torch.equal(got.argmax(1)[decided], ref.argmax(1)[decided])
+    for p in m.patch_classifier.parameters():
+        p.requires_grad = False
+    m.train()
+    m.patch_classifier.eval()
+    logits = m.forward_nhwc([x8.unsqueeze(0), xc.unsqueeze(0)])
+    logits.retain_grad()
+    loss, stats, preds = GF.masked_cross_entropy(logits.reshape(-1, C), y.unsqueeze(0), 1)
+    loss.backward()
+    fg = y.reshape(-1) > 0
+    assert int(stats[0]) == int(fg.sum()) and 0 <= int(stats[1]) <= int(stats[0])
+    grad = logits.grad.reshape(-1, C)
+    assert float(grad[~fg].abs().max()) == 0.0
+    assert float(grad[fg].sum(1).abs().max()) < 1e-7
+    assert torch.isfinite(loss).item() and m.corrector[8].kernel1.grad.abs().sum().item() > 0
+
+
+@pytest.mark.parametrize("P", [224])
+def test_densenet121_at_the_reference_patch_size_224(P):
+    """The reference's own patch geometry (/root/reference/scripts/multimodal_model_test.py:32-36, Tutorial_visium_image.ipynb:
+    (3, 224, 224); maps 56 / 28 / 14 / 7): DenseNet-121 eval logits against the fp32 CPU oracle (1e-3 of the logit scale), all
+    364 gradients under running statistics against the fp64 oracle (every parameter as close as the fp32 CPU run, x4), and
+    one GridNetHexMM tutorial-mode step after g."""
+    import gridnext_amd as ga
+    from gridnext_amd import functional as GF
+    from gridnext_amd.synthetic import count_mlp
+    from oracle import densenet as odn, gridnet as ogn, masked_ce as oce
+    cfg = odn.DenseNetCfg(num_classes=8, **odn.DENSENET121)
+    n = 6
+    labels = torch.tensor([0, 3, 5, 7, 1, 2])
+    m = ga.DenseNet(num_classes=8, **odn.DENSENET121)
+    m.load_state_dict(odn.closed_form_state(cfg))
+    m.to(DEV).eval()
+    x = odn.closed_form_images(n, P)
+    sd = odn.closed_form_state(cfg)
+    with torch.no_grad():
+        out = m(x.to(DEV))
+        ref = odn.forward(sd, x, cfg)
+        out8 = m((x * 255).round().to(torch.uint8).to(DEV))                         # uint8 patches: ToTensor inside
+        ref8 = odn.forward(sd, (x * 255).round() / 255, cfg)
+    close(out, ref, rtol=1e-3, what='224 px eval logits')
+    close(out8, ref8, rtol=1e-3, what='224 px eval logits, uint8 patches')
+    # gradients (f trained through f_opt: eval statistics), direct conv2 form as in the closed-form tests; the yardstick
+    # is the one of test_densenet121_gradients_as_accurate_as_fp32_reference: per parameter as close to the fp64 oracle as the
+    # fp32 CPU run of the same network (x4 slack, floor 1e-3 of the gradient's scale)
+    m.winograd = False
+    _, loss64, g64, _ = _oracle_grads(cfg, labels, False, torch.float64, P)
+    _, loss32, g32, _ = _oracle_grads(cfg, labels, False, torch.float32, P)
+    loss = nn.functional.cross_entropy(m(x.to(DEV)), labels.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - loss64) < max(4 * abs(loss32 - loss64), 1e-4)
+    errs_hip, errs_cpu = [], []
+    for k, p in m.named_parameters():
+        ref = g64[k]
+        scale = ref.abs().max().item() + 1e-30
+        errs_hip.append((p.grad.double().cpu() - ref).abs().max().item() / scale)
+        errs_cpu.append((g32[k] - ref).abs().max().item() / scale)
+    assert len(errs_hip) == 364
+    # 6 x 784 ... 6 x 49 rows are ragged tiles: the generic kernels sum in another order than the oracle, and the closed-form
+    # network has pre-activations that are exactly 0 in one order and +-1 ulp in another - single ReLU masks differ (as in the
+    # 64-px test); per parameter that is at most a percent of its scale, and the bulk sits at fp32 round-off
+    print("224 px gradients: median err %.2e (CPU fp32 %.2e), p99 %.2e, max %.2e" % (
+        np.median(errs_hip), np.median(errs_cpu), np.percentile(errs_hip, 99), max(errs_hip)))
+    assert np.median(errs_hip) <= 3 * np.median(errs_cpu) + 1e-4 and np.percentile(errs_hip, 90) <= 1e-3 and max(errs_hip) <= 1e-2
+    # grid level: GridNetHexMM, tutorial mode, after g
+    torch.manual_seed(3)
+    G, H, W, C = 40, 3, 4, 8
+    f_cnt = count_mlp(G, C)
+    m.winograd = True
+    g = ga.GridNetHexMM(m, f_cnt, (3, P, P), (G,), (H, W), C)
+    o_img = odn.DenseNet(num_classes=C, **odn.DENSENET121)
+    o_img.load_named_state(m.state_dict())
+    og = ogn.GridNetHexMM(o_img, count_mlp(G, C), (3, P, P), (G,), (H, W), C)
+    og.count_classifier.load_state_dict(f_cnt.state_dict())
+    og.corrector.load_state_dict(g.corrector.state_dict())
+    gen = torch.Generator().manual_seed(4)
+    xi = torch.rand(1, H, W, 3, P, P, generator=gen)
+    xc = torch.randint(0, 10, (1, G, H, W), generator=gen).float()
+    y = torch.randint(0, C + 1, (1, H, W), generator=gen)
+    for mod in (g, og):
+        mod.train()
+        mod.patch_classifier.eval()
+        for p in mod.patch_classifier.parameters():
+            p.requires_grad = False
+    g.to(DEV)
+    logits = g.forward_nhwc([xi.to(DEV), xc.to(DEV)])
+    lh, _, _ = GF.masked_cross_entropy(logits.reshape(-1, C), y.to(DEV), 1)
+    lh.backward()
+    lo, _, _ = oce.masked_ce(og([xi, xc]), y, 1)
+    lo.backward()
+    assert abs(lh.item() - lo.item()) < 1e-4
+    close(g.corrector[0].kernel0.grad, og.corrector[0].kernel0.grad, rtol=1e-3, atol=1e-6, what='224 px: dW of g')
+
+
 def test_config5_grid_level_fp16_path_against_oracle_after_g():
     """BASELINE config 5 as a GRID-level step: GridNetHexMM with the image f on the fp16-MFMA path - uint8
     patches, fp16 block buffers, every dense layer as one fused kernel, statistics as loaded - + count MLP + hex g on a
