@@ -71,13 +71,18 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_f16_kernel(const _Float16* __
                                                               const _Float16* __restrict__ X, long ldx,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               float* __restrict__ ws, long M, int N, int K, long tiles_per_slab,
-                                                              int n_kb, int n_nb) {
+                                                              int n_kb, int n_nb, long n_slabs) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 64 * T_RS];
     char* const Pt = smem;
     char* const Qt = smem + 64 * T_RS;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-    const int bx = blockIdx.x, kb = bx % n_kb, nb = (bx / n_kb) % n_nb;
-    const long slab = bx / (n_kb * n_nb);
+    // block order: the n_kb * n_nb workgroups of one slab (they read the same dY / X rows) get ids 8 apart - one XCD, launched
+    // together - so the rows they share come out of that XCD's L2 after the first read
+    const int nblk = n_kb * n_nb;
+    const int bx = blockIdx.x, rem8 = bx % (8 * nblk), kn = rem8 / 8;
+    const int kb = kn % n_kb, nb = kn / n_kb;
+    const long slab = (long)(bx / (8 * nblk)) * 8 + (rem8 & 7);
+    if (slab >= n_slabs) return;                                    // (padding of the last group of 8; whole workgroup)
     const int chunk = t & 15, row0 = t >> 4;
     const int ncol = nb * 128 + chunk * 8, kcol = kb * 128 + chunk * 8;
     const bool nok = ncol < N, kok = kcol < K;
@@ -180,9 +185,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_f16_kernel(const _Float16* __
 #pragma unroll
     for (int k = 0; k < 9; ++k) zero_acc(acc[k]);
     const int S2 = S * S;
-    for (long tile = tile0; tile < tile1; ++tile) {
+    h8 av[4], sv[4];
+    auto fetch = [&](long tile) {
         const long P0 = tile * 64;
-        h8 av[4], sv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long row = P0 + row0 + 16 * i;
@@ -194,6 +199,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_f16_kernel(const _Float16* __
             const long u = P0 - S - 1 + (item >> 2);
             sv[i] = ((item >> 2) < nrows && u >= 0 && u < M) ? ldg8(dY + u * lddy + (item & 3) * 8) : zero8();
         }
+    };
+    if (tile0 < tile1) fetch(tile0);
+    for (long tile = tile0; tile < tile1; ++tile) {
+        const long P0 = tile * 64;
+        const int rem0 = (int)(P0 % S2);                            // position of the tile's first pixel inside its image
         lds_barrier();                                              // the previous tile's reads are done
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<h8*>(At + (row0 + 16 * i) * T_RS + chunk * 16) = av[i];
@@ -203,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_f16_kernel(const _Float16* __
             if ((item >> 2) < nrows) *reinterpret_cast<h8*>(strip + (item >> 2) * 64 + (item & 3) * 16) = sv[i];
         }
         lds_barrier();
+        if (tile + 1 < tile1) fetch(tile + 1);                      // in flight while this tile multiplies
 #pragma unroll 1
         for (int ks = 0; ks < 4; ++ks) {
             const char* pb = At + (16 * ks + trow) * T_RS + (32 * wave + tcol) * 2;
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_f16_kernel(const _Float16* __
             // which taps may read the rows this lane supplies (pixel p of A; its partner is the output pixel p - (dy, dx))
             unsigned vlo = 0, vhi = 0;
             {
-                const int rem_lo = (int)((P0 + 16 * ks + trow) % S2), rem_hi = (int)((P0 + 16 * ks + trow + 4) % S2);
+                const int rem_lo = (rem0 + 16 * ks + trow) % S2, rem_hi = (rem0 + 16 * ks + trow + 4) % S2;
                 const int ylo = rem_lo / S, xlo = rem_lo - ylo * S, yhi = rem_hi / S, xhi = rem_hi - yhi * S;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
@@ -271,28 +282,42 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16*
 #pragma unroll
     for (int i = 0; i < 16; ++i) S0[i] = S1[i] = 0.f;
     const int S2 = S * S;
-    const int strip_items = nrows * 4;
-    for (long tile = tile0; tile < tile1; ++tile) {
+    const int strip_items = nrows * 4;                              // <= 1032: five per thread
+    h8 av[8], sv[5];
+    auto fetch = [&](long tile) {
         const long P0 = tile * 128;
-        lds_barrier();                                              // the previous tile's store-out reads are done
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const long row = P0 + row0 + 16 * i;
-            const h8 v = row < M ? ldg8(A + row * 128 + chunk * 8) : zero8();
-            *reinterpret_cast<h8*>(At + (row0 + 16 * i) * R_RS + chunk * 16) = v;
+            av[i] = row < M ? ldg8(A + row * 128 + chunk * 8) : zero8();
         }
-        for (int item = t; item < strip_items; item += 256) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int item = t + 256 * i;
             const long u = P0 - S - 1 + (item >> 2);
-            const h8 v = (u >= 0 && u < M) ? ldg8(dY + u * lddy + (item & 3) * 8) : zero8();
-            *reinterpret_cast<h8*>(strip + (item >> 2) * Y_RS + (item & 3) * 16) = v;
+            sv[i] = (item < strip_items && u >= 0 && u < M) ? ldg8(dY + u * lddy + (item & 3) * 8) : zero8();
+        }
+    };
+    if (tile0 < tile1) fetch(tile0);
+    for (long tile = tile0; tile < tile1; ++tile) {
+        const long P0 = tile * 128;
+        const int rem0 = (int)(P0 % S2);
+        lds_barrier();                                              // the previous tile's store-out reads are done
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<h8*>(At + (row0 + 16 * i) * R_RS + chunk * 16) = av[i];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int item = t + 256 * i;
+            if (item < strip_items) *reinterpret_cast<h8*>(strip + (item >> 2) * Y_RS + (item & 3) * 16) = sv[i];
         }
         lds_barrier();
+        if (tile + 1 < tile1) fetch(tile + 1);                      // in flight while this tile multiplies
 #pragma unroll 1
         for (int c = 0; c < 4; ++c) {
             f32x16 acc;
             zero_acc(acc);
             const int px = 32 * c + r;
-            const int rem = (int)((P0 + px) % S2);
+            const int rem = (rem0 + px) % S2;
             const int y = rem / S, x = rem - y * S;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
@@ -361,15 +386,17 @@ __global__ __launch_bounds__(256, 3) void dgrad1x1_bn_f16_kernel(const _Float16*
                                                                  _Float16* __restrict__ G, long ldg,
                                                                  const float* __restrict__ scale, const float* __restrict__ shift,
                                                                  const float* __restrict__ mean, float* __restrict__ ws, long M,
-                                                                 int cin, int n_cb, long tiles_per_slab) {
+                                                                 int cin, int n_cb, long tiles_per_slab, long n_slabs) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 64 * R_RS + 3 * 128 * 4];
     char* const Bt = smem;
     char* const Xt = smem + 64 * R_RS;
     char* const Gt = smem + 2 * 64 * R_RS;
     float* const cst = reinterpret_cast<float*>(smem + 3 * 64 * R_RS);     // [scale | shift | mean][128]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
-    const int cb = blockIdx.x % n_cb;
-    const long slab = blockIdx.x / n_cb;
+    // block order as in the 1x1 weight gradient: the n_cb workgroups of one slab (same dB rows) share an XCD
+    const int rem8 = blockIdx.x % (8 * n_cb), cb = rem8 / 8;
+    const long slab = (long)(blockIdx.x / (8 * n_cb)) * 8 + (rem8 & 7);
+    if (slab >= n_slabs) return;
     const int cbase = cb * 128;
     const bool active = cbase + 32 * wave < cin;                           // 32 | cin: a wave's channels are all in or all out
     const long ntiles = (M + 63) / 64;
@@ -617,50 +644,75 @@ __global__ __launch_bounds__(256) void h16_cols_to_f32_kernel(const _Float16* __
 // ------------------------------------------------------------------------------------------------ fixed-order slab reductions
 // out[map(i)] (+)= inv * sum_s ws[s * n + i].  mode 0: map = identity; mode 1: i = (tap, n, k) of [9][32][128] -> torch's
 // conv2.weight order [n][k][tap].
+// Sixteen lanes share an output element: lane j sums slabs j, j + 16, ... in order, the sixteen partial sums are added in a
+// fixed tree (deterministic).  Consecutive 16-lane groups take consecutive elements: a slab row is read in 64-B pieces.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ ws, long nslab, long n, float* __restrict__ out,
                                                            const float* __restrict__ ls, int accumulate, int mode,
                                                            int* __restrict__ flag) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    const int sl = threadIdx.x >> 4;                               // slab lane
+    const long i = (long)blockIdx.x * 16 + (threadIdx.x & 15);     // element: a block owns 16 consecutive elements
     float s = 0.f;
-    for (long k = 0; k < nslab; ++k) s += ws[k * n + i];
-    s *= ls ? ls[1] : 1.f;
-    long o = i;
-    if (mode == 1) {
-        const int tap = (int)(i / (32 * 128)), rem = (int)(i % (32 * 128));
-        o = (long)rem * 9 + tap;
+    if (i < n)
+        for (long k = sl; k < nslab; k += 16) s += ws[k * n + i];
+    __shared__ float part[256];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && i < n) {
+        float tot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tot += part[threadIdx.x + 16 * j];
+        tot *= ls ? ls[1] : 1.f;
+        long o = i;
+        if (mode == 1) {
+            const int tap = (int)(i / (32 * 128)), rem = (int)(i % (32 * 128));
+            o = (long)rem * 9 + tap;
+        }
+        if (accumulate) tot += out[o];
+        out[o] = tot;
+        if (flag && !(fabsf(tot) <= 3.0e38f)) atomicOr(flag, 1);
     }
-    if (accumulate) s += out[o];
-    out[o] = s;
-    if (flag && !(fabsf(s) <= 3.0e38f)) atomicOr(flag, 1);
 }
 // BatchNorm sums: slabs [s][2][cw] of (S0, S1) -> dbeta[c] = inv S0, dgamma[c] = inv f(S0, S1):
 // mode 0: dgamma = S1 p0[c] (S1 = sum d (x - mean), p0 = invstd);  mode 1: dgamma = (S1 - p1[c] S0) / p0[c] (S1 = sum d a with
 // a = relu(gamma x_hat + beta) the stored activation, p0 = gamma, p1 = beta: x_hat = (a - beta) / gamma where d != 0).
+// A 256-thread block owns 16 channels x 16 slab lanes (same scheme as above).
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ ws, long nslab, int C, long cw,
                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                         const float* __restrict__ p0, const float* __restrict__ p1, int mode,
                                                         const float* __restrict__ ls, int accumulate, int* __restrict__ flag) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int sl = threadIdx.x >> 4;
     float s0 = 0.f, s1 = 0.f;
-    for (long k = 0; k < nslab; ++k) {
-        s0 += ws[(2 * k) * cw + c];
-        s1 += ws[(2 * k + 1) * cw + c];
+    if (c < C)
+        for (long k = sl; k < nslab; k += 16) {
+            s0 += ws[(2 * k) * cw + c];
+            s1 += ws[(2 * k + 1) * cw + c];
+        }
+    __shared__ float part[2][256];
+    part[0][threadIdx.x] = s0;
+    part[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (threadIdx.x < 16 && c < C) {
+        s0 = s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            s0 += part[0][threadIdx.x + 16 * j];
+            s1 += part[1][threadIdx.x + 16 * j];
+        }
+        const float inv = ls ? ls[1] : 1.f;
+        float dg = mode == 0 ? s1 * p0[c] : (s1 - p1[c] * s0) / p0[c];
+        dg *= inv;
+        float db = s0 * inv;
+        if (dgamma) {
+            if (accumulate) dg += dgamma[c];
+            dgamma[c] = dg;
+        }
+        if (dbeta) {
+            if (accumulate) db += dbeta[c];
+            dbeta[c] = db;
+        }
+        if (flag && (!(fabsf(dg) <= 3.0e38f) || !(fabsf(db) <= 3.0e38f))) atomicOr(flag, 1);
     }
-    const float inv = ls ? ls[1] : 1.f;
-    float dg = mode == 0 ? s1 * p0[c] : (s1 - p1[c] * s0) / p0[c];
-    dg *= inv;
-    float db = s0 * inv;
-    if (dgamma) {
-        if (accumulate) dg += dgamma[c];
-        dgamma[c] = dg;
-    }
-    if (dbeta) {
-        if (accumulate) db += dbeta[c];
-        dbeta[c] = db;
-    }
-    if (flag && (!(fabsf(dg) <= 3.0e38f) || !(fabsf(db) <= 3.0e38f))) atomicOr(flag, 1);
 }
 
 bool al16b(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -681,7 +733,7 @@ SlabPlan plan_slabs(long M, int tile, long want) {
 }
 SlabPlan plan_wgrad1(long M, int N, int K) {
     const long blocks = (long)((K + 127) / 128) * ((N + 127) / 128);
-    return plan_slabs(M, 64, (512 + blocks - 1) / blocks);
+    return plan_slabs(M, 64, (768 + blocks - 1) / blocks);          // three workgroups per CU
 }
 SlabPlan plan_dgrad1(long M, int K) {
     const long n_cb = (K + 127) / 128;
@@ -701,15 +753,15 @@ GNX_EXPORT int gnx_wgrad1x1_f16(const void* dY16, long lddy, const void* X16, lo
     if (N % 8 || K % 8 || lddy % 8 || ldx % 8 || !al16b(dY16) || !al16b(X16)) return GNX_ERR_UNSUPPORTED;
     const SlabPlan p = plan_wgrad1(M, N, K);
     const int n_kb = (K + 127) / 128, n_nb = (N + 127) / 128;
-    const long grid = p.slabs * n_kb * n_nb;
+    const long grid = (p.slabs + 7) / 8 * 8 * n_kb * n_nb;
     const _Float16* dY = reinterpret_cast<const _Float16*>(dY16);
     const _Float16* X = reinterpret_cast<const _Float16*>(X16);
     if (scale)
-        wgrad1x1_f16_kernel<true><<<(int)grid, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, N, K, p.per, n_kb, n_nb);
+        wgrad1x1_f16_kernel<true><<<(int)grid, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, N, K, p.per, n_kb, n_nb, p.slabs);
     else
-        wgrad1x1_f16_kernel<false><<<(int)grid, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, N, K, p.per, n_kb, n_nb);
+        wgrad1x1_f16_kernel<false><<<(int)grid, 256, 0, stream>>>(dY, lddy, X, ldx, scale, shift, workspace, M, N, K, p.per, n_kb, n_nb, p.slabs);
     const long n = (long)N * K;
-    reduce_slabs_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(workspace, p.slabs, n, dW, ls, accumulate, 0, flag);
+    reduce_slabs_kernel<<<(int)((n + 15) / 16), 256, 0, stream>>>(workspace, p.slabs, n, dW, ls, accumulate, 0, flag);
     return gnx_launch_status();
 }
 
@@ -724,7 +776,7 @@ GNX_EXPORT int gnx_wgrad3x3_f16(const void* dY16, long lddy, const void* A16, fl
     wgrad3x3_f16_kernel<<<(int)p.slabs, 256, lds, stream>>>(reinterpret_cast<const _Float16*>(dY16), lddy,
                                                            reinterpret_cast<const _Float16*>(A16), workspace, M, S, p.per);
     const long n = 9L * 32 * 128;
-    reduce_slabs_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(workspace, p.slabs, n, dW, ls, accumulate, 1, flag);
+    reduce_slabs_kernel<<<(int)((n + 15) / 16), 256, 0, stream>>>(workspace, p.slabs, n, dW, ls, accumulate, 1, flag);
     return gnx_launch_status();
 }
 
@@ -746,7 +798,7 @@ GNX_EXPORT int gnx_conv3x3_dgrad_bnrelu_bwd_f16(const void* dY16, long lddy, con
                                                               reinterpret_cast<const _Float16*>(A16),
                                                               reinterpret_cast<_Float16*>(dB16), scale2, workspace, M, S, p.per);
     if (dgamma || dbeta)
-        bn_reduce_kernel<<<1, 256, 0, stream>>>(workspace, p.slabs, 128, 128, dgamma, dbeta, gamma2, beta2, 1, ls, accumulate, flag);
+        bn_reduce_kernel<<<8, 256, 0, stream>>>(workspace, p.slabs, 128, 128, dgamma, dbeta, gamma2, beta2, 1, ls, accumulate, flag);
     return gnx_launch_status();
 }
 
@@ -765,13 +817,13 @@ GNX_EXPORT int gnx_conv1x1_dgrad_bnrelu_bwd_f16(const void* dB16, const void* W1
     if (K % 32 || ldx % 8 || ldg % 8 || !al16b(dB16) || !al16b(W1t16) || !al16b(X16) || !al16b(G16)) return GNX_ERR_UNSUPPORTED;
     const SlabPlan p = plan_dgrad1(M, K);
     const int n_cb = (K + 127) / 128;
-    dgrad1x1_bn_f16_kernel<<<(int)(p.slabs * n_cb), 256, 0, stream>>>(reinterpret_cast<const _Float16*>(dB16),
+    dgrad1x1_bn_f16_kernel<<<(int)((p.slabs + 7) / 8 * 8 * n_cb), 256, 0, stream>>>(reinterpret_cast<const _Float16*>(dB16),
                                                                      reinterpret_cast<const _Float16*>(W1t16),
                                                                      reinterpret_cast<const _Float16*>(X16), ldx,
                                                                      reinterpret_cast<_Float16*>(G16), ldg, scale, shift, mean,
-                                                                     workspace, M, K, n_cb, p.per);
+                                                                     workspace, M, K, n_cb, p.per, p.slabs);
     if (dgamma || dbeta)
-        bn_reduce_kernel<<<(K + 255) / 256, 256, 0, stream>>>(workspace, p.slabs, K, (long)n_cb * 128, dgamma, dbeta, invstd, nullptr, 0,
+        bn_reduce_kernel<<<(K + 15) / 16, 256, 0, stream>>>(workspace, p.slabs, K, (long)n_cb * 128, dgamma, dbeta, invstd, nullptr, 0,
                                                              ls, accumulate, flag);
     return gnx_launch_status();
 }
@@ -797,7 +849,7 @@ GNX_EXPORT int gnx_tail_bwd_f16(const float* dfeats, long ldf, const void* X16, 
                                                                          reinterpret_cast<_Float16*>(G16), ldg, scale, shift, mean,
                                                                          ls, workspace, imgs, C, S2, (int)slots);
     if (dgamma || dbeta)
-        bn_reduce_kernel<<<(C + 255) / 256, 256, 0, stream>>>(workspace, slots, C, C, dgamma, dbeta, invstd, nullptr, 0, nullptr,
+        bn_reduce_kernel<<<(C + 15) / 16, 256, 0, stream>>>(workspace, slots, C, C, dgamma, dbeta, invstd, nullptr, 0, nullptr,
                                                              accumulate, flag);
     return gnx_launch_status();
 }
@@ -824,7 +876,7 @@ GNX_EXPORT int gnx_trans_bwd_f16(const void* dP16, long ldp, const void* X16, lo
                                                                           reinterpret_cast<_Float16*>(G16), ldg, scale, shift, mean,
                                                                           workspace, imgs, C, S, (int)slots);
     if (dgamma || dbeta)
-        bn_reduce_kernel<<<(C + 255) / 256, 256, 0, stream>>>(workspace, slots, C, C, dgamma, dbeta, invstd, nullptr, 0, ls, accumulate,
+        bn_reduce_kernel<<<(C + 15) / 16, 256, 0, stream>>>(workspace, slots, C, C, dgamma, dbeta, invstd, nullptr, 0, ls, accumulate,
                                                              flag);
     return gnx_launch_status();
 }

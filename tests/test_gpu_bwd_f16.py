@@ -36,7 +36,8 @@ def f32(n):
 
 
 @pytest.mark.parametrize("M,N,K,lddy,ldx,pro,s", [(1000, 128, 96, 128, 160, True, 1.0), (4096, 128, 992, 128, 1024, True, 8.0),
-                                                  (777, 256, 160, 320, 160, False, 4.0), (64, 128, 64, 128, 64, True, 1.0)])
+                                                  (777, 256, 160, 320, 160, False, 4.0), (64, 128, 64, 128, 64, True, 1.0),
+                                                  (70000, 128, 96, 128, 96, True, 2.0)])       # several tiles per workgroup
 def test_wgrad1x1_f16(L, M, N, K, lddy, ldx, pro, s):
     g = torch.Generator().manual_seed(M + K)
     dY = (torch.randn(M, lddy, generator=g) * s).to(H).to(DEV)
@@ -69,7 +70,7 @@ def _conv_case(imgs, S, seed):
     return M, ld, Gbuf, A, W
 
 
-@pytest.mark.parametrize("imgs,S", [(8, 4), (3, 8), (2, 16), (1, 32), (2, 7), (1, 64)])
+@pytest.mark.parametrize("imgs,S", [(8, 4), (3, 8), (2, 16), (1, 32), (2, 7), (1, 64), (40, 32)])
 def test_wgrad3x3_f16(L, imgs, S):
     M, ld, Gbuf, A, W = _conv_case(imgs, S, 11 * S + imgs)
     dY = Gbuf[:, 32:64]
@@ -84,7 +85,7 @@ def test_wgrad3x3_f16(L, imgs, S):
     assert rel(dW, ref) < 2e-4 and int(flag.item()) == 0
 
 
-@pytest.mark.parametrize("imgs,S", [(8, 4), (3, 8), (2, 16), (1, 32), (2, 7), (1, 64), (5, 8)])
+@pytest.mark.parametrize("imgs,S", [(8, 4), (3, 8), (2, 16), (1, 32), (2, 7), (1, 64), (5, 8), (72, 32)])
 def test_conv3x3_dgrad_bnrelu_bwd_f16(L, imgs, S):
     M, ld, Gbuf, A, W = _conv_case(imgs, S, 13 * S + imgs)
     dY = Gbuf[:, 32:64]
@@ -109,7 +110,8 @@ def test_conv3x3_dgrad_bnrelu_bwd_f16(L, imgs, S):
     assert int(flag.item()) == 0
 
 
-@pytest.mark.parametrize("M,K,ld", [(1000, 96, 160), (4096, 992, 1024), (640, 64, 64), (130, 224, 256)])
+@pytest.mark.parametrize("M,K,ld", [(1000, 96, 160), (4096, 992, 1024), (640, 64, 64), (130, 224, 256), (70000, 96, 96),
+                                    (20000, 288, 320)])
 def test_conv1x1_dgrad_bnrelu_bwd_f16(L, M, K, ld):
     g = torch.Generator().manual_seed(M + K)
     dB = torch.randn(M, 128, generator=g).to(H).to(DEV)
