@@ -797,7 +797,8 @@ def config5_trained_series(args, device, rank, world, steps=3, warmup=1):
     KINDS16 = {'conv1x1': 'conv1x1_h16_kernel (taped forward: stores the activated bottleneck, fp16)',
                'conv3x3': 'conv3x3_dma_kernel<H16, O16> (taped forward)',
                'wgrad3x3_f16': 'wgrad3x3_f16_kernel', 'dgrad3x3_bn2_f16': 'dgrad3x3_bn_f16_kernel',
-               'wgrad1x1_f16': 'wgrad1x1_f16_kernel', 'dgrad1x1_bn1_f16': 'dgrad1x1_bn_f16_kernel'}
+               'wgrad1x1_f16': 'wgrad1x1_f16_kernel', 'dgrad1x1_bn1_f16': 'dgrad1x1_bn_f16_kernel<false>',
+               'dgrad_wgrad1x1_bn1_f16': 'dgrad1x1_bn_f16_kernel<true> (conv1 data gradient + norm1 adjoint + conv1 weight gradient)'}
     kt = {}
     for kind, name in KINDS16.items():
         recs = [r for r in (probe or []) if r[0] == kind]

@@ -63,6 +63,8 @@ SIGNATURES = {
     'gnx_conv3x3_dgrad_bnrelu_bwd_f16': (_I, [_P, _L, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'gnx_conv1x1_dgrad_bnrelu_bwd_f16_workspace': (_L, [_L, _I]),
     'gnx_conv1x1_dgrad_bnrelu_bwd_f16': (_I, [_P, _P, _P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'gnx_conv1x1_dgrad_wgrad_f16_workspace': (_L, [_L, _I]),
+    'gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16': (_I, [_P, _P, _P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'gnx_tail_bwd_f16_workspace': (_L, [_L, _I]),
     'gnx_tail_bwd_f16': (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'gnx_trans_bwd_f16_workspace': (_L, [_L, _I, _I]),

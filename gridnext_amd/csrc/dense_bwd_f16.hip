@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_f16_kernel(const _Float16* __
 #pragma unroll
     for (int k = 0; k < 9; ++k) zero_acc(acc[k]);
     const int S2 = S * S;
+    const int lg = (S & (S - 1)) == 0 ? __builtin_ctz(S) : -1;
     h8 av[4], sv[4];
     auto fetch = [&](long tile) {
         const long P0 = tile * 64;
@@ -221,8 +222,14 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_f16_kernel(const _Float16* __
             // which taps may read the rows this lane supplies (pixel p of A; its partner is the output pixel p - (dy, dx))
             unsigned vlo = 0, vhi = 0;
             {
-                const int rem_lo = (rem0 + 16 * ks + trow) % S2, rem_hi = (rem0 + 16 * ks + trow + 4) % S2;
-                const int ylo = rem_lo / S, xlo = rem_lo - ylo * S, yhi = rem_hi / S, xhi = rem_hi - yhi * S;
+                int ylo, xlo, yhi, xhi;
+                if (lg >= 0) {                                      // power-of-two maps: no integer division in the loop
+                    const int rem_lo = (rem0 + 16 * ks + trow) & (S2 - 1), rem_hi = (rem0 + 16 * ks + trow + 4) & (S2 - 1);
+                    ylo = rem_lo >> lg, xlo = rem_lo & (S - 1), yhi = rem_hi >> lg, xhi = rem_hi & (S - 1);
+                } else {
+                    const int rem_lo = (rem0 + 16 * ks + trow) % S2, rem_hi = (rem0 + 16 * ks + trow + 4) % S2;
+                    ylo = rem_lo / S, xlo = rem_lo - ylo * S, yhi = rem_hi / S, xhi = rem_hi - yhi * S;
+                }
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int dy = tap / 3 - 1, dx = tap % 3 - 1;
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16*
 #pragma unroll
     for (int i = 0; i < 16; ++i) S0[i] = S1[i] = 0.f;
     const int S2 = S * S;
+    const int lg = (S & (S - 1)) == 0 ? __builtin_ctz(S) : -1;
     const int strip_items = nrows * 4;                              // <= 1032: five per thread
     h8 av[8], sv[5];
     auto fetch = [&](long tile) {
@@ -317,8 +325,14 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16*
             f32x16 acc;
             zero_acc(acc);
             const int px = 32 * c + r;
-            const int rem = (rem0 + px) % S2;
-            const int y = rem / S, x = rem - y * S;
+            int y, x;
+            if (lg >= 0) {
+                const int rem = (rem0 + px) & (S2 - 1);
+                y = rem >> lg, x = rem & (S - 1);
+            } else {
+                const int rem = (rem0 + px) % S2;
+                y = rem / S, x = rem - y * S;
+            }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int dy = tap / 3 - 1, dx = tap % 3 - 1;
@@ -381,12 +395,16 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16*
 // G[p][c] += scale1[c] d,  d = [scale1[c] X[p][c] + shift1[c] > 0] sum_m dB[p][m] W1[m][c];  S0[c] = sum_p d,
 // S1[c] = sum_p d (X[p][c] - mean[c]).  A workgroup owns 128 input channels (a wave 32, its weight slice in registers) and a
 // contiguous range of 64-pixel tiles; D = [channel][pixel].
-__global__ __launch_bounds__(256, 3) void dgrad1x1_bn_f16_kernel(const _Float16* __restrict__ dB, const _Float16* __restrict__ W1t,
-                                                                 const _Float16* __restrict__ X, long ldx,
-                                                                 _Float16* __restrict__ G, long ldg,
-                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                 const float* __restrict__ mean, float* __restrict__ ws, long M,
-                                                                 int cin, int n_cb, long tiles_per_slab, long n_slabs) {
+// WGRAD: the same pass also takes conv1's WEIGHT gradient from the tiles it has staged - wsw[slab][m][c] = sum over the slab's
+// pixels of dB[p][m] relu(bn1(X[p][c])) - with both operands read out of the row-major tiles by transposing reads (the
+// activation is applied to the fragment: a lane holds 8 pixels of ONE channel): gnx_wgrad1x1_f16's pass over dB and X (a
+// quarter of this kernel's bytes) is not made.  64 more accumulator registers: two workgroups per CU instead of three.
+template <bool WGRAD>
+__global__ __launch_bounds__(256, WGRAD ? 2 : 3) void dgrad1x1_bn_f16_kernel(
+    const _Float16* __restrict__ dB, const _Float16* __restrict__ W1t, const _Float16* __restrict__ X, long ldx,
+    _Float16* __restrict__ G, long ldg, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, float* __restrict__ ws, long M, int cin, int n_cb, long tiles_per_slab, long n_slabs,
+    float* __restrict__ wsw) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 64 * R_RS + 3 * 128 * 4];
     char* const Bt = smem;
     char* const Xt = smem + 64 * R_RS;
@@ -416,6 +434,11 @@ __global__ __launch_bounds__(256, 3) void dgrad1x1_bn_f16_kernel(const _Float16*
     float S0[16], S1[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) S0[i] = S1[i] = 0.f;
+    f32x16 wacc[WGRAD ? 4 : 1];
+#pragma unroll
+    for (int i = 0; i < (WGRAD ? 4 : 1); ++i) zero_acc(wacc[i]);
+    const int trow = 8 * h + ((lane & 15) >> 2);
+    const int tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     h8 bv[4], xv[4], gv[4];
     auto fetch = [&](long tile) {
         const long m0 = tile * 64;
@@ -440,6 +463,23 @@ __global__ __launch_bounds__(256, 3) void dgrad1x1_bn_f16_kernel(const _Float16*
         }
         lds_barrier();
         if (tile + 1 < tile1) fetch(tile + 1);                      // (G rows of the next tile: written by nobody else)
+        if (WGRAD && active) {
+            // dW1[m][c] += sum_p dB[p][m] act(X[p][c]): D = [m][c], k = pixels; this wave's 32 channels, all 128 m
+            const float wsc = cst[32 * wave + r], wsh = cst[128 + 32 * wave + r];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const char* px_ = Xt + (16 * ks + trow) * R_RS + (32 * wave + tcol) * 2;
+                h8 b = tr8(px_, px_ + 4 * R_RS);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] = (_Float16)fmaxf(fmaf((float)b[j], wsc, wsh), 0.f);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const char* pa = Bt + (16 * ks + trow) * R_RS + (32 * mt + tcol) * 2;
+                    const h8 a = tr8(pa, pa + 4 * R_RS);
+                    wacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, wacc[mt], 0, 0, 0);
+                }
+            }
+        }
         if (active) {
 #pragma unroll 1
             for (int c = 0; c < 2; ++c) {
@@ -501,6 +541,14 @@ __global__ __launch_bounds__(256, 3) void dgrad1x1_bn_f16_kernel(const _Float16*
             out[c] = S0[i];
             out[cw + c] = S1[i];
         }
+    }
+    if (WGRAD && active) {
+        const long cw = (long)n_cb * 128;
+        float* const out = wsw + slab * 128 * cw + cbase + 32 * wave + r;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) out[(long)(32 * mt + (i & 3) + 8 * (i >> 2) + 4 * h) * cw] = wacc[mt][i];
     }
 }
 
@@ -643,7 +691,7 @@ __global__ __launch_bounds__(256) void h16_cols_to_f32_kernel(const _Float16* __
 
 // ------------------------------------------------------------------------------------------------ fixed-order slab reductions
 // out[map(i)] (+)= inv * sum_s ws[s * n + i].  mode 0: map = identity; mode 1: i = (tap, n, k) of [9][32][128] -> torch's
-// conv2.weight order [n][k][tap].
+// conv2.weight order [n][k][tap]; mode -K: i = (row, col) of [rows][128 ceil(K / 128)] -> [rows][K] (columns past K dropped).
 // Sixteen lanes share an output element: lane j sums slabs j, j + 16, ... in order, the sixteen partial sums are added in a
 // fixed tree (deterministic).  Consecutive 16-lane groups take consecutive elements: a slab row is read in 64-B pieces.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ ws, long nslab, long n, float* __restrict__ out,
@@ -666,6 +714,11 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
         if (mode == 1) {
             const int tap = (int)(i / (32 * 128)), rem = (int)(i % (32 * 128));
             o = (long)rem * 9 + tap;
+        } else if (mode < 0) {                                      // slabs [rows][cw] (cw = 128 ceil(K / 128)) -> out [rows][K], K = -mode
+            const long K = -mode, cw = (K + 127) / 128 * 128;
+            const long row = i / cw, col = i - row * cw;
+            if (col >= K) return;
+            o = row * K + col;
         }
         if (accumulate) tot += out[o];
         out[o] = tot;
@@ -735,9 +788,9 @@ SlabPlan plan_wgrad1(long M, int N, int K) {
     const long blocks = (long)((K + 127) / 128) * ((N + 127) / 128);
     return plan_slabs(M, 64, (768 + blocks - 1) / blocks);          // three workgroups per CU
 }
-SlabPlan plan_dgrad1(long M, int K) {
+SlabPlan plan_dgrad1(long M, int K, bool wgrad = false) {
     const long n_cb = (K + 127) / 128;
-    return plan_slabs(M, 64, (768 + n_cb - 1) / n_cb);
+    return plan_slabs(M, 64, ((wgrad ? 512 : 768) + n_cb - 1) / n_cb);
 }
 
 }  // namespace
@@ -807,25 +860,57 @@ GNX_EXPORT int gnx_conv3x3_dgrad_bnrelu_bwd_f16(const void* dY16, long lddy, con
 GNX_EXPORT long gnx_conv1x1_dgrad_bnrelu_bwd_f16_workspace(long M, int K) {
     return plan_dgrad1(M, K).slabs * 2L * ((K + 127) / 128) * 128;
 }
-GNX_EXPORT int gnx_conv1x1_dgrad_bnrelu_bwd_f16(const void* dB16, const void* W1t16, const void* X16, long ldx, void* G16, long ldg,
-                                                long M, int K, const float* scale, const float* shift, const float* mean,
-                                                const float* invstd, float* dgamma, float* dbeta, float* workspace,
-                                                const float* ls, int accumulate, int* flag, hipStream_t stream) {
+// with dW != NULL the pass also produces conv1's weight gradient dW[128][K] (fp32, (+)=) - then `workspace` must hold
+// gnx_conv1x1_dgrad_wgrad_f16_workspace(M, K) floats
+GNX_EXPORT long gnx_conv1x1_dgrad_wgrad_f16_workspace(long M, int K) {
+    return plan_dgrad1(M, K, true).slabs * (2L + 128) * ((K + 127) / 128) * 128;
+}
+static int dgrad1_launch(const void* dB16, const void* W1t16, const void* X16, long ldx, void* G16, long ldg, long M, int K,
+                         const float* scale, const float* shift, const float* mean, const float* invstd, float* dgamma,
+                         float* dbeta, float* dW, float* workspace, const float* ls, int accumulate, int* flag, hipStream_t stream) {
     if (!dB16 || !W1t16 || !X16 || !G16 || !scale || !shift || !mean || !invstd || !workspace || !ls || M <= 0 || K <= 0 ||
         ldx < K || ldg < K)
         return GNX_ERR_BAD_ARG;
     if (K % 32 || ldx % 8 || ldg % 8 || !al16b(dB16) || !al16b(W1t16) || !al16b(X16) || !al16b(G16)) return GNX_ERR_UNSUPPORTED;
-    const SlabPlan p = plan_dgrad1(M, K);
+    const SlabPlan p = plan_dgrad1(M, K, dW != nullptr);
     const int n_cb = (K + 127) / 128;
-    dgrad1x1_bn_f16_kernel<<<(int)((p.slabs + 7) / 8 * 8 * n_cb), 256, 0, stream>>>(reinterpret_cast<const _Float16*>(dB16),
-                                                                     reinterpret_cast<const _Float16*>(W1t16),
-                                                                     reinterpret_cast<const _Float16*>(X16), ldx,
-                                                                     reinterpret_cast<_Float16*>(G16), ldg, scale, shift, mean,
-                                                                     workspace, M, K, n_cb, p.per, p.slabs);
+    const long cw = (long)n_cb * 128;
+    float* const wsw = workspace + p.slabs * 2 * cw;
+    const int grid = (int)((p.slabs + 7) / 8 * 8 * n_cb);
+    const _Float16* dB = reinterpret_cast<const _Float16*>(dB16);
+    const _Float16* Wt = reinterpret_cast<const _Float16*>(W1t16);
+    const _Float16* X = reinterpret_cast<const _Float16*>(X16);
+    _Float16* G = reinterpret_cast<_Float16*>(G16);
+    if (dW)
+        dgrad1x1_bn_f16_kernel<true><<<grid, 256, 0, stream>>>(dB, Wt, X, ldx, G, ldg, scale, shift, mean, workspace, M, K, n_cb, p.per,
+                                                              p.slabs, wsw);
+    else
+        dgrad1x1_bn_f16_kernel<false><<<grid, 256, 0, stream>>>(dB, Wt, X, ldx, G, ldg, scale, shift, mean, workspace, M, K, n_cb, p.per,
+                                                               p.slabs, nullptr);
     if (dgamma || dbeta)
-        bn_reduce_kernel<<<(K + 15) / 16, 256, 0, stream>>>(workspace, p.slabs, K, (long)n_cb * 128, dgamma, dbeta, invstd, nullptr, 0,
-                                                             ls, accumulate, flag);
+        bn_reduce_kernel<<<(K + 15) / 16, 256, 0, stream>>>(workspace, p.slabs, K, cw, dgamma, dbeta, invstd, nullptr, 0, ls, accumulate,
+                                                           flag);
+    if (dW) {
+        const long n = 128 * cw;
+        reduce_slabs_kernel<<<(int)((n + 15) / 16), 256, 0, stream>>>(wsw, p.slabs, n, dW, ls, accumulate, -K, flag);
+    }
     return gnx_launch_status();
+}
+GNX_EXPORT int gnx_conv1x1_dgrad_bnrelu_bwd_f16(const void* dB16, const void* W1t16, const void* X16, long ldx, void* G16, long ldg,
+                                                long M, int K, const float* scale, const float* shift, const float* mean,
+                                                const float* invstd, float* dgamma, float* dbeta, float* workspace,
+                                                const float* ls, int accumulate, int* flag, hipStream_t stream) {
+    return dgrad1_launch(dB16, W1t16, X16, ldx, G16, ldg, M, K, scale, shift, mean, invstd, dgamma, dbeta, nullptr, workspace, ls,
+                         accumulate, flag, stream);
+}
+GNX_EXPORT int gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16(const void* dB16, const void* W1t16, const void* X16, long ldx, void* G16,
+                                                      long ldg, long M, int K, const float* scale, const float* shift,
+                                                      const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                                      float* dW, float* workspace, const float* ls, int accumulate, int* flag,
+                                                      hipStream_t stream) {
+    if (!dW) return GNX_ERR_BAD_ARG;
+    return dgrad1_launch(dB16, W1t16, X16, ldx, G16, ldg, M, K, scale, shift, mean, invstd, dgamma, dbeta, dW, workspace, ls,
+                         accumulate, flag, stream);
 }
 
 // norm_final -> relu -> global average pool, backward: G16[M][C] = s * ..., dgamma / dbeta (fp32).  8 | C.

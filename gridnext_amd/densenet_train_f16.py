@@ -256,21 +256,24 @@ class _DenseNetF16Fn(Function):
                        L.ptr(s2[0]), L.ptr(layer.norm2.weight), L.ptr(layer.norm2.bias), L.ptr(dg2), L.ptr(db2), L.ptr(wsd3), lp, 0,
                        fp, st)
                 model._probe_mark('dgrad3x3_bn2_f16', t0, 2 * M * 9 * mid * g, 2 * M * (g + 2 * mid))
+                # conv1: data gradient + norm1 -> relu1's adjoint into the block gradient, and - from the same staged tiles - the
+                # weight gradient (ONE pass over dB, X and G)
                 w1 = layer.conv1.weight
-                if want(w1):
-                    ws1 = _f32(L.query('gnx_wgrad1x1_f16_workspace', M, mid, cin), dev)
-                    t0 = model._probe_begin()
-                    L.call('gnx_wgrad1x1_f16', dB.data_ptr(), mid, X.data_ptr(), c_total, L.ptr(s1[0]), L.ptr(s1[1]),
-                           L.ptr(new_like(w1)), L.ptr(ws1), M, mid, cin, lp, 0, fp, st)
-                    model._probe_mark('wgrad1x1_f16', t0, 2 * M * cin * mid, 2 * M * (cin + mid))
                 w1t = w1.detach().reshape(mid, cin).t().to(H16).contiguous()                         # [cin][128]
                 dg1, db1 = bn_out(layer.norm1)
-                wsd1 = _f32(L.query('gnx_conv1x1_dgrad_bnrelu_bwd_f16_workspace', M, cin), dev)
                 t0 = model._probe_begin()
-                L.call('gnx_conv1x1_dgrad_bnrelu_bwd_f16', dB.data_ptr(), w1t.data_ptr(), X.data_ptr(), c_total, G.data_ptr(), c_total,
-                       M, cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s1[2]), L.ptr(s1[3]), L.ptr(dg1), L.ptr(db1), L.ptr(wsd1), lp, 0, fp,
-                       st)
-                model._probe_mark('dgrad1x1_bn1_f16', t0, 2 * M * cin * mid, 2 * M * (mid + 3 * cin))
+                if want(w1):
+                    wsd1 = _f32(L.query('gnx_conv1x1_dgrad_wgrad_f16_workspace', M, cin), dev)
+                    L.call('gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16', dB.data_ptr(), w1t.data_ptr(), X.data_ptr(), c_total, G.data_ptr(),
+                           c_total, M, cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s1[2]), L.ptr(s1[3]), L.ptr(dg1), L.ptr(db1),
+                           L.ptr(new_like(w1)), L.ptr(wsd1), lp, 0, fp, st)
+                    model._probe_mark('dgrad_wgrad1x1_bn1_f16', t0, 4 * M * cin * mid, 2 * M * (mid + 3 * cin))
+                else:
+                    wsd1 = _f32(L.query('gnx_conv1x1_dgrad_bnrelu_bwd_f16_workspace', M, cin), dev)
+                    L.call('gnx_conv1x1_dgrad_bnrelu_bwd_f16', dB.data_ptr(), w1t.data_ptr(), X.data_ptr(), c_total, G.data_ptr(),
+                           c_total, M, cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s1[2]), L.ptr(s1[3]), L.ptr(dg1), L.ptr(db1), L.ptr(wsd1),
+                           lp, 0, fp, st)
+                    model._probe_mark('dgrad1x1_bn1_f16', t0, 2 * M * cin * mid, 2 * M * (mid + 3 * cin))
                 tape.layers[bi][li] = None
                 del a
             del dB, ws3, wsd3

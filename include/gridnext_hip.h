@@ -343,6 +343,13 @@ int gnx_conv1x1_dgrad_bnrelu_bwd_f16(const void* dB16, const void* W1t16, const 
                                      int K, const float* scale, const float* shift, const float* mean, const float* invstd,
                                      float* dgamma, float* dbeta, float* workspace, const float* ls, int accumulate, int* flag,
                                      gnx_stream_t stream);
+/* The same pass also producing conv1's weight gradient dW[128][K] (fp32, (+)=; = gnx_wgrad1x1_f16(dB16, X16, scale, shift)) from
+ * the tiles it stages: the separate pass over dB16 and X16 is not made.  workspace: gnx_conv1x1_dgrad_wgrad_f16_workspace floats. */
+long gnx_conv1x1_dgrad_wgrad_f16_workspace(long M, int K);
+int gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16(const void* dB16, const void* W1t16, const void* X16, long ldx, void* G16, long ldg,
+                                           long M, int K, const float* scale, const float* shift, const float* mean,
+                                           const float* invstd, float* dgamma, float* dbeta, float* dW, float* workspace,
+                                           const float* ls, int accumulate, int* flag, gnx_stream_t stream);
 long gnx_tail_bwd_f16_workspace(long imgs, int C);
 int gnx_tail_bwd_f16(const float* dfeats, long ldf, const void* X16, long ldx, void* G16, long ldg, long imgs, int C, int S2,
                      const float* scale, const float* shift, const float* mean, const float* invstd, float* dgamma, float* dbeta,

@@ -140,6 +140,17 @@ def test_conv1x1_dgrad_bnrelu_bwd_f16(L, M, K, ld):
     assert rel(db, d.sum(0) / 2.0) < 2e-4
     assert rel(dg, (d * (x - mean.double())).sum(0) * invstd.double() / 2.0) < 2e-4
     assert int(flag.item()) == 0
+    # the same pass with conv1's weight gradient taken from the staged tiles: G, dgamma, dbeta as before, dW = gnx_wgrad1x1_f16's
+    G2 = G0.clone()
+    dg2, db2, dW = torch.zeros(K, device=DEV), torch.zeros(K, device=DEV), torch.full((128, K), 3.0, device=DEV)
+    ws = f32(L.query('gnx_conv1x1_dgrad_wgrad_f16_workspace', M, K))
+    L.call('gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16', dB.data_ptr(), W1t.data_ptr(), X.data_ptr(), ld, G2.data_ptr(), ld, M, K,
+           L.ptr(sc), L.ptr(sh), L.ptr(mean), L.ptr(invstd), L.ptr(dg2), L.ptr(db2), L.ptr(dW), L.ptr(ws), L.ptr(ls_tensor(2.0)), 0,
+           flag.data_ptr(), L.stream())
+    assert torch.equal(G2, G), "the fused pass must leave the data gradient bit-identical"
+    assert rel(db2, db) < 1e-5 and rel(dg2, dg) < 1e-5        # (other slab boundaries: two workgroups per CU)
+    xa = torch.relu(torch.addcmul(sh, X[:, :K].float(), sc)).to(H).double()
+    assert rel(dW, dB.double().t() @ xa / 2.0) < 2e-4 and int(flag.item()) == 0
 
 
 def test_tail_trans_and_conversion_f16(L):
