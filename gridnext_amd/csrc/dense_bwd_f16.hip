@@ -237,14 +237,18 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_f16_kernel(const _Float16* __
                     if (yhi - dy >= 0 && yhi - dy < S && xhi - dx >= 0 && xhi - dx < S) vhi |= 1u << tap;
                 }
             }
+            // all nine taps' dY fragments are requested before the first of them is multiplied (one wait per k-step, not per MFMA)
+            h8 a[9];
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int off = (tap / 3 - 1) * S + (tap % 3 - 1);
                 const char* lo = ((vlo >> tap) & 1) ? strip + (16 * ks + trow - off + S + 1) * 64 + tcol * 2 : zrow + tcol * 2;
                 const char* hi = ((vhi >> tap) & 1) ? strip + (16 * ks + trow + 4 - off + S + 1) * 64 + tcol * 2 : zrow + tcol * 2;
-                const h8 a = tr8(lo, hi);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[tap], 0, 0, 0);
+                a[tap] = tr8(lo, hi);
             }
+            __builtin_amdgcn_sched_barrier(0);                      // (the scheduler otherwise sinks each read pair to its MFMA)
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tap], b, acc[tap], 0, 0, 0);
         }
     }
     float* const out = ws + slab * (9L * 32 * 128);
@@ -334,15 +338,21 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16*
                 y = rem / S, x = rem - y * S;
             }
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-                const bool ok = y - dy >= 0 && y - dy < S && x - dx >= 0 && x - dx < S;
-                const char* src = ok ? strip + (px - dy * S - dx + S + 1) * Y_RS : zrow;
+            for (int ky = 0; ky < 3; ++ky) {
+                // a kernel row's six fragments (three taps x two 16-channel steps) are requested together, then multiplied
+                h8 b[6];
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const h8 b = *reinterpret_cast<const h8*>(src + (16 * s + 8 * h) * 2);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[tap][s], b, acc, 0, 0, 0);
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int dy = ky - 1, dx = kx - 1;
+                    const bool ok = y - dy >= 0 && y - dy < S && x - dx >= 0 && x - dx < S;
+                    const char* src = ok ? strip + (px - dy * S - dx + S + 1) * Y_RS : zrow;
+                    b[2 * kx] = *reinterpret_cast<const h8*>(src + (8 * h) * 2);
+                    b[2 * kx + 1] = *reinterpret_cast<const h8*>(src + (16 + 8 * h) * 2);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[3 * ky + (j >> 1)][j & 1], b[j], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             // adjoint of norm2 -> relu2 on the accumulators; the tile is rewritten in place (each element by the lane that
             // read it; the matrix operands above come from the strip, never from this tile)
@@ -472,12 +482,15 @@ __global__ __launch_bounds__(256, WGRAD ? 2 : 3) void dgrad1x1_bn_f16_kernel(
                 h8 b = tr8(px_, px_ + 4 * R_RS);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) b[j] = (_Float16)fmaxf(fmaf((float)b[j], wsc, wsh), 0.f);
+                h8 a[4];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const char* pa = Bt + (16 * ks + trow) * R_RS + (32 * mt + tcol) * 2;
-                    const h8 a = tr8(pa, pa + 4 * R_RS);
-                    wacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, wacc[mt], 0, 0, 0);
+                    a[mt] = tr8(pa, pa + 4 * R_RS);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) wacc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], b, wacc[mt], 0, 0, 0);
             }
         }
         if (active) {
@@ -485,11 +498,12 @@ __global__ __launch_bounds__(256, WGRAD ? 2 : 3) void dgrad1x1_bn_f16_kernel(
             for (int c = 0; c < 2; ++c) {
                 f32x16 acc;
                 zero_acc(acc);
+                h8 b[8];
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    const h8 b = *reinterpret_cast<const h8*>(Bt + (32 * c + r) * R_RS + (16 * s + 8 * h) * 2);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], b, acc, 0, 0, 0);
-                }
+                for (int s = 0; s < 8; ++s) b[s] = *reinterpret_cast<const h8*>(Bt + (32 * c + r) * R_RS + (16 * s + 8 * h) * 2);
+                __builtin_amdgcn_sched_barrier(0);                  // all eight fragments requested, then multiplied
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], b[s], acc, 0, 0, 0);
                 const int px = 32 * c + r;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
