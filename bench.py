@@ -687,7 +687,7 @@ def patch224_series(args, device, rank, world, steps=3, warmup=1, P=224):
     return out
 
 
-def config5_trained_series(args, device, rank, world, steps=3, warmup=1):
+def config5_trained_series(args, device, rank, world, steps=3, warmup=1, P=256):
     """SURVEY 8d's "everything trained" column at config 5's geometry (22.21 GFLOP per spot): the multimodal step on one
     256-px array with both classifiers trained through f_opt on the fp16-MFMA path - `DenseNet.mfma = 'f16'` on the gradient
     path: fp16 tape (block buffers + activated bottlenecks, one chunk: ~110 GB), fp16-MFMA backward with fp32 accumulation
@@ -700,7 +700,6 @@ def config5_trained_series(args, device, rank, world, steps=3, warmup=1):
     from gridnext_amd import distributed as gdist
     from gridnext_amd import training as gtrain
     from gridnext_amd import densenet_train as dt
-    P = 256
     crit = nn.CrossEntropyLoss()
     gen = torch.Generator(device=device).manual_seed(950 + rank)
     y = torch.randint(0, CLASSES + 1, (1, H, W), device=device, generator=gen)
@@ -781,10 +780,11 @@ def config5_trained_series(args, device, rank, world, steps=3, warmup=1):
            "warmup": warmup, "dtype": "f16", "final_loss": r16["losses"][-1], "peak_hbm_gb": r16["peak_hbm_gb"],
            "recomputed_chunks": 0 if r16["chunks"] == 1 else r16["chunks"], "chunk_spots": r16["chunk_spots"],
            "loss_scale": r16["loss_scale"], "grad_overflow_flag": r16["overflow"],
-           "algorithmic_tflops": 22.21e9 * H * W * world * steps / elapsed / 1e12,
-           "workload": "BASELINE config 5's geometry, everything trained: multimodal f (DenseNet-121 @256 px, fp16-MFMA forward AND "
+           "algorithmic_tflops": (22.21e9 if P == 256 else 5.557e9) * H * W * world * steps / elapsed / 1e12, "patch": P,
+           "workload": "%s, everything trained: multimodal f (DenseNet-121 @%d px, fp16-MFMA forward AND "
                        "backward, fp32 accumulate / parameter gradients) + count MLP + hex g, 1 array (4992 spots) per step, f and "
-                       "g trained (f_opt), eval-mode BN (calibrated statistics), uint8 patches resident in HBM"}
+                       "g trained (f_opt), eval-mode BN (calibrated statistics), uint8 patches resident in HBM"
+                       % ("BASELINE config 5's geometry" if P == 256 else "config 4's geometry on config 5's fp16 path", P)}
     if world == 1:
         r32 = run('f32', 0, warmup + steps, False)
         out["ce_vs_fp32_path"] = {"f16": r16["losses"], "f32": r32["losses"],
@@ -1054,6 +1054,10 @@ def worker_main(args):
     # ---- and its "everything trained" column: 256 px, fp32, f in recomputed chunks (bounded tape)
     if more and not args.train_f and args.mfma == 'f32' and args.patch == 128:
         optional("config5_everything_trained_256px", lambda: config5_trained_series(args, device, rank, world))
+
+    # ---- the f-trained step of the headline geometry (128 px) on the fp16-MFMA gradient path
+    if more and not args.train_f and args.mfma == 'f32' and args.patch == 128:
+        optional("train_f_f16_128px", lambda: config5_trained_series(args, device, rank, world, P=128))
 
     # ---- second series of SURVEY 8d in the same run: f trained (DenseNet forward + backward)
     if not args.train_f and more and args.mfma == 'f32' and args.patch == 128:

@@ -456,6 +456,13 @@ class DenseNet(nn.Module):
         if x.dtype not in (torch.uint8, torch.float32):
             x = x.float()
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        # fp16 path, running statistics: its kernels take whole groups of 8 spots (128-row tiles on the 4 x 4 maps).  A ragged
+        # batch is padded with empty patches and the extra rows dropped: spots are independent under running statistics, and on
+        # the gradient path the padding rows receive a zero output gradient, so they add nothing to any parameter gradient.
+        pad = (-x.shape[0]) % 8
+        if self.mfma == 'f16' and pad and x.shape[0] > 0 and not self.training and not x.requires_grad and self.f16_buffers:
+            xp = torch.cat([x, x.new_zeros((pad,) + tuple(x.shape[1:]))], 0)
+            return self.forward(xp)[:x.shape[0]]
         if self.training or needs_grad:
             from .densenet_train import densenet_autograd       # training / gradient path
             return densenet_autograd(self, x)

@@ -392,3 +392,15 @@ def test_f16_gradient_path_matches_fp32_hip_path_and_recompute():
     # chunks: every kernel's per-row arithmetic is independent of the batch; the pixel sums differ in their slab order only
     cos2 = (res['f16'] @ res['f16_chunks'] / (res['f16'].norm() * res['f16_chunks'].norm())).item()
     assert cos2 >= 0.99999, cos2
+    # a ragged batch (13 patches) is padded to 16 with empty patches whose output gradient is zero: the gradients are those
+    # of the 13 patches - compare with the padded batch given explicitly and a loss over its first 13 rows
+    m.tape_budget = 150 * 1024 ** 3
+    m.zero_grad()
+    nn.functional.cross_entropy(m(x[:13]), labels[:13]).backward()
+    assert 'f16_grad_scale' in m.__dict__
+    g13 = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).double()
+    m.zero_grad()
+    xp = torch.cat([x[:13], torch.zeros_like(x[:3])], 0)
+    nn.functional.cross_entropy(m(xp)[:13], labels[:13]).backward()
+    g16 = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).double()
+    assert torch.equal(g13, g16)
