@@ -261,6 +261,101 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_f16_kernel(const _Float16* __
         }
 }
 
+// The same for power-of-two maps (every DenseNet-121 map at 128 / 256 px) without any per-tap address arithmetic: the dY rows a
+// 64-pixel tile needs - its own image rows and the one above / below - are staged as a ZERO-PADDED image, (rows + 2) x (S + 2)
+// positions per image, so that "the output pixel p - (dy, dx)" is the padded position of p minus a compile-time constant and
+// is a zero wherever it leaves the image.  A lane's two row addresses are computed once per k-step; the nine taps are nine
+// immediates.  (The general kernel spends ~150 vector instructions per k-step and wave on validity masks and selects
+// against 9 MFMAs.)
+template <int S>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_f16_p2_kernel(const _Float16* __restrict__ dY, long lddy,
+                                                                 const _Float16* __restrict__ A, float* __restrict__ ws, long M,
+                                                                 long tiles_per_slab) {
+    constexpr int NIMG = S >= 8 ? 1 : 64 / (S * S);                 // images per tile
+    constexpr int NR = S >= 8 ? 64 / S : S;                         // image rows per tile and image
+    constexpr int PW = S + 2, PIMG = (NR + 2) * PW;                 // padded row length, padded positions per image
+    constexpr int NPOS = NIMG * PIMG;
+    constexpr int ITEMS = NIMG * (NR + 2) * S * 4;                  // (padded row, column, 16-B piece) to stage per tile
+    constexpr int LG = S == 4 ? 2 : S == 8 ? 3 : S == 16 ? 4 : S == 32 ? 5 : 6;
+    __shared__ __attribute__((aligned(16))) char smem[64 * T_RS + NPOS * 64];
+    char* const At = smem;
+    char* const strip = smem + 64 * T_RS;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long slab = blockIdx.x;
+    const long ntiles = (M + 63) / 64;
+    const long tile0 = slab * tiles_per_slab;
+    const long tile1 = tile0 + tiles_per_slab < ntiles ? tile0 + tiles_per_slab : ntiles;
+    const int chunk = t & 15, row0 = t >> 4;
+    const int trow = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    for (int i = t; i < NPOS * 4; i += 256) *reinterpret_cast<h8*>(strip + i * 16) = zero8();   // incl. the pad columns, for good
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) zero_acc(acc[k]);
+    constexpr int NSV = (ITEMS + 255) / 256;
+    h8 av[4], sv[NSV];
+    auto fetch = [&](long tile) {
+        const long P0 = tile * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long row = P0 + row0 + 16 * i;
+            av[i] = row < M ? ldg8(A + row * 128 + chunk * 8) : zero8();
+        }
+        const int y0 = S >= 8 ? (int)((P0 & (S * S - 1)) >> LG) : 0;      // the tile's first row inside its image
+        const long img0 = P0 - ((long)y0 << LG);                           // first pixel of the (first) image
+#pragma unroll
+        for (int i = 0; i < NSV; ++i) {
+            const int item = t + 256 * i, piece = item & 3, x = (item >> 2) & (S - 1), pr = ((item >> 2) >> LG) % (NR + 2),
+                      j = ((item >> 2) >> LG) / (NR + 2);
+            const int y = y0 - 1 + pr;
+            const long u = img0 + (long)j * S * S + ((long)y << LG) + x;
+            sv[i] = (item < ITEMS && y >= 0 && y < S && u < M) ? ldg8(dY + u * lddy + piece * 8) : zero8();
+        }
+    };
+    if (tile0 < tile1) fetch(tile0);
+    for (long tile = tile0; tile < tile1; ++tile) {
+        lds_barrier();                                              // the previous tile's reads are done
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<h8*>(At + (row0 + 16 * i) * T_RS + chunk * 16) = av[i];
+#pragma unroll
+        for (int i = 0; i < NSV; ++i) {
+            const int item = t + 256 * i, piece = item & 3, x = (item >> 2) & (S - 1), pr = ((item >> 2) >> LG) % (NR + 2),
+                      j = ((item >> 2) >> LG) / (NR + 2);
+            if (item < ITEMS) *reinterpret_cast<h8*>(strip + (j * PIMG + pr * PW + x + 1) * 64 + piece * 16) = sv[i];
+        }
+        lds_barrier();
+        if (tile + 1 < tile1) fetch(tile + 1);                      // in flight while this tile multiplies
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const char* pb = At + (16 * ks + trow) * T_RS + (32 * wave + tcol) * 2;
+            const h8 b = tr8(pb, pb + 4 * T_RS);
+            // padded position of this lane's row pixels (local index i of the tile): image j, local row, column
+            const int ilo = 16 * ks + trow, ihi = ilo + 4;
+            const int plo = (S >= 8 ? 0 : (ilo >> (2 * LG)) * PIMG) + (((ilo >> LG) & (NR - 1)) + 1) * PW + (ilo & (S - 1)) + 1;
+            const int phi = (S >= 8 ? 0 : (ihi >> (2 * LG)) * PIMG) + (((ihi >> LG) & (NR - 1)) + 1) * PW + (ihi & (S - 1)) + 1;
+            const char* lo = strip + plo * 64 + tcol * 2;
+            const char* hi = strip + phi * 64 + tcol * 2;
+            h8 a[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int off = -((tap / 3 - 1) * PW + (tap % 3 - 1)) * 64;              // compile-time: an instruction immediate
+                a[tap] = tr8(lo + off, hi + off);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tap], b, acc[tap], 0, 0, 0);
+        }
+    }
+    float* const out = ws + slab * (9L * 32 * 128);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            out[(tap * 32 + n) * 128 + 32 * wave + (lane & 31)] = acc[tap][r];
+        }
+}
+
 // ------------------------------------------------------------------------------------------------ conv2 data gradient + norm2/relu2 adjoint
 // dB[p][m] = scale2[m] [A[p][m] > 0] sum_{tap, n} dY[p - (dy, dx)][n] W2[n][m][tap]; S0[m] = sum_p d, S1[m] = sum_p d A[p][m]
 // with d the masked gradient.  D = [m][pixel]: wave w owns bottleneck channels 32 w .. 32 w + 31 (its weights, nine taps x two
@@ -839,9 +934,17 @@ GNX_EXPORT int gnx_wgrad3x3_f16(const void* dY16, long lddy, const void* A16, fl
     if (!dY16 || !A16 || !dW || !workspace || !ls || M <= 0 || S <= 0 || lddy < 32 || M % ((long)S * S) != 0) return GNX_ERR_BAD_ARG;
     if (lddy % 8 || !al16b(dY16) || !al16b(A16) || S > 64) return GNX_ERR_UNSUPPORTED;
     const SlabPlan p = plan_slabs(M, 64, 512);
+    const _Float16* dY = reinterpret_cast<const _Float16*>(dY16);
+    const _Float16* A = reinterpret_cast<const _Float16*>(A16);
     const size_t lds = (size_t)64 * T_RS + (size_t)(66 + 2 * S) * 64 + 64;
-    wgrad3x3_f16_kernel<<<(int)p.slabs, 256, lds, stream>>>(reinterpret_cast<const _Float16*>(dY16), lddy,
-                                                           reinterpret_cast<const _Float16*>(A16), workspace, M, S, p.per);
+    switch (M % 64 == 0 ? S : 0) {                                  // power-of-two maps, whole tiles: the padded-image form
+        case 4: wgrad3x3_f16_p2_kernel<4><<<(int)p.slabs, 256, 0, stream>>>(dY, lddy, A, workspace, M, p.per); break;
+        case 8: wgrad3x3_f16_p2_kernel<8><<<(int)p.slabs, 256, 0, stream>>>(dY, lddy, A, workspace, M, p.per); break;
+        case 16: wgrad3x3_f16_p2_kernel<16><<<(int)p.slabs, 256, 0, stream>>>(dY, lddy, A, workspace, M, p.per); break;
+        case 32: wgrad3x3_f16_p2_kernel<32><<<(int)p.slabs, 256, 0, stream>>>(dY, lddy, A, workspace, M, p.per); break;
+        case 64: wgrad3x3_f16_p2_kernel<64><<<(int)p.slabs, 256, 0, stream>>>(dY, lddy, A, workspace, M, p.per); break;
+        default: wgrad3x3_f16_kernel<<<(int)p.slabs, 256, lds, stream>>>(dY, lddy, A, workspace, M, S, p.per);
+    }
     const long n = 9L * 32 * 128;
     reduce_slabs_kernel<<<(int)((n + 15) / 16), 256, 0, stream>>>(workspace, p.slabs, n, dW, ls, accumulate, 1, flag);
     return gnx_launch_status();

@@ -14,6 +14,9 @@ import sys
 
 
 def short(name):
+    m = re.match(r'_ZN12_GLOBAL__N_1\d+([a-z0-9_]+?_kernel)(ILb([01])E)?', name)       # names hipcc's demangler gives up on (_Float16)
+    if m:
+        return m.group(1) + ('<%s>' % ('true' if m.group(3) == '1' else 'false') if m.group(2) else '')
     m = re.search(r'(\w+_kernel)(<[^>]*>)?', name)
     return (m.group(1) + (m.group(2) or '')) if m else name[:60]
 

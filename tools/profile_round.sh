@@ -20,8 +20,24 @@ F="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --mfma f16 --patch
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_h_fetch -o r --output-format csv -- $F > $R/gpurun_out/${tag}_h_fetch.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_h_write -o r --output-format csv -- $F > $R/gpurun_out/${tag}_h_write.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_h_stats -o r --output-format csv -- $F > $R/gpurun_out/${tag}_h_stats.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA -d $R/gpurun_out/${tag}_h_mfma -o r --output-format csv -- $F > $R/gpurun_out/${tag}_h_mfma.log 2>&1 || exit 1
+# config 5 with everything trained on the fp16-MFMA gradient path (round 4)
+G="python3 $R/tools/bench_c5_trained.py --no-fp32 --steps 2 --warmup 1"
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_g_stats -o r --output-format csv -- $G > $R/gpurun_out/${tag}_g_stats.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_g_fetch -o r --output-format csv -- $G > $R/gpurun_out/${tag}_g_fetch.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_g_write -o r --output-format csv -- $G > $R/gpurun_out/${tag}_g_write.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA -d $R/gpurun_out/${tag}_g_mfma -o r --output-format csv -- $G > $R/gpurun_out/${tag}_g_mfma.log 2>&1 || exit 1
 cd $R
+python3 tools/pmc_traffic.py gpurun_out/${tag}_g_fetch gpurun_out/${tag}_g_write > gpurun_out/${tag}_pmc_traffic_c5trained.json
+python3 tools/pmc_mfma_util.py gpurun_out/${tag}_mfma > gpurun_out/${tag}_pmc_mfma_util.json
+python3 tools/pmc_mfma_util.py gpurun_out/${tag}_h_mfma > gpurun_out/${tag}_pmc_mfma_util_f16_256.json
+python3 tools/pmc_mfma_util.py gpurun_out/${tag}_g_mfma > gpurun_out/${tag}_pmc_mfma_util_c5trained.json
 python3 tools/pmc_traffic.py gpurun_out/${tag}_fetch gpurun_out/${tag}_write > gpurun_out/${tag}_pmc_traffic.json
 python3 tools/pmc_traffic.py gpurun_out/${tag}_tf_fetch gpurun_out/${tag}_tf_write > gpurun_out/${tag}_pmc_traffic_trainf.json
 python3 tools/pmc_traffic.py gpurun_out/${tag}_h_fetch gpurun_out/${tag}_h_write > gpurun_out/${tag}_pmc_traffic_f16_256.json
+for pair in stats:bench trainf:bench_trainf h_stats:bench_f16_256 g_stats:bench_c5trained; do
+  find gpurun_out/${tag}_${pair%%:*} -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_${pair##*:}_kernel_stats.csv \;
+done
+# keep the summaries, drop the raw per-dispatch traces (hundreds of MB)
+for d in stats fetch write mfma trainf tf_fetch tf_write h_fetch h_write h_stats h_mfma g_stats g_fetch g_write g_mfma; do rm -rf gpurun_out/${tag}_$d; done
 echo done
