@@ -361,13 +361,22 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_f16_p2_kernel(const _Float16*
 // with d the masked gradient.  D = [m][pixel]: wave w owns bottleneck channels 32 w .. 32 w + 31 (its weights, nine taps x two
 // 16-channel steps, are register fragments), all 128 pixels of the tile; lanes are pixels, so a pixel whose tap leaves the
 // image reads the zero row instead (address select, never a data select).
+// SP > 0: S = SP is a power of two and tiles are whole - the dY rows of a tile are staged as a zero-padded image (as in
+// wgrad3x3_f16_p2_kernel): a lane's nine tap addresses are its pixel's padded position plus nine immediates, no validity test.
+template <int SP>
 __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16* __restrict__ dY, long lddy,
                                                                  const _Float16* __restrict__ W2b,
                                                                  const _Float16* __restrict__ A, _Float16* __restrict__ dB,
                                                                  const float* __restrict__ scale2, float* __restrict__ ws, long M,
-                                                                 int S, long tiles_per_wg) {
+                                                                 int S_rt, long tiles_per_wg) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
-    const int nrows = 130 + 2 * S;
+    const int S = SP > 0 ? SP : S_rt;
+    constexpr int NIMG = SP >= 16 ? 1 : (SP > 0 ? 128 / (SP * SP) : 1);
+    constexpr int NR = SP >= 16 ? 128 / SP : (SP > 0 ? SP : 1);
+    constexpr int PW = SP + 2, PIMG = (NR + 2) * PW, NPOS = NIMG * PIMG;
+    constexpr int LG = SP == 4 ? 2 : SP == 8 ? 3 : SP == 16 ? 4 : SP == 32 ? 5 : 6;
+    constexpr int P_ITEMS = NIMG * (NR + 2) * (SP > 0 ? SP : 1) * 4;
+    const int nrows = SP > 0 ? NPOS : 130 + 2 * S;
     char* const At = dyn;
     char* const strip = dyn + 128 * R_RS;
     char* const zrow = strip + nrows * Y_RS;
@@ -378,6 +387,8 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16*
     const long tile1 = tile0 + tiles_per_wg < ntiles ? tile0 + tiles_per_wg : ntiles;
     const int chunk = t & 15, row0 = t >> 4;
     if (t < 5) *reinterpret_cast<h8*>(zrow + 16 * t) = zero8();
+    if (SP > 0)
+        for (int i = t; i < NPOS * 5; i += 256) *reinterpret_cast<h8*>(strip + i * 16) = zero8();   // incl. the pad columns, for good
     if (t < 128) sc2[t] = scale2[t];
     h8 wf[9][2];
 #pragma unroll
@@ -389,8 +400,9 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16*
     for (int i = 0; i < 16; ++i) S0[i] = S1[i] = 0.f;
     const int S2 = S * S;
     const int lg = (S & (S - 1)) == 0 ? __builtin_ctz(S) : -1;
-    const int strip_items = nrows * 4;                              // <= 1032: five per thread
-    h8 av[8], sv[5];
+    const int strip_items = SP > 0 ? P_ITEMS : nrows * 4;           // <= 1032: five per thread (padded form: four)
+    constexpr int NSV = SP > 0 ? (P_ITEMS + 255) / 256 : 5;
+    h8 av[8], sv[NSV];
     auto fetch = [&](long tile) {
         const long P0 = tile * 128;
 #pragma unroll
@@ -398,11 +410,24 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16*
             const long row = P0 + row0 + 16 * i;
             av[i] = row < M ? ldg8(A + row * 128 + chunk * 8) : zero8();
         }
+        if constexpr (SP > 0) {
+            const int y0 = SP >= 16 ? (int)((P0 & (SP * SP - 1)) >> LG) : 0;
+            const long img0 = P0 - ((long)y0 << LG);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int item = t + 256 * i;
-            const long u = P0 - S - 1 + (item >> 2);
-            sv[i] = (item < strip_items && u >= 0 && u < M) ? ldg8(dY + u * lddy + (item & 3) * 8) : zero8();
+            for (int i = 0; i < NSV; ++i) {
+                const int item = t + 256 * i, piece = item & 3, x = (item >> 2) & (SP - 1), pr = ((item >> 2) >> LG) % (NR + 2),
+                          j = ((item >> 2) >> LG) / (NR + 2);
+                const int y = y0 - 1 + pr;
+                const long u = img0 + (long)j * SP * SP + ((long)y << LG) + x;
+                sv[i] = (item < P_ITEMS && y >= 0 && y < SP && u < M) ? ldg8(dY + u * lddy + piece * 8) : zero8();
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NSV; ++i) {
+                const int item = t + 256 * i;
+                const long u = P0 - S - 1 + (item >> 2);
+                sv[i] = (item < strip_items && u >= 0 && u < M) ? ldg8(dY + u * lddy + (item & 3) * 8) : zero8();
+            }
         }
     };
     if (tile0 < tile1) fetch(tile0);
@@ -413,9 +438,14 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16*
 #pragma unroll
         for (int i = 0; i < 8; ++i) *reinterpret_cast<h8*>(At + (row0 + 16 * i) * R_RS + chunk * 16) = av[i];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < NSV; ++i) {
             const int item = t + 256 * i;
-            if (item < strip_items) *reinterpret_cast<h8*>(strip + (item >> 2) * Y_RS + (item & 3) * 16) = sv[i];
+            if constexpr (SP > 0) {
+                const int piece = item & 3, x = (item >> 2) & (SP - 1), pr = ((item >> 2) >> LG) % (NR + 2), j = ((item >> 2) >> LG) / (NR + 2);
+                if (item < P_ITEMS) *reinterpret_cast<h8*>(strip + (j * PIMG + pr * PW + x + 1) * Y_RS + piece * 16) = sv[i];
+            } else {
+                if (item < strip_items) *reinterpret_cast<h8*>(strip + (item >> 2) * Y_RS + (item & 3) * 16) = sv[i];
+            }
         }
         lds_barrier();
         if (tile + 1 < tile1) fetch(tile + 1);                      // in flight while this tile multiplies
@@ -424,8 +454,11 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16*
             f32x16 acc;
             zero_acc(acc);
             const int px = 32 * c + r;
-            int y, x;
-            if (lg >= 0) {
+            int y = 0, x = 0;
+            const char* centre = strip;
+            if constexpr (SP > 0) {
+                centre = strip + ((SP >= 16 ? 0 : (px >> (2 * LG)) * PIMG) + (((px >> LG) & (NR - 1)) + 1) * PW + (px & (SP - 1)) + 1) * Y_RS;
+            } else if (lg >= 0) {
                 const int rem = (rem0 + px) & (S2 - 1);
                 y = rem >> lg, x = rem & (S - 1);
             } else {
@@ -439,8 +472,13 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16*
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int dy = ky - 1, dx = kx - 1;
-                    const bool ok = y - dy >= 0 && y - dy < S && x - dx >= 0 && x - dx < S;
-                    const char* src = ok ? strip + (px - dy * S - dx + S + 1) * Y_RS : zrow;
+                    const char* src;
+                    if constexpr (SP > 0) {
+                        src = centre - (dy * PW + dx) * Y_RS;       // an immediate
+                    } else {
+                        const bool ok = y - dy >= 0 && y - dy < S && x - dx >= 0 && x - dx < S;
+                        src = ok ? strip + (px - dy * S - dx + S + 1) * Y_RS : zrow;
+                    }
                     b[2 * kx] = *reinterpret_cast<const h8*>(src + (8 * h) * 2);
                     b[2 * kx + 1] = *reinterpret_cast<const h8*>(src + (16 + 8 * h) * 2);
                 }
@@ -962,11 +1000,23 @@ GNX_EXPORT int gnx_conv3x3_dgrad_bnrelu_bwd_f16(const void* dY16, long lddy, con
         return GNX_ERR_BAD_ARG;
     if (lddy % 8 || !al16b(dY16) || !al16b(A16) || !al16b(dB16) || !al16b(W2b16) || S > 64) return GNX_ERR_UNSUPPORTED;
     const SlabPlan p = plan_slabs(M, 128, 512);
-    const size_t lds = (size_t)128 * R_RS + (size_t)(130 + 2 * S) * Y_RS + Y_RS + 512;
-    dgrad3x3_bn_f16_kernel<<<(int)p.slabs, 256, lds, stream>>>(reinterpret_cast<const _Float16*>(dY16), lddy,
-                                                              reinterpret_cast<const _Float16*>(W2b16),
-                                                              reinterpret_cast<const _Float16*>(A16),
-                                                              reinterpret_cast<_Float16*>(dB16), scale2, workspace, M, S, p.per);
+    const _Float16* dY = reinterpret_cast<const _Float16*>(dY16);
+    const _Float16* Wb = reinterpret_cast<const _Float16*>(W2b16);
+    const _Float16* A = reinterpret_cast<const _Float16*>(A16);
+    _Float16* dB = reinterpret_cast<_Float16*>(dB16);
+    const int grid = (int)p.slabs;
+#define GNX_DG3(SS, NPOS)                                                                                                    \
+    dgrad3x3_bn_f16_kernel<SS><<<grid, 256, (size_t)128 * R_RS + (size_t)(NPOS) * Y_RS + Y_RS + 512, stream>>>(dY, lddy, Wb, A, dB, \
+                                                                                                              scale2, workspace, M, S, p.per)
+    switch (M % 128 == 0 ? S : 0) {                                 // power-of-two maps, whole tiles: the padded-image form
+        case 4: GNX_DG3(4, 8 * 36); break;
+        case 8: GNX_DG3(8, 2 * 100); break;
+        case 16: GNX_DG3(16, 10 * 18); break;
+        case 32: GNX_DG3(32, 6 * 34); break;
+        case 64: GNX_DG3(64, 4 * 66); break;
+        default: GNX_DG3(0, 130 + 2 * S);
+    }
+#undef GNX_DG3
     if (dgamma || dbeta)
         bn_reduce_kernel<<<8, 256, 0, stream>>>(workspace, p.slabs, 128, 128, dgamma, dbeta, gamma2, beta2, 1, ls, accumulate, flag);
     return gnx_launch_status();
