@@ -136,6 +136,8 @@ KINDS = {
                          n_l * (_first_map(patch) >> b) ** 2 * 4 * 128 for b, n_l in enumerate(DENSENET121['block_config']))),
     'dgrad1x1_bn1': ('conv1x1_ws_kernel<..., dgrad + norm1/relu1 adjoint>', conv1x1_flops_per_spot,
                      dgrad1x1_bytes_per_spot),
+    'dgrad_wgrad1x1_bn1': ('dgrad_wgrad1x1_f32_kernel (conv1: data gradient + norm1/relu1 adjoint + weight gradient, one pass)',
+                           lambda patch: 2 * conv1x1_flops_per_spot(patch), dgrad1x1_bytes_per_spot),
 }
 
 
@@ -191,6 +193,7 @@ KIND_SOURCES = {
     'conv3x3': ('conv3x3.hip', 'fwd_common.h', 'common.h'),
     'stem': ('stem_pool.hip', 'fwd_common.h', 'common.h'),
     'dgrad1x1_bn1': ('conv1x1.hip', 'fwd_common.h', 'common.h'),
+    'dgrad_wgrad1x1_bn1': ('dgrad_wgrad_f32.hip', 'common.h'),
     'dgrad3x3_bn2': ('conv3x3.hip', 'fwd_common.h', 'common.h'),
     'wgrad1x1': ('densenet_bwd.hip', 'common.h'),
     'wgrad3x3': ('densenet_bwd.hip', 'common.h'),

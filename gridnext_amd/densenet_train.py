@@ -433,15 +433,38 @@ class _DenseNetFn(Function):
                 # conv1
                 w1_call = (lambda layer=layer, tB=tB, s1=s1, cin=cin:
                            wgrad(layer.conv1.weight, L.ptr(tB), mid, L.ptr(buf), c_total, s1, M, mid, cin, s, 1, 0))
-                if side is not None:
-                    deferred.append(w1_call)
-                else:
-                    w1_call()
                 w1t = w1ts[layer.conv1.weight]
+                # Optional (`model.fused_conv1_backward = True`): data gradient + norm1/relu1 adjoint into the block gradient AND
+                # the weight gradient from the same staged tiles, ONE pass over dB, X and G (gnx_conv1x1_dgrad_wgrad_bnrelu_bwd).
+                # Not the default: with both products the fp32 pass is bound by the matrix pipe at ~100 TFLOP/s (93 ms per
+                # 128-px array) - the same time as the two separate passes it replaces (50 + 42 ms); on the
+                # fp16 path, where the matrix work is 16x cheaper, the same fusion is the default (densenet_train_f16)
+                rc = L.ERR_UNSUPPORTED
+                done_w1 = False
+                if not training and side is None and mid == 128 and cin % 32 == 0 and M % 32 == 0 and want(layer.conv1.weight) and \
+                        model.__dict__.get('fused_conv1_backward', False):
+                    bn1 = layer.norm1
+                    dg = new_like(bn1.weight) if want(bn1.weight) else None
+                    db = new_like(bn1.bias) if want(bn1.bias) else None
+                    ws = torch.empty(L.query('gnx_conv1x1_dgrad_wgrad_workspace', M, cin), device=dev, dtype=F32)
+                    dw1 = new_like(layer.conv1.weight)
+                    t0 = model._probe_begin()
+                    rc = L.query('gnx_conv1x1_dgrad_wgrad_bnrelu_bwd', L.ptr(tB), mid, L.ptr(w1t), L.ptr(buf), c_total, L.ptr(dbuf),
+                                 c_total, M, cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s1[2]), L.ptr(s1[3]), L.ptr(dg), L.ptr(db),
+                                 L.ptr(dw1), L.ptr(ws), 0, st)
+                    if rc not in (0, L.ERR_UNSUPPORTED):
+                        raise RuntimeError("gnx_conv1x1_dgrad_wgrad_bnrelu_bwd failed (%d)" % rc)
+                    if rc == 0:
+                        done_w1 = True
+                        model._probe_mark('dgrad_wgrad1x1_bn1', t0, 4 * M * cin * mid, 4 * M * (mid + 3 * cin))
+                if not done_w1:
+                    if side is not None:
+                        deferred.append(w1_call)
+                    else:
+                        w1_call()
                 # conv1's data gradient + norm1/relu1 backward, accumulated into the block-buffer gradient: one kernel where
                 # the statistics are the running ones and the tiles are whole (3 passes over [M][cin] instead of 5)
-                rc = L.ERR_UNSUPPORTED
-                if not training:
+                if not done_w1 and not training:
                     bn1 = layer.norm1
                     dg = new_like(bn1.weight) if want(bn1.weight) else None
                     db = new_like(bn1.bias) if want(bn1.bias) else None

@@ -135,6 +135,15 @@ int gnx_conv1x1_dgrad_bnrelu_bwd(const float* dY, long lddy, const float* Wt, co
                                  long M, int N, int K, const float* scale, const float* shift, const float* mean,
                                  const float* invstd, float* dgamma, float* dbeta, int accumulate, float* workspace,
                                  gnx_stream_t stream);
+/* The same pass ALSO producing conv1's weight gradient dW[K][N] (= gnx_wgrad_bnrelu(taps = 1) with the forward's BN + ReLU
+ * prologue) from the tiles it stages: one pass over dY, X and dX instead of two (round 4).  Argument names as above, but with
+ * N = 128 bottleneck channels fixed: dB [M][128] (lddb), W1t = conv1.weight transposed [K][128], G = the block gradient
+ * (+= in columns [0, K)), 32 | K.  workspace: gnx_conv1x1_dgrad_wgrad_workspace(M, K) floats. */
+long gnx_conv1x1_dgrad_wgrad_workspace(long M, int K);
+int gnx_conv1x1_dgrad_wgrad_bnrelu_bwd(const float* dB, long lddb, const float* W1t, const float* X, long ldx, float* G, long ldg,
+                                       long M, int K, const float* scale, const float* shift, const float* mean,
+                                       const float* invstd, float* dgamma, float* dbeta, float* dW, float* workspace,
+                                       int accumulate, gnx_stream_t stream);
 /* conv2's data gradient fused with norm2 -> relu2's adjoint (eval statistics; A_act = the ACTIVATED bottleneck the training
  * forward stored): dX = scale * g * [A_act > 0] with g = conv3x3(dY, Wb), dbeta / dgamma from the same pass.  Replaces
  * gnx_conv3x3_bnrelu(dY, Wb) + gnx_bn_relu_bwd(relu = 2) (torch.autograd through densenet.py:41).  N == 128, K == 32. */

@@ -332,6 +332,59 @@ def test_conv1x1_bnrelu_act(L, M, K, N):
                                           None, None, L.stream()) != 0       # both output vectors are required
 
 
+@pytest.mark.parametrize("M,N,ld", [(128, 64, 64), (992, 96, 256), (128 * 600, 224, 256), (2048, 992, 1024), (40000, 160, 160)])
+def test_conv1x1_dgrad_and_wgrad_in_one_pass(L, M, N, ld):
+    """gnx_conv1x1_dgrad_wgrad_bnrelu_bwd (round 4): conv1's data gradient + norm1/relu1 adjoint + BatchNorm sums + conv1's
+    WEIGHT gradient from one pass over dB, X and G == gnx_conv1x1_bnrelu + gnx_bn_relu_bwd (data side) and
+    gnx_wgrad_bnrelu(taps = 1) (weight side) on the same inputs, and fp64 torch arithmetic; whole 32-row tiles (others:
+    UNSUPPORTED), several tiles per workgroup, partial channel blocks."""
+    K = 128
+    g = torch.Generator().manual_seed(M + N)
+    dY = torch.randn(M, K, generator=g).to(DEV)
+    W1 = (torch.randn(K, N, generator=g) * 0.1).to(DEV)                  # conv1.weight [mid][cin]
+    Wt = W1.t().contiguous()
+    X = torch.randn(M, ld, generator=g).to(DEV)
+    dX0 = torch.randn(M, ld, generator=g).to(DEV)
+    gamma, beta = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.3
+    gamma[1::6] *= -1.0
+    mean, var = torch.randn(N, generator=g) * 0.2, torch.rand(N, generator=g) + 0.5
+    inv = 1.0 / torch.sqrt(var + 1e-5)
+    sc, sh = (gamma * inv).to(DEV), (beta - mean * gamma * inv).to(DEV)
+    meand, invd = mean.to(DEV), inv.to(DEV)
+    # the separate kernels
+    tC = torch.empty(M, ld, device=DEV)
+    L.call('gnx_conv1x1_bnrelu', L.ptr(dY), K, L.ptr(Wt), L.ptr(tC), ld, M, N, K, None, None, 0, 0, L.stream())
+    dX_ref = dX0.clone()
+    dg_ref, db_ref = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    ws = torch.empty(L.query('gnx_bn_workspace', M, N), device=DEV)
+    L.call('gnx_bn_relu_bwd', L.ptr(tC), ld, L.ptr(X), ld, L.ptr(dX_ref), ld, M, N, L.ptr(sc), L.ptr(sh), L.ptr(meand),
+           L.ptr(invd), L.ptr(dg_ref), L.ptr(db_ref), 1, 0, 0, 1, L.ptr(ws), L.stream())
+    dW_ref = torch.empty(K, N, device=DEV)
+    wsw = torch.empty(L.query('gnx_wgrad_workspace', M, K, N, 1), device=DEV)
+    L.call('gnx_wgrad_bnrelu', L.ptr(dY), K, L.ptr(X), ld, L.ptr(sc), L.ptr(sh), L.ptr(dW_ref), L.ptr(wsw), M, K, N, 0, 1, 0, 0,
+           L.stream())
+    # one pass
+    dX = dX0.clone()
+    dg, db, dW = torch.empty(N, device=DEV), torch.empty(N, device=DEV), torch.full((K, N), 5.0, device=DEV)
+    ws2 = torch.empty(L.query('gnx_conv1x1_dgrad_wgrad_workspace', M, N), device=DEV)
+    assert L.query('gnx_conv1x1_dgrad_wgrad_bnrelu_bwd', L.ptr(dY), K, L.ptr(Wt), L.ptr(X), ld, L.ptr(dX), ld, M - 8, N, L.ptr(sc),
+                   L.ptr(sh), L.ptr(meand), L.ptr(invd), L.ptr(dg), L.ptr(db), L.ptr(dW), L.ptr(ws2), 0, L.stream()) == L.ERR_UNSUPPORTED
+    L.call('gnx_conv1x1_dgrad_wgrad_bnrelu_bwd', L.ptr(dY), K, L.ptr(Wt), L.ptr(X), ld, L.ptr(dX), ld, M, N, L.ptr(sc), L.ptr(sh),
+           L.ptr(meand), L.ptr(invd), L.ptr(dg), L.ptr(db), L.ptr(dW), L.ptr(ws2), 0, L.stream())
+    close(dX[:, :N], dX_ref[:, :N], rtol=1e-5)
+    assert torch.equal(dX[:, N:], dX0[:, N:])                           # columns past cin untouched
+    close(dg, dg_ref, rtol=2e-5, atol=1e-3)
+    close(db, db_ref, rtol=2e-5, atol=1e-3)
+    close(dW, dW_ref, rtol=2e-5, atol=1e-4)
+    act = torch.relu(X[:, :N].double() * sc.double() + sh.double())
+    close(dW, dY.double().t() @ act, rtol=1e-5, atol=1e-4, what='dW vs fp64')
+    # accumulate
+    L.call('gnx_conv1x1_dgrad_wgrad_bnrelu_bwd', L.ptr(dY), K, L.ptr(Wt), L.ptr(X), ld, L.ptr(dX0.clone()), ld, M, N, L.ptr(sc),
+           L.ptr(sh), L.ptr(meand), L.ptr(invd), L.ptr(dg), L.ptr(db), L.ptr(dW), L.ptr(ws2), 1, L.stream())
+    close(dW, 2 * dW_ref, rtol=2e-5, atol=2e-4)
+    close(db, 2 * db_ref, rtol=2e-5, atol=2e-3)
+
+
 @pytest.mark.parametrize("M,N,ld", [(128, 64, 64), (1024, 96, 256), (128 * 600, 224, 256), (2048, 992, 1024)])
 def test_conv1x1_dgrad_fused_with_bn_relu_backward(L, M, N, ld):
     """conv1's data gradient with norm1 -> relu1's backward in its store == the two separate kernels (dX accumulated into the
