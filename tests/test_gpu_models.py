@@ -487,6 +487,33 @@ def test_winograd_training_forward_gradients():
     assert cos > 0.999 and np.median(errs) < 3e-2 and errs.max() < 0.5, (cos, np.median(errs), errs.max())
 
 
+def test_conv1_backward_in_one_pass_gives_the_two_pass_gradients():
+    """`model.fused_conv1_backward = True` (opt-in, fp32): conv1's data gradient, norm1 adjoint and WEIGHT gradient from one pass
+    (gnx_conv1x1_dgrad_wgrad_bnrelu_bwd) - all 364 gradients of DenseNet-121 equal the default two-pass path's to fp32
+    round-off (other summation order over pixels)."""
+    import gridnext_amd as ga
+    from oracle import densenet as odn
+    torch.manual_seed(12)
+    m = ga.DenseNet(num_classes=8, **odn.DENSENET121).to(DEV)
+    x = torch.rand(8, 3, 64, 64, device=DEV)
+    bns = [b for b in m.modules() if isinstance(b, nn.BatchNorm2d)]
+    for b in bns:
+        b.momentum = 1.0
+    m.train()
+    with torch.no_grad():
+        m(x)
+    m.eval()
+    labels = torch.arange(8, device=DEV) % 8
+    res = {}
+    for fused in (False, True):
+        m.fused_conv1_backward = fused
+        m.zero_grad()
+        nn.functional.cross_entropy(m(x), labels).backward()
+        res[fused] = {k: p.grad.clone() for k, p in m.named_parameters()}
+    worst = max(((res[True][k] - g).abs().max() / (g.abs().max() + 1e-30)).item() for k, g in res[False].items())
+    assert worst < 2e-4, worst
+
+
 def test_all_fgd_predictions_including_multimodal_lists():
     """utils.all_fgd_predictions (reference utils.py:20-57) on the HIP path vs the oracle's masked softmax/argmax;
     list inputs work here (the reference helper cannot take them)."""
