@@ -332,6 +332,46 @@ def test_conv1x1_bnrelu_act(L, M, K, N):
                                           None, None, L.stream()) != 0       # both output vectors are required
 
 
+def test_frozen_count_mlp_composed_into_affine_stages(GF):
+    """A frozen count MLP in eval mode (train_gridwise's tutorial recipe, training.py:126) evaluates as three affine stages -
+    Linear -> Linear -> BatchNorm1d composed into one map each (there is no activation between the paired Linears,
+    Tutorial_visium_count.ipynb cell 12): equal to the layer-by-layer evaluation and to fp64 torch to fp32 round-off, on rows and
+    on a K-major count grid; not used once a parameter trains, in train mode, or with `fold_frozen = False`; recomposed when a
+    parameter changes."""
+    from gridnext_amd.synthetic import count_mlp
+    torch.manual_seed(3)
+    G, C = 2000, 8
+    f = count_mlp(G, C).to(DEV)
+    for bn in (m for m in f if isinstance(m, nn.BatchNorm1d)):
+        bn.running_mean.normal_(0, 0.5)
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.normal_(0, 0.3)
+    f.eval()
+    for p in f.parameters():
+        p.requires_grad = False
+    x = torch.randint(0, 10, (4992, G), device=DEV).float()
+    ref = f.double()(x.double()).float()
+    f.float()
+    y = GF.sequential_forward(f, x)
+    assert len(f.__dict__['_gnx_affine_plan'][1]) == 3
+    close(y, ref, rtol=2e-5, what='composed vs fp64')
+    f.fold_frozen = False
+    y_layers = GF.sequential_forward(f, x)
+    f.fold_frozen = True
+    close(y, y_layers, rtol=2e-5, what='composed vs layer by layer')
+    grid = x.t().reshape(1, G, 78, 64).contiguous()                     # K-major count grid, read in place
+    close(GF.sequential_forward(f, grid.reshape(1, G, -1), kmajor=True), y, rtol=1e-6, what='K-major')
+    with torch.no_grad():
+        f[0].weight.mul_(1.5)                                           # a changed parameter: recomposed
+    close(GF.sequential_forward(f, x), f.double()(x.double()).float(), rtol=2e-5, what='after a change')
+    f.float()
+    for p in f.parameters():
+        p.requires_grad = True
+    out = GF.sequential_forward(f, x[:256])                             # trainable: the layer-by-layer path with a tape
+    assert out.requires_grad
+
+
 @pytest.mark.parametrize("M,N,ld", [(128, 64, 64), (992, 96, 256), (128 * 600, 224, 256), (2048, 992, 1024), (40000, 160, 160)])
 def test_conv1x1_dgrad_and_wgrad_in_one_pass(L, M, N, ld):
     """gnx_conv1x1_dgrad_wgrad_bnrelu_bwd (round 4): conv1's data gradient + norm1/relu1 adjoint + BatchNorm sums + conv1's
