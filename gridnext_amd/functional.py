@@ -63,6 +63,23 @@ def hexconv(x_nhwc, kernel0, kernel1, bias, oddr):
 
 
 # ----------------------------------------------------------------------------- batch norm (+ReLU)
+def bump_versions(*tensors):
+    """Tell torch that tensors written through raw pointers changed (host-side only, no launch): whatever is cached on their
+    `_version` - the composed affine stages of a frozen MLP below - is then rebuilt."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+
+
+def bump_batchnorm_versions(modules):
+    """The same for every BatchNorm buffer under `modules`: called by the hipGraph steppers after replaying a TRAIN step, whose
+    BatchNorm kernels updated running statistics without any Python running."""
+    for mod in modules:
+        for m in mod.modules():
+            if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.running_mean is not None and m.training:
+                bump_versions(m.running_mean, m.running_var, m.num_batches_tracked)
+
+
 class _BNReLU(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps,
@@ -81,6 +98,7 @@ class _BNReLU(Function):
                    L.ptr(running_var), L.ptr(num_batches_tracked, torch.int64), float(momentum), float(eps),
                    L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(y), C, 1 if relu else 0,
                    L.ptr(ws), L.stream())
+            bump_versions(running_mean, running_var, num_batches_tracked)   # (the kernel wrote them through raw pointers)
         else:
             L.call('gnx_bn_fold_eval', C, L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var),
                    float(eps), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.stream())
@@ -245,7 +263,7 @@ def is_hip_sequential(module):
 
 def _frozen_affine_plan(seq):
     """[(W, b, relu)] - the network as it EVALUATES when nothing in it trains and its BatchNorms run on running statistics
-    (the count f of `train_gridwise`'s tutorial recipe: frozen, `patch_classifier.eval()`, training.py:126): the tutorial MLP
+    (the count f of `train_gridwise`'s tutorial recipe: every parameter frozen, `patch_classifier.eval()`, training.py:126): the tutorial MLP
     has no activation between its paired Linears (Tutorial_visium_count.ipynb cell 12), so Linear -> Linear -> BatchNorm1d is
     ONE affine map, W = diag(s) W2 W1, b = s (W2 b1 + b2) + t - 2000 -> 100 instead of 2000 -> 500 -> 100: a fifth of the
     multiply-adds of the layer that is 93 % of f, and three launches instead of nine.  Composed in fp64, rounded once; the
@@ -297,19 +315,23 @@ def _frozen_affine_plan(seq):
 def sequential_forward(seq, x, kmajor=False):
     """Run the user's own nn.Sequential (its parameters, its BN buffers) through the HIP kernels.
     x: [M, K] rows, or with kmajor a [B, K, S] count grid (see _Linear)."""
-    frozen = not seq.training and not x.requires_grad and \
-        not (torch.is_grad_enabled() and any(p.requires_grad for p in seq.parameters()))
+    # (a network with a trainable parameter is never composed, also not in its no-grad validation passes: the eager and the
+    #  graph-replayed loops must evaluate it the same way, bit for bit)
+    frozen = not seq.training and not x.requires_grad and not any(p.requires_grad for p in seq.parameters())
     if frozen and getattr(seq, 'fold_frozen', True) and x.is_cuda:
         capturing = torch.cuda.is_current_stream_capturing()
         # Under hipGraph capture the composed weights become constants of the graph: only a network that CANNOT change between
         # replays (no parameter takes gradients) may use them, and only a plan that already exists (made by the eager warm-up
         # batches: nothing composed inside a capture may end up in the cache)
-        if capturing and (any(p.requires_grad for p in seq.parameters()) or
+        if capturing and (any(p.requires_grad for p in seq.parameters()) or any(m.training for m in seq.modules()) or
                           seq.__dict__.get('_gnx_affine_plan', (None,))[0] !=
                           tuple((t._version, t.data_ptr()) for t in list(seq.parameters()) + list(seq.buffers()))):
             plan = None
         else:
             plan = _frozen_affine_plan(seq)
+        if plan is not None and capturing:
+            # the graph keeps raw pointers to these tensors: they must outlive the cache entry they came from
+            seq.__dict__.setdefault('_gnx_pinned_plans', []).append(plan)
         if plan is not None:
             first = True
             for W, b, relu in plan:

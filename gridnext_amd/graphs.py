@@ -93,8 +93,9 @@ class GridStepGraph:
     """One captured step for one (phase, shapes).  `step_fn(inputs, labels) -> (loss, correct, n_fg)` is the eager step
     WITHOUT the backward; `train` adds `loss.backward()` to the capture."""
 
-    def __init__(self, step_fn, params, train):
+    def __init__(self, step_fn, params, train, models=()):
         self.step_fn, self.train = step_fn, train
+        self.models = tuple(models)
         self.params = [p for p in params if p.requires_grad] if train else []
         self.graph = None
         self.out_grads = None
@@ -137,6 +138,9 @@ class GridStepGraph:
         self.graph.replay()
         if self.train:
             self._deliver_gradients()
+            if self.models:
+                from .functional import bump_batchnorm_versions
+                bump_batchnorm_versions(self.models)             # (train-mode BatchNorm kernels ran inside the graph)
         return self.outs
 
     def _deliver_gradients(self):
@@ -192,7 +196,7 @@ class GridStepGraphs:
         if st is None:
             if len(self.table) >= MAX_GRAPHS:
                 return None
-            st = self.table[key] = GridStepGraph(self.step_fn, self.params, train)
+            st = self.table[key] = GridStepGraph(self.step_fn, self.params, train, self.models)
         if st.failed:
             return None
         if not st.ready():

@@ -124,7 +124,7 @@ def train_spotwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
             loss, stats, _ = GF.masked_cross_entropy(outputs, labels, 1, label_base=0)
             return loss, stats[1], None
         stepper = graphs.GridStepGraphs(_spot_step, model.parameters(),
-                                        drop_derived=getattr(model, 'invalidate_cache', None))
+                                        drop_derived=getattr(model, 'invalidate_cache', None), models=(model,))
 
     for epoch in range(num_epochs):
         _banner(epoch, num_epochs)

@@ -370,6 +370,8 @@ def test_frozen_count_mlp_composed_into_affine_stages(GF):
         p.requires_grad = True
     out = GF.sequential_forward(f, x[:256])                             # trainable: the layer-by-layer path with a tape
     assert out.requires_grad
+    with torch.no_grad():                                               # ... also in its no-grad (validation) passes
+        assert torch.equal(GF.sequential_forward(f, x[:256]), out.detach())
 
 
 @pytest.mark.parametrize("M,N,ld", [(128, 64, 64), (992, 96, 256), (128 * 600, 224, 256), (2048, 992, 1024), (40000, 160, 160)])
