@@ -140,13 +140,27 @@ def batch_norm_relu(x2d, bn, relu):
                          training, bn.momentum, bn.eps, relu)
 
 
+_UNIT = {}
+
+
+def _unit_vectors(C, device):
+    """(ones[C], zeros[C]) on `device`, made once (constants: nothing writes them)."""
+    key = (C, str(device))
+    hit = _UNIT.get(key)
+    if hit is None:
+        with torch.no_grad():
+            hit = (torch.ones(C, device=device, dtype=F32), torch.zeros(C, device=device, dtype=F32))
+        if not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            _UNIT[key] = hit                                        # (never cache what a graph capture allocated)
+    return hit
+
+
 class _ReLURows(Function):
     @staticmethod
     def forward(ctx, x):
         x, ld = _rows(x)
         M, C = x.shape
-        one = torch.ones(C, device=x.device, dtype=F32)
-        zero = torch.zeros(C, device=x.device, dtype=F32)
+        one, zero = _unit_vectors(C, x.device)                          # (cached: two fill launches per call otherwise)
         y = torch.empty((M, C), device=x.device, dtype=F32)
         L.call('gnx_scale_shift_relu', L.ptr(x), ld, L.ptr(y), C, M, C, L.ptr(one), L.ptr(zero), 1, L.stream())
         ctx.save_for_backward(x, one, zero)
