@@ -72,6 +72,8 @@ SIGNATURES = {
     'gnx_trans_bwd_f16_workspace': (_L, [_L, _I, _I]),
     'gnx_trans_bwd_f16': (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'gnx_h16_cols_to_f32': (_I, [_P, _L, _P, _L, _L, _I, _P, _P, _P]),
+    'gnx_stem_bwd_f16_workspace': (_L, [_L, _I]),
+    'gnx_stem_bwd_f16': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P, _P]),
     'gnx_dense_layer_f16_pack': (_I, [_P, _P, _P, _P, _I, _P]),
     'gnx_dense_layer_f16': (_I, [_P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     'gnx_conv_stem_bnrelu_maxpool_f16mul_cb': (_I, [_P, _I, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),

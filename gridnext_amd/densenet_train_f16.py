@@ -13,9 +13,12 @@ binades down to the smallest normal.  Every fp16 gradient tensor holds s x the t
 by 1/s (exact) where its partial sums are reduced.  `model.f16_grad_overflow` (device int32) is OR-ed with 1 by any kernel
 that reduces a non-finite value; `model.f16_grad_scale` holds {s, 1/s} of the last backward.
 
-The stem (conv0 .. pool0) and the classifier keep their fp32 kernels (4 % of the step): the pooled stem map is computed in
-fp32 with its window indices (densenet_train's running-statistics stem), copied into block 1's first columns as fp16, and
-the gradient of those columns is converted back (gnx_h16_cols_to_f32) for the fp32 stem adjoints.
+The stem (conv0 .. pool0, 64 channels) runs on fp16 matrix operands too: the forward is the inference kernel
+(gnx_conv_stem_bnrelu_maxpool_f16mul) writing block 1's first columns, the backward (gnx_stem_bwd_f16) one pass over the
+patches that recomputes the conv0 rows it needs, finds pool0's winners and contracts the routed gradient with the im2col of
+the staged rows - no window indices, no fp32 conv0-map gradient in HBM.  Other stem widths (and `model.f16_stem = False`) keep
+the fp32 stem with recorded window indices and its fp32 adjoints (gnx_h16_cols_to_f32 hands them the gradient).  The
+classifier is fp32.
 """
 import torch
 from torch.autograd import Function
@@ -84,16 +87,24 @@ class _DenseNetF16Fn(Function):
         tape.x, tape.N, tape.P, tape.hs, tape.sizes = x, N, P, hs, sizes
         bufs = [torch.empty((N * s * s, c_total), device=dev, dtype=H16) for (_, _, _, c_total), s in zip(model._blocks, sizes)]
         tape.bufs = bufs
-        # ---- stem in fp32 with window indices (running statistics), then into block 1's first columns as fp16
         w0 = conv0.weight.detach().contiguous()
         hp = (hs + 2 - 3) // 2 + 1
         s0 = _bn(model.features.norm0, None, c0, N * hs * hs, False, dev, st)
-        stem32 = torch.empty((N * hp * hp, c0), device=dev, dtype=F32)
-        tape.pool_idx = torch.empty((N * hp * hp, c0), device=dev, dtype=torch.uint8)
-        L.call('gnx_conv_stem_bnrelu_maxpool_argmax', L.ptr(x), L.ptr(w0), L.ptr(stem32), c0, tape.pool_idx.data_ptr(), N, 3, P, P,
-               c0, 7, 7, 2, 3, L.ptr(s0[0]), L.ptr(s0[1]), st)
-        bufs[0][:, :c0].copy_(stem32)
-        tape.stem32, tape.stats0 = stem32, s0
+        tape.stats0 = s0
+        tape.stem32 = tape.pool_idx = None
+        if c0 == 64 and model.f16_stem:
+            # ---- stem on fp16 matrix operands, straight into block 1's first columns; its backward (gnx_stem_bwd_f16)
+            #      recomputes the conv0 rows it needs from the patches - no window indices, no fp32 pooled map
+            L.call('gnx_conv_stem_bnrelu_maxpool_f16mul', L.ptr(x), 0, L.ptr(w0), bufs[0].data_ptr(), bufs[0].shape[1], N, 3, P, P,
+                   c0, 7, 7, 2, 3, L.ptr(s0[0]), L.ptr(s0[1]), None, st)
+        else:
+            # ---- stem in fp32 with window indices (running statistics), then into block 1's first columns as fp16
+            stem32 = torch.empty((N * hp * hp, c0), device=dev, dtype=F32)
+            tape.pool_idx = torch.empty((N * hp * hp, c0), device=dev, dtype=torch.uint8)
+            L.call('gnx_conv_stem_bnrelu_maxpool_argmax', L.ptr(x), L.ptr(w0), L.ptr(stem32), c0, tape.pool_idx.data_ptr(), N, 3, P,
+                   P, c0, 7, 7, 2, 3, L.ptr(s0[0]), L.ptr(s0[1]), st)
+            bufs[0][:, :c0].copy_(stem32)
+            tape.stem32 = stem32
         w1h = model._conv1_f16()                 # {layer: conv1.weight [128][cin] halves}
         w2h = model._repacked_conv2_f16()        # {layer: conv2.weight tap-major [9][32][128] halves}
         wth = model._trans_f16()                 # {transition: conv.weight [c_out][c_total] halves}
@@ -310,7 +321,19 @@ class _DenseNetF16Fn(Function):
         conv0 = model.features.conv0
         norm0 = model.features.norm0
         c0 = conv0.out_channels
-        if want(conv0.weight) or want(norm0.weight) or want(norm0.bias):
+        if tape.pool_idx is None and (want(conv0.weight) or want(norm0.weight) or want(norm0.bias)):
+            # one pass over the patches: conv0 rows recomputed, pool0's winners found, gradient routed and contracted
+            t0 = model._probe_begin()
+            ws = _f32(L.query('gnx_stem_bwd_f16_workspace', N, P), dev)
+            s0 = tape.stats0
+            dg0, db0 = bn_out(norm0)
+            L.call('gnx_stem_bwd_f16', L.ptr(tape.x), L.ptr(conv0.weight.detach().contiguous()), L.ptr(s0[0]), L.ptr(s0[1]), L.ptr(norm0.weight),
+                   L.ptr(norm0.bias), dbufs[0].data_ptr(), bufs[0].shape[1],
+                   L.ptr(new_like(conv0.weight)) if want(conv0.weight) else None, L.ptr(dg0), L.ptr(db0), L.ptr(ws), N, P, c0, lp, 0,
+                   fp, st)
+            model._probe_mark('stem_bwd_f16', t0, 6 * N * hs * hs * c0 * 147, 4 * N * 3 * P * P + 2 * N * (hs // 2) ** 2 * c0)
+            dbufs[0] = None
+        elif want(conv0.weight) or want(norm0.weight) or want(norm0.bias):
             hp = (hs + 2 - 3) // 2 + 1
             M1, M0 = N * hp * hp, N * hs * hs
             c_total1 = bufs[0].shape[1]

@@ -336,7 +336,11 @@ int gnx_conv0_wgrad(const float* x, const float* dS, long ldd, float* dW, float*
  *                     conv1.weight transposed to [K][128] halves; 32 | K
  *   gnx_tail_bwd_f16: norm_final -> relu -> adaptive_avg_pool (:153-156): G16 [imgs S2][C] = s * scale [bn(X16) > 0] dfeats / S2
  *   gnx_trans_bwd_f16: transition norm -> relu -> avgpool 2x2 (:48-53, pool-first) from the pooled gradient dP16: writes G16
- *   gnx_h16_cols_to_f32: out[M][C] = G16[:, :C] / s (the gradient of the pooled stem map, handed to the fp32 stem adjoints) */
+ *   gnx_h16_cols_to_f32: out[M][C] = G16[:, :C] / s (the gradient of the pooled stem map, handed to the fp32 stem adjoints)
+ *   gnx_stem_bwd_f16: conv0 -> norm0 -> relu0 -> pool0 (:105-110) differentiated in one pass over the PATCHES (P = 128 / 256,
+ *                     64 channels): the conv0 rows are recomputed exactly as gnx_conv_stem_bnrelu_maxpool_f16mul computes them,
+ *                     pool0's winners found by torch's first-maximum rule, G16[:, :64] (s x the pooled map's gradient) routed to
+ *                     them and contracted with the im2col of the staged rows: dW [64][3][7][7], dgamma / dbeta [64] (gamma != 0) */
 long gnx_wgrad1x1_f16_workspace(long M, int N, int K);
 int gnx_wgrad1x1_f16(const void* dY16, long lddy, const void* X16, long ldx, const float* scale, const float* shift, float* dW,
                      float* workspace, long M, int N, int K, const float* ls, int accumulate, int* flag, gnx_stream_t stream);
@@ -369,6 +373,10 @@ int gnx_trans_bwd_f16(const void* dP16, long ldp, const void* X16, long ldx, voi
                       float* workspace, const float* ls, int accumulate, int* flag, gnx_stream_t stream);
 int gnx_h16_cols_to_f32(const void* G16, long ldg, float* out, long ldo, long M, int C, const float* ls, int* flag,
                         gnx_stream_t stream);
+long gnx_stem_bwd_f16_workspace(long imgs, int P);
+int gnx_stem_bwd_f16(const float* x, const float* w, const float* scale, const float* shift, const float* gamma, const float* beta,
+                     const void* G16, long ldg, float* dW, float* dgamma, float* dbeta, float* workspace, long imgs, int P, int O,
+                     const float* ls, int accumulate, int* flag, gnx_stream_t stream);
 
 #ifdef __cplusplus
 }
