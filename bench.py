@@ -46,6 +46,7 @@ DENSENET121 = dict(growth_rate=32, block_config=(6, 12, 24, 16), num_init_featur
                    small_inputs=False)
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E
+PEAK_F16_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
 SUB_H, SUB_W = 26, 16               # the sub-grid of the CPU leg (416 spots)
 
 
@@ -202,6 +203,7 @@ KIND_SOURCES = {
     'dgrad3x3_bn2_f16': ('dense_bwd_f16.hip', 'common.h'),
     'wgrad3x3_f16': ('dense_bwd_f16.hip', 'common.h'),
     'wgrad1x1_f16': ('dense_bwd_f16.hip', 'common.h'),
+    'stem_bwd_f16': ('stem_bwd_f16.hip', 'common.h'),
 }
 
 
@@ -806,7 +808,10 @@ def config5_trained_series(args, device, rank, world, steps=3, warmup=1, P=256):
                'conv3x3': 'conv3x3_dma_kernel<H16, O16> (taped forward)',
                'wgrad3x3_f16': 'wgrad3x3_f16_kernel', 'dgrad3x3_bn2_f16': 'dgrad3x3_bn_f16_kernel',
                'wgrad1x1_f16': 'wgrad1x1_f16_kernel', 'dgrad1x1_bn1_f16': 'dgrad1x1_bn_f16_kernel<false>',
-               'dgrad_wgrad1x1_bn1_f16': 'dgrad1x1_bn_f16_kernel<true> (conv1 data gradient + norm1 adjoint + conv1 weight gradient)'}
+               'dgrad_wgrad1x1_bn1_f16': 'dgrad1x1_bn_f16_kernel<true> (conv1 data gradient + norm1 adjoint + conv1 weight gradient)',
+               'stem_bwd_f16': 'stem_bwd_f16_kernel (conv0 rows recomputed + pool0 / norm0 adjoint + conv0 weight gradient, + its '
+                               'two slab reductions)'}
+    MFMA_BOUND = ('stem_bwd_f16',)        # 3 kB of patch per spot-row against 2 x 1.5 x 64 x 147 x 2 flops per conv0 position
     kt = {}
     for kind, name in KINDS16.items():
         recs = [r for r in (probe or []) if r[0] == kind]
@@ -815,10 +820,13 @@ def config5_trained_series(args, device, rank, world, steps=3, warmup=1, P=256):
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         flops, nbytes = sum(r[3] for r in recs), sum(r[4] for r in recs)
         gbs = nbytes / (ms * 1e-3) / 1e9
+        tfl = flops / (ms * 1e-3) / 1e12
         kt[kind] = {"bound": "hbm", "kernel": name, "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                     "traffic": None, "launches": len(recs), "avg_launch_ms": ms / len(recs),
-                    "algorithmic_bytes_per_launch_avg": nbytes / len(recs), "matrix_tflops": flops / (ms * 1e-3) / 1e12,
-                    "ms_per_step": ms / steps}
+                    "algorithmic_bytes_per_launch_avg": nbytes / len(recs), "matrix_tflops": tfl, "ms_per_step": ms / steps}
+        if kind in MFMA_BOUND:
+            kt[kind].update({"bound": "mfma", "achieved": tfl, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tfl / PEAK_F16_TFLOPS})
     if P == 256:
         attach_traffic(kt, '_c5trained')
     if kt:

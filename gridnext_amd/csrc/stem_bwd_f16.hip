@@ -43,9 +43,12 @@ __device__ __forceinline__ h8 tr8(const char* lo, const char* hi) {
     return __builtin_bit_cast(h8, v);
 }
 
-// WO = width of the conv0 map: 64 (128-px patches) or 128 (256-px patches); 64 output channels.
-template <int WO>
-__global__ __launch_bounds__(256, WO == 64 ? 2 : 1) void stem_bwd_f16_kernel(
+// WO = width of the conv0 map: 64 (128-px patches) or 128 (256-px patches); 64 output channels.  NTHR threads: 256 (two
+// workgroups per CU at WO = 64) or 512 (WO = 128, whose 94 KB of LDS allow one workgroup per CU: eight waves, two per SIMD, so
+// that one's LDS round trips hide behind the other's matrix / vector work; the two wave quartets split the positions of the
+// weight-gradient contraction and write a slab each).
+template <int WO, int NTHR>
+__global__ __launch_bounds__(NTHR, WO == 64 ? 2 : 1) void stem_bwd_f16_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ scale, const float* __restrict__ shift,
     const _Float16* __restrict__ G, long ldg, float* __restrict__ ws_bn, float* __restrict__ ws_dw, long imgs) {
     constexpr int CIN = 3, KH = 7, KW = 7, STRIDE = 2, PAD = 3;
@@ -54,34 +57,38 @@ __global__ __launch_bounds__(256, WO == 64 ? 2 : 1) void stem_bwd_f16_kernel(
     constexpr int PH = STRIDE * (NR - 1) + KH;              // 11 input rows per channel
     constexpr int PW = ((WO - 1) * STRIDE + 8 + 1 + 1 + 7) & ~7;
     constexpr int F4R = WO * STRIDE / 4;                    // 4-pixel pieces per input row
-    constexpr int NPC = CIN * PH * F4R, NPRE = (NPC + 255) / 256;
+    constexpr int NW = NTHR / 64, NKH = NW / 4;              // waves; position halves of the weight-gradient contraction
+    constexpr int NPC = CIN * PH * F4R, NPRE = (NPC + NTHR - 1) / NTHR;
     constexpr int NG = CIN * KH, NSTEP = (NG + 1) / 2;      // 21 (c, ky) groups of 8 kx, two per MFMA
     constexpr int LDBH = NSTEP * 16 + 8;                    // halves per weight row (184)
     constexpr int NPOS = NR * WO, NT = NPOS / 32;           // positions per step, 32-position tiles
-    constexpr int NQ = (NT + 3) / 4;                        // tiles per wave
+    constexpr int NQ = (NT + NW - 1) / NW;                  // tiles per wave
     constexpr int HP = WO / 2;                              // pooled map side
-    constexpr int NPX = HP / 16;                            // pooled columns per thread
+    constexpr int NGRP = NTHR / 16;                         // pooled-column groups (16 threads = 64 channels each)
+    constexpr int NPX = HP / NGRP;                          // pooled columns per thread
     constexpr int NCOL = 2 * NPX + 3;                       // conv columns a thread looks at: 2 px0 - 1 .. 2 (px0 + NPX) + 1
     extern __shared__ __attribute__((aligned(16))) char smem[];
     _Float16* const Bs = reinterpret_cast<_Float16*>(smem);                 // [64][LDBH]
     _Float16* const Ps = Bs + 64 * LDBH;                                    // [CIN][PH][PW]
     _Float16* const Ts = Ps + CIN * PH * PW;                                // [NPOS][SB_LDT]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
-    for (int idx = t; idx < 64 * LDBH; idx += 256) {
+    for (int idx = t; idx < 64 * LDBH; idx += NTHR) {
         const int n = idx / LDBH, rem = idx - n * LDBH;
         const int kx = rem & 7, cky = rem >> 3;
         float v = 0.f;
         if (kx < KW && cky < NG) v = w[((long)n * CIN * KH + cky) * KW + kx];
         Bs[idx] = (_Float16)v;
     }
-    for (int idx = t; idx < CIN * PH * PW; idx += 256) Ps[idx] = (_Float16)0.f;     // the pad columns stay zero for good
+    for (int idx = t; idx < CIN * PH * PW; idx += NTHR) Ps[idx] = (_Float16)0.f;     // the pad columns stay zero for good
     const _Float16* const pb = Bs + i * LDBH + 8 * h;
     const float sc0 = scale[i], sh0 = shift[i], sc1 = scale[32 + i], sh1 = shift[32 + i];
     // pooling items: 4 channels x NPX pooled columns per thread
     const int c4 = t & 15, pxg = t >> 4, px0 = NPX * pxg;
     float S0[4] = {0.f, 0.f, 0.f, 0.f}, S1[4] = {0.f, 0.f, 0.f, 0.f};
-    // weight gradient: 2 (o) x 6 (k) tiles of 32 x 32, three per wave: tile T = 3 wave + u -> (k tile T >> 1, o tile T & 1)
-    const int ntA = (3 * wave) >> 1, ntB = (3 * wave + 2) >> 1;
+    // weight gradient: 2 (o) x 6 (k) tiles of 32 x 32, three per wave of a quartet: tile T = 3 trip + u -> (k tile T >> 1, o tile
+    // T & 1); quartet kh takes the kh-th part of the step's positions
+    const int trip = wave & 3, kh = wave >> 2;
+    const int ntA = (3 * trip) >> 1, ntB = (3 * trip + 2) >> 1;
     f32x16 wacc[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u)
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256, WO == 64 ? 2 : 1) void stem_bwd_f16_kernel(
         const int iy0 = 2 * STRIDE * py - STRIDE - PAD;      // input row of conv row 2py-1, tap 0
 #pragma unroll
         for (int q = 0; q < NPRE; ++q) {
-            const int j = t + 256 * q;
+            const int j = t + NTHR * q;
             const int f4 = j % F4R, prow = (j / F4R) % PH, c = (j / F4R) / PH;
             const int iy = iy0 + prow;
             pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256, WO == 64 ? 2 : 1) void stem_bwd_f16_kernel(
             __syncthreads();                                 // the previous step's fragment reads are done
 #pragma unroll
             for (int q = 0; q < NPRE; ++q) {
-                const int j = t + 256 * q;
+                const int j = t + NTHR * q;
                 if (j < NPC) {
                     _Float16* d = Ps + (j / F4R) * PW + PAD + 4 * (j % F4R);
                     const float4 v = pre[q];
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256, WO == 64 ? 2 : 1) void stem_bwd_f16_kernel(
             // ---- 1. the three conv rows, activated, as the forward computes them
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const int tl = wave + 4 * q;
+                const int tl = wave + NW * q;
                 if (tl < NT) {
                     const int p = 32 * tl + i, rr = p / WO, ox = p % WO;
                     const _Float16* const pa = Ps + (STRIDE * rr) * PW + STRIDE * ox;
@@ -242,9 +249,12 @@ __global__ __launch_bounds__(256, WO == 64 ? 2 : 1) void stem_bwd_f16_kernel(
             __syncthreads();
             // ---- 3. dW0[o][k] += sum_pos dz[pos][o] col[pos][k]
 #pragma unroll
-            for (int ks = 0; ks < NPOS / 16; ++ks) {
-                const int pos0 = 16 * ks, rr = pos0 / WO, ox0 = pos0 % WO;
-                const int coff = (STRIDE * rr) * PW + STRIDE * ox0;
+            for (int kk = 0; kk < NPOS / 16 / NKH; ++kk) {
+                // (both quartets' offsets are compile-time constants; the quartet selects)
+                const int p0 = 16 * kk, p1 = 16 * kk + NPOS / 2;
+                const int c0 = (STRIDE * (p0 / WO)) * PW + STRIDE * (p0 % WO), c1 = (STRIDE * (p1 / WO)) * PW + STRIDE * (p1 % WO);
+                const bool second = NKH == 2 && kh != 0;
+                const int pos0 = second ? p1 : p0, coff = second ? c1 : c0;
                 const char* const pz = ptr0 + pos0 * (SB_LDT * 2);
                 const h8 a0 = tr8(pz, pz + 4 * SB_LDT * 2);
                 const h8 a1 = tr8(pz + 64, pz + 64 + 4 * SB_LDT * 2);
@@ -254,7 +264,7 @@ __global__ __launch_bounds__(256, WO == 64 ? 2 : 1) void stem_bwd_f16_kernel(
                     bA[j] = pcA[coff + 2 * j];
                     bB[j] = pcB[coff + 2 * j];
                 }
-                if (wave & 1) {
+                if (trip & 1) {
                     wacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bA, wacc[0], 0, 0, 0);
                     wacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bB, wacc[1], 0, 0, 0);
                     wacc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bB, wacc[2], 0, 0, 0);
@@ -268,10 +278,10 @@ __global__ __launch_bounds__(256, WO == 64 ? 2 : 1) void stem_bwd_f16_kernel(
     }
     // ---- the workgroup's slabs
     {
-        float* const out = ws_dw + (long)blockIdx.x * 64 * SB_NK;
+        float* const out = ws_dw + ((long)blockIdx.x * NKH + kh) * 64 * SB_NK;
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
-            const int T = 3 * wave + u, nt = T >> 1, mt = T & 1;
+            const int T = 3 * trip + u, nt = T >> 1, mt = T & 1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(256, WO == 64 ? 2 : 1) void stem_bwd_f16_kernel(
         }
     }
     __syncthreads();
-    float* const red = reinterpret_cast<float*>(Ts);         // [16 column groups][S0 | S1][64]
+    float* const red = reinterpret_cast<float*>(Ts);         // [column groups][S0 | S1][64]
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         red[pxg * 128 + 4 * c4 + e] = S0[e];
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(256, WO == 64 ? 2 : 1) void stem_bwd_f16_kernel(
     if (t < 128) {
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s += red[k * 128 + t];
+        for (int k = 0; k < NGRP; ++k) s += red[k * 128 + t];
         ws_bn[(long)blockIdx.x * 128 + t] = s;
     }
 }
@@ -366,6 +376,7 @@ int stem_bwd_grid(long imgs, int P) {
     const long cap = P == 128 ? 512 : 256;
     return (int)(imgs < cap ? imgs : cap);
 }
+int stem_bwd_slabs(long imgs, int P) { return stem_bwd_grid(imgs, P) * (P == 128 ? 1 : 2); }
 
 }  // namespace
 
@@ -373,7 +384,9 @@ int stem_bwd_grid(long imgs, int P) {
 // [64][3][7][7], scale / shift = norm0 folded (running statistics), gamma / beta = norm0.weight / .bias, G16 = the block-1
 // gradient buffer [imgs (P/4)^2][ldg] halves whose first 64 columns hold s x the gradient of the pooled stem map.
 // dW [64][3][7][7], dgamma, dbeta [64] (fp32, (+)= when accumulate; any of them may be NULL).  ls = {s, 1/s} on the device.
-GNX_EXPORT long gnx_stem_bwd_f16_workspace(long imgs, int P) { return (long)stem_bwd_grid(imgs, P) * (128 + 64 * SB_NK); }
+GNX_EXPORT long gnx_stem_bwd_f16_workspace(long imgs, int P) {
+    return (long)stem_bwd_grid(imgs, P) * 128 + (long)stem_bwd_slabs(imgs, P) * 64 * SB_NK;
+}
 GNX_EXPORT int gnx_stem_bwd_f16(const float* x, const float* w, const float* scale, const float* shift, const float* gamma,
                                 const float* beta, const void* G16, long ldg, float* dW, float* dgamma, float* dbeta,
                                 float* workspace, long imgs, int P, int O, const float* ls, int accumulate, int* flag,
@@ -388,18 +401,20 @@ GNX_EXPORT int gnx_stem_bwd_f16(const float* x, const float* w, const float* sca
     const _Float16* G = reinterpret_cast<const _Float16*>(G16);
     static bool conf = false;
     if (!conf) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_bwd_f16_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)stem_bwd_lds<128>()) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(stem_bwd_f16_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)stem_bwd_lds<64>()) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_bwd_f16_kernel<128, 512>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)stem_bwd_lds<128>()) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(stem_bwd_f16_kernel<64, 256>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)stem_bwd_lds<64>()) != hipSuccess)
             return GNX_ERR_LAUNCH;
         conf = true;
     }
     if (P == 256)
-        stem_bwd_f16_kernel<128><<<grid, 256, stem_bwd_lds<128>(), stream>>>(x, w, scale, shift, G, ldg, ws_bn, ws_dw, imgs);
+        stem_bwd_f16_kernel<128, 512><<<grid, 512, stem_bwd_lds<128>(), stream>>>(x, w, scale, shift, G, ldg, ws_bn, ws_dw, imgs);
     else
-        stem_bwd_f16_kernel<64><<<grid, 256, stem_bwd_lds<64>(), stream>>>(x, w, scale, shift, G, ldg, ws_bn, ws_dw, imgs);
-    if (dW) stem_dw_reduce_kernel<<<(64 * 147 + 15) / 16, 256, 0, stream>>>(ws_dw, grid, dW, scale, ls, accumulate, flag);
+        stem_bwd_f16_kernel<64, 256><<<grid, 256, stem_bwd_lds<64>(), stream>>>(x, w, scale, shift, G, ldg, ws_bn, ws_dw, imgs);
+    if (dW)
+        stem_dw_reduce_kernel<<<(64 * 147 + 15) / 16, 256, 0, stream>>>(ws_dw, stem_bwd_slabs(imgs, P), dW, scale, ls, accumulate,
+                                                                       flag);
     if (dgamma || dbeta) stem_bn_reduce_kernel<<<4, 256, 0, stream>>>(ws_bn, grid, dgamma, dbeta, gamma, beta, ls, accumulate, flag);
     return gnx_launch_status();
 }
