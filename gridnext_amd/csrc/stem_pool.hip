@@ -1,5 +1,6 @@
 // DenseNet-BC forward: stem (conv0, optionally fused with norm0/relu0/pool0), BN+ReLU+maxpool, BN+ReLU+global average
 // pool (densenet.py:98-112, :153-156).
+#include <type_traits>
 #include "fwd_common.h"
 
 namespace {
@@ -499,9 +500,14 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
     const uint8_t* __restrict__ x8 = reinterpret_cast<const uint8_t*>(xv);
     constexpr int CIN = 3, KH = 7, KW = 7, STRIDE = 2, PAD = 3;
     constexpr int RT = 128 / WO;                          // conv rows per tile
-    constexpr int PH = STRIDE * (RT - 1) + KH, PW = ((WO - 1) * STRIDE + 8 + 1 + 1 + 7) & ~7;   // patch per channel (halves)
+    // The input rows live in a RING of PH slots per channel (row iy in slot (iy + PAD) mod PH): a tile's conv rows read the
+    // 2 RT + 5 rows iy = 2 RT tt - 3 ... 2 RT tt + 2 RT + 1, of which only the last NEW = 2 RT are new - the tile stages those
+    // (the full window per tile was 3.5x / 2.25x the loads, conversions and LDS writes: 2.4 of the 5.0 ms of a 256-px array).
+    // An image starts with NV stage-only steps (tt < 0) that bring in rows -3 ... 1 (zeros outside the image).
+    constexpr int PH = 2 * RT + 5, NEW = STRIDE * RT, NV = RT == 1 ? 3 : 2;    // (exactly the window: 52 KB of LDS, 3 per CU)
+    constexpr int PW = (WO - 1) * STRIDE + 8;             // halves per patch row: columns 2 ox ... 2 ox + 7 (4-B aligned rows)
     constexpr int F4R = WO * STRIDE / 4;                  // 4-pixel pieces per input row (row width 2 WO)
-    constexpr int NPC = CIN * PH * F4R, NPRE = (NPC + 255) / 256;
+    constexpr int NPC = CIN * NEW * F4R, NPRE = (NPC + 255) / 256;
     constexpr int NIT = (WO / 2) * 16 / 256;             // pooled (position, 4-channel group) items per thread: all 64 channels at once
     constexpr int NG = CIN * KH, NSTEP = (NG + 1) / 2;    // 21 (c, ky) groups of 8 kx, two per MFMA
     constexpr int LDBH = NSTEP * 16 + 8;                  // halves per weight row (184: 23 sixteen-byte slots)
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
     _Float16* Ps = Bs + 64 * LDBH;                        // [CIN][PH][PW]
     // The activated conv tile is kept as fp16: rounding is monotonic, so the maximum of the rounded values IS the rounded
     // maximum the fp32 tile gave - bit-identical output, half the tile (20 -> 9 KB: three workgroups per CU instead of two)
-    _Float16* Ts = Ps + CIN * PH * PW;                    // [128 positions][SP_LDTH]
+    _Float16* Ts = Ps + ((CIN * PH * PW + 7) & ~7);       // [128 positions][SP_LDTH], 16-B aligned
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
     for (int idx = t; idx < 64 * LDBH; idx += 256) {
         const int n = idx / LDBH, rem = idx - n * LDBH;
@@ -521,7 +527,8 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
     }
     for (int idx = t; idx < CIN * PH * PW; idx += 256) Ps[idx] = (_Float16)0.f;     // the pad columns stay zero for good
     const int trow = 32 * wave + i;                       // this lane's position in the RT x WO tile
-    const _Float16* pa = Ps + (STRIDE * (trow / WO)) * PW + STRIDE * (trow % WO);
+    const _Float16* pa = Ps + STRIDE * (trow % WO);
+    const int rr2 = STRIDE * (trow / WO);                 // (wave-uniform: 32 | WO)
     const _Float16* pb = Bs + i * LDBH + 8 * h;
     const float sc0 = i < O ? scale[i] : 0.f, sh0 = i < O ? shift[i] : 0.f;
     const float sc1 = 32 + i < O ? scale[32 + i] : 0.f, sh1 = 32 + i < O ? shift[32 + i] : 0.f;
@@ -533,11 +540,11 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
     uint32_t pre8[U8 ? NPRE : 1];
     bool in8[U8 ? NPRE : 1];
     auto fetch_patch = [&](long img, int tt) {
-        const int iy0 = RT * tt * STRIDE - PAD;
+        const int iy0 = NEW * tt + 2;                     // the tile's new rows
 #pragma unroll
         for (int q = 0; q < NPRE; ++q) {
             const int j = t + 256 * q;
-            const int f4 = j % F4R, py = (j / F4R) % PH, c = (j / F4R) / PH;
+            const int f4 = j % F4R, py = (j / F4R) % NEW, c = (j / F4R) / NEW;
             const int iy = iy0 + py;
             const bool inside = j < NPC && iy >= 0 && iy < H;
             if constexpr (U8) {
@@ -551,15 +558,17 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
             }
         }
     };
-    auto stash_patch = [&]() {
+    auto stash_patch = [&](int tt) {
 #pragma unroll
         for (int q = 0; q < NPRE; ++q) {
             const int j = t + 256 * q;
             if (j < NPC) {
-                _Float16* d = Ps + (j / F4R) * PW + PAD + 4 * (j % F4R);       // patch column = ix + PAD (odd: 3 + 4 f4)
+                const int py = (j / F4R) % NEW, cc = (j / F4R) / NEW;
+                const int slot = (NEW * tt + 2 + py + PAD + 4 * PH) % PH;
+                _Float16* d = Ps + (cc * PH + slot) * PW + PAD + 4 * (j % F4R);  // patch column = ix + PAD (odd: 3 + 4 f4)
                 float4 v;
                 if constexpr (U8) {
-                    const int c = (j / F4R) / PH;
+                    const int c = (j / F4R) / NEW;
                     const bool norm = nrm != nullptr;
                     v = in8[q] ? u8x4_pixels(pre8[q], norm, norm ? nrm[c] : 0.f, norm ? nrm[3 + c] : 1.f, norm ? nrm[6 + c] : 1.f)
                                : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -575,42 +584,61 @@ __global__ __launch_bounds__(256) void conv_stem_pool_f16_kernel(const void* __r
         }
     };
     __syncthreads();                                      // Bs and the zeroed patch are in place
-    fetch_patch(blockIdx.x, 0);
+    fetch_patch(blockIdx.x, -NV);
 
     for (long img = blockIdx.x; img < imgs; img += gridDim.x) {
         sp_half4 carry[NIT], carry2[NIT];
         const sp_half4 hz = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
 #pragma unroll
         for (int q = 0; q < NIT; ++q) carry[q] = carry2[q] = hz;
-        for (int tt = 0; tt < ntt; ++tt) {
+        for (int tt = -NV; tt < ntt; ++tt) {
             __syncthreads();
-            stash_patch();
+            stash_patch(tt);
             {
                 long nimg = img;
                 int nt2 = tt + 1;
-                if (nt2 == ntt) { nt2 = 0; nimg += gridDim.x; }
+                if (nt2 == ntt) { nt2 = -NV; nimg += gridDim.x; }
                 if (nimg >= imgs) nimg = blockIdx.x;
                 fetch_patch(nimg, nt2);
             }
             asm volatile("" ::: "memory");
+            if (tt < 0) continue;                         // stage-only steps at the top of an image
             __syncthreads();
+            // slot of this wave's conv row, tap ky: (base + ky) mod PH with base = (NEW tt + rr2) mod PH, wave-uniform.
+            // One copy of the multiply loop per value: the patch-row offsets stay instruction immediates.
+            const int base = __builtin_amdgcn_readfirstlane((NEW * tt + rr2) % PH);
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            auto multiply = [&](auto bc) {
+                constexpr int B = decltype(bc)::value;
 #pragma unroll
-            for (int s = 0; s < NSTEP; ++s) {
-                // group 2 s + h: (c, ky) -> patch row; the missing 22nd group re-reads the 21st (its weights are zero)
-                const int g0 = 2 * s, g1 = 2 * s + 1 < NG ? 2 * s + 1 : NG - 1;
-                const int off0 = ((g0 / KH) * PH + (g0 % KH)) * PW, off1 = ((g1 / KH) * PH + (g1 % KH)) * PW;
-                // the 8 kx of position ox are patch columns 2 ox .. 2 ox + 7: four dwords at dword index ox of the row
-                const uint32_t* ap = reinterpret_cast<const uint32_t*>(pa + (h ? off1 : off0));
-                typedef unsigned u32x4a __attribute__((ext_vector_type(4)));
-                const u32x4a av = {ap[0], ap[1], ap[2], ap[3]};
-                const sp_half8 a = __builtin_bit_cast(sp_half8, av);
-                const sp_half8 b0 = *reinterpret_cast<const sp_half8*>(pb + 16 * s);
-                const sp_half8 b1 = *reinterpret_cast<const sp_half8*>(pb + 32 * LDBH + 16 * s);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b1, acc1, 0, 0, 0);
+                for (int s = 0; s < NSTEP; ++s) {
+                    // group 2 s + h: (c, ky) -> patch row; the missing 22nd group re-reads the 21st (its weights are zero)
+                    const int g0 = 2 * s, g1 = 2 * s + 1 < NG ? 2 * s + 1 : NG - 1;
+                    const int off0 = ((g0 / KH) * PH + (B + g0 % KH) % PH) * PW;
+                    const int off1 = ((g1 / KH) * PH + (B + g1 % KH) % PH) * PW;
+                    // the 8 kx of position ox are patch columns 2 ox .. 2 ox + 7: four dwords at dword index ox of the row
+                    const uint32_t* ap = reinterpret_cast<const uint32_t*>(pa + (h ? off1 : off0));
+                    typedef unsigned u32x4a __attribute__((ext_vector_type(4)));
+                    const u32x4a av = {ap[0], ap[1], ap[2], ap[3]};
+                    const sp_half8 a = __builtin_bit_cast(sp_half8, av);
+                    const sp_half8 b0 = *reinterpret_cast<const sp_half8*>(pb + 16 * s);
+                    const sp_half8 b1 = *reinterpret_cast<const sp_half8*>(pb + 32 * LDBH + 16 * s);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b1, acc1, 0, 0, 0);
+                }
+            };
+            switch (base) {
+                case 0: multiply(std::integral_constant<int, 0>{}); break;
+                case 1: multiply(std::integral_constant<int, 1>{}); break;
+                case 2: multiply(std::integral_constant<int, 2>{}); break;
+                case 3: multiply(std::integral_constant<int, 3>{}); break;
+                case 4: multiply(std::integral_constant<int, 4>{}); break;
+                case 5: multiply(std::integral_constant<int, 5>{}); break;
+                case 6: multiply(std::integral_constant<int, 6>{}); break;
+                case 7: multiply(std::integral_constant<int, 7 % PH>{}); break;       // (RT = 2 only)
+                default: multiply(std::integral_constant<int, 8 % PH>{}); break;
             }
             // both 32-channel halves of the tile go to the LDS together (a position's row holds all 64 channels), ONE barrier,
             // one pooling sweep - three barriers per tile instead of five
@@ -916,9 +944,9 @@ static int stem_pool_f16_launch(const void* x, const float* w, void* out16, long
         (reinterpret_cast<uintptr_t>(x) & (U8 ? 3 : 15)) != 0)
         return GNX_ERR_UNSUPPORTED;
     if (imgs == 0) return GNX_OK;
-    const int RT = 128 / Wo, PH = 2 * (RT - 1) + 7, PW = ((Wo - 1) * 2 + 8 + 2 + 7) & ~7;
-    const size_t lds_bytes = ((size_t)64 * (11 * 16 + 8) + (size_t)3 * PH * PW + (size_t)128 * SP_LDTH) * 2;
-    const int per_cu = lds_bytes <= 53 * 1024 ? 3 : 2;     // 256-px geometry: 52.2 KB, three workgroups per CU
+    const int RT = 128 / Wo, PH = 2 * RT + 5, PW = (Wo - 1) * 2 + 8;           // (the kernel's ring of input rows)
+    const size_t lds_bytes = ((size_t)64 * (11 * 16 + 8) + (size_t)((3 * PH * PW + 7) & ~7) + (size_t)128 * SP_LDTH) * 2;
+    const int per_cu = lds_bytes <= 53 * 1024 ? 3 : 2;     // 256-px geometry: 52 992 B, three workgroups per CU
     const int grid = (int)(imgs < 256 * per_cu ? imgs : 256 * per_cu);
     _Float16* o = reinterpret_cast<_Float16*>(out16);
     if (Wo == 64)

@@ -27,7 +27,7 @@ GROUPS = [                                   # first match wins; names as bench.
     ('dgrad_wgrad1x1_bn1_f16', lambda n: 'dgrad1x1_bn_f16_kernel' in n and ('ILb1' in n or '<true>' in n)),
     ('dgrad1x1_bn1_f16', lambda n: 'dgrad1x1_bn_f16_kernel' in n),
     ('dgrad3x3_bn2_f16', lambda n: 'dgrad3x3_bn_f16_kernel' in n),
-    ('wgrad3x3_f16', lambda n: 'wgrad3x3_f16_kernel' in n),
+    ('wgrad3x3_f16', lambda n: 'wgrad3x3_f16_kernel' in n or 'wgrad3x3_f16_p2_kernel' in n),
     ('wgrad1x1_f16', lambda n: 'wgrad1x1_f16_kernel' in n),
     ('dgrad_wgrad1x1_bn1', lambda n: 'dgrad_wgrad1x1_f32_kernel' in n),
     ('dense_layer', lambda n: 'dense_layer_f16_kernel' in n or 'dense_layer_f16_s64_kernel' in n),
