@@ -74,15 +74,40 @@ class _PhaseMeter:
 
 
 class _BestKeeper:
+    """`best_model_wts = copy.deepcopy(model.state_dict())` of the reference (training.py:29, :87-89, :121, :197-199) - a
+    snapshot of every parameter and buffer whenever the validation loss improves.  The snapshot lives in buffers allocated once
+    and is refreshed with one multi-tensor copy per (device, dtype) instead of one small copy per entry: a count-only grid model
+    holds 47 entries (~8 us of device queue each, a tenth of an epoch of ten arrays), DenseNet-121 more than 700."""
+
     def __init__(self, model):
         self.model = model
         self.best_loss = float('inf')
-        self.best_wts = copy.deepcopy(model.state_dict())
+        self.best_wts = None
+        self._snapshot()
+
+    def _snapshot(self):
+        sd = self.model.state_dict()
+        tensors = {k: v for k, v in sd.items() if torch.is_tensor(v)}
+        best = self.best_wts
+        stale = best is None or list(best.keys()) != list(sd.keys()) or any(
+            (not torch.is_tensor(best[k])) or best[k].shape != v.shape or best[k].dtype != v.dtype or best[k].device != v.device
+            for k, v in tensors.items())
+        if stale or len(tensors) != len(sd):
+            self.best_wts = copy.deepcopy(sd)                 # first snapshot (or an unusual state_dict): the reference's way
+            return
+        groups = {}
+        for k, v in tensors.items():
+            d, srcs = groups.setdefault((v.device, v.dtype), ([], []))
+            d.append(best[k])
+            srcs.append(v.detach())
+        with torch.no_grad():
+            for dsts, srcs in groups.values():
+                torch._foreach_copy_(dsts, srcs)
 
     def offer(self, epoch_loss):
         if epoch_loss < self.best_loss:
             self.best_loss = epoch_loss
-            self.best_wts = copy.deepcopy(self.model.state_dict())
+            self._snapshot()
             return True
         return False
 

@@ -498,3 +498,34 @@ def test_count_grid_dataset_matches_reference_in_splotch_mode():
     assert str(g['st_grid_noannot_error']) == 'UnboundLocalError'          # what the reference does without annotations
     x0, y0 = CountGridDataset(cf, None, Visium=False, h_st=6, w_st=5)[0]
     assert np.array_equal(x0.numpy(), g['st_grid_x']) and int(y0.abs().sum()) == 0
+
+
+def test_best_weights_keeper_snapshots_like_deepcopy():
+    """training.py:87-89 / :197-199 of the reference keep `copy.deepcopy(model.state_dict())` of the best epoch; the loops here
+    refresh ONE set of snapshot buffers with multi-tensor copies - same contents, independent of the live parameters."""
+    import copy
+    import torch
+    import torch.nn as nn
+    from gridnext_amd.training import _BestKeeper
+    torch.manual_seed(0)
+    m = nn.Sequential(nn.Linear(6, 5), nn.BatchNorm1d(5), nn.ReLU(), nn.Linear(5, 3))
+    k = _BestKeeper(m)
+    first = copy.deepcopy(m.state_dict())
+    m.train()
+    m(torch.randn(8, 6))                                       # running statistics and num_batches_tracked move
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(1.0)
+    for key, v in first.items():
+        assert torch.equal(k.best_wts[key], v), key             # the snapshot did not follow the live tensors
+    assert k.offer(0.5) and not k.offer(0.7)
+    second = copy.deepcopy(m.state_dict())
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(2.0)
+    assert list(k.best_wts.keys()) == list(second.keys())
+    for key, v in second.items():
+        assert torch.equal(k.best_wts[key], v) and k.best_wts[key].dtype == v.dtype, key
+    m.load_state_dict(k.best_wts)
+    for key, v in second.items():
+        assert torch.equal(m.state_dict()[key], v), key
