@@ -11,7 +11,9 @@ that enters the network (no host synchronisation): s = 2^floor(12 - log2(max |df
 largest element of the last block's gradient lands in [2^11, 2^12) - a factor 16 of headroom before fp16 overflows and 26
 binades down to the smallest normal.  Every fp16 gradient tensor holds s x the true gradient; every fp32 result is multiplied
 by 1/s (exact) where its partial sums are reduced.  `model.f16_grad_overflow` (device int32) is OR-ed with 1 by any kernel
-that reduces a non-finite value; `model.f16_grad_scale` holds {s, 1/s} of the last backward.
+that reduces a non-finite value; `model.f16_grad_scale` holds {s, 1/s} of the last backward.  At every transition the scale
+is re-centred for the block in front (another power of two, from the largest element of the pooled gradient that enters it):
+`model.f16_grad_block_scales` lists the blocks' {s, 1/s}, last block first.
 
 The stem (conv0 .. pool0, 64 channels) runs on fp16 matrix operands too: the forward is the inference kernel
 (gnx_conv_stem_bnrelu_maxpool_f16mul) writing block 1's first columns, the backward (gnx_stem_bwd_f16) one pass over the
@@ -230,6 +232,9 @@ class _DenseNetF16Fn(Function):
         ls = torch.stack([s_val, 1.0 / s_val]).to(F32).contiguous()
         model.__dict__['f16_grad_scale'] = ls
         lp = L.ptr(ls)
+        block_scales = [ls]                                  # one {s, 1/s} per dense block, last block first (see the transitions)
+        ls_cur = ls
+        model.__dict__['f16_grad_block_scales'] = block_scales
 
         # ---- tail: norm_final -> relu -> global average
         bufs = tape.bufs
@@ -309,9 +314,23 @@ class _DenseNetF16Fn(Function):
                 dbufs[bi - 1] = torch.empty_like(bufs[bi - 1])
                 dgt, dbt = bn_out(p_trans.norm)
                 wst = _f32(L.query('gnx_trans_bwd_f16_workspace', N, p_total, ps), dev)
+                # Re-centre the scale for the block in front: gradients of an untrained network grow towards the input (x 4-16
+                # per block measured), and a dense block adds up to 24 layers' contributions on top.  f = the power of two that
+                # puts the largest pooled-gradient element back at 2^12; it rides on the transition norm's folded (scale, shift)
+                # - the ReLU mask's sign test is unchanged by a positive factor, the BatchNorm sums do not use them - so the kernel
+                # writes f x its block gradient while its own sums still carry the old scale.
+                amax = dPool.abs().amax().to(F32)
+                f_e = torch.where(amax > 0, torch.floor(12.0 - torch.log2(amax.clamp_min(1e-30))), torch.zeros_like(amax))
+                f_e = torch.minimum(torch.maximum(f_e, -24.0 - torch.log2(ls_cur[0])), 60.0 - torch.log2(ls_cur[0])).clamp(-12.0, 12.0)
+                f_val = torch.exp2(f_e)
+                sc_f, sh_f = (stt[0] * f_val).contiguous(), (stt[1] * f_val).contiguous()      # (kept alive across the call)
                 L.call('gnx_trans_bwd_f16', dPool.data_ptr(), p_total, bufs[bi - 1].data_ptr(), p_total, dbufs[bi - 1].data_ptr(),
-                       p_total, N, p_total, ps, L.ptr(stt[0]), L.ptr(stt[1]), L.ptr(stt[2]), L.ptr(stt[3]), L.ptr(dgt), L.ptr(dbt),
+                       p_total, N, p_total, ps, L.ptr(sc_f), L.ptr(sh_f), L.ptr(stt[2]), L.ptr(stt[3]), L.ptr(dgt), L.ptr(dbt),
                        L.ptr(wst), lp, 0, fp, st)
+                s_new = ls_cur[0] * f_val
+                ls_cur = torch.stack([s_new, 1.0 / s_new]).to(F32).contiguous()
+                block_scales.append(ls_cur)
+                lp = L.ptr(ls_cur)
                 del dPool, wst
                 dbufs[bi] = None
                 bufs[bi] = None
@@ -331,7 +350,7 @@ class _DenseNetF16Fn(Function):
                    L.ptr(norm0.bias), dbufs[0].data_ptr(), bufs[0].shape[1],
                    L.ptr(new_like(conv0.weight)) if want(conv0.weight) else None, L.ptr(dg0), L.ptr(db0), L.ptr(ws), N, P, c0, lp, 0,
                    fp, st)
-            model._probe_mark('stem_bwd_f16', t0, 6 * N * hs * hs * c0 * 147, 4 * N * 3 * P * P + 2 * N * (hs // 2) ** 2 * c0)
+            model._probe_mark('stem_bwd_f16', t0, 4 * N * hs * hs * c0 * 147, 4 * N * 3 * P * P + 2 * N * (hs // 2) ** 2 * c0)
             dbufs[0] = None
         elif want(conv0.weight) or want(norm0.weight) or want(norm0.bias):
             hp = (hs + 2 - 3) // 2 + 1

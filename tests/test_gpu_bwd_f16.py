@@ -255,6 +255,11 @@ def test_stem_bwd_f16(L, P, imgs):
     # accumulate
     L.call('gnx_stem_bwd_f16', *args, 1, flag.data_ptr(), L.stream())
     assert rel(dW, 2 * ref_dW) < 1.5e-3 and rel(db, 2 * ref_db) < 1e-3
+    # a position that wins four windows adds four fp16 gradients: even at the top of the fp16 range the routed tile stays finite
+    dPd.fill_(60000.0)
+    L.call('gnx_stem_bwd_f16', *args, 0, flag.data_ptr(), L.stream())
+    assert int(flag.item()) == 0 and bool(torch.isfinite(dW).all()) and bool(torch.isfinite(dg).all())
+    assert rel(db, (y > 0).double().mul(0).sum((0, 2, 3)) + (pooled > 0).double().mul(mult.view(-1, 1, 1, 1)).sum((0, 2, 3)) * 60000.0 / s) < 1e-3
 
 
 def _calibrated_densenet121(seed, x):
@@ -333,6 +338,8 @@ def test_f16_backward_equals_fp32_backward_on_the_same_tape(capsys):
     out = m(x)
     nn.functional.cross_entropy(out, labels).backward()
     assert int(m.f16_grad_overflow.item()) == 0
+    scales = [float(b[0].item()) for b in m.f16_grad_block_scales]       # one power of two per dense block, re-centred at the transitions
+    assert len(scales) == 4 and all(sv == 2.0 ** round(np.log2(sv)) for sv in scales), scales
     dout = (torch.softmax(out.detach(), 1) - nn.functional.one_hot(labels, 8).float()) / 16
     out2, ref = _fp32_backward_on_f16_tape(m, x, dout)
     assert torch.equal(out2, out.detach())
