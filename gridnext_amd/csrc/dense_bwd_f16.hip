@@ -931,13 +931,21 @@ SlabPlan plan_slabs(long M, int tile, long want) {
     if (p.slabs < 1) p.slabs = 1;
     return p;
 }
+// Pixel slabs for kernels whose grid is (slabs rounded up to 8) x `blocks` channel blocks: the largest multiple of 8 that keeps
+// the WHOLE grid co-resident (`cap` workgroups = 256 CUs x 2 or 3).  ceil(cap / blocks) did not: with 3, 5, 6 or 7 channel
+// blocks (cin = 288-384, 544-896: 32 of DenseNet-121's 58 dense layers) it launched 520-560 workgroups for 512 places, and
+// the handful left over ran as a second round after the first workgroups had finished - 1.3-1.4x the time of those layers.
+long slabs_for(long cap, long blocks) {
+    const long s = cap / blocks / 8 * 8;
+    return s < 8 ? 8 : s;
+}
 SlabPlan plan_wgrad1(long M, int N, int K) {
     const long blocks = (long)((K + 127) / 128) * ((N + 127) / 128);
-    return plan_slabs(M, 64, (768 + blocks - 1) / blocks);          // three workgroups per CU
+    return plan_slabs(M, 64, slabs_for(768, blocks));               // three workgroups per CU
 }
 SlabPlan plan_dgrad1(long M, int K, bool wgrad = false) {
     const long n_cb = (K + 127) / 128;
-    return plan_slabs(M, 64, ((wgrad ? 512 : 768) + n_cb - 1) / n_cb);
+    return plan_slabs(M, 64, slabs_for(wgrad ? 512 : 768, n_cb));
 }
 
 }  // namespace

@@ -4,8 +4,23 @@
 # rocprofv3 rules of this pool: program directly after `--`, PMC passes separate from each other and with
 # --kernel-trace only.
 tag=${1:-rXX}
+only=${2:-all}        # "c5trained": only the four passes of the config-5 everything-trained step (a change to the fp16 backward kernels)
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
+if [ "$only" = "c5trained" ]; then
+  G="python3 $R/tools/bench_c5_trained.py --no-fp32 --steps 2 --warmup 1"
+  rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_g_stats -o r --output-format csv -- $G > $R/gpurun_out/${tag}_g_stats.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_g_fetch -o r --output-format csv -- $G > $R/gpurun_out/${tag}_g_fetch.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_g_write -o r --output-format csv -- $G > $R/gpurun_out/${tag}_g_write.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA -d $R/gpurun_out/${tag}_g_mfma -o r --output-format csv -- $G > $R/gpurun_out/${tag}_g_mfma.log 2>&1 || exit 1
+  cd $R
+  python3 tools/pmc_traffic.py gpurun_out/${tag}_g_fetch gpurun_out/${tag}_g_write > gpurun_out/${tag}_pmc_traffic_c5trained.json
+  python3 tools/pmc_mfma_util.py gpurun_out/${tag}_g_mfma > gpurun_out/${tag}_pmc_mfma_util_c5trained.json
+  find gpurun_out/${tag}_g_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_bench_c5trained_kernel_stats.csv \;
+  for d in g_stats g_fetch g_write g_mfma; do rm -rf gpurun_out/${tag}_$d; done
+  echo done
+  exit 0
+fi
 B="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-series"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_stats -o r --output-format csv -- $B > $R/gpurun_out/${tag}_stats.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_fetch -o r --output-format csv -- $B --no-kernel-timing > $R/gpurun_out/${tag}_fetch.log 2>&1 || exit 1
