@@ -697,7 +697,7 @@ def patch224_series(args, device, rank, world, steps=3, warmup=1, P=224):
     return out
 
 
-def config5_trained_series(args, device, rank, world, steps=3, warmup=1, P=256):
+def config5_trained_series(args, device, rank, world, steps=3, warmup=1, P=256, probe_dump=None):
     """SURVEY 8d's "everything trained" column at config 5's geometry (22.21 GFLOP per spot): the multimodal step on one
     256-px array with both classifiers trained through f_opt on the fp16-MFMA path - `DenseNet.mfma = 'f16'` on the gradient
     path: fp16 tape (block buffers + activated bottlenecks, one chunk: ~110 GB), fp16-MFMA backward with fp32 accumulation
@@ -804,6 +804,9 @@ def config5_trained_series(args, device, rank, world, steps=3, warmup=1, P=256):
                                   "fp32_path_ms_per_step": 1e3 * r32["elapsed"] / max(warmup + steps - 1, 1),
                                   "fp32_path_recomputed_chunks": r32["chunks"], "fp32_path_peak_hbm_gb": r32["peak_hbm_gb"]}
     probe = r16["probe"]
+    if probe_dump:                                           # per-launch records, in launch order (tools/bench_c5_trained.py --layers)
+        with open(probe_dump, 'w') as fh:
+            json.dump([{"kind": r[0], "ms": r[1].elapsed_time(r[2]), "flops": r[3], "bytes": r[4]} for r in (probe or [])], fh)
     KINDS16 = {'conv1x1': 'conv1x1_h16_kernel (taped forward: stores the activated bottleneck, fp16)',
                'conv3x3': 'conv3x3_dma_kernel<H16, O16> (taped forward)',
                'wgrad3x3_f16': 'wgrad3x3_f16_kernel', 'dgrad3x3_bn2_f16': 'dgrad3x3_bn_f16_kernel',
