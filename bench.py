@@ -608,6 +608,9 @@ def config5_series(args, device, rank, world, steps=4, warmup=2):
     if rank == 0 and world == 1 and not getattr(args, 'no_cpu_baseline', False):
         _, out["ce_vs_ref"] = cpu_leg(model, P, 'f16', device, timed_steps=0, sub_hw=(13, 8), u8=True)
         out["fused_dense_layers"] = bool(getattr(f_img, '_used_f16_fused', False))
+    if os.environ.get('GNX_PROBE_DUMP'):                         # per-launch records in launch order (tools/diag/c5_layers.py)
+        with open(os.environ['GNX_PROBE_DUMP'], 'w') as fh:
+            json.dump([{"kind": r[0], "ms": r[1].elapsed_time(r[2]), "flops": r[3], "bytes": r[4]} for r in (probe or [])], fh)
     kt = kernel_table(probe, P, steps)
     for kind in kt:                                              # fp16 operands (2 B, stated per launch); priced against HBM
         kk = kt[kind]
