@@ -1008,6 +1008,9 @@ def worker_main(args):
         # (distributed.BackwardReducer); frozen-f steps have one 108 KB flat call into a persistent buffer
         "allreduce_overlapped": bool(gdist.BackwardReducer.wanted()),
     }
+    if probe and os.environ.get('GNX_PROBE_DUMP'):               # per-launch records in launch order (tools/diag/c5_layers.py)
+        with open(os.environ['GNX_PROBE_DUMP'], 'w') as fh:
+            json.dump([{"kind": r[0], "ms": r[1].elapsed_time(r[2]), "flops": r[3], "bytes": r[4]} for r in probe], fh)
     if probe:
         kern = kernel_table(probe, args.patch, args.steps)
         # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE in separate
