@@ -319,7 +319,8 @@ class _DenseNetF16Fn(Function):
                 # puts the largest pooled-gradient element back at 2^12; it rides on the transition norm's folded (scale, shift)
                 # - the ReLU mask's sign test is unchanged by a positive factor, the BatchNorm sums do not use them - so the kernel
                 # writes f x its block gradient while its own sums still carry the old scale.
-                amax = dPool.abs().amax().to(F32)
+                mn, mx = torch.aminmax(dPool)                   # (one pass; abs() would write a copy of the tensor first)
+                amax = torch.maximum(mx, -mn).to(F32)
                 f_e = torch.where(amax > 0, torch.floor(12.0 - torch.log2(amax.clamp_min(1e-30))), torch.zeros_like(amax))
                 f_e = torch.minimum(torch.maximum(f_e, -24.0 - torch.log2(ls_cur[0])), 60.0 - torch.log2(ls_cur[0])).clamp(-12.0, 12.0)
                 f_val = torch.exp2(f_e)
