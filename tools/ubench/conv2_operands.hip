@@ -9,8 +9,8 @@
 //           pixel column n, so a shift by one pixel is v_mov_b32_dpp wave_shr:1 / wave_shl:1 on the fragment's 4 VGPRs plus a
 //           select for the two lanes at the ends of each 32-lane half (their neighbour pixel comes from one extra 16-B read per
 //           row): 2 reads + 8 DPP moves + 8 selects per THREE MFMAs.
-// One workgroup per CU, NW waves (4 = one per SIMD; 8 = two, mode 0 only: modes 1 / 2 hold 136 registers of weights and
-// accumulators per wave).  Prints the matrix rate of the whole chip.
+// One workgroup per CU, NW waves (4 = one per SIMD; 8 = two - in modes 1 / 2 the k-slice of a wave is then one k-step: 36
+// registers of weights, eight partial sums to add).  Prints the matrix rate of the whole chip.
 //   hipcc -w --offload-arch=gfx950 -O3 tools/ubench/conv2_operands.hip -o tools/ubench/build/conv2_operands && tools/ubench/build/conv2_operands
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(64 * NW) void k(float* out, int iters) {
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    constexpr int KSW = (MODE >= 1 && NW == 8) ? 1 : 2;   // k-steps of a wave's slice of the 128 bottleneck channels (modes 1, 2)
     h8 wreg[18];
     if (MODE >= 1) {
 #pragma unroll
@@ -79,9 +80,9 @@ __global__ __launch_bounds__(64 * NW) void k(float* out, int iters) {
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
+                    for (int ks = 0; ks < KSW; ++ks) {
                         const int row = 34 + rot + (tap / 3) * 32 + (tap % 3) - 1 + n + 32 * pt;
-                        const h8 b = *reinterpret_cast<const h8*>(act + row * RS + (32 * (wave & 3) + 16 * ks + 8 * h) * 2);
+                        const h8 b = *reinterpret_cast<const h8*>(act + row * RS + (16 * KSW * (wave & 7) + 16 * ks + 8 * h) * 2);
                         acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[tap * 2 + ks], b, acc[pt], 0, 0, 0);
                     }
         } else {
@@ -92,9 +93,9 @@ __global__ __launch_bounds__(64 * NW) void k(float* out, int iters) {
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
+                    for (int ks = 0; ks < KSW; ++ks) {
                         const int row = 34 + rot + dy * 32 + n + 32 * pt;
-                        const int col = (32 * (wave & 3) + 16 * ks + 8 * h) * 2;
+                        const int col = (16 * KSW * (wave & 7) + 16 * ks + 8 * h) * 2;
                         const h8 b = *reinterpret_cast<const h8*>(act + row * RS + col);
                         // lanes 0 / 32 fetch the pixel left of the tile, lanes 31 / 63 the one right of it, everyone else its own
                         const int erow = n == 0 ? row - 1 : (n == 31 ? row + 1 : row);
@@ -133,7 +134,7 @@ static void run(const char* what) {
     hipEventSynchronize(b);
     float ms = 0.f;
     hipEventElapsedTime(&ms, a, b);
-    const double mfma = (double)grid * NW * iters * 72.0;
+    const double mfma = (double)grid * NW * iters * ((MODE >= 1 && NW == 8) ? 36.0 : 72.0);
     const double tf = mfma * 2.0 * 32 * 32 * 16 / (ms * 1e-3) / 1e12;
     printf("%-68s %d waves: %7.3f ms  %7.1f TFLOP/s  (%.1f %% of 2500)\n", what, NW, ms, tf, tf / 25.0);
     hipFree(out);
@@ -143,6 +144,8 @@ int main() {
     run<0, 4>("mode 0: W2 and activations from LDS (1.5 reads / MFMA)");
     run<0, 8>("mode 0: W2 and activations from LDS (1.5 reads / MFMA)");
     run<1, 4>("mode 1: W2 in registers, activations from LDS (1 read / MFMA)");
+    run<1, 8>("mode 1: W2 in registers (k split over 8 waves), activations from LDS");
     run<2, 4>("mode 2: + dx shifts by DPP (2 reads + 16 VALU / 3 MFMAs)");
+    run<2, 8>("mode 2: + dx shifts by DPP, k split over 8 waves");
     return 0;
 }
