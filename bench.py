@@ -23,7 +23,8 @@ Rank 0 prints ONE JSON line (contract in the task description) with
                     sub-grid, physical cores, CPU model string, the SAME weights as the GPU leg;
   * `ce_vs_ref`     BASELINE.json's "CE vs ref": the masked CE of that sub-grid through the HIP path and through the
                     oracle, same weights and inputs (|dCE| <= 1e-4 asserted for f32), argmax agreement on decided spots;
-  * `series`        further series on the same box: `from_host` = the same step fed from pageable host memory (uint8
+  * `series_summary` / `series_file`   further series on the same box (value and ms/step in the line, the full objects
+                    with their rooflines in the file): `from_host` = the same step fed from pageable host memory (uint8
                     patches, DataLoader, pinned double-buffered H2D prefetcher; PCIe inside the timed region - never the
                     headline `value`); `config5_f16_256px` = BASELINE config 5's step (256-px patches, fp16 MFMA conv
                     path) on this GPU; `train_f` = the second series of SURVEY 8d, both classifiers trained through f_opt
@@ -342,7 +343,34 @@ def _host_cpu():
     return max(1, n_phys), model
 
 
-def cpu_leg(model, patch, mfma, device, timed_steps=2, sub_hw=None, u8=False):
+def _chunked_frozen_f(f, chunk):
+    """The oracle's image classifier over a whole grid in chunks (a frozen, eval-mode f treats spots independently, so this is
+    the same function as one call - it only bounds the oracle's memory and keeps its convolutions cache-sized)."""
+    import torch
+
+    class ChunkedFrozenF(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.f = f
+
+        def forward(self, x):
+            assert not self.f.training
+            with torch.no_grad():
+                return torch.cat([self.f(x[i:i + chunk]) for i in range(0, len(x), chunk)], 0)
+
+    return ChunkedFrozenF()
+
+
+def full_grid_ce(model, patch, mfma, device, inputs=None, chunk=256):
+    """BASELINE's "CE vs ref" at the benchmark's OWN size: ONE full 78 x 64 array (4992 spots of `patch`-px patches + 2000
+    genes) through GridNetHexMM -> masked CE on the HIP path and through the CPU oracle (forward + CE only), same state_dict,
+    same inputs, tutorial mode - g's train-mode BatchNorm statistics and n_fg are those of the timed step, not of a sub-grid
+    (/root/reference/gridnext/training.py:146-160, gridnet_models.py:226-235).  The oracle's frozen image f runs in chunks."""
+    _, ce = cpu_leg(model, patch, mfma, device, timed_steps=0, sub_hw=(H, W), inputs=inputs, oracle_chunk=chunk)
+    return ce
+
+
+def cpu_leg(model, patch, mfma, device, timed_steps=2, sub_hw=None, u8=False, inputs=None, oracle_chunk=None):
     """The CPU oracle (oracle/, kind 'port') and the HIP path on the SAME bounded sample and the SAME weights: a 26x16
     = 416-spot sub-grid of synthetic array 0 (`sub_hw`: another sub-grid), tutorial mode.  Returns (cpu_baseline, ce_vs_ref).
     The HIP side runs first (forward + masked CE), on copies of the trainable parts so the benchmark model is untouched;
@@ -360,16 +388,20 @@ def cpu_leg(model, patch, mfma, device, timed_steps=2, sub_hw=None, u8=False):
     torch.set_num_threads(cores)
     SUB_H, SUB_W = sub_hw or (globals()['SUB_H'], globals()['SUB_W'])
     gen = torch.Generator().manual_seed(12345)
-    if u8:
-        x_img8 = torch.randint(0, 256, (1, SUB_H, SUB_W, 3, patch, patch), generator=gen, dtype=torch.uint8)
-        x_img = x_img8.float() / 255
+    if inputs is not None:                                       # (x_img (1,h,w,3,P,P) float, x_cnt (1,G,h,w), y (1,h,w)) on the CPU
+        x_img, x_cnt, y = inputs
+        x_hip = x_img
     else:
-        x_img = torch.rand((1, SUB_H, SUB_W, 3, patch, patch), generator=gen)
-    x_cnt = torch.randint(0, 10, (1, GENES, SUB_H, SUB_W), generator=gen).float()
-    y = torch.randint(0, CLASSES + 1, (1, SUB_H, SUB_W), generator=gen)
-    x_img *= (y > 0).float().view(1, SUB_H, SUB_W, 1, 1, 1)
-    x_cnt *= (y > 0).float().view(1, 1, SUB_H, SUB_W)
-    x_hip = (x_img8 * (y > 0).to(torch.uint8).view(1, SUB_H, SUB_W, 1, 1, 1)) if u8 else x_img
+        if u8:
+            x_img8 = torch.randint(0, 256, (1, SUB_H, SUB_W, 3, patch, patch), generator=gen, dtype=torch.uint8)
+            x_img = x_img8.float() / 255
+        else:
+            x_img = torch.rand((1, SUB_H, SUB_W, 3, patch, patch), generator=gen)
+        x_cnt = torch.randint(0, 10, (1, GENES, SUB_H, SUB_W), generator=gen).float()
+        y = torch.randint(0, CLASSES + 1, (1, SUB_H, SUB_W), generator=gen)
+        x_img *= (y > 0).float().view(1, SUB_H, SUB_W, 1, 1, 1)
+        x_cnt *= (y > 0).float().view(1, 1, SUB_H, SUB_W)
+        x_hip = (x_img8 * (y > 0).to(torch.uint8).view(1, SUB_H, SUB_W, 1, 1, 1)) if u8 else x_img
 
     # ---- HIP path on the sub-grid: the benchmark model's own image f (frozen: shared), copies of count f and corrector
     sub = ga.GridNetHexMM(model.image_classifier, copy.deepcopy(model.count_classifier), (3, patch, patch), (GENES,),
@@ -392,6 +424,8 @@ def cpu_leg(model, patch, mfma, device, timed_steps=2, sub_hw=None, u8=False):
     f_cnt = count_mlp(GENES, CLASSES)
     f_cnt.load_state_dict({k[len('count_classifier.'):]: v for k, v in state.items()
                            if k.startswith('count_classifier.')})
+    if oracle_chunk:
+        f_img = _chunked_frozen_f(f_img, oracle_chunk)
     g = ogn.GridNetHexMM(f_img, f_cnt, (3, patch, patch), (GENES,), (SUB_H, SUB_W), CLASSES)
     g.corrector.load_state_dict({k[len('corrector.'):]: v for k, v in state.items() if k.startswith('corrector.')})
     for p in g.patch_classifier.parameters():
@@ -700,7 +734,7 @@ def patch224_series(args, device, rank, world, steps=3, warmup=1, P=224):
     return out
 
 
-def config5_trained_series(args, device, rank, world, steps=3, warmup=1, P=256, probe_dump=None):
+def config5_trained_series(args, device, rank, world, steps=3, warmup=1, P=256, probe_dump=None, compare_fp32=True):
     """SURVEY 8d's "everything trained" column at config 5's geometry (22.21 GFLOP per spot): the multimodal step on one
     256-px array with both classifiers trained through f_opt on the fp16-MFMA path - `DenseNet.mfma = 'f16'` on the gradient
     path: fp16 tape (block buffers + activated bottlenecks, one chunk: ~110 GB), fp16-MFMA backward with fp32 accumulation
@@ -798,7 +832,7 @@ def config5_trained_series(args, device, rank, world, steps=3, warmup=1, P=256, 
                        "backward, fp32 accumulate / parameter gradients) + count MLP + hex g, 1 array (4992 spots) per step, f and "
                        "g trained (f_opt), eval-mode BN (calibrated statistics), uint8 patches resident in HBM"
                        % ("BASELINE config 5's geometry" if P == 256 else "config 4's geometry on config 5's fp16 path", P)}
-    if world == 1:
+    if world == 1 and compare_fp32:
         r32 = run('f32', 1, warmup + steps - 1, False)           # (its first step - allocator growth - is not in its timing)
         out["ce_vs_fp32_path"] = {"f16": r16["losses"], "f32": r32["losses"],
                                   "abs_diff": [abs(a - b) for a, b in zip(r16["losses"], r32["losses"])],
@@ -979,6 +1013,16 @@ def worker_main(args):
         cpu_base, ce = cpu_leg(model, args.patch, args.mfma, device)
         if args.mfma == 'f32':
             assert ce["abs_diff"] <= 1e-4, "CE of the HIP path differs from the CPU oracle by %.3e (> 1e-4)" % ce["abs_diff"]
+    # ---- the same comparison at the benchmark's OWN size: the first resident array, whole (forward + CE on the CPU: 1-3 min)
+    ce_full = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_full_grid_ce and args.patch <= 128:
+        (xi, xc), yy = arrays[0]
+        t0 = time.time()
+        ce_full = full_grid_ce(model, args.patch, args.mfma, device, inputs=(xi.cpu(), xc.cpu(), yy.cpu()))
+        ce_full["seconds"] = time.time() - t0
+        if args.mfma == 'f32':
+            assert ce_full["abs_diff"] <= 1e-4, "full-grid CE of the HIP path differs from the CPU oracle by %.3e" % ce_full["abs_diff"]
+            assert ce_full["argmax_agree"] == ce_full["argmax_compared"], "full-grid argmax disagreement on decided spots"
 
     elapsed, last_loss, probe = run_series(args.train_f, args.steps, args.warmup, not args.no_kernel_timing)
 
@@ -1048,6 +1092,8 @@ def worker_main(args):
                                                                                 "launches")} for k in order[2:]}
     if ce is not None:
         result["ce_vs_ref"] = ce
+    if ce_full is not None:
+        result["ce_vs_ref_full_grid"] = ce_full
     if cpu_base is not None:
         result["cpu_baseline"] = cpu_base
 
@@ -1114,6 +1160,33 @@ def worker_main(args):
     if world == 1 and not args.no_series and not args.train_f and args.mfma == 'f32' and args.patch == 128:
         optional("other_configs", lambda: other_configs(device))
     if rank == 0:
+        # ONE lean JSON line on stdout (the contract); the further series - each with its own roofline object - go to a
+        # file (default gpurun_out/bench_series.json; the copy of the round's final run is committed as profiles/rNN_series.json)
+        # and, one summary line each, to stderr
+        series = result.pop("series", None)
+        if series:
+            path = args.series_out or os.path.join(ROOT, 'gpurun_out', 'bench_series.json')
+            try:
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                with open(path, 'w') as fh:
+                    json.dump({"headline": {k: result[k] for k in ("value", "unit", "ms_per_step", "n_gpus", "steps", "dtype")},
+                               "series": series}, fh, indent=1)
+                result["series_file"] = os.path.relpath(path, ROOT)
+            except OSError as exc:
+                result["series_file"] = "not written (%s)" % exc
+            result["series_summary"] = {}
+            for name, ser in series.items():
+                if isinstance(ser, dict) and "value" in ser:
+                    result["series_summary"][name] = {"value": ser["value"], "unit": ser.get("unit"), "ms_per_step": ser.get("ms_per_step")}
+                    sys.stderr.write("series %-36s %12.1f %s  %s ms/step\n" % (name, ser["value"], ser.get("unit", ""), ser.get("ms_per_step")))
+                elif isinstance(ser, dict) and "error" in ser:
+                    result["series_summary"][name] = {"error": ser["error"]}
+                    sys.stderr.write("series %-36s FAILED: %s\n" % (name, ser["error"]))
+                elif isinstance(ser, dict):
+                    result["series_summary"][name] = {k: v.get("value") for k, v in ser.items() if isinstance(v, dict)}
+        for key in ("cpu_baseline", "ce_vs_ref", "ce_vs_ref_full_grid"):       # (last in the line: the driver keeps its tail)
+            if key in result:
+                result[key] = result.pop(key)
         print(json.dumps(result), flush=True)
     if gdist.is_active():
         torch.distributed.barrier()
@@ -1207,12 +1280,16 @@ def parse(argv):
     ap.add_argument('--backend', default=None, help='torch.distributed backend (default nccl = RCCL)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--full-grid-ce', action='store_true',
+                    help='(default at N = 1) CE vs the CPU oracle on ONE whole 78x64 array: `ce_vs_ref_full_grid`')
+    ap.add_argument('--no-full-grid-ce', action='store_true', help='skip the whole-array CE comparison (1-3 min of CPU forward)')
     ap.add_argument('--no-series', action='store_true', help='skip the extra series appended to the default run')
     ap.add_argument('--all-series', action='store_true',
                     help='with --gpus N > 1: also run the single-GPU characterisation series on every rank')
     ap.add_argument('--from-host', action='store_true',
                     help='(with --no-series) still run the fed-from-host-memory series: uint8 patches through the prefetcher')
     ap.add_argument('--series-steps', type=int, default=3)
+    ap.add_argument('--series-out', default=None, help='where the further series go as JSON (default gpurun_out/bench_series.json)')
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 

@@ -460,7 +460,10 @@ class DenseNet(nn.Module):
         # batch is padded with empty patches and the extra rows dropped: spots are independent under running statistics, and on
         # the gradient path the padding rows receive a zero output gradient, so they add nothing to any parameter gradient.
         pad = (-x.shape[0]) % 8
-        if self.mfma == 'f16' and pad and x.shape[0] > 0 and not self.training and not x.requires_grad and self.f16_buffers:
+        if self.mfma == 'f16' and pad and x.shape[0] > 0 and not self.training and not x.requires_grad and self.f16_buffers \
+                and not self.small_inputs and x.shape[2] in (128, 256) and self.growth_rate == 32 \
+                and (self.bn_size * self.growth_rate) % 128 == 0:     # (only calls the fp16-buffer kernels can take: others
+            #                                                            would pay the copy and 7 extra spots for nothing)
             xp = torch.cat([x, x.new_zeros((pad,) + tuple(x.shape[1:]))], 0)
             return self.forward(xp)[:x.shape[0]]
         if self.training or needs_grad:

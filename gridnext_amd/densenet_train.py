@@ -335,6 +335,8 @@ class _DenseNetFn(Function):
         # backward (distributed.BackwardReducer); what autograd receives is already the average over ranks
         from . import distributed as gdist
         reducer = gdist.BackwardReducer() if gdist.BackwardReducer.wanted() else None
+        if gdist.is_active():
+            gdist.note_backward(reducer is not None)     # (all backwards of one optimizer step must deliver alike)
         sent = set()
 
         def send_bucket():

@@ -11,7 +11,9 @@ that enters the network (no host synchronisation): s = 2^floor(12 - log2(max |df
 largest element of the last block's gradient lands in [2^11, 2^12) - a factor 16 of headroom before fp16 overflows and 26
 binades down to the smallest normal.  Every fp16 gradient tensor holds s x the true gradient; every fp32 result is multiplied
 by 1/s (exact) where its partial sums are reduced.  `model.f16_grad_overflow` (device int32) is OR-ed with 1 by any kernel
-that reduces a non-finite value; `model.f16_grad_scale` holds {s, 1/s} of the last backward.  At every transition the scale
+that reduces a non-finite value - STICKY across backwards (gradient accumulation), read and cleared by the training loop
+before every optimizer step (`training._F16StepGuard`: an overflowed step is skipped and `model.f16_grad_target`, the
+exponent 12 above, is lowered by one); `model.f16_grad_scale` holds {s, 1/s} of the last backward.  At every transition the scale
 is re-centred for the block in front (another power of two, from the largest element of the pooled gradient that enters it):
 `model.f16_grad_block_scales` lists the blocks' {s, 1/s}, last block first.
 
@@ -192,6 +194,8 @@ class _DenseNetF16Fn(Function):
 
         from . import distributed as gdist
         reducer = gdist.BackwardReducer() if gdist.BackwardReducer.wanted() else None
+        if gdist.is_active():
+            gdist.note_backward(reducer is not None)     # (all backwards of one optimizer step must deliver alike)
         sent = set()
 
         def send_bucket():
@@ -226,8 +230,11 @@ class _DenseNetF16Fn(Function):
         sf = tape.statsf
         s_last = sizes[-1]
         S2 = s_last * s_last
+        # (the target exponent: 12 = 16x of headroom below the fp16 maximum; the training loops lower it after a step that
+        #  overflowed and restore it after a run of clean steps - training._F16StepGuard)
+        tgt = float(model.__dict__.get('f16_grad_target', 12.0))
         top = dfeats.abs().max() * sf[0][:c_last].abs().max() / S2
-        e = torch.where(top > 0, torch.floor(12.0 - torch.log2(top.clamp_min(1e-38))), torch.zeros_like(top)).clamp(-24.0, 60.0)
+        e = torch.where(top > 0, torch.floor(tgt - torch.log2(top.clamp_min(1e-38))), torch.zeros_like(top)).clamp(-24.0, 60.0)
         s_val = torch.exp2(e)
         ls = torch.stack([s_val, 1.0 / s_val]).to(F32).contiguous()
         model.__dict__['f16_grad_scale'] = ls
@@ -321,7 +328,7 @@ class _DenseNetF16Fn(Function):
                 # writes f x its block gradient while its own sums still carry the old scale.
                 mn, mx = torch.aminmax(dPool)                   # (one pass; abs() would write a copy of the tensor first)
                 amax = torch.maximum(mx, -mn).to(F32)
-                f_e = torch.where(amax > 0, torch.floor(12.0 - torch.log2(amax.clamp_min(1e-30))), torch.zeros_like(amax))
+                f_e = torch.where(amax > 0, torch.floor(tgt - torch.log2(amax.clamp_min(1e-30))), torch.zeros_like(amax))
                 f_e = torch.minimum(torch.maximum(f_e, -24.0 - torch.log2(ls_cur[0])), 60.0 - torch.log2(ls_cur[0])).clamp(-12.0, 12.0)
                 f_val = torch.exp2(f_e)
                 sc_f, sh_f = (stt[0] * f_val).contiguous(), (stt[1] * f_val).contiguous()      # (kept alive across the call)

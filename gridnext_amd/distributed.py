@@ -21,6 +21,7 @@ the loss is the mean over the foreground spots of all ranks (an all-reduce of n_
 step on a single batch of `world` arrays.
 """
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -85,18 +86,44 @@ def optimizer_params(*optimizers):
     return out
 
 
-_FLAT = {}            # (device, dtype, numel-signature) -> persistent flat gradient buffer
+_FLAT = {}            # (device, dtype, identity of the parameter set) -> persistent flat gradient buffer
 _EARLY = set()        # id(p) of parameters whose CURRENT gradient contributions were already averaged inside backward
+_STEP_MODE = [None]   # how the backwards since the last step delivered a trained DenseNet's gradients: 'early' | 'late'
 
 
 def _flat_buffer(params):
-    """One persistent flat tensor holding the gradients of `params` back to back (allocated once per parameter set, reused
-    by every step: no `cat` allocation, no copy-back)."""
-    key = (params[0].device, params[0].dtype, tuple(p.numel() for p in params))
+    """One persistent flat tensor holding the gradients of `params` back to back (allocated once per parameter SET, reused
+    by every step: no `cat` allocation, no copy-back).  Keyed on the parameters' identity - two models of the same
+    architecture (cross-validation folds, ensembles) own different buffers, so one set's `.grad` views are never overwritten
+    by the other's reduction - and dropped when the set's first parameter dies."""
+    key = (params[0].device, params[0].dtype, tuple(id(p) for p in params))
     flat = _FLAT.get(key)
     if flat is None:
-        flat = _FLAT[key] = torch.zeros(sum(key[2]), device=key[0], dtype=key[1])
+        flat = _FLAT[key] = torch.zeros(sum(p.numel() for p in params), device=key[0], dtype=key[1])
+        weakref.finalize(params[0], _FLAT.pop, key, None)
     return flat
+
+
+def note_backward(early):
+    """A trained DenseNet's backward reports how it delivered its gradients: averaged inside the backward (`early`, through a
+    BackwardReducer) or raw, for the step's flat call.  All backwards that accumulate into ONE optimizer step must agree -
+    otherwise a parameter's gradient would be the sum of an averaged and an un-averaged part and `allreduce_gradients` could
+    repair neither.  The first backward after a step decides; `BackwardReducer.wanted()` follows a 'late' decision, and an
+    'early' decision that a later backward cannot honour (a backward under graph capture, GNX_DP_OVERLAP changed mid-step)
+    is an error instead of a silent divergence of the ranks."""
+    mode = 'early' if early else 'late'
+    if _STEP_MODE[0] is None:
+        _STEP_MODE[0] = mode
+    elif _STEP_MODE[0] != mode:
+        raise RuntimeError("gridnext_amd.distributed: the backwards accumulated into one optimizer step delivered their "
+                           "gradients both averaged-inside-backward and raw; set GNX_DP_OVERLAP=0 for steps that mix eager "
+                           "and graph-captured backwards")
+
+
+def discard_step():
+    """Forget the per-step bookkeeping of gradients that will NOT be applied (a skipped optimizer step)."""
+    _EARLY.clear()
+    _STEP_MODE[0] = None
 
 
 def allreduce_gradients(params):
@@ -106,10 +133,10 @@ def allreduce_gradients(params):
     back.  Parameters whose gradients were already averaged bucket by bucket inside backward (`BackwardReducer`: a trained
     DenseNet's dense blocks) are skipped."""
     if not is_active():
-        _EARLY.clear()
+        discard_step()
         return
     params = [p for p in params if p.requires_grad and id(p) not in _EARLY]
-    _EARLY.clear()
+    discard_step()
     by = {}
     for p in params:
         by.setdefault((p.device, p.dtype), []).append(p)
@@ -154,16 +181,17 @@ class BackwardReducer:
     @staticmethod
     def wanted():
         return is_active() and os.environ.get('GNX_DP_OVERLAP', '1') != '0' and not sync_active() and \
-            not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+            _STEP_MODE[0] != 'late' and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
 
     def bucket(self, tensors, params):
         if not tensors:
             return
-        key = ('bucket', len(self.pending)) + tuple(t.numel() for t in tensors)
-        flat = _FLAT.get((tensors[0].device, tensors[0].dtype, key))
+        key = (tensors[0].device, tensors[0].dtype, ('bucket', len(self.pending)) + tuple(id(p) for p in params))
+        flat = _FLAT.get(key)
         if flat is None:
-            flat = _FLAT[(tensors[0].device, tensors[0].dtype, key)] = torch.empty(
-                sum(t.numel() for t in tensors), device=tensors[0].device, dtype=tensors[0].dtype)
+            flat = _FLAT[key] = torch.empty(sum(t.numel() for t in tensors), device=tensors[0].device, dtype=tensors[0].dtype)
+            if params:
+                weakref.finalize(params[0], _FLAT.pop, key, None)
         views, off = [], 0
         for t in tensors:
             views.append(flat[off:off + t.numel()].view_as(t))

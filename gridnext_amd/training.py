@@ -112,6 +112,54 @@ class _BestKeeper:
         return False
 
 
+class _F16StepGuard:
+    """Skip-step on fp16 gradient overflow (new with the fp16-MFMA gradient path; the fp32 reference needs none).
+
+    A DenseNet whose backward ran on the fp16 kernels (`densenet_train_f16`) owns a sticky device flag, `f16_grad_overflow`,
+    that any of those kernels sets when it reduces a non-finite value.  `ok()` is called right before the optimizers step:
+    it reads AND clears the flags (one 4-byte read-back per optimizer step, only once a model has used that path; with
+    several ranks the flag is MAX-reduced first so that every rank takes the same decision).  On overflow the caller skips
+    both optimizers and drops the accumulated gradients; the loss-scale target of the affected network
+    (`f16_grad_target`, the exponent the largest gradient element is centred on: 12) goes down by one - half the scale - and
+    comes back up by one after `GROWTH_INTERVAL` consecutive clean steps, as torch's GradScaler does."""
+    GROWTH_INTERVAL = 200
+    TARGET_MAX, TARGET_MIN = 12.0, 2.0
+
+    def __init__(self, model):
+        self.model = model
+        self.skipped = 0
+        self.clean = 0
+
+    def _nets(self):
+        return [m for m in self.model.modules() if m.__dict__.get('f16_grad_overflow') is not None]
+
+    def ok(self):
+        nets = self._nets()
+        if not nets:
+            return True
+        flags = torch.stack([m.__dict__['f16_grad_overflow'].reshape(()) for m in nets])
+        if gdist.is_active():
+            torch.distributed.all_reduce(flags, op=torch.distributed.ReduceOp.MAX)
+        hit = flags.tolist()
+        if not any(hit):
+            self.clean += 1
+            if self.clean >= self.GROWTH_INTERVAL:
+                self.clean = 0
+                for m in nets:
+                    m.f16_grad_target = min(self.TARGET_MAX, float(m.__dict__.get('f16_grad_target', self.TARGET_MAX)) + 1.0)
+            return True
+        self.clean = 0
+        self.skipped += 1
+        for m, h in zip(nets, hit):
+            m.__dict__['f16_grad_overflow'].zero_()
+            if h:
+                m.f16_grad_target = max(self.TARGET_MIN, float(m.__dict__.get('f16_grad_target', self.TARGET_MAX)) - 1.0)
+        if gdist.rank() == 0:
+            print('fp16 gradient overflow: optimizer step skipped, loss-scale target lowered to 2^%d'
+                  % int(min(float(m.__dict__.get('f16_grad_target', self.TARGET_MAX)) for m in nets)), flush=True)
+        return False
+
+
 def _banner(epoch, num_epochs):
     if gdist.rank() == 0:
         print('Epoch {}/{}'.format(epoch, num_epochs - 1), flush=True)
@@ -138,6 +186,7 @@ def train_spotwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
     device = gdist.default_device()
     model.to(device)
     fused_ok = _plain_ce(criterion)
+    guard = _F16StepGuard(model)
     hip_mlp = GF.is_hip_sequential(model)
     # an MLP step is ~40 kernels of a few microseconds: launched one by one the loop is bound by the host (1 ms per batch of
     # 128 against ~0.15 ms of kernel time).  Forward, fused CE and backward of each (phase, batch shape) are captured into a
@@ -193,8 +242,11 @@ def train_spotwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
                     on_device = outputs.is_cuda
                     del outputs
                 if phase == 'train':
-                    gdist.allreduce_gradients(gdist.optimizer_params(optimizer))
-                    optimizer.step()
+                    if guard.ok():
+                        gdist.allreduce_gradients(gdist.optimizer_params(optimizer))
+                        optimizer.step()
+                    else:
+                        gdist.discard_step()
                 meter.add(loss if on_device else loss.item(), batch_size, correct, batch_size)
                 loss = correct = None
             loss_sum, n_right, _, seen = meter.totals()
@@ -246,6 +298,7 @@ def train_gridwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
     model.to(device)
     fused_ok = _plain_ce(criterion)
     stepped = gdist.optimizer_params(optimizer, f_opt)
+    guard = _F16StepGuard(model)
     # launch-bound models (count-only f + g: ~60 kernels of 5-20 us per array): the step is captured once per phase and input
     # shape into a hipGraph and replayed (graphs.py); optimizer, all-reduce and statistics stay eager
     stepper = None
@@ -279,11 +332,15 @@ def train_gridwise(model, dataloaders, criterion, optimizer, num_epochs=10, outf
                             loss.backward()
                     if phase == 'train':
                         if batch_ind % accum_iters == 0:
-                            gdist.allreduce_gradients(stepped)
-                            optimizer.step()
+                            if guard.ok():
+                                gdist.allreduce_gradients(stepped)
+                                optimizer.step()
+                                if f_opt is not None:
+                                    f_opt.step()
+                            else:                           # a non-finite fp16 gradient: nothing of this step is applied
+                                gdist.discard_step()
                             optimizer.zero_grad()
                             if f_opt is not None:
-                                f_opt.step()
                                 f_opt.zero_grad()
                 meter.add(loss if labels.is_cuda else loss.item(), batch_size, correct, n_fg)
             loss_sum, n_right, n_fg_total, seen = meter.totals()

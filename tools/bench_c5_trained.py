@@ -16,17 +16,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--no-fp32', action='store_true', help='skip the fp32-path comparison run (world > 1 semantics)')
+    ap.add_argument('--no-fp32', action='store_true', help='skip the fp32-path comparison run')
     ap.add_argument('--layers', default='', help='write the per-launch probe records (kind, ms, flops, bytes) to this JSON file')
     ap.add_argument('--patch', type=int, default=256)
     a = ap.parse_args()
     import torch
     from gridnext_amd import distributed as gdist
     rank, world, device = gdist.init_from_env(None)
-    out = bench.config5_trained_series(argparse.Namespace(), device, rank, 2 if a.no_fp32 else world, steps=a.steps, warmup=a.warmup,
-                                       P=a.patch, probe_dump=a.layers or None)
-    if a.no_fp32:
-        out["value"] /= 2
+    out = bench.config5_trained_series(argparse.Namespace(), device, rank, world, steps=a.steps, warmup=a.warmup,
+                                       P=a.patch, probe_dump=a.layers or None, compare_fp32=not a.no_fp32)
     print(json.dumps(out))
 
 
