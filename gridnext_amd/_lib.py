@@ -76,6 +76,13 @@ SIGNATURES = {
     'gnx_stem_bwd_f16': (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P, _P]),
     'gnx_dense_layer_f16_pack': (_I, [_P, _P, _P, _P, _I, _P]),
     'gnx_dense_layer_f16': (_I, [_P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    'gnx_dense_layer_f16_tape': (_I, [_P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    'gnx_wgrad3x3_f16_lb': (_I, [_P, _L, _P, _L, _L, _P, _P, _L, _I, _P, _I, _P, _P]),
+    'gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb': (_I, [_P, _L, _P, _P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16_lb': (_I, [_P, _P, _P, _L, _L, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I,
+                                                       _P, _P]),
+    'gnx_tail_bwd_f16_lb': (_I, [_P, _L, _P, _L, _L, _P, _L, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'gnx_trans_bwd_f16_lb': (_I, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'gnx_conv_stem_bnrelu_maxpool_f16mul_cb': (_I, [_P, _I, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'gnx_conv1x1_bnrelu_h16_cb': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _P, _P, _P]),
     'gnx_bnrelu_avgpool2_h16_cb': (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _P]),

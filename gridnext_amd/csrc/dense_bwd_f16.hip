@@ -22,6 +22,12 @@
 // MFMA fragments for a workgroup's lifetime (conv2's nine taps: 72 registers; a 128-channel slice of conv1: 32).
 // Sums over pixels (weight gradients, BatchNorm adjoint sums) are per-workgroup slabs reduced in a fixed order: deterministic,
 // no float atomics.
+//
+// LAYOUTS (round 5).  The block buffers, their gradients and the activated bottleneck are addressed through (ld, bs): element
+// (row, c) lies at row * ld + (c >> 5) * bs + (c & 31).  bs = 32 is the row-major [rows][ld] matrix described above;
+// ld = 32, bs = rows_total * 32 is the CHANNEL-BLOCKED form [C / 32][rows_total][32] the fused forward kernel
+// (gnx_dense_layer_f16_tape) reads and writes - the gradient path of densenet_train_f16.py runs on that one, so forward and
+// backward share buffers; a layer's 32 new channels (its dY) are then one contiguous [rows][32] matrix.
 #include "common.h"
 
 namespace {
@@ -165,8 +171,8 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_f16_kernel(const _Float16* __
 // P0 + 64 + S + 1) is staged once and read at nine row offsets; rows a tap may not read are redirected - by the lane that
 // supplies that row's address - to a row of zeros.  Wave w owns channels k = 32 w .. 32 w + 31 for all nine taps.
 __global__ __launch_bounds__(256, 2) void wgrad3x3_f16_kernel(const _Float16* __restrict__ dY, long lddy,
-                                                              const _Float16* __restrict__ A, float* __restrict__ ws, long M,
-                                                              int S, long tiles_per_slab) {
+                                                              const _Float16* __restrict__ A, long lda, long bsa,
+                                                              float* __restrict__ ws, long M, int S, long tiles_per_slab) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     const int nrows = 66 + 2 * S;
     char* const At = dyn;
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_f16_kernel(const _Float16* __
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long row = P0 + row0 + 16 * i;
-            av[i] = row < M ? ldg8(A + row * 128 + chunk * 8) : zero8();
+            av[i] = row < M ? ldg8(A + row * lda + (chunk >> 2) * bsa + (chunk & 3) * 8) : zero8();
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -269,8 +275,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_f16_kernel(const _Float16* __
 // against 9 MFMAs.)
 template <int S>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_f16_p2_kernel(const _Float16* __restrict__ dY, long lddy,
-                                                                 const _Float16* __restrict__ A, float* __restrict__ ws, long M,
-                                                                 long tiles_per_slab) {
+                                                                 const _Float16* __restrict__ A, long lda, long bsa,
+                                                                 float* __restrict__ ws, long M, long tiles_per_slab) {
     constexpr int NIMG = S >= 8 ? 1 : 64 / (S * S);                 // images per tile
     constexpr int NR = S >= 8 ? 64 / S : S;                         // image rows per tile and image
     constexpr int PW = S + 2, PIMG = (NR + 2) * PW;                 // padded row length, padded positions per image
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_f16_p2_kernel(const _Float16*
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long row = P0 + row0 + 16 * i;
-            av[i] = row < M ? ldg8(A + row * 128 + chunk * 8) : zero8();
+            av[i] = row < M ? ldg8(A + row * lda + (chunk >> 2) * bsa + (chunk & 3) * 8) : zero8();
         }
         const int y0 = S >= 8 ? (int)((P0 & (S * S - 1)) >> LG) : 0;      // the tile's first row inside its image
         const long img0 = P0 - ((long)y0 << LG);                           // first pixel of the (first) image
@@ -366,7 +372,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_f16_p2_kernel(const _Float16*
 template <int SP>
 __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16* __restrict__ dY, long lddy,
                                                                  const _Float16* __restrict__ W2b,
-                                                                 const _Float16* __restrict__ A, _Float16* __restrict__ dB,
+                                                                 const _Float16* __restrict__ A, long lda, long bsa,
+                                                                 _Float16* __restrict__ dB,
                                                                  const float* __restrict__ scale2, float* __restrict__ ws, long M,
                                                                  int S_rt, long tiles_per_wg) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16*
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const long row = P0 + row0 + 16 * i;
-            av[i] = row < M ? ldg8(A + row * 128 + chunk * 8) : zero8();
+            av[i] = row < M ? ldg8(A + row * lda + (chunk >> 2) * bsa + (chunk & 3) * 8) : zero8();
         }
         if constexpr (SP > 0) {
             const int y0 = SP >= 16 ? (int)((P0 & (SP * SP - 1)) >> LG) : 0;
@@ -544,8 +551,8 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16*
 // quarter of this kernel's bytes) is not made.  64 more accumulator registers: two workgroups per CU instead of three.
 template <bool WGRAD>
 __global__ __launch_bounds__(256, WGRAD ? 2 : 3) void dgrad1x1_bn_f16_kernel(
-    const _Float16* __restrict__ dB, const _Float16* __restrict__ W1t, const _Float16* __restrict__ X, long ldx,
-    _Float16* __restrict__ G, long ldg, const float* __restrict__ scale, const float* __restrict__ shift,
+    const _Float16* __restrict__ dB, const _Float16* __restrict__ W1t, const _Float16* __restrict__ X, long ldx, long bsx,
+    _Float16* __restrict__ G, long ldg, long bsg, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, float* __restrict__ ws, long M, int cin, int n_cb, long tiles_per_slab, long n_slabs,
     float* __restrict__ wsw) {
     __shared__ __attribute__((aligned(16))) char smem[3 * 64 * R_RS + 3 * 128 * 4];
@@ -565,6 +572,8 @@ __global__ __launch_bounds__(256, WGRAD ? 2 : 3) void dgrad1x1_bn_f16_kernel(
     const long tile1 = tile0 + tiles_per_slab < ntiles ? tile0 + tiles_per_slab : ntiles;
     const int chunk = t & 15, row0 = t >> 4;
     const bool cok = cbase + chunk * 8 < cin;
+    const long xcol = (long)((cbase >> 5) + (chunk >> 2)) * bsx + (chunk & 3) * 8;     // this thread's 8 channels: (c >> 5) bs + (c & 31)
+    const long gcol = (long)((cbase >> 5) + (chunk >> 2)) * bsg + (chunk & 3) * 8;
     if (t < 128) {
         const bool ok = cbase + t < cin;
         cst[t] = ok ? scale[cbase + t] : 0.f;
@@ -590,8 +599,8 @@ __global__ __launch_bounds__(256, WGRAD ? 2 : 3) void dgrad1x1_bn_f16_kernel(
             const long row = m0 + row0 + 16 * i;
             const bool ok = row < M;
             bv[i] = ok ? ldg8(dB + row * 128 + chunk * 8) : zero8();
-            xv[i] = (ok && cok) ? ldg8(X + row * ldx + cbase + chunk * 8) : zero8();
-            gv[i] = (ok && cok) ? ldg8(G + row * ldg + cbase + chunk * 8) : zero8();
+            xv[i] = (ok && cok) ? ldg8(X + row * ldx + xcol) : zero8();
+            gv[i] = (ok && cok) ? ldg8(G + row * ldg + gcol) : zero8();
         }
     };
     if (tile0 < tile1) fetch(tile0);
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(256, WGRAD ? 2 : 3) void dgrad1x1_bn_f16_kernel(
             for (int i = 0; i < 4; ++i) {
                 const long row = m0 + row0 + 16 * i;
                 if (row < M)
-                    *reinterpret_cast<h8*>(G + row * ldg + cbase + chunk * 8) =
+                    *reinterpret_cast<h8*>(G + row * ldg + gcol) =
                         *reinterpret_cast<const h8*>(Gt + (row0 + 16 * i) * R_RS + chunk * 16);
             }
         }
@@ -702,18 +711,35 @@ __global__ __launch_bounds__(256, WGRAD ? 2 : 3) void dgrad1x1_bn_f16_kernel(
 // ------------------------------------------------------------------------------------------------ elementwise adjoints (HBM passes)
 // norm_final -> relu -> global average (densenet.py:153-156): G[p][c] = s * scale[c] [bn(X[p][c]) > 0] dfeats[img][c] / S2 and the
 // BatchNorm sums (true scale: computed from the fp32 gradient).  One thread = 8 channels of one image slot.
+// Thread -> (slot, 8 channels): row-major buffers give consecutive threads consecutive 16-B columns of one row; channel-
+// blocked buffers (`blocked`) give a wave ONE 32-channel block of 16 slots - 4 threads per 64-B block row - so that its
+// accesses stay whole contiguous pieces of memory.
+__device__ __forceinline__ bool slot_chunk(long gid, int C, bool blocked, long slots, long& slot, int& chunk) {
+    if (blocked) {
+        const int nb = C >> 5;
+        const long rest = gid >> 6;
+        chunk = (int)(rest % nb) * 4 + (int)(gid & 3);
+        slot = (rest / nb) * 16 + ((gid >> 2) & 15);
+    } else {
+        const int nch = C / 8;
+        chunk = (int)(gid % nch);
+        slot = gid / nch;
+    }
+    return slot < slots;
+}
 __global__ __launch_bounds__(256) void tail_bwd_f16_kernel(const float* __restrict__ dfeats, long ldf,
-                                                           const _Float16* __restrict__ X, long ldx, _Float16* __restrict__ G,
-                                                           long ldg, const float* __restrict__ scale,
+                                                           const _Float16* __restrict__ X, long ldx, long bsx,
+                                                           _Float16* __restrict__ G, long ldg, long bsg,
+                                                           const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ mean,
                                                            const float* __restrict__ ls, float* __restrict__ ws, long imgs, int C,
-                                                           int S2, int slots) {
-    const int nch = C / 8;
+                                                           int S2, int slots, int blocked) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const int chunk = (int)(gid % nch);
-    const long slot = gid / nch;
-    if (slot >= slots) return;
+    int chunk;
+    long slot;
+    if (!slot_chunk(gid, C, blocked != 0, slots, slot, chunk)) return;
     const int c0 = chunk * 8;
+    const long xcol = (long)(c0 >> 5) * bsx + (c0 & 31), gcol = (long)(c0 >> 5) * bsg + (c0 & 31);
     float sc[8], sh[8], mu[8], S0[8], S1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -734,7 +760,7 @@ __global__ __launch_bounds__(256) void tail_bwd_f16_kernel(const float* __restri
         }
         for (int p = 0; p < S2; ++p) {
             const long row = img * S2 + p;
-            const h8 x = ldg8(X + row * ldx + c0);
+            const h8 x = ldg8(X + row * ldx + xcol);
             h8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -744,7 +770,7 @@ __global__ __launch_bounds__(256) void tail_bwd_f16_kernel(const float* __restri
                 S1[j] += v * (xf - mu[j]);
                 o[j] = (_Float16)(v * sc[j] * s);
             }
-            *reinterpret_cast<h8*>(G + row * ldg + c0) = o;
+            *reinterpret_cast<h8*>(G + row * ldg + gcol) = o;
         }
     }
     float* const out = ws + slot * 2L * C;
@@ -758,17 +784,20 @@ __global__ __launch_bounds__(256) void tail_bwd_f16_kernel(const float* __restri
 // Transition norm -> relu -> (conv) -> avgpool 2x2 (densenet.py:47-54, evaluated pool-first): given the gradient of the POOLED
 // activated map dP [imgs (S/2)^2][C], G[p][c] = scale[c] [bn(X[p][c]) > 0] dP[pool(p)][c] / 4 for all four source pixels (this
 // INITIALISES the block gradient) and the BatchNorm sums (scaled by s like dP).  One thread = 8 channels of one pooled pixel.
-__global__ __launch_bounds__(256) void trans_bwd_f16_kernel(const _Float16* __restrict__ dP, long ldp,
-                                                            const _Float16* __restrict__ X, long ldx, _Float16* __restrict__ G,
-                                                            long ldg, const float* __restrict__ scale,
+__global__ __launch_bounds__(256) void trans_bwd_f16_kernel(const _Float16* __restrict__ dP, long ldp, long bsp,
+                                                            const _Float16* __restrict__ X, long ldx, long bsx,
+                                                            _Float16* __restrict__ G, long ldg, long bsg,
+                                                            const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const float* __restrict__ mean,
-                                                            float* __restrict__ ws, long imgs, int C, int S, int slots) {
-    const int nch = C / 8;
+                                                            float* __restrict__ ws, long imgs, int C, int S, int slots,
+                                                            int blocked) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const int chunk = (int)(gid % nch);
-    const long slot = gid / nch;
-    if (slot >= slots) return;
+    int chunk;
+    long slot;
+    if (!slot_chunk(gid, C, blocked != 0, slots, slot, chunk)) return;
     const int c0 = chunk * 8;
+    const long pcol = (long)(c0 >> 5) * bsp + (c0 & 31), xcol = (long)(c0 >> 5) * bsx + (c0 & 31),
+               gcol = (long)(c0 >> 5) * bsg + (c0 & 31);
     float sc[8], sh[8], mu[8], S0[8], S1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -783,14 +812,14 @@ __global__ __launch_bounds__(256) void trans_bwd_f16_kernel(const _Float16* __re
         const long img = q / (So * So);
         const int rem = (int)(q - img * So * So);
         const int oy = rem / So, ox = rem - oy * So;
-        const h8 dp = ldg8(dP + q * ldp + c0);
+        const h8 dp = ldg8(dP + q * ldp + pcol);
         float d[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) d[j] = 0.25f * (float)dp[j];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const long row = (img * S + 2 * oy + (k >> 1)) * S + 2 * ox + (k & 1);
-            const h8 x = ldg8(X + row * ldx + c0);
+            const h8 x = ldg8(X + row * ldx + xcol);
             h8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -800,7 +829,7 @@ __global__ __launch_bounds__(256) void trans_bwd_f16_kernel(const _Float16* __re
                 S1[j] += v * (xf - mu[j]);
                 o[j] = (_Float16)(v * sc[j]);
             }
-            *reinterpret_cast<h8*>(G + row * ldg + c0) = o;
+            *reinterpret_cast<h8*>(G + row * ldg + gcol) = o;
         }
     }
     float* const out = ws + slot * 2L * C;
@@ -975,38 +1004,47 @@ GNX_EXPORT int gnx_wgrad1x1_f16(const void* dY16, long lddy, const void* X16, lo
 
 // dW2[32][128][3][3] (fp32, torch layout, (+)=) = 1/s sum_p dY16[p - (dy, dx)][n] A16[p][k] over S x S images.
 GNX_EXPORT long gnx_wgrad3x3_f16_workspace(long M) { return plan_slabs(M, 64, 512).slabs * 9L * 32 * 128; }
-GNX_EXPORT int gnx_wgrad3x3_f16(const void* dY16, long lddy, const void* A16, float* dW, float* workspace, long M, int S,
-                                const float* ls, int accumulate, int* flag, hipStream_t stream) {
-    if (!dY16 || !A16 || !dW || !workspace || !ls || M <= 0 || S <= 0 || lddy < 32 || M % ((long)S * S) != 0) return GNX_ERR_BAD_ARG;
-    if (lddy % 8 || !al16b(dY16) || !al16b(A16) || S > 64) return GNX_ERR_UNSUPPORTED;
+// `_lb`: A16 given as (lda, bsa) - element (row, k) at row * lda + (k >> 5) * bsa + (k & 31); (128, 32) is the row-major
+// [M][128] matrix of gnx_wgrad3x3_f16, (32, rows_total * 32) the channel-blocked tape of gnx_dense_layer_f16_tape.
+GNX_EXPORT int gnx_wgrad3x3_f16_lb(const void* dY16, long lddy, const void* A16, long lda, long bsa, float* dW, float* workspace,
+                                   long M, int S, const float* ls, int accumulate, int* flag, hipStream_t stream) {
+    if (!dY16 || !A16 || !dW || !workspace || !ls || M <= 0 || S <= 0 || lddy < 32 || M % ((long)S * S) != 0 || lda < 32 || bsa < 32)
+        return GNX_ERR_BAD_ARG;
+    if (lddy % 8 || lda % 8 || bsa % 8 || !al16b(dY16) || !al16b(A16) || S > 64) return GNX_ERR_UNSUPPORTED;
     const SlabPlan p = plan_slabs(M, 64, 512);
     const _Float16* dY = reinterpret_cast<const _Float16*>(dY16);
     const _Float16* A = reinterpret_cast<const _Float16*>(A16);
     const size_t lds = (size_t)64 * T_RS + (size_t)(66 + 2 * S) * 64 + 64;
     switch (M % 64 == 0 ? S : 0) {                                  // power-of-two maps, whole tiles: the padded-image form
-        case 4: wgrad3x3_f16_p2_kernel<4><<<(int)p.slabs, 256, 0, stream>>>(dY, lddy, A, workspace, M, p.per); break;
-        case 8: wgrad3x3_f16_p2_kernel<8><<<(int)p.slabs, 256, 0, stream>>>(dY, lddy, A, workspace, M, p.per); break;
-        case 16: wgrad3x3_f16_p2_kernel<16><<<(int)p.slabs, 256, 0, stream>>>(dY, lddy, A, workspace, M, p.per); break;
-        case 32: wgrad3x3_f16_p2_kernel<32><<<(int)p.slabs, 256, 0, stream>>>(dY, lddy, A, workspace, M, p.per); break;
-        case 64: wgrad3x3_f16_p2_kernel<64><<<(int)p.slabs, 256, 0, stream>>>(dY, lddy, A, workspace, M, p.per); break;
-        default: wgrad3x3_f16_kernel<<<(int)p.slabs, 256, lds, stream>>>(dY, lddy, A, workspace, M, S, p.per);
+        case 4: wgrad3x3_f16_p2_kernel<4><<<(int)p.slabs, 256, 0, stream>>>(dY, lddy, A, lda, bsa, workspace, M, p.per); break;
+        case 8: wgrad3x3_f16_p2_kernel<8><<<(int)p.slabs, 256, 0, stream>>>(dY, lddy, A, lda, bsa, workspace, M, p.per); break;
+        case 16: wgrad3x3_f16_p2_kernel<16><<<(int)p.slabs, 256, 0, stream>>>(dY, lddy, A, lda, bsa, workspace, M, p.per); break;
+        case 32: wgrad3x3_f16_p2_kernel<32><<<(int)p.slabs, 256, 0, stream>>>(dY, lddy, A, lda, bsa, workspace, M, p.per); break;
+        case 64: wgrad3x3_f16_p2_kernel<64><<<(int)p.slabs, 256, 0, stream>>>(dY, lddy, A, lda, bsa, workspace, M, p.per); break;
+        default: wgrad3x3_f16_kernel<<<(int)p.slabs, 256, lds, stream>>>(dY, lddy, A, lda, bsa, workspace, M, S, p.per);
     }
     const long n = 9L * 32 * 128;
     reduce_slabs_kernel<<<(int)((n + 15) / 16), 256, 0, stream>>>(workspace, p.slabs, n, dW, ls, accumulate, 1, flag);
     return gnx_launch_status();
 }
+GNX_EXPORT int gnx_wgrad3x3_f16(const void* dY16, long lddy, const void* A16, float* dW, float* workspace, long M, int S,
+                                const float* ls, int accumulate, int* flag, hipStream_t stream) {
+    return gnx_wgrad3x3_f16_lb(dY16, lddy, A16, 128, 32, dW, workspace, M, S, ls, accumulate, flag, stream);
+}
 
 // dB16[M][128] = scale2 * conv3x3^T(dY16, W2) * [A16 > 0]; dgamma2 / dbeta2 (fp32, (+)=) with x_hat recovered from the stored
 // activation (gamma2 != 0 everywhere).  W2b16: conv2.weight as [tap][128][32] halves (W2b[tap][m][n] = W[n][m][tap]).
 GNX_EXPORT long gnx_conv3x3_dgrad_bnrelu_bwd_f16_workspace(long M) { return plan_slabs(M, 128, 512).slabs * 256L; }
-GNX_EXPORT int gnx_conv3x3_dgrad_bnrelu_bwd_f16(const void* dY16, long lddy, const void* W2b16, const void* A16, void* dB16, long M,
-                                                int S, const float* scale2, const float* gamma2, const float* beta2,
-                                                float* dgamma, float* dbeta, float* workspace, const float* ls, int accumulate,
-                                                int* flag, hipStream_t stream) {
+// `_lb`: A16 as (lda, bsa), see gnx_wgrad3x3_f16_lb; dB16 stays the row-major [M][128] scratch matrix.
+GNX_EXPORT int gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb(const void* dY16, long lddy, const void* W2b16, const void* A16, long lda, long bsa,
+                                                   void* dB16, long M, int S, const float* scale2, const float* gamma2,
+                                                   const float* beta2, float* dgamma, float* dbeta, float* workspace,
+                                                   const float* ls, int accumulate, int* flag, hipStream_t stream) {
     if (!dY16 || !W2b16 || !A16 || !dB16 || !scale2 || !gamma2 || !beta2 || !workspace || !ls || M <= 0 || S <= 0 || lddy < 32 ||
-        M % ((long)S * S) != 0)
+        M % ((long)S * S) != 0 || lda < 32 || bsa < 32)
         return GNX_ERR_BAD_ARG;
-    if (lddy % 8 || !al16b(dY16) || !al16b(A16) || !al16b(dB16) || !al16b(W2b16) || S > 64) return GNX_ERR_UNSUPPORTED;
+    if (lddy % 8 || lda % 8 || bsa % 8 || !al16b(dY16) || !al16b(A16) || !al16b(dB16) || !al16b(W2b16) || S > 64)
+        return GNX_ERR_UNSUPPORTED;
     const SlabPlan p = plan_slabs(M, 128, 512);
     const _Float16* dY = reinterpret_cast<const _Float16*>(dY16);
     const _Float16* Wb = reinterpret_cast<const _Float16*>(W2b16);
@@ -1014,8 +1052,8 @@ GNX_EXPORT int gnx_conv3x3_dgrad_bnrelu_bwd_f16(const void* dY16, long lddy, con
     _Float16* dB = reinterpret_cast<_Float16*>(dB16);
     const int grid = (int)p.slabs;
 #define GNX_DG3(SS, NPOS)                                                                                                    \
-    dgrad3x3_bn_f16_kernel<SS><<<grid, 256, (size_t)128 * R_RS + (size_t)(NPOS) * Y_RS + Y_RS + 512, stream>>>(dY, lddy, Wb, A, dB, \
-                                                                                                              scale2, workspace, M, S, p.per)
+    dgrad3x3_bn_f16_kernel<SS><<<grid, 256, (size_t)128 * R_RS + (size_t)(NPOS) * Y_RS + Y_RS + 512, stream>>>(dY, lddy, Wb, A, lda, bsa, \
+                                                                                                              dB, scale2, workspace, M, S, p.per)
     switch (M % 128 == 0 ? S : 0) {                                 // power-of-two maps, whole tiles: the padded-image form
         case 4: GNX_DG3(4, 8 * 36); break;
         case 8: GNX_DG3(8, 2 * 100); break;
@@ -1029,6 +1067,13 @@ GNX_EXPORT int gnx_conv3x3_dgrad_bnrelu_bwd_f16(const void* dY16, long lddy, con
         bn_reduce_kernel<<<8, 256, 0, stream>>>(workspace, p.slabs, 128, 128, dgamma, dbeta, gamma2, beta2, 1, ls, accumulate, flag);
     return gnx_launch_status();
 }
+GNX_EXPORT int gnx_conv3x3_dgrad_bnrelu_bwd_f16(const void* dY16, long lddy, const void* W2b16, const void* A16, void* dB16, long M,
+                                                int S, const float* scale2, const float* gamma2, const float* beta2,
+                                                float* dgamma, float* dbeta, float* workspace, const float* ls, int accumulate,
+                                                int* flag, hipStream_t stream) {
+    return gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb(dY16, lddy, W2b16, A16, 128, 32, dB16, M, S, scale2, gamma2, beta2, dgamma, dbeta,
+                                               workspace, ls, accumulate, flag, stream);
+}
 
 // G16[:, :K] += scale1 * (dB16 . W1) * [bn1(X16) > 0]; dgamma1 / dbeta1 (fp32, (+)=).  W1t16: conv1.weight transposed to
 // [K][128] halves.  32 | K.
@@ -1040,13 +1085,15 @@ GNX_EXPORT long gnx_conv1x1_dgrad_bnrelu_bwd_f16_workspace(long M, int K) {
 GNX_EXPORT long gnx_conv1x1_dgrad_wgrad_f16_workspace(long M, int K) {
     return plan_dgrad1(M, K, true).slabs * (2L + 128) * ((K + 127) / 128) * 128;
 }
-static int dgrad1_launch(const void* dB16, const void* W1t16, const void* X16, long ldx, void* G16, long ldg, long M, int K,
-                         const float* scale, const float* shift, const float* mean, const float* invstd, float* dgamma,
-                         float* dbeta, float* dW, float* workspace, const float* ls, int accumulate, int* flag, hipStream_t stream) {
+static int dgrad1_launch(const void* dB16, const void* W1t16, const void* X16, long ldx, long bsx, void* G16, long ldg, long bsg,
+                         long M, int K, const float* scale, const float* shift, const float* mean, const float* invstd,
+                         float* dgamma, float* dbeta, float* dW, float* workspace, const float* ls, int accumulate, int* flag,
+                         hipStream_t stream) {
     if (!dB16 || !W1t16 || !X16 || !G16 || !scale || !shift || !mean || !invstd || !workspace || !ls || M <= 0 || K <= 0 ||
-        ldx < K || ldg < K)
+        ldx < 32 || ldg < 32 || bsx < 32 || bsg < 32 || (bsx == 32 && ldx < K) || (bsg == 32 && ldg < K))
         return GNX_ERR_BAD_ARG;
-    if (K % 32 || ldx % 8 || ldg % 8 || !al16b(dB16) || !al16b(W1t16) || !al16b(X16) || !al16b(G16)) return GNX_ERR_UNSUPPORTED;
+    if (K % 32 || ldx % 8 || ldg % 8 || bsx % 8 || bsg % 8 || !al16b(dB16) || !al16b(W1t16) || !al16b(X16) || !al16b(G16))
+        return GNX_ERR_UNSUPPORTED;
     const SlabPlan p = plan_dgrad1(M, K, dW != nullptr);
     const int n_cb = (K + 127) / 128;
     const long cw = (long)n_cb * 128;
@@ -1057,11 +1104,11 @@ static int dgrad1_launch(const void* dB16, const void* W1t16, const void* X16, l
     const _Float16* X = reinterpret_cast<const _Float16*>(X16);
     _Float16* G = reinterpret_cast<_Float16*>(G16);
     if (dW)
-        dgrad1x1_bn_f16_kernel<true><<<grid, 256, 0, stream>>>(dB, Wt, X, ldx, G, ldg, scale, shift, mean, workspace, M, K, n_cb, p.per,
-                                                              p.slabs, wsw);
+        dgrad1x1_bn_f16_kernel<true><<<grid, 256, 0, stream>>>(dB, Wt, X, ldx, bsx, G, ldg, bsg, scale, shift, mean, workspace, M, K, n_cb,
+                                                              p.per, p.slabs, wsw);
     else
-        dgrad1x1_bn_f16_kernel<false><<<grid, 256, 0, stream>>>(dB, Wt, X, ldx, G, ldg, scale, shift, mean, workspace, M, K, n_cb, p.per,
-                                                               p.slabs, nullptr);
+        dgrad1x1_bn_f16_kernel<false><<<grid, 256, 0, stream>>>(dB, Wt, X, ldx, bsx, G, ldg, bsg, scale, shift, mean, workspace, M, K, n_cb,
+                                                               p.per, p.slabs, nullptr);
     if (dgamma || dbeta)
         bn_reduce_kernel<<<(K + 15) / 16, 256, 0, stream>>>(workspace, p.slabs, K, cw, dgamma, dbeta, invstd, nullptr, 0, ls, accumulate,
                                                            flag);
@@ -1075,8 +1122,8 @@ GNX_EXPORT int gnx_conv1x1_dgrad_bnrelu_bwd_f16(const void* dB16, const void* W1
                                                 long M, int K, const float* scale, const float* shift, const float* mean,
                                                 const float* invstd, float* dgamma, float* dbeta, float* workspace,
                                                 const float* ls, int accumulate, int* flag, hipStream_t stream) {
-    return dgrad1_launch(dB16, W1t16, X16, ldx, G16, ldg, M, K, scale, shift, mean, invstd, dgamma, dbeta, nullptr, workspace, ls,
-                         accumulate, flag, stream);
+    return dgrad1_launch(dB16, W1t16, X16, ldx, 32, G16, ldg, 32, M, K, scale, shift, mean, invstd, dgamma, dbeta, nullptr, workspace,
+                         ls, accumulate, flag, stream);
 }
 GNX_EXPORT int gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16(const void* dB16, const void* W1t16, const void* X16, long ldx, void* G16,
                                                       long ldg, long M, int K, const float* scale, const float* shift,
@@ -1084,7 +1131,17 @@ GNX_EXPORT int gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16(const void* dB16, const vo
                                                       float* dW, float* workspace, const float* ls, int accumulate, int* flag,
                                                       hipStream_t stream) {
     if (!dW) return GNX_ERR_BAD_ARG;
-    return dgrad1_launch(dB16, W1t16, X16, ldx, G16, ldg, M, K, scale, shift, mean, invstd, dgamma, dbeta, dW, workspace, ls,
+    return dgrad1_launch(dB16, W1t16, X16, ldx, 32, G16, ldg, 32, M, K, scale, shift, mean, invstd, dgamma, dbeta, dW, workspace, ls,
+                         accumulate, flag, stream);
+}
+// `_lb`: X16 and G16 given as (ld, bs) - element (row, c) at row * ld + (c >> 5) * bs + (c & 31): (c_total, 32) = row-major,
+// (32, rows_total * 32) = the channel-blocked block buffers of the fused forward.  dW == NULL: no weight gradient.
+GNX_EXPORT int gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16_lb(const void* dB16, const void* W1t16, const void* X16, long ldx, long bsx,
+                                                         void* G16, long ldg, long bsg, long M, int K, const float* scale,
+                                                         const float* shift, const float* mean, const float* invstd,
+                                                         float* dgamma, float* dbeta, float* dW, float* workspace, const float* ls,
+                                                         int accumulate, int* flag, hipStream_t stream) {
+    return dgrad1_launch(dB16, W1t16, X16, ldx, bsx, G16, ldg, bsg, M, K, scale, shift, mean, invstd, dgamma, dbeta, dW, workspace, ls,
                          accumulate, flag, stream);
 }
 
@@ -1095,23 +1152,34 @@ static long tail_slots(long imgs, int C) {
     return slots < 1 ? 1 : slots;
 }
 GNX_EXPORT long gnx_tail_bwd_f16_workspace(long imgs, int C) { return tail_slots(imgs, C) * 2L * C; }
-GNX_EXPORT int gnx_tail_bwd_f16(const float* dfeats, long ldf, const void* X16, long ldx, void* G16, long ldg, long imgs, int C,
-                                int S2, const float* scale, const float* shift, const float* mean, const float* invstd,
-                                float* dgamma, float* dbeta, float* workspace, const float* ls, int accumulate, int* flag,
-                                hipStream_t stream) {
+// `_lb`: X16 / G16 as (ld, bs), see gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16_lb (channel-blocked: 32 | C).
+GNX_EXPORT int gnx_tail_bwd_f16_lb(const float* dfeats, long ldf, const void* X16, long ldx, long bsx, void* G16, long ldg, long bsg,
+                                   long imgs, int C, int S2, const float* scale, const float* shift, const float* mean,
+                                   const float* invstd, float* dgamma, float* dbeta, float* workspace, const float* ls,
+                                   int accumulate, int* flag, hipStream_t stream) {
     if (!dfeats || !X16 || !G16 || !scale || !shift || !mean || !invstd || !workspace || !ls || imgs <= 0 || C <= 0 || S2 <= 0 ||
-        ldf < C || ldx < C || ldg < C)
+        ldf < C || ldx < 32 || ldg < 32 || bsx < 32 || bsg < 32 || (bsx == 32 && ldx < C) || (bsg == 32 && ldg < C))
         return GNX_ERR_BAD_ARG;
-    if (C % 8 || ldf % 4 || ldx % 8 || ldg % 8 || !al16b(dfeats) || !al16b(X16) || !al16b(G16)) return GNX_ERR_UNSUPPORTED;
+    const int blocked = (bsx != 32 || bsg != 32) ? 1 : 0;
+    if (C % 8 || ldf % 4 || ldx % 8 || ldg % 8 || bsx % 8 || bsg % 8 || !al16b(dfeats) || !al16b(X16) || !al16b(G16) ||
+        (blocked && C % 32))
+        return GNX_ERR_UNSUPPORTED;
     const long slots = tail_slots(imgs, C);
-    const long threads = slots * (C / 8);
-    tail_bwd_f16_kernel<<<(int)((threads + 255) / 256), 256, 0, stream>>>(dfeats, ldf, reinterpret_cast<const _Float16*>(X16), ldx,
-                                                                         reinterpret_cast<_Float16*>(G16), ldg, scale, shift, mean,
-                                                                         ls, workspace, imgs, C, S2, (int)slots);
+    const long threads = (blocked ? (slots + 15) / 16 * 16 : slots) * (C / 8);
+    tail_bwd_f16_kernel<<<(int)((threads + 255) / 256), 256, 0, stream>>>(dfeats, ldf, reinterpret_cast<const _Float16*>(X16), ldx, bsx,
+                                                                         reinterpret_cast<_Float16*>(G16), ldg, bsg, scale, shift,
+                                                                         mean, ls, workspace, imgs, C, S2, (int)slots, blocked);
     if (dgamma || dbeta)
         bn_reduce_kernel<<<(C + 15) / 16, 256, 0, stream>>>(workspace, slots, C, C, dgamma, dbeta, invstd, nullptr, 0, nullptr,
                                                              accumulate, flag);
     return gnx_launch_status();
+}
+GNX_EXPORT int gnx_tail_bwd_f16(const float* dfeats, long ldf, const void* X16, long ldx, void* G16, long ldg, long imgs, int C,
+                                int S2, const float* scale, const float* shift, const float* mean, const float* invstd,
+                                float* dgamma, float* dbeta, float* workspace, const float* ls, int accumulate, int* flag,
+                                hipStream_t stream) {
+    return gnx_tail_bwd_f16_lb(dfeats, ldf, X16, ldx, 32, G16, ldg, 32, imgs, C, S2, scale, shift, mean, invstd, dgamma, dbeta,
+                               workspace, ls, accumulate, flag, stream);
 }
 
 // transition norm -> relu -> avgpool 2x2, backward from the pooled gradient dP16 [imgs (S/2)^2][C]: G16[imgs S^2][C] (written),
@@ -1122,23 +1190,35 @@ static long trans_slots(long Mp, int C) {
     return slots < 1 ? 1 : slots;
 }
 GNX_EXPORT long gnx_trans_bwd_f16_workspace(long imgs, int C, int S) { return trans_slots(imgs * (S / 2) * (S / 2), C) * 2L * C; }
-GNX_EXPORT int gnx_trans_bwd_f16(const void* dP16, long ldp, const void* X16, long ldx, void* G16, long ldg, long imgs, int C, int S,
-                                 const float* scale, const float* shift, const float* mean, const float* invstd, float* dgamma,
-                                 float* dbeta, float* workspace, const float* ls, int accumulate, int* flag, hipStream_t stream) {
+// `_lb`: dP16, X16 and G16 each as (ld, bs), see gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16_lb (channel-blocked: 32 | C).
+GNX_EXPORT int gnx_trans_bwd_f16_lb(const void* dP16, long ldp, long bsp, const void* X16, long ldx, long bsx, void* G16, long ldg,
+                                    long bsg, long imgs, int C, int S, const float* scale, const float* shift, const float* mean,
+                                    const float* invstd, float* dgamma, float* dbeta, float* workspace, const float* ls,
+                                    int accumulate, int* flag, hipStream_t stream) {
     if (!dP16 || !X16 || !G16 || !scale || !shift || !mean || !invstd || !workspace || !ls || imgs <= 0 || C <= 0 || S < 2 ||
-        ldp < C || ldx < C || ldg < C)
+        ldp < 32 || ldx < 32 || ldg < 32 || bsp < 32 || bsx < 32 || bsg < 32 || (bsp == 32 && ldp < C) || (bsx == 32 && ldx < C) ||
+        (bsg == 32 && ldg < C))
         return GNX_ERR_BAD_ARG;
-    if (C % 8 || S % 2 || ldp % 8 || ldx % 8 || ldg % 8 || !al16b(dP16) || !al16b(X16) || !al16b(G16)) return GNX_ERR_UNSUPPORTED;
+    const int blocked = (bsp != 32 || bsx != 32 || bsg != 32) ? 1 : 0;
+    if (C % 8 || S % 2 || ldp % 8 || ldx % 8 || ldg % 8 || bsp % 8 || bsx % 8 || bsg % 8 || !al16b(dP16) || !al16b(X16) ||
+        !al16b(G16) || (blocked && C % 32))
+        return GNX_ERR_UNSUPPORTED;
     const long slots = trans_slots(imgs * (S / 2) * (S / 2), C);
-    const long threads = slots * (C / 8);
-    trans_bwd_f16_kernel<<<(int)((threads + 255) / 256), 256, 0, stream>>>(reinterpret_cast<const _Float16*>(dP16), ldp,
-                                                                          reinterpret_cast<const _Float16*>(X16), ldx,
-                                                                          reinterpret_cast<_Float16*>(G16), ldg, scale, shift, mean,
-                                                                          workspace, imgs, C, S, (int)slots);
+    const long threads = (blocked ? (slots + 15) / 16 * 16 : slots) * (C / 8);
+    trans_bwd_f16_kernel<<<(int)((threads + 255) / 256), 256, 0, stream>>>(reinterpret_cast<const _Float16*>(dP16), ldp, bsp,
+                                                                          reinterpret_cast<const _Float16*>(X16), ldx, bsx,
+                                                                          reinterpret_cast<_Float16*>(G16), ldg, bsg, scale, shift,
+                                                                          mean, workspace, imgs, C, S, (int)slots, blocked);
     if (dgamma || dbeta)
         bn_reduce_kernel<<<(C + 15) / 16, 256, 0, stream>>>(workspace, slots, C, C, dgamma, dbeta, invstd, nullptr, 0, ls, accumulate,
                                                              flag);
     return gnx_launch_status();
+}
+GNX_EXPORT int gnx_trans_bwd_f16(const void* dP16, long ldp, const void* X16, long ldx, void* G16, long ldg, long imgs, int C, int S,
+                                 const float* scale, const float* shift, const float* mean, const float* invstd, float* dgamma,
+                                 float* dbeta, float* workspace, const float* ls, int accumulate, int* flag, hipStream_t stream) {
+    return gnx_trans_bwd_f16_lb(dP16, ldp, 32, X16, ldx, 32, G16, ldg, 32, imgs, C, S, scale, shift, mean, invstd, dgamma, dbeta,
+                                workspace, ls, accumulate, flag, stream);
 }
 
 // out[M][C] (fp32, ldo) = G16[:, :C] / s.  8 | C.

@@ -75,7 +75,8 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
                                                               const _Float16* __restrict__ w1p,
                                                               const _Float16* __restrict__ w2p,
                                                               const float* __restrict__ sc1, const float* __restrict__ sh1,
-                                                              const float* __restrict__ sc2, const float* __restrict__ sh2
+                                                              const float* __restrict__ sc2, const float* __restrict__ sh2,
+                                                              _Float16* __restrict__ Aout, long abstride
                                                               GNX_DL_STAMP_PARAM) {
     constexpr int J = S >= 16 ? S * S / 128 : 1;           // steps per unit
     constexpr int LOG2S = S == 32 ? 5 : S == 16 ? 4 : S == 8 ? 3 : 2;
@@ -451,6 +452,21 @@ __global__ __launch_bounds__(512) void dense_layer_f16_kernel(_Float16* __restri
             DL_LAP(3);
             preload_w();                                       // the next step's first stages (the same weights): behind E, not
                                                                // in front of it - every wave of the workgroup waits for E
+            if (Aout) {
+                // the TAPE of the gradient path (gnx_dense_layer_f16_tape): the step's activated bottleneck tile, LDS -> HBM, as
+                // [4 channel blocks][rows][32] halves.  Consumer w copies channel block w (16-B columns 4w .. 4w + 3) of all 128
+                // pixels: lane = (pixel & 15, column & 3), so a read is conflict-free (16 consecutive pixels of one column are 256
+                // contiguous bytes) and a store is 1 KB of contiguous memory.  The tile is stable until the next step's first
+                // pair barrier, which no wave passes before every consumer has left this step.
+                const unsigned la = lb + DL_BT + (4 * nb + (lane >> 4)) * 256 + (lane & 15) * 16;
+                _Float16* const ga = Aout + nb * abstride + ((((long)u * J + j) * 128) + (lane & 15)) * 32 + (lane >> 4) * 8;
+                f32x4 tv[8];
+                static_for<0, 8>([&](auto k_c) { tv[decltype(k_c)::value] = lds_read4<decltype(k_c)::value * 4096>(la); });
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]),
+                                                      "+v"(tv[6]), "+v"(tv[7]));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) *reinterpret_cast<f32x4*>(ga + k * 16 * 32) = tv[k];
+            }
             conv2_step(u, j, a0, a1);
         }
     if (wave == 0) DL_OUT(0);
@@ -471,7 +487,8 @@ __global__ __launch_bounds__(512) void dense_layer_f16_s64_kernel(_Float16* __re
                                                               const _Float16* __restrict__ w1p,
                                                               const _Float16* __restrict__ w2p,
                                                               const float* __restrict__ sc1, const float* __restrict__ sh1,
-                                                              const float* __restrict__ sc2, const float* __restrict__ sh2
+                                                              const float* __restrict__ sc2, const float* __restrict__ sh2,
+                                                              _Float16* __restrict__ Aout, long abstride
                                                               GNX_DL_STAMP_PARAM) {
     constexpr int S = 64, J = S * S / 128, LOG2S = 6;      // 32 steps of two image rows per unit
     __shared__ __attribute__((aligned(16))) char lds[DL_LDS];
@@ -614,6 +631,20 @@ __global__ __launch_bounds__(512) void dense_layer_f16_s64_kernel(_Float16* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
         for (int n = 0; n <= N; ++n) {                         // barrier n: tile n is complete, tile n - 1 is free
+            if (n >= 1 && Aout) {
+                // the tape (see dense_layer_f16_kernel): back wave w copies channel block w of tile n - 1, LDS -> HBM.  The front
+                // waves' loads are hand-counted (vmcnt); these stores belong to the back waves, whose memory operations are the
+                // compiler's to count.
+                const int m = n - 1, u = bid + (m / J) * G, j = m & (J - 1);
+                const unsigned la = lb + DL_BT + (m & 1) * DL_BT_BYTES + (4 * wave + (lane >> 4)) * 256 + (lane & 15) * 16;
+                _Float16* const ga = Aout + wave * abstride + ((((long)u * J + j) * 128) + (lane & 15)) * 32 + (lane >> 4) * 8;
+                f32x4 tv[8];
+                static_for<0, 8>([&](auto k_c) { tv[decltype(k_c)::value] = lds_read4<decltype(k_c)::value * 4096>(la); });
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]),
+                                                      "+v"(tv[6]), "+v"(tv[7]));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) *reinterpret_cast<f32x4*>(ga + k * 16 * 32) = tv[k];
+            }
             if (n >= 1) conv2_step(n - 1, a0, a1);
             DL_LAP(6);
             if (n < N) lds_barrier();
@@ -862,15 +893,17 @@ GNX_EXPORT void gnx_dense_layer_f16_set_stamps(void* buf, int abl) {
 // blocks [0, K / 32), writes block K / 32.  bn_size * growth = 128 and growth = 32 are fixed; S in {4, 8, 16, 32, 64};
 // 32 | K, 64 <= K <= 1024; X16 16-B aligned; n_img * S * S a multiple of 128.  scale / shift: the folded running-statistics
 // BatchNorms (norm1: K, norm2: 128).
-GNX_EXPORT int gnx_dense_layer_f16(void* X16, long rows_total, long n_img, int S, int K, const void* w1p, const void* w2p,
-                                   const float* scale1, const float* shift1, const float* scale2, const float* shift2,
-                                   hipStream_t stream) {
+static int dense_layer_launch(void* X16, long rows_total, long n_img, int S, int K, const void* w1p, const void* w2p,
+                              const float* scale1, const float* shift1, const float* scale2, const float* shift2, void* A16,
+                              long a_rows_total, hipStream_t stream) {
     if (!X16 || !w1p || !w2p || !scale1 || !shift1 || !scale2 || !shift2 || n_img < 0 || K <= 0 || S <= 0 ||
-        rows_total < n_img * (long)S * S)
+        rows_total < n_img * (long)S * S || (A16 && a_rows_total < n_img * (long)S * S))
         return GNX_ERR_BAD_ARG;
     if (K % 32 != 0 || K < 64 || K > 1024 || !al16(X16) || !al16(w1p) || !al16(w2p) || (n_img * S * S) % 128 != 0 ||
-        n_img * (long)S * S / 128 >= (1L << 31))
+        n_img * (long)S * S / 128 >= (1L << 31) || (A16 && !al16(A16)))
         return GNX_ERR_UNSUPPORTED;
+    _Float16* const At = reinterpret_cast<_Float16*>(A16);
+    const long abs_ = a_rows_total * 32;
     if (n_img == 0) return GNX_OK;
     const long units = S >= 16 ? n_img : n_img * S * S / 128;
     static int cus = 0;
@@ -891,7 +924,7 @@ GNX_EXPORT int gnx_dense_layer_f16(void* X16, long rows_total, long n_img, int S
 #endif
 #define GNX_DL(SS)                                                                                                   \
     dense_layer_f16_kernel<SS><<<grid, 512, 0, stream>>>(X, rows_total * 32, (int)units, K, w1, w2, scale1, shift1, scale2,  \
-                                                          shift2                                                      \
+                                                          shift2, At, abs_                                            \
                                                           GNX_DL_STAMP_ARG);                                          \
     return gnx_launch_status()
     switch (S) {
@@ -901,10 +934,25 @@ GNX_EXPORT int gnx_dense_layer_f16(void* X16, long rows_total, long n_img, int S
         case 32: GNX_DL(32);
         case 64:
             dense_layer_f16_s64_kernel<<<grid, 512, 0, stream>>>(X, rows_total * 32, (int)units, K, w1, w2, scale1, shift1,
-                                                                 scale2, shift2 GNX_DL_STAMP_ARG);
+                                                                 scale2, shift2, At, abs_ GNX_DL_STAMP_ARG);
             return gnx_launch_status();
         default: break;
     }
 #undef GNX_DL
     return GNX_ERR_UNSUPPORTED;
+}
+GNX_EXPORT int gnx_dense_layer_f16(void* X16, long rows_total, long n_img, int S, int K, const void* w1p, const void* w2p,
+                                   const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                                   hipStream_t stream) {
+    return dense_layer_launch(X16, rows_total, n_img, S, K, w1p, w2p, scale1, shift1, scale2, shift2, nullptr, 0, stream);
+}
+// The same layer as the TAPED forward of the fp16 gradient path (gridnext_amd/densenet_train_f16.py): additionally stores the
+// activated bottleneck relu2(norm2(conv1(...))) - the tile the kernel holds in the LDS anyway - as A16 [4][a_rows_total][32]
+// halves (channel-blocked like X16; rows = n_img * S * S), the operand of conv2's weight gradient and of norm2's adjoint.
+// Everything else, bit for bit, is gnx_dense_layer_f16.
+GNX_EXPORT int gnx_dense_layer_f16_tape(void* X16, long rows_total, long n_img, int S, int K, const void* w1p, const void* w2p,
+                                        const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                                        void* A16, long a_rows_total, hipStream_t stream) {
+    if (!A16) return GNX_ERR_BAD_ARG;
+    return dense_layer_launch(X16, rows_total, n_img, S, K, w1p, w2p, scale1, shift1, scale2, shift2, A16, a_rows_total, stream);
 }

@@ -2,9 +2,12 @@
 
 `DenseNet.mfma = 'f16'` on the gradient path under running statistics - `train_gridwise` with `f_opt`
 (/root/reference/gridnext/training.py:126 keeps f in eval mode, :164-171 steps it) - runs here: the taped forward of
-/root/reference/gridnext/densenet.py:35-54 on fp16 block buffers (row-major [rows][c_total] halves; every dense layer's
-bottleneck is stored activated, fp16 [rows][128]) and the backward of csrc/dense_bwd_f16.hip - fp16 matrix operands and
-fp16 gradient tensors, fp32 accumulation, fp32 parameter gradients.
+/root/reference/gridnext/densenet.py:35-54 IS the eval forward of config 5 - every dense layer ONE kernel on channel-blocked
+fp16 block buffers [c_total / 32][rows][32] (gnx_dense_layer_f16_tape: the same kernel, bit for bit, which also copies the
+activated bottleneck tile it holds in the LDS out as the tape, [4][rows][32] halves) - and the backward of
+csrc/dense_bwd_f16.hip runs on the SAME buffers (`_lb` entry points: (ld, bs) addressing) - fp16 matrix operands and fp16
+gradient tensors, fp32 accumulation, fp32 parameter gradients.  (Round 4 ran the unfused forward pair on row-major buffers:
+conv1 wrote the bottleneck, conv2 read it back.)
 
 Scaling policy for the fp16 gradients: ONE power-of-two loss scale `s` per backward, chosen on the device from the gradient
 that enters the network (no host synchronisation): s = 2^floor(12 - log2(max |dfeats| * max |scale_final| / S^2)), i.e. the
@@ -34,7 +37,8 @@ F32, H16 = torch.float32, torch.float16
 
 
 def eligible(model, x):
-    """Shapes / modes the fp16 gradient path takes; anything else runs the fp32 path (densenet_train._DenseNetFn)."""
+    """Shapes / modes the fp16 gradient path takes; anything else runs the fp32 path (densenet_train._DenseNetFn).  The taped
+    forward is the fused dense-layer kernel on channel-blocked buffers (gnx_dense_layer_f16_tape): its limits apply."""
     if model.mfma != 'f16' or model.training or model.small_inputs or x.requires_grad:
         return False
     if model.growth_rate != 32 or model.bn_size * model.growth_rate != 128 or model.drop_rate > 0:
@@ -43,12 +47,14 @@ def eligible(model, x):
     if P not in (128, 256) or N % 8 != 0 or N == 0:
         return False
     c0 = model.features.conv0.out_channels
-    if c0 % 32 != 0 or any(blk[0] % 32 != 0 for blk in model._blocks) or model.num_features % 8 != 0:
+    if c0 % 32 != 0 or c0 < 64 or model.num_features % 32 != 0:
+        return False
+    if any(blk[0] % 32 != 0 or blk[0] < 64 or blk[3] > 1024 + 32 for blk in model._blocks):
         return False
     hs, sizes = model._geometry(P)
     if any(s not in (4, 8, 16, 32, 64) for s in sizes):
         return False
-    if any(t is not None and (t.conv.out_channels % 8 != 0) for _, _, t, _ in model._blocks):
+    if any(t is not None and (t.conv.out_channels % 32 != 0) for _, _, t, _ in model._blocks):
         return False
     return gammas_nonzero(model)
 
@@ -66,14 +72,14 @@ def tape_bytes_per_spot(model, P):
     return 2 * (total + biggest) + 4 * 3 * P * P + 4 * 3 * sizes[0] * sizes[0] * c0
 
 
-def _conv2_rows(c_total, S):
-    """Rows one gnx_conv3x3_f16_dma_h launch may take (32-bit element offsets inside that kernel), in whole groups of 8 images."""
-    lim = (2 ** 31 - 1) // max(c_total, 128)
-    return max(8, lim // (S * S) // 8 * 8) * S * S
-
-
 def _f32(n, dev):
     return torch.empty(max(int(n), 1), device=dev, dtype=F32)
+
+
+def _rows_of_blocks(t, nblocks):
+    """The first `nblocks` channel blocks of a channel-blocked buffer [C / 32][rows][32] as a row-major [rows][32 nblocks]
+    matrix (one copy; for the few narrow operands whose consumers read rows: a transition's output gradient, the stem's)."""
+    return t[:nblocks].permute(1, 0, 2).reshape(t.shape[1], 32 * nblocks).contiguous()
 
 
 class _DenseNetF16Fn(Function):
@@ -89,7 +95,10 @@ class _DenseNetF16Fn(Function):
         c0 = conv0.out_channels
         tape = _Tape()
         tape.x, tape.N, tape.P, tape.hs, tape.sizes = x, N, P, hs, sizes
-        bufs = [torch.empty((N * s * s, c_total), device=dev, dtype=H16) for (_, _, _, c_total), s in zip(model._blocks, sizes)]
+        # channel-blocked block buffers [c_total / 32][rows][32] (include/gridnext_hip.h: gnx_dense_layer_f16): the buffers the
+        # eval forward of config 5 runs on - the taped forward IS that forward (the same kernels, bit for bit), plus the tape
+        bufs = [torch.empty((c_total // 32, N * s * s, 32), device=dev, dtype=H16)
+                for (_, _, _, c_total), s in zip(model._blocks, sizes)]
         tape.bufs = bufs
         w0 = conv0.weight.detach().contiguous()
         hp = (hs + 2 - 3) // 2 + 1
@@ -97,51 +106,46 @@ class _DenseNetF16Fn(Function):
         tape.stats0 = s0
         tape.stem32 = tape.pool_idx = None
         if c0 == 64 and model.f16_stem:
-            # ---- stem on fp16 matrix operands, straight into block 1's first columns; its backward (gnx_stem_bwd_f16)
+            # ---- stem on fp16 matrix operands, straight into block 1's first channel blocks; its backward (gnx_stem_bwd_f16)
             #      recomputes the conv0 rows it needs from the patches - no window indices, no fp32 pooled map
-            L.call('gnx_conv_stem_bnrelu_maxpool_f16mul', L.ptr(x), 0, L.ptr(w0), bufs[0].data_ptr(), bufs[0].shape[1], N, 3, P, P,
+            L.call('gnx_conv_stem_bnrelu_maxpool_f16mul_cb', L.ptr(x), 0, L.ptr(w0), bufs[0].data_ptr(), bufs[0].shape[1], N, 3, P, P,
                    c0, 7, 7, 2, 3, L.ptr(s0[0]), L.ptr(s0[1]), None, st)
         else:
-            # ---- stem in fp32 with window indices (running statistics), then into block 1's first columns as fp16
+            # ---- stem in fp32 with window indices (running statistics), then into block 1's first channel blocks as fp16
             stem32 = torch.empty((N * hp * hp, c0), device=dev, dtype=F32)
             tape.pool_idx = torch.empty((N * hp * hp, c0), device=dev, dtype=torch.uint8)
             L.call('gnx_conv_stem_bnrelu_maxpool_argmax', L.ptr(x), L.ptr(w0), L.ptr(stem32), c0, tape.pool_idx.data_ptr(), N, 3, P,
                    P, c0, 7, 7, 2, 3, L.ptr(s0[0]), L.ptr(s0[1]), st)
-            bufs[0][:, :c0].copy_(stem32)
+            bufs[0][:c0 // 32].copy_(stem32.view(N * hp * hp, c0 // 32, 32).permute(1, 0, 2))
             tape.stem32 = stem32
-        w1h = model._conv1_f16()                 # {layer: conv1.weight [128][cin] halves}
-        w2h = model._repacked_conv2_f16()        # {layer: conv2.weight tap-major [9][32][128] halves}
+        dlp = model._dense_f16_packed()          # {layer: (conv1, conv2) weights in the fused kernel's fragment order, fp16}
         wth = model._trans_f16()                 # {transition: conv.weight [c_out][c_total] halves}
         tape.layers, tape.trans = [], []
         for bi, ((c_in, layers, trans, c_total), s) in enumerate(zip(model._blocks, sizes)):
             buf = bufs[bi]
             M = N * s * s
-            step = _conv2_rows(c_total, s)
             recs = []
             for li, layer in enumerate(layers):
                 cin = c_in + li * g
                 s1 = _bn(layer.norm1, None, cin, M, False, dev, st)
                 s2 = _bn(layer.norm2, None, mid, M, False, dev, st)
-                a = torch.empty((M, mid), device=dev, dtype=H16)
+                # ONE kernel per dense layer (norm1 .. conv2, the bottleneck tile in the LDS); its tape: the activated
+                # bottleneck, copied out of the LDS tile as [4][M][32] halves
+                a = torch.empty((mid // 32, M, 32), device=dev, dtype=H16)
                 t0 = model._probe_begin()
-                L.call('gnx_conv1x1_bnrelu_h16', buf.data_ptr(), c_total, w1h[layer].data_ptr(), a.data_ptr(), mid, M, mid, cin,
-                       L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s2[0]), L.ptr(s2[1]), st)
-                t0 = model._probe_mark('conv1x1', t0, 2 * M * cin * mid, 2 * M * (cin + mid))
-                for r0 in range(0, M, step):
-                    rows = min(step, M - r0)
-                    L.call('gnx_conv3x3_f16_dma_h', a.data_ptr() + 2 * r0 * mid, mid, w2h[layer].data_ptr(),
-                           buf.data_ptr() + 2 * (r0 * c_total + cin), c_total, rows, g, mid, s, st)
-                model._probe_mark('conv3x3', t0, 2 * M * 9 * mid * g, 2 * M * (mid + g))
+                L.call('gnx_dense_layer_f16_tape', buf.data_ptr(), M, N, s, cin, dlp[layer][0].data_ptr(), dlp[layer][1].data_ptr(),
+                       L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s2[0]), L.ptr(s2[1]), a.data_ptr(), M, st)
+                model._probe_mark('dense_layer_tape', t0, 2 * M * (cin * mid + 9 * mid * g), 2 * M * (cin + g + mid))
                 recs.append((a, s1, s2))
             tape.layers.append(recs)
             if trans is not None:
                 nxt = bufs[bi + 1]
                 so = s // 2
                 stt = _bn(trans.norm, None, c_total, M, False, dev, st)
-                pooled = torch.empty((N * so * so, c_total), device=dev, dtype=H16)
-                L.call('gnx_bnrelu_avgpool2_h16', buf.data_ptr(), c_total, pooled.data_ptr(), c_total, N, c_total, s, L.ptr(stt[0]),
+                pooled = torch.empty((N * so * so, c_total), device=dev, dtype=H16)     # (row-major: the weight gradient's operand)
+                L.call('gnx_bnrelu_avgpool2_h16_cb', buf.data_ptr(), M, pooled.data_ptr(), c_total, N, c_total, s, L.ptr(stt[0]),
                        L.ptr(stt[1]), st)
-                L.call('gnx_conv1x1_bnrelu_h16', pooled.data_ptr(), c_total, wth[trans].data_ptr(), nxt.data_ptr(), nxt.shape[1],
+                L.call('gnx_conv1x1_bnrelu_h16_cb', pooled.data_ptr(), c_total, wth[trans].data_ptr(), nxt.data_ptr(), nxt.shape[1],
                        N * so * so, trans.conv.out_channels, c_total, None, None, None, None, st)
                 tape.trans.append((stt, pooled))
             else:
@@ -150,8 +154,8 @@ class _DenseNetF16Fn(Function):
         sf = _bn(model.features.norm_final, None, c_last, N * s_last * s_last, False, dev, st)
         tape.statsf = sf
         feats = torch.empty((N, c_last), device=dev, dtype=F32)
-        L.call('gnx_bnrelu_avgpool_h16', bufs[-1].data_ptr(), bufs[-1].shape[1], L.ptr(feats), c_last, N, c_last, s_last * s_last,
-               L.ptr(sf[0]), L.ptr(sf[1]), st)
+        L.call('gnx_bnrelu_avgpool_h16_cb', bufs[-1].data_ptr(), bufs[-1].shape[1], L.ptr(feats), c_last, N, c_last,
+               s_last * s_last, L.ptr(sf[0]), L.ptr(sf[1]), st)
         tape.feats = feats
         tape.versions = [(p, p._version, p.data_ptr()) for p in params]
         ctx.tape, ctx.model = tape, model
@@ -243,14 +247,15 @@ class _DenseNetF16Fn(Function):
         ls_cur = ls
         model.__dict__['f16_grad_block_scales'] = block_scales
 
-        # ---- tail: norm_final -> relu -> global average
+        # ---- tail: norm_final -> relu -> global average.  Every block buffer and block gradient is channel-blocked: (ld, bs)
+        #      = (32, rows * 32) in the `_lb` entry points
         bufs = tape.bufs
         dbufs = [None] * len(bufs)
         dbufs[-1] = torch.empty_like(bufs[-1])
-        ldl = bufs[-1].shape[1]
+        bsl = bufs[-1].shape[1] * 32
         dgf, dbf = bn_out(model.features.norm_final)
         ws = _f32(L.query('gnx_tail_bwd_f16_workspace', N, c_last), dev)
-        L.call('gnx_tail_bwd_f16', L.ptr(dfeats), c_last, bufs[-1].data_ptr(), ldl, dbufs[-1].data_ptr(), ldl, N, c_last, S2,
+        L.call('gnx_tail_bwd_f16_lb', L.ptr(dfeats), c_last, bufs[-1].data_ptr(), 32, bsl, dbufs[-1].data_ptr(), 32, bsl, N, c_last, S2,
                L.ptr(sf[0]), L.ptr(sf[1]), L.ptr(sf[2]), L.ptr(sf[3]), L.ptr(dgf), L.ptr(dbf), L.ptr(ws), lp, 0, fp, st)
 
         # ---- dense blocks, last to first
@@ -259,23 +264,24 @@ class _DenseNetF16Fn(Function):
             s = sizes[bi]
             M = N * s * s
             X, G = bufs[bi], dbufs[bi]
-            dB = torch.empty((M, mid), device=dev, dtype=H16)
+            bs = M * 32                                      # halves between two channel blocks of X, G and the taped A
+            dB = torch.empty((M, mid), device=dev, dtype=H16)          # (scratch of this block's layers: row-major)
             ws3 = _f32(L.query('gnx_wgrad3x3_f16_workspace', M), dev)
             wsd3 = _f32(L.query('gnx_conv3x3_dgrad_bnrelu_bwd_f16_workspace', M), dev)
             for li in range(len(layers) - 1, -1, -1):
                 layer = layers[li]
                 a, s1, s2 = tape.layers[bi][li]
                 cin = c_in + li * g
-                dy = G.data_ptr() + 2 * cin
+                dy = G.data_ptr() + 2 * (cin // 32) * bs     # the layer's 32 gradient columns: ONE contiguous [M][32] matrix
                 w2 = layer.conv2.weight
                 if want(w2):
                     t0 = model._probe_begin()
-                    L.call('gnx_wgrad3x3_f16', dy, c_total, a.data_ptr(), L.ptr(new_like(w2)), L.ptr(ws3), M, s, lp, 0, fp, st)
+                    L.call('gnx_wgrad3x3_f16_lb', dy, 32, a.data_ptr(), 32, bs, L.ptr(new_like(w2)), L.ptr(ws3), M, s, lp, 0, fp, st)
                     model._probe_mark('wgrad3x3_f16', t0, 2 * M * 9 * mid * g, 2 * M * (mid + g))
                 w2b = w2.detach().permute(2, 3, 1, 0).reshape(9, mid, g).to(H16).contiguous()      # [tap][m][n]
                 dg2, db2 = bn_out(layer.norm2)
                 t0 = model._probe_begin()
-                L.call('gnx_conv3x3_dgrad_bnrelu_bwd_f16', dy, c_total, w2b.data_ptr(), a.data_ptr(), dB.data_ptr(), M, s,
+                L.call('gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb', dy, 32, w2b.data_ptr(), a.data_ptr(), 32, bs, dB.data_ptr(), M, s,
                        L.ptr(s2[0]), L.ptr(layer.norm2.weight), L.ptr(layer.norm2.bias), L.ptr(dg2), L.ptr(db2), L.ptr(wsd3), lp, 0,
                        fp, st)
                 model._probe_mark('dgrad3x3_bn2_f16', t0, 2 * M * 9 * mid * g, 2 * M * (g + 2 * mid))
@@ -285,39 +291,38 @@ class _DenseNetF16Fn(Function):
                 w1t = w1.detach().reshape(mid, cin).t().to(H16).contiguous()                         # [cin][128]
                 dg1, db1 = bn_out(layer.norm1)
                 t0 = model._probe_begin()
-                if want(w1):
-                    wsd1 = _f32(L.query('gnx_conv1x1_dgrad_wgrad_f16_workspace', M, cin), dev)
-                    L.call('gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16', dB.data_ptr(), w1t.data_ptr(), X.data_ptr(), c_total, G.data_ptr(),
-                           c_total, M, cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s1[2]), L.ptr(s1[3]), L.ptr(dg1), L.ptr(db1),
-                           L.ptr(new_like(w1)), L.ptr(wsd1), lp, 0, fp, st)
-                    model._probe_mark('dgrad_wgrad1x1_bn1_f16', t0, 4 * M * cin * mid, 2 * M * (mid + 3 * cin))
-                else:
-                    wsd1 = _f32(L.query('gnx_conv1x1_dgrad_bnrelu_bwd_f16_workspace', M, cin), dev)
-                    L.call('gnx_conv1x1_dgrad_bnrelu_bwd_f16', dB.data_ptr(), w1t.data_ptr(), X.data_ptr(), c_total, G.data_ptr(),
-                           c_total, M, cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s1[2]), L.ptr(s1[3]), L.ptr(dg1), L.ptr(db1), L.ptr(wsd1),
-                           lp, 0, fp, st)
-                    model._probe_mark('dgrad1x1_bn1_f16', t0, 2 * M * cin * mid, 2 * M * (mid + 3 * cin))
+                wg = want(w1)
+                wsd1 = _f32(L.query('gnx_conv1x1_dgrad_wgrad_f16_workspace' if wg else 'gnx_conv1x1_dgrad_bnrelu_bwd_f16_workspace',
+                                    M, cin), dev)
+                L.call('gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16_lb', dB.data_ptr(), w1t.data_ptr(), X.data_ptr(), 32, bs, G.data_ptr(),
+                       32, bs, M, cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s1[2]), L.ptr(s1[3]), L.ptr(dg1), L.ptr(db1),
+                       L.ptr(new_like(w1)) if wg else None, L.ptr(wsd1), lp, 0, fp, st)
+                model._probe_mark('dgrad_wgrad1x1_bn1_f16' if wg else 'dgrad1x1_bn1_f16', t0, (4 if wg else 2) * M * cin * mid,
+                                  2 * M * (mid + 3 * cin))
                 tape.layers[bi][li] = None
                 del a
             del dB, ws3, wsd3
             if bi > 0:
-                # transition bi-1 -> bi: its output gradient is columns [0, c_in) of this block's gradient
+                # transition bi-1 -> bi: its output gradient is the first c_out / 32 channel blocks of this block's gradient;
+                # the two GEMMs that consume it read rows, so those blocks are copied out once as a row-major matrix
                 p_c_in, p_layers, p_trans, p_total = model._blocks[bi - 1]
                 ps = sizes[bi - 1]
                 stt, pooled = tape.trans[bi - 1]
                 c_out = p_trans.conv.out_channels
                 wt = p_trans.conv.weight
+                Gn = _rows_of_blocks(G, c_out // 32)                                                   # [M][c_out]
                 if want(wt):
                     wsw = _f32(L.query('gnx_wgrad1x1_f16_workspace', M, c_out, p_total), dev)
-                    L.call('gnx_wgrad1x1_f16', G.data_ptr(), c_total, pooled.data_ptr(), p_total, None, None, L.ptr(new_like(wt)),
+                    L.call('gnx_wgrad1x1_f16', Gn.data_ptr(), c_out, pooled.data_ptr(), p_total, None, None, L.ptr(new_like(wt)),
                            L.ptr(wsw), M, c_out, p_total, lp, 0, fp, st)
                     del wsw
                 tape.trans[bi - 1] = None
                 del pooled
                 wtt = wt.detach().reshape(c_out, p_total).t().to(H16).contiguous()                    # [p_total][c_out]
-                dPool = torch.empty((M, p_total), device=dev, dtype=H16)
-                L.call('gnx_conv1x1_bnrelu_h16', G.data_ptr(), c_total, wtt.data_ptr(), dPool.data_ptr(), p_total, M, p_total, c_out,
+                dPool = torch.empty((p_total // 32, M, 32), device=dev, dtype=H16)                     # (channel-blocked)
+                L.call('gnx_conv1x1_bnrelu_h16_cb', Gn.data_ptr(), c_out, wtt.data_ptr(), dPool.data_ptr(), M, M, p_total, c_out,
                        None, None, None, None, st)
+                del Gn
                 dbufs[bi - 1] = torch.empty_like(bufs[bi - 1])
                 dgt, dbt = bn_out(p_trans.norm)
                 wst = _f32(L.query('gnx_trans_bwd_f16_workspace', N, p_total, ps), dev)
@@ -332,8 +337,9 @@ class _DenseNetF16Fn(Function):
                 f_e = torch.minimum(torch.maximum(f_e, -24.0 - torch.log2(ls_cur[0])), 60.0 - torch.log2(ls_cur[0])).clamp(-12.0, 12.0)
                 f_val = torch.exp2(f_e)
                 sc_f, sh_f = (stt[0] * f_val).contiguous(), (stt[1] * f_val).contiguous()      # (kept alive across the call)
-                L.call('gnx_trans_bwd_f16', dPool.data_ptr(), p_total, bufs[bi - 1].data_ptr(), p_total, dbufs[bi - 1].data_ptr(),
-                       p_total, N, p_total, ps, L.ptr(sc_f), L.ptr(sh_f), L.ptr(stt[2]), L.ptr(stt[3]), L.ptr(dgt), L.ptr(dbt),
+                pbs = bufs[bi - 1].shape[1] * 32
+                L.call('gnx_trans_bwd_f16_lb', dPool.data_ptr(), 32, bs, bufs[bi - 1].data_ptr(), 32, pbs, dbufs[bi - 1].data_ptr(),
+                       32, pbs, N, p_total, ps, L.ptr(sc_f), L.ptr(sh_f), L.ptr(stt[2]), L.ptr(stt[3]), L.ptr(dgt), L.ptr(dbt),
                        L.ptr(wst), lp, 0, fp, st)
                 s_new = ls_cur[0] * f_val
                 ls_cur = torch.stack([s_new, 1.0 / s_new]).to(F32).contiguous()
@@ -344,29 +350,29 @@ class _DenseNetF16Fn(Function):
                 bufs[bi] = None
             send_bucket()
 
-        # ---- stem (fp32): the gradient of the pooled map back in fp32, then densenet_train's running-statistics adjoints
+        # ---- stem: the gradient of the pooled map = the first c0 / 32 channel blocks of block 1's gradient, as rows
         conv0 = model.features.conv0
         norm0 = model.features.norm0
         c0 = conv0.out_channels
-        if tape.pool_idx is None and (want(conv0.weight) or want(norm0.weight) or want(norm0.bias)):
+        need0 = want(conv0.weight) or want(norm0.weight) or want(norm0.bias)
+        Gs = _rows_of_blocks(dbufs[0], c0 // 32) if need0 else None                                    # [M1][c0]
+        dbufs[0] = None
+        if tape.pool_idx is None and need0:
             # one pass over the patches: conv0 rows recomputed, pool0's winners found, gradient routed and contracted
             t0 = model._probe_begin()
             ws = _f32(L.query('gnx_stem_bwd_f16_workspace', N, P), dev)
             s0 = tape.stats0
             dg0, db0 = bn_out(norm0)
             L.call('gnx_stem_bwd_f16', L.ptr(tape.x), L.ptr(conv0.weight.detach().contiguous()), L.ptr(s0[0]), L.ptr(s0[1]), L.ptr(norm0.weight),
-                   L.ptr(norm0.bias), dbufs[0].data_ptr(), bufs[0].shape[1],
+                   L.ptr(norm0.bias), Gs.data_ptr(), c0,
                    L.ptr(new_like(conv0.weight)) if want(conv0.weight) else None, L.ptr(dg0), L.ptr(db0), L.ptr(ws), N, P, c0, lp, 0,
                    fp, st)
             model._probe_mark('stem_bwd_f16', t0, 4 * N * hs * hs * c0 * 147, 4 * N * 3 * P * P + 2 * N * (hs // 2) ** 2 * c0)
-            dbufs[0] = None
-        elif want(conv0.weight) or want(norm0.weight) or want(norm0.bias):
+        elif need0:
             hp = (hs + 2 - 3) // 2 + 1
             M1, M0 = N * hp * hp, N * hs * hs
-            c_total1 = bufs[0].shape[1]
             dO = torch.empty((M1, c0), device=dev, dtype=F32)
-            L.call('gnx_h16_cols_to_f32', dbufs[0].data_ptr(), c_total1, L.ptr(dO), c0, M1, c0, lp, fp, st)
-            dbufs[0] = None
+            L.call('gnx_h16_cols_to_f32', Gs.data_ptr(), c0, L.ptr(dO), c0, M1, c0, lp, fp, st)
             s0 = tape.stats0
             dS = torch.empty((M0, c0), device=dev, dtype=F32)
             L.call('gnx_maxpool_bwd_argmax_bnrelu', tape.pool_idx.data_ptr(), L.ptr(dO), c0, L.ptr(tape.stem32), c0, L.ptr(s0[0]),
@@ -379,6 +385,7 @@ class _DenseNetF16Fn(Function):
                 ws = _f32(L.query('gnx_conv0_wgrad_workspace', N, P, P, c0, 7, 7, 2, 3), dev)
                 L.call('gnx_conv0_wgrad', L.ptr(tape.x), L.ptr(dS), c0, L.ptr(new_like(conv0.weight)), L.ptr(ws), N, P, P, c0, 7, 7,
                        2, 3, 0, st)
+        del Gs
         if reducer is not None:
             send_bucket()
             reducer.finish()

@@ -269,6 +269,13 @@ int gnx_transition_f16(const void* X16, long rows_in, long n_img, int S, int K, 
 int gnx_dense_layer_f16_pack(const float* w1, const float* w2, void* w1p, void* w2p, int K, gnx_stream_t stream);
 int gnx_dense_layer_f16(void* X16, long rows_total, long n_img, int S, int K, const void* w1p, const void* w2p,
                         const float* scale1, const float* shift1, const float* scale2, const float* shift2, gnx_stream_t stream);
+/* The same layer as the TAPED forward of the fp16 gradient path (training.py:164-171 stepping f_opt): additionally stores the
+ * activated bottleneck relu2(norm2(conv1(.))) - the tile the kernel holds in the LDS anyway - as A16 [4][a_rows_total][32]
+ * halves (channel-blocked like X16), the operand of conv2's weight gradient and of norm2's adjoint.  Everything else is
+ * gnx_dense_layer_f16 bit for bit. */
+int gnx_dense_layer_f16_tape(void* X16, long rows_total, long n_img, int S, int K, const void* w1p, const void* w2p,
+                             const float* scale1, const float* shift1, const float* scale2, const float* shift2, void* A16,
+                             long a_rows_total, gnx_stream_t stream);
 int gnx_conv_stem_bnrelu_maxpool_f16mul_cb(const void* x, int x_is_u8, const float* w, void* out16, long rows_total, long imgs,
                                            int Cin, int H, int W, int O, int KH, int KW, int stride, int pad, const float* scale,
                                            const float* shift, const float* norm, gnx_stream_t stream);
@@ -373,6 +380,31 @@ int gnx_trans_bwd_f16(const void* dP16, long ldp, const void* X16, long ldx, voi
                       float* workspace, const float* ls, int accumulate, int* flag, gnx_stream_t stream);
 int gnx_h16_cols_to_f32(const void* G16, long ldg, float* out, long ldo, long M, int C, const float* ls, int* flag,
                         gnx_stream_t stream);
+/* `_lb` forms (round 5): the same kernels with the block buffer X16, its gradient G16, the pooled gradient dP16 and the
+ * activated bottleneck A16 each addressed through (ld, bs) - element (row, c) at row * ld + (c >> 5) * bs + (c & 31).
+ * (ld, 32) is the row-major [rows][ld] matrix of the entry points above; (32, rows_total * 32) is the CHANNEL-BLOCKED form
+ * [C / 32][rows_total][32] of gnx_dense_layer_f16_tape, so the gradient path of gridnext/densenet.py:35-54 runs forward and
+ * backward on the same buffers (a layer's dY = its own 32-channel block: pass that block's address with lddy = 32).
+ * Same workspaces; gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16_lb with dW == NULL is the pass without the weight gradient
+ * (workspace gnx_conv1x1_dgrad_bnrelu_bwd_f16_workspace). */
+int gnx_wgrad3x3_f16_lb(const void* dY16, long lddy, const void* A16, long lda, long bsa, float* dW, float* workspace, long M, int S,
+                        const float* ls, int accumulate, int* flag, gnx_stream_t stream);
+int gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb(const void* dY16, long lddy, const void* W2b16, const void* A16, long lda, long bsa,
+                                        void* dB16, long M, int S, const float* scale2, const float* gamma2, const float* beta2,
+                                        float* dgamma, float* dbeta, float* workspace, const float* ls, int accumulate, int* flag,
+                                        gnx_stream_t stream);
+int gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16_lb(const void* dB16, const void* W1t16, const void* X16, long ldx, long bsx, void* G16,
+                                              long ldg, long bsg, long M, int K, const float* scale, const float* shift,
+                                              const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dW,
+                                              float* workspace, const float* ls, int accumulate, int* flag, gnx_stream_t stream);
+int gnx_tail_bwd_f16_lb(const float* dfeats, long ldf, const void* X16, long ldx, long bsx, void* G16, long ldg, long bsg, long imgs,
+                        int C, int S2, const float* scale, const float* shift, const float* mean, const float* invstd,
+                        float* dgamma, float* dbeta, float* workspace, const float* ls, int accumulate, int* flag,
+                        gnx_stream_t stream);
+int gnx_trans_bwd_f16_lb(const void* dP16, long ldp, long bsp, const void* X16, long ldx, long bsx, void* G16, long ldg, long bsg,
+                         long imgs, int C, int S, const float* scale, const float* shift, const float* mean, const float* invstd,
+                         float* dgamma, float* dbeta, float* workspace, const float* ls, int accumulate, int* flag,
+                         gnx_stream_t stream);
 long gnx_stem_bwd_f16_workspace(long imgs, int P);
 int gnx_stem_bwd_f16(const float* x, const float* w, const float* scale, const float* shift, const float* gamma, const float* beta,
                      const void* G16, long ldg, float* dW, float* dgamma, float* dbeta, float* workspace, long imgs, int P, int O,

@@ -262,6 +262,103 @@ def test_stem_bwd_f16(L, P, imgs):
     assert rel(db, (y > 0).double().mul(0).sum((0, 2, 3)) + (pooled > 0).double().mul(mult.view(-1, 1, 1, 1)).sum((0, 2, 3)) * 60000.0 / s) < 1e-3
 
 
+def _blocked(t):
+    """row-major [rows][C] halves -> the channel-blocked [C / 32][rows][32] form of the fused forward's buffers"""
+    return t.reshape(t.shape[0], -1, 32).permute(1, 0, 2).contiguous()
+
+
+@pytest.mark.parametrize("imgs,S,cin,ct", [(8, 4, 96, 160), (2, 16, 224, 256), (1, 64, 64, 128), (24, 8, 992, 1024)])
+def test_lb_entry_points_on_channel_blocked_buffers_equal_the_row_major_ones(L, imgs, S, cin, ct):
+    """Round 5: the backward kernels address block buffers, block gradients and the activated bottleneck through (ld, bs) -
+    element (row, c) at row * ld + (c >> 5) * bs + (c & 31) - so that they run on the channel-blocked buffers of the fused
+    forward.  Every `_lb` entry point on the blocked form of an operand set against the row-major entry point on the same
+    values: fp16 outputs (dB, G) bit for bit (the tiles a workgroup stages are the same), parameter gradients bit for bit
+    where the slab plan is the same (conv1 / conv2 passes) and to 1e-6 where the thread -> slot map differs (tail, transition)."""
+    g = torch.Generator().manual_seed(imgs * 100 + S + cin)
+    M = imgs * S * S
+    X = (torch.randn(M, ct, generator=g)).half().to(DEV)
+    G0 = (torch.randn(M, ct, generator=g) * 4).half().to(DEV)
+    A = torch.relu(torch.randn(M, 128, generator=g)).half().to(DEV)
+    W2 = (torch.randn(32, 128, 3, 3, generator=g) * 0.05).to(DEV)
+    w2b = W2.permute(2, 3, 1, 0).reshape(9, 128, 32).half().contiguous()
+    W1t = (torch.randn(cin, 128, generator=g) * 0.05).half().to(DEV)
+    gam2, bet2 = (torch.rand(128, generator=g) + 0.5).to(DEV), (torch.randn(128, generator=g) * 0.1).to(DEV)
+    sc2 = (gam2 * 0.9).contiguous()
+    sc1, sh1 = (torch.rand(ct, generator=g) + 0.5).to(DEV), (torch.randn(ct, generator=g) * 0.3).to(DEV)
+    mu1, inv1 = (torch.randn(ct, generator=g) * 0.1).to(DEV), (torch.rand(ct, generator=g) + 0.5).to(DEV)
+    ls, st = ls_tensor(4.0), L.stream()
+    Xb, Ab = _blocked(X), _blocked(A)
+    bs = M * 32
+    res = {}
+    for tag in ('rows', 'blocked'):
+        blk = tag == 'blocked'
+        G = _blocked(G0) if blk else G0.clone()
+        dy = G.data_ptr() + 2 * ((cin // 32) * bs if blk else cin)
+        lddy = 32 if blk else ct
+        flag = flag_tensor()
+        dW2 = torch.zeros(32, 128, 3, 3, device=DEV)
+        ws = f32(L.query('gnx_wgrad3x3_f16_workspace', M))
+        dB = torch.empty(M, 128, device=DEV, dtype=H)
+        dg2, db2 = torch.zeros(128, device=DEV), torch.zeros(128, device=DEV)
+        wsd = f32(L.query('gnx_conv3x3_dgrad_bnrelu_bwd_f16_workspace', M))
+        if blk:
+            L.call('gnx_wgrad3x3_f16_lb', dy, lddy, Ab.data_ptr(), 32, bs, L.ptr(dW2), L.ptr(ws), M, S, L.ptr(ls), 0, flag.data_ptr(), st)
+            L.call('gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb', dy, lddy, w2b.data_ptr(), Ab.data_ptr(), 32, bs, dB.data_ptr(), M, S, L.ptr(sc2),
+                   L.ptr(gam2), L.ptr(bet2), L.ptr(dg2), L.ptr(db2), L.ptr(wsd), L.ptr(ls), 0, flag.data_ptr(), st)
+        else:
+            L.call('gnx_wgrad3x3_f16', dy, lddy, A.data_ptr(), L.ptr(dW2), L.ptr(ws), M, S, L.ptr(ls), 0, flag.data_ptr(), st)
+            L.call('gnx_conv3x3_dgrad_bnrelu_bwd_f16', dy, lddy, w2b.data_ptr(), A.data_ptr(), dB.data_ptr(), M, S, L.ptr(sc2),
+                   L.ptr(gam2), L.ptr(bet2), L.ptr(dg2), L.ptr(db2), L.ptr(wsd), L.ptr(ls), 0, flag.data_ptr(), st)
+        dW1 = torch.zeros(128, cin, device=DEV)
+        dg1, db1 = torch.zeros(cin, device=DEV), torch.zeros(cin, device=DEV)
+        ws1 = f32(L.query('gnx_conv1x1_dgrad_wgrad_f16_workspace', M, cin))
+        if blk:
+            L.call('gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16_lb', dB.data_ptr(), W1t.data_ptr(), Xb.data_ptr(), 32, bs, G.data_ptr(), 32, bs,
+                   M, cin, L.ptr(sc1), L.ptr(sh1), L.ptr(mu1), L.ptr(inv1), L.ptr(dg1), L.ptr(db1), L.ptr(dW1), L.ptr(ws1), L.ptr(ls),
+                   0, flag.data_ptr(), st)
+        else:
+            L.call('gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16', dB.data_ptr(), W1t.data_ptr(), X.data_ptr(), ct, G.data_ptr(), ct, M, cin,
+                   L.ptr(sc1), L.ptr(sh1), L.ptr(mu1), L.ptr(inv1), L.ptr(dg1), L.ptr(db1), L.ptr(dW1), L.ptr(ws1), L.ptr(ls), 0,
+                   flag.data_ptr(), st)
+        # tail (writes a whole gradient buffer) and transition adjoint (from a pooled gradient), on fresh buffers
+        Gt = torch.empty_like(Xb if blk else X)
+        dfe = torch.randn(imgs, ct, generator=torch.Generator().manual_seed(5)).to(DEV)
+        dgt, dbt = torch.zeros(ct, device=DEV), torch.zeros(ct, device=DEV)
+        wst = f32(L.query('gnx_tail_bwd_f16_workspace', imgs, ct))
+        Gp = torch.empty_like(Xb if blk else X)
+        dP0 = (torch.randn(imgs * (S // 2) ** 2, ct, generator=torch.Generator().manual_seed(6)) * 3).half().to(DEV)
+        dgp, dbp = torch.zeros(ct, device=DEV), torch.zeros(ct, device=DEV)
+        wsp = f32(L.query('gnx_trans_bwd_f16_workspace', imgs, ct, S))
+        if blk:
+            L.call('gnx_tail_bwd_f16_lb', L.ptr(dfe), ct, Xb.data_ptr(), 32, bs, Gt.data_ptr(), 32, bs, imgs, ct, S * S, L.ptr(sc1),
+                   L.ptr(sh1), L.ptr(mu1), L.ptr(inv1), L.ptr(dgt), L.ptr(dbt), L.ptr(wst), L.ptr(ls), 0, flag.data_ptr(), st)
+            dPb = _blocked(dP0)
+            L.call('gnx_trans_bwd_f16_lb', dPb.data_ptr(), 32, dPb.shape[1] * 32, Xb.data_ptr(), 32, bs, Gp.data_ptr(), 32, bs, imgs, ct,
+                   S, L.ptr(sc1), L.ptr(sh1), L.ptr(mu1), L.ptr(inv1), L.ptr(dgp), L.ptr(dbp), L.ptr(wsp), L.ptr(ls), 0,
+                   flag.data_ptr(), st)
+        else:
+            L.call('gnx_tail_bwd_f16', L.ptr(dfe), ct, X.data_ptr(), ct, Gt.data_ptr(), ct, imgs, ct, S * S, L.ptr(sc1), L.ptr(sh1),
+                   L.ptr(mu1), L.ptr(inv1), L.ptr(dgt), L.ptr(dbt), L.ptr(wst), L.ptr(ls), 0, flag.data_ptr(), st)
+            L.call('gnx_trans_bwd_f16', dP0.data_ptr(), ct, X.data_ptr(), ct, Gp.data_ptr(), ct, imgs, ct, S, L.ptr(sc1), L.ptr(sh1),
+                   L.ptr(mu1), L.ptr(inv1), L.ptr(dgp), L.ptr(dbp), L.ptr(wsp), L.ptr(ls), 0, flag.data_ptr(), st)
+        torch.cuda.synchronize()
+        rows = (lambda t: _rows(t)) if blk else (lambda t: t)
+        res[tag] = dict(dW2=dW2, dB=dB, dg2=dg2, db2=db2, G=rows(G), dW1=dW1, dg1=dg1, db1=db1, Gt=rows(Gt), dgt=dgt, dbt=dbt,
+                        Gp=rows(Gp), dgp=dgp, dbp=dbp, flag=int(flag.item()))
+    a, b = res['rows'], res['blocked']
+    assert a['flag'] == 0 and b['flag'] == 0
+    for k in ('dW2', 'dB', 'dg2', 'db2', 'G', 'dW1', 'dg1', 'db1', 'Gt', 'Gp'):
+        assert torch.equal(a[k], b[k]), k
+    for k in ('dgt', 'dbt', 'dgp', 'dbp'):
+        assert rel(b[k], a[k]) <= 1e-5, (k, rel(b[k], a[k]))
+
+
+def _rows(t):
+    """A channel-blocked tape tensor [C / 32][rows][32] (densenet_train_f16: block buffers, activated bottlenecks) as the
+    row-major [rows][C] matrix it stands for."""
+    return t.permute(1, 0, 2).reshape(t.shape[1], -1)
+
+
 def _calibrated_densenet121(seed, x):
     """DenseNet-121 with random weights and running statistics calibrated on `x` (one train-mode forward, momentum 1): the
     state any network that has seen data is in; with untouched statistics the activations of a fresh network reach 1e6 and
@@ -297,7 +394,7 @@ def _fp32_backward_on_f16_tape(m, x, dout):
     t16 = ctx.tape
     tape = dt._Tape()
     tape.x, tape.N, tape.P, tape.hs, tape.sizes, tape.training = t16.x, t16.N, t16.P, t16.hs, t16.sizes, False
-    tape.bufs = [b.float() for b in t16.bufs]
+    tape.bufs = [_rows(b).float().contiguous() for b in t16.bufs]
     tape.stem_out, tape.pool_idx, tape.stats0 = None, t16.pool_idx, t16.stats0
     if tape.pool_idx is None:
         # the fp16 stem records no window indices (its backward recomputes the conv0 rows): give the fp32 adjoints torch's
@@ -313,7 +410,7 @@ def _fp32_backward_on_f16_tape(m, x, dout):
         px = torch.arange(hp, device=idx.device).view(1, 1, 1, hp)
         k = 3 * (idx // hs - (2 * py - 1)) + (idx % hs - (2 * px - 1))
         tape.pool_idx = k.permute(0, 2, 3, 1).reshape(-1, idx.shape[1]).to(torch.uint8).contiguous()
-    tape.layers = [[(a.float(), s1, s2, True, None) for (a, s1, s2) in recs] for recs in t16.layers]
+    tape.layers = [[(_rows(a).float().contiguous(), s1, s2, True, None) for (a, s1, s2) in recs] for recs in t16.layers]
     tape.trans = [None if t is None else t[0] for t in t16.trans]
     tape.statsf, tape.feats, tape.versions = t16.statsf, t16.feats, t16.versions
     ctx2 = Ctx()
@@ -393,17 +490,18 @@ def test_densenet121_f16_gradients_vs_fp64_oracle(capsys):
     def nchw(rows, s):
         return rows.double().cpu().reshape(n, s, s, rows.shape[1]).permute(0, 3, 1, 2).contiguous()
 
-    stored = {'stem': nchw(tape.bufs[0][:, :m.features.conv0.out_channels], tape.sizes[0])}
+    rows = [_rows(b) for b in tape.bufs]                             # (the tape is channel-blocked)
+    stored = {'stem': nchw(rows[0][:, :m.features.conv0.out_channels], tape.sizes[0])}
     for bi, ((c_in, layers, trans, c_total), s) in enumerate(zip(m._blocks, tape.sizes)):
         for li in range(len(layers)):
             p = 'features.denseblock%d.denselayer%d' % (bi + 1, li + 1)
             cin = c_in + 32 * li
-            stored[p + '.a'] = nchw(tape.layers[bi][li][0], s)
-            stored[p + '.out'] = nchw(tape.bufs[bi][:, cin:cin + 32], s)
+            stored[p + '.a'] = nchw(_rows(tape.layers[bi][li][0]), s)
+            stored[p + '.out'] = nchw(rows[bi][:, cin:cin + 32], s)
         if trans is not None:
             p = 'features.transition%d' % (bi + 1)
             stored[p + '.pooled'] = nchw(tape.trans[bi][1], s // 2)
-            stored[p + '.out'] = nchw(tape.bufs[bi + 1][:, :trans.conv.out_channels], s // 2)
+            stored[p + '.out'] = nchw(rows[bi + 1][:, :trans.conv.out_channels], s // 2)
     dout = (torch.softmax(out, 1) - nn.functional.one_hot(labels, 8).float().to(DEV)) / n
     loss = nn.functional.cross_entropy(out, labels.to(DEV)).item()
     grads = dt16._DenseNetF16Fn.backward(ctx, dout)[2:]
@@ -527,7 +625,7 @@ def _relu_mask_flips(m, x):
         m.mfma = tag
         with torch.no_grad():
             fn.forward(ctx, m, x, *params)
-        bufs[tag] = [b.float() for b in ctx.tape.bufs]
+        bufs[tag] = [(b if b.dim() == 2 else _rows(b)).float() for b in ctx.tape.bufs]     # (the fp16 tape is channel-blocked)
     fold = m._folded_eval()
     out = []
     for bi, (c_in, layers, trans, c_total) in enumerate(m._blocks):

@@ -770,6 +770,22 @@ def test_dense_layer_f16_fused(L, S, n, K, ct):
     err = (out - ref).abs().max().item()
     tol = 3e-3 * ref.abs().max().item()
     assert err <= tol, "S=%d n=%d K=%d: max abs err %.3e > %.3e" % (S, n, K, err, tol)
+    # the TAPED form (gnx_dense_layer_f16_tape, the forward of the fp16 gradient path): the same output bit for bit, plus the
+    # activated bottleneck copied out of the LDS tile as [4][rows][32] halves - against relu2(norm2(conv1(relu1(norm1(x)))))
+    # in double with the kernel's rounding points (one fp16 rounding of the value; conv1's fp32 sum in another order can
+    # move a value by one more ulp: 2e-3 of the range)
+    Xt = blocked(x).to(DEV)
+    At = torch.full((4, rows + 5, 32), 3.0, device=DEV, dtype=H)
+    L.call('gnx_dense_layer_f16_tape', L.ptr(Xt, H), rows, n, S, K, L.ptr(w1p, H), L.ptr(w2p, H), L.ptr(d[0]), L.ptr(d[1]), L.ptr(d[2]),
+           L.ptr(d[3]), L.ptr(At, H), rows + 5, st)
+    torch.cuda.synchronize()
+    assert torch.equal(Xt, X), "the taped form changed the layer's output"
+    assert float(At[:, rows:].float().min()) == 3.0 and float(At[:, rows:].float().max()) == 3.0
+    a_got = At[:, :rows].permute(1, 0, 2).reshape(n, S, S, 128).cpu()[pick].double()
+    xa = torch.relu(torch.addcmul(sh1, x[pick][..., :K].float(), sc1)).half()
+    a_ref = torch.relu(torch.einsum('nyxk,ok->nyxo', xa.double(), W1.half().double()).float() * sc2 + sh2).half().double()
+    a_err = (a_got - a_ref).abs().max().item()
+    assert a_err <= 2e-3 * a_ref.abs().max().item(), "S=%d n=%d K=%d: taped bottleneck max abs err %.3e" % (S, n, K, a_err)
     # every image, cheaply: the column sums of the new channels against the same sums of a second launch on a permuted
     # batch (a work unit is an image or a tile of whole images: the result must not depend on which workgroup ran it)
     if n >= 16:
