@@ -204,6 +204,7 @@ KIND_SOURCES = {
     'dgrad1x1_bn1_f16': ('dense_bwd_f16.hip', 'common.h'),
     'dgrad3x3_bn2_f16': ('dense_bwd_f16.hip', 'common.h'),
     'wgrad3x3_f16': ('dense_bwd_f16.hip', 'common.h'),
+    'conv3x3_bwd_f16': ('dense_bwd_f16.hip', 'common.h'),
     'wgrad1x1_f16': ('dense_bwd_f16.hip', 'common.h'),
     'stem_bwd_f16': ('stem_bwd_f16.hip', 'common.h'),
 }
@@ -850,6 +851,7 @@ def config5_trained_series(args, device, rank, world, steps=3, warmup=1, P=256, 
             json.dump([{"kind": r[0], "ms": r[1].elapsed_time(r[2]), "flops": r[3], "bytes": r[4]} for r in (probe or [])], fh)
     KINDS16 = {'dense_layer_tape': 'dense_layer_f16_kernel / dense_layer_f16_s64_kernel (taped forward: norm1 .. conv2 in ONE kernel per '
                                    'dense layer on channel-blocked buffers; also copies the activated bottleneck tile out of the LDS)',
+               'conv3x3_bwd_f16': 'conv3x3_bwd_f16_kernel (conv2: data gradient + norm2 adjoint + weight gradient, one pass over dY and A)',
                'wgrad3x3_f16': 'wgrad3x3_f16_kernel', 'dgrad3x3_bn2_f16': 'dgrad3x3_bn_f16_kernel',
                'wgrad1x1_f16': 'wgrad1x1_f16_kernel', 'dgrad1x1_bn1_f16': 'dgrad1x1_bn_f16_kernel<false>',
                'dgrad_wgrad1x1_bn1_f16': 'dgrad1x1_bn_f16_kernel<true> (conv1 data gradient + norm1 adjoint + conv1 weight gradient)',

@@ -79,6 +79,8 @@ SIGNATURES = {
     'gnx_dense_layer_f16_tape': (_I, [_P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     'gnx_wgrad3x3_f16_lb': (_I, [_P, _L, _P, _L, _L, _P, _P, _L, _I, _P, _I, _P, _P]),
     'gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb': (_I, [_P, _L, _P, _P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'gnx_conv3x3_bwd_f16_workspace': (_L, [_L]),
+    'gnx_conv3x3_bwd_f16_lb': (_I, [_P, _L, _P, _P, _L, _L, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16_lb': (_I, [_P, _P, _P, _L, _L, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I,
                                                        _P, _P]),
     'gnx_tail_bwd_f16_lb': (_I, [_P, _L, _P, _L, _L, _P, _L, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),

@@ -541,6 +541,208 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16*
     }
 }
 
+// ------------------------------------------------------------------------------------------------ conv2 backward in ONE pass (round 5)
+// The two kernels above read the same operands - the layer's dY strip and the activated bottleneck A - once each: 320 of the
+// 896 bytes per pixel the pair moves.  Here ONE workgroup of eight waves stages a 128-pixel tile once and splits the work by
+// ROLE (the waves of a role are the kernels above, unchanged in their arithmetic and summation order):
+//   waves 0-3  data gradient + norm2 -> relu2 adjoint (dgrad3x3_bn_f16_kernel): D = [m][pixel], wave w = bottleneck channels
+//              32 w .., W2's nine taps as 72 register fragments, dB written over the tile copy it reads A from;
+//   waves 4-7  weight gradient (wgrad3x3_f16_p2_kernel): D = [n][k] per tap, wave w = channels k = 32 w .., nine accumulators
+//              (144 registers) alive for the workgroup's lifetime, both operands by transposing reads.
+// 72 MFMAs per wave and tile either way.  The two roles want different LDS row strides (rows read by ds_read_b128 need
+// 4 x odd dwords, transposing reads 16 mod 64), so A and the zero-padded dY image are staged twice - LDS writes are cheap,
+// HBM reads are what the pass is bound by: 64 + 256 bytes per pixel in, 256 out.  Power-of-two maps, whole 128-pixel tiles.
+template <int SP>
+__global__ __launch_bounds__(512, 1) void conv3x3_bwd_f16_kernel(const _Float16* __restrict__ dY, long lddy,
+                                                                 const _Float16* __restrict__ W2b,
+                                                                 const _Float16* __restrict__ A, long lda, long bsa,
+                                                                 _Float16* __restrict__ dB, const float* __restrict__ scale2,
+                                                                 float* __restrict__ ws_bn, float* __restrict__ ws_w, long M,
+                                                                 long tiles_per_wg) {
+    constexpr int NIMG = SP >= 16 ? 1 : 128 / (SP * SP);            // images per tile
+    constexpr int NR = SP >= 16 ? 128 / SP : SP;                    // image rows per tile and image
+    constexpr int PW = SP + 2, PIMG = (NR + 2) * PW, NPOS = NIMG * PIMG;
+    constexpr int LG = SP == 4 ? 2 : SP == 8 ? 3 : SP == 16 ? 4 : SP == 32 ? 5 : 6;
+    constexpr int P_ITEMS = NIMG * (NR + 2) * SP * 4;               // (padded row, column, 16-B piece) to stage per tile
+    constexpr int NSV = (P_ITEMS + 511) / 512;
+    __shared__ __attribute__((aligned(16))) char smem[128 * R_RS + 128 * T_RS + NPOS * (Y_RS + 64) + 512];
+    char* const AtR = smem;                                         // rows (the data-gradient role; rewritten with dB)
+    char* const AtT = smem + 128 * R_RS;                            // transposing reads (the weight-gradient role)
+    char* const stripR = AtT + 128 * T_RS;
+    char* const stripT = stripR + NPOS * Y_RS;
+    float* const sc2 = reinterpret_cast<float*>(stripT + NPOS * 64);
+    const int t = threadIdx.x, lane = t & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const long ntiles = M / 128;
+    const long tile0 = blockIdx.x * tiles_per_wg;
+    const long tile1 = tile0 + tiles_per_wg < ntiles ? tile0 + tiles_per_wg : ntiles;
+    const int chunk = t & 15, row0 = t >> 4;                        // staging: 16-B column, rows row0 + 32 i
+    for (int i = t; i < NPOS * 5; i += 512) *reinterpret_cast<h8*>(stripR + i * 16) = zero8();   // incl. the pad columns, for good
+    for (int i = t; i < NPOS * 4; i += 512) *reinterpret_cast<h8*>(stripT + i * 16) = zero8();
+    if (t < 128) sc2[t] = scale2[t];
+    const long acol = (long)(chunk >> 2) * bsa + (chunk & 3) * 8;
+    h8 av[4], sv[NSV];
+    auto fetch = [&](long tile) {
+        const long P0 = tile * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = ldg8(A + (P0 + row0 + 32 * i) * lda + acol);
+        const int y0 = SP >= 16 ? (int)((P0 & (SP * SP - 1)) >> LG) : 0;
+        const long img0 = P0 - ((long)y0 << LG);
+#pragma unroll
+        for (int i = 0; i < NSV; ++i) {
+            const int item = t + 512 * i, piece = item & 3, x = (item >> 2) & (SP - 1), pr = ((item >> 2) >> LG) % (NR + 2),
+                      j = ((item >> 2) >> LG) / (NR + 2);
+            const int y = y0 - 1 + pr;
+            const long u = img0 + (long)j * SP * SP + ((long)y << LG) + x;
+            sv[i] = (item < P_ITEMS && y >= 0 && y < SP && u < M) ? ldg8(dY + u * lddy + piece * 8) : zero8();
+        }
+    };
+    const int wq = wave & 3;
+    const int trow = 8 * h + ((lane & 15) >> 2);
+    const int tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    auto stage = [&]() {                                            // registers -> both copies of the tile and of the padded dY image
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<h8*>(AtR + (row0 + 32 * i) * R_RS + chunk * 16) = av[i];
+            *reinterpret_cast<h8*>(AtT + (row0 + 32 * i) * T_RS + chunk * 16) = av[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NSV; ++i) {
+            const int item = t + 512 * i, piece = item & 3, x = (item >> 2) & (SP - 1), pr = ((item >> 2) >> LG) % (NR + 2),
+                      j = ((item >> 2) >> LG) / (NR + 2);
+            if (item < P_ITEMS) {
+                *reinterpret_cast<h8*>(stripR + (j * PIMG + pr * PW + x + 1) * Y_RS + piece * 16) = sv[i];
+                *reinterpret_cast<h8*>(stripT + (j * PIMG + pr * PW + x + 1) * 64 + piece * 16) = sv[i];
+            }
+        }
+    };
+    auto store_out = [&](long P0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<h8*>(dB + (P0 + row0 + 32 * i) * 128 + chunk * 8) =
+                *reinterpret_cast<const h8*>(AtR + (row0 + 32 * i) * R_RS + chunk * 16);
+    };
+    if (tile0 < tile1) fetch(tile0);
+    // The two roles are two separate tile loops with the same three barriers per tile (a workgroup barrier counts waves, not
+    // code addresses): written as one loop with a role branch inside, the register state of BOTH roles - 72 + 32 and 144 -
+    // was live across it in every wave (560 spills).
+    if (wave < 4) {
+        // ------------------------------------------------ data gradient + adjoint (as dgrad3x3_bn_f16_kernel)
+        h8 wf[9][2];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) wf[tap][q] = ldg8(W2b + ((tap * 128 + 32 * wq + r) * 32 + 16 * q + 8 * h));
+        float S0[16], S1[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S0[i] = S1[i] = 0.f;
+        for (long tile = tile0; tile < tile1; ++tile) {
+            lds_barrier();                                          // the previous tile's reads (and its store-out) are done
+            stage();
+            lds_barrier();
+            if (tile + 1 < tile1) fetch(tile + 1);                  // in flight while this tile multiplies
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c) {
+                f32x16 acc;
+                zero_acc(acc);
+                const int px = 32 * c + r;
+                const char* const centre =
+                    stripR + ((SP >= 16 ? 0 : (px >> (2 * LG)) * PIMG) + (((px >> LG) & (NR - 1)) + 1) * PW + (px & (SP - 1)) + 1) * Y_RS;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    h8 b[6];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const char* src = centre - ((ky - 1) * PW + (kx - 1)) * Y_RS;       // an immediate
+                        b[2 * kx] = *reinterpret_cast<const h8*>(src + (8 * h) * 2);
+                        b[2 * kx + 1] = *reinterpret_cast<const h8*>(src + (16 + 8 * h) * 2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[3 * ky + (j >> 1)][j & 1], b[j], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int m0 = 32 * wq + 8 * g + 4 * h;
+                    h4* const cell = reinterpret_cast<h4*>(AtR + px * R_RS + m0 * 2);
+                    const h4 a4 = *cell;
+                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(sc2 + m0);
+                    h4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float af = (float)a4[e];
+                        const float d = af > 0.f ? acc[4 * g + e] : 0.f;
+                        S0[4 * g + e] += d;
+                        S1[4 * g + e] += d * af;
+                        o[e] = (_Float16)(d * s4[e]);
+                    }
+                    *cell = o;
+                }
+            }
+            lds_barrier();
+            store_out(tile * 128);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                S0[i] += __shfl_xor(S0[i], o, 64);
+                S1[i] += __shfl_xor(S1[i], o, 64);
+            }
+        }
+        if (r == 0) {
+            float* const out = ws_bn + (long)blockIdx.x * 256;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = 32 * wq + 8 * (i >> 2) + 4 * h + (i & 3);
+                out[m] = S0[i];
+                out[128 + m] = S1[i];
+            }
+        }
+    } else {
+        // ------------------------------------------------ weight gradient (as wgrad3x3_f16_p2_kernel, 8 k-steps of 16 pixels)
+        f32x16 wacc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) zero_acc(wacc[k]);
+        for (long tile = tile0; tile < tile1; ++tile) {
+            lds_barrier();
+            stage();
+            lds_barrier();
+            if (tile + 1 < tile1) fetch(tile + 1);
+#pragma unroll 1
+            for (int ks = 0; ks < 8; ++ks) {
+                const char* pb = AtT + (16 * ks + trow) * T_RS + (32 * wq + tcol) * 2;
+                const h8 b = tr8(pb, pb + 4 * T_RS);
+                const int ilo = 16 * ks + trow, ihi = ilo + 4;
+                const int plo = (SP >= 16 ? 0 : (ilo >> (2 * LG)) * PIMG) + (((ilo >> LG) & (NR - 1)) + 1) * PW + (ilo & (SP - 1)) + 1;
+                const int phi = (SP >= 16 ? 0 : (ihi >> (2 * LG)) * PIMG) + (((ihi >> LG) & (NR - 1)) + 1) * PW + (ihi & (SP - 1)) + 1;
+                const char* lo = stripT + plo * 64 + tcol * 2;
+                const char* hi = stripT + phi * 64 + tcol * 2;
+                h8 a[9];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int off = -((tap / 3 - 1) * PW + (tap % 3 - 1)) * 64;              // compile-time: an instruction immediate
+                    a[tap] = tr8(lo + off, hi + off);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) wacc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tap], b, wacc[tap], 0, 0, 0);
+            }
+            lds_barrier();
+            store_out(tile * 128);
+        }
+        float* const out = ws_w + (long)blockIdx.x * (9L * 32 * 128);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int n = (q & 3) + 8 * (q >> 2) + 4 * h;
+                out[(tap * 32 + n) * 128 + 32 * wq + (lane & 31)] = wacc[tap][q];
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ conv1 data gradient + norm1/relu1 adjoint
 // G[p][c] += scale1[c] d,  d = [scale1[c] X[p][c] + shift1[c] > 0] sum_m dB[p][m] W1[m][c];  S0[c] = sum_p d,
 // S1[c] = sum_p d (X[p][c] - mean[c]).  A workgroup owns 128 input channels (a wave 32, its weight slice in registers) and a
@@ -1073,6 +1275,50 @@ GNX_EXPORT int gnx_conv3x3_dgrad_bnrelu_bwd_f16(const void* dY16, long lddy, con
                                                 int* flag, hipStream_t stream) {
     return gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb(dY16, lddy, W2b16, A16, 128, 32, dB16, M, S, scale2, gamma2, beta2, dgamma, dbeta,
                                                workspace, ls, accumulate, flag, stream);
+}
+
+// conv2's whole backward in ONE pass over dY16 and A16 (round 5): dB16 (as gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb), dgamma2 / dbeta2
+// AND dW2 [32][128][3][3] (as gnx_wgrad3x3_f16_lb) - one workgroup of eight waves stages each 128-pixel tile once, four waves
+// take the data gradient, four the weight gradient.  S in {4, 8, 16, 32, 64} and 128 | M; anything else: GNX_ERR_UNSUPPORTED
+// (callers make the two calls).  workspace: gnx_conv3x3_bwd_f16_workspace(M) floats.
+static long conv3_bwd_grid(long M) {
+    const long tiles = M / 128;
+    return tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256;            // one 512-thread workgroup per compute unit
+}
+GNX_EXPORT long gnx_conv3x3_bwd_f16_workspace(long M) { return conv3_bwd_grid(M) * (256L + 9L * 32 * 128); }
+GNX_EXPORT int gnx_conv3x3_bwd_f16_lb(const void* dY16, long lddy, const void* W2b16, const void* A16, long lda, long bsa, void* dB16,
+                                      float* dW, long M, int S, const float* scale2, const float* gamma2, const float* beta2,
+                                      float* dgamma, float* dbeta, float* workspace, const float* ls, int accumulate, int* flag,
+                                      hipStream_t stream) {
+    if (!dY16 || !W2b16 || !A16 || !dB16 || !dW || !scale2 || !gamma2 || !beta2 || !workspace || !ls || M <= 0 || S <= 0 ||
+        lddy < 32 || M % ((long)S * S) != 0 || lda < 32 || bsa < 32)
+        return GNX_ERR_BAD_ARG;
+    if (lddy % 8 || lda % 8 || bsa % 8 || !al16b(dY16) || !al16b(A16) || !al16b(dB16) || !al16b(W2b16) || M % 128 != 0 ||
+        (S != 4 && S != 8 && S != 16 && S != 32 && S != 64))
+        return GNX_ERR_UNSUPPORTED;
+    const long grid = conv3_bwd_grid(M);
+    const long tiles = M / 128, per = (tiles + grid - 1) / grid;
+    const long used = (tiles + per - 1) / per;                      // workgroups that own at least one tile (slabs written)
+    float* const ws_bn = workspace;
+    float* const ws_w = workspace + grid * 256;
+    const _Float16* dY = reinterpret_cast<const _Float16*>(dY16);
+    const _Float16* Wb = reinterpret_cast<const _Float16*>(W2b16);
+    const _Float16* A = reinterpret_cast<const _Float16*>(A16);
+    _Float16* dB = reinterpret_cast<_Float16*>(dB16);
+#define GNX_C3B(SS) conv3x3_bwd_f16_kernel<SS><<<(int)used, 512, 0, stream>>>(dY, lddy, Wb, A, lda, bsa, dB, scale2, ws_bn, ws_w, M, per)
+    switch (S) {
+        case 4: GNX_C3B(4); break;
+        case 8: GNX_C3B(8); break;
+        case 16: GNX_C3B(16); break;
+        case 32: GNX_C3B(32); break;
+        default: GNX_C3B(64);
+    }
+#undef GNX_C3B
+    if (dgamma || dbeta)
+        bn_reduce_kernel<<<8, 256, 0, stream>>>(ws_bn, used, 128, 128, dgamma, dbeta, gamma2, beta2, 1, ls, accumulate, flag);
+    const long n = 9L * 32 * 128;
+    reduce_slabs_kernel<<<(int)((n + 15) / 16), 256, 0, stream>>>(ws_w, used, n, dW, ls, accumulate, 1, flag);
+    return gnx_launch_status();
 }
 
 // G16[:, :K] += scale1 * (dB16 . W1) * [bn1(X16) > 0]; dgamma1 / dbeta1 (fp32, (+)=).  W1t16: conv1.weight transposed to

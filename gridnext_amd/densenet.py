@@ -71,6 +71,7 @@ class DenseNet(nn.Module):
         self.f16_stem = True        # ... and, with fp16 block buffers, conv0's matrix operands in fp16 too
         self.f16_fused = True       # ... and every dense layer as ONE kernel, the bottleneck in LDS only (gnx_dense_layer_f16)
         self.f16_fused_transitions = True   # ... and every transition as ONE kernel, the pooled operand in LDS only (gnx_transition_f16)
+        self.f16_fused_conv2_backward = True    # fp16 gradient path: conv2's data + weight gradient in one pass (gnx_conv3x3_bwd_f16_lb)
         self.input_norm = None      # (mean[3], std[3]) of a torchvision Normalize to apply to UINT8 input patches after the
                                     # u8 / 255 of ToTensor (fused into the stem's operand load); float inputs are taken as
                                     # already transformed by the dataset, as in the reference

@@ -268,23 +268,32 @@ class _DenseNetF16Fn(Function):
             dB = torch.empty((M, mid), device=dev, dtype=H16)          # (scratch of this block's layers: row-major)
             ws3 = _f32(L.query('gnx_wgrad3x3_f16_workspace', M), dev)
             wsd3 = _f32(L.query('gnx_conv3x3_dgrad_bnrelu_bwd_f16_workspace', M), dev)
+            wsc3 = _f32(L.query('gnx_conv3x3_bwd_f16_workspace', M), dev)
             for li in range(len(layers) - 1, -1, -1):
                 layer = layers[li]
                 a, s1, s2 = tape.layers[bi][li]
                 cin = c_in + li * g
                 dy = G.data_ptr() + 2 * (cin // 32) * bs     # the layer's 32 gradient columns: ONE contiguous [M][32] matrix
                 w2 = layer.conv2.weight
-                if want(w2):
-                    t0 = model._probe_begin()
-                    L.call('gnx_wgrad3x3_f16_lb', dy, 32, a.data_ptr(), 32, bs, L.ptr(new_like(w2)), L.ptr(ws3), M, s, lp, 0, fp, st)
-                    model._probe_mark('wgrad3x3_f16', t0, 2 * M * 9 * mid * g, 2 * M * (mid + g))
                 w2b = w2.detach().permute(2, 3, 1, 0).reshape(9, mid, g).to(H16).contiguous()      # [tap][m][n]
                 dg2, db2 = bn_out(layer.norm2)
-                t0 = model._probe_begin()
-                L.call('gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb', dy, 32, w2b.data_ptr(), a.data_ptr(), 32, bs, dB.data_ptr(), M, s,
-                       L.ptr(s2[0]), L.ptr(layer.norm2.weight), L.ptr(layer.norm2.bias), L.ptr(dg2), L.ptr(db2), L.ptr(wsd3), lp, 0,
-                       fp, st)
-                model._probe_mark('dgrad3x3_bn2_f16', t0, 2 * M * 9 * mid * g, 2 * M * (g + 2 * mid))
+                if want(w2) and model.f16_fused_conv2_backward:
+                    # conv2's whole backward - data gradient + norm2 adjoint AND weight gradient - in ONE pass over dY and A
+                    t0 = model._probe_begin()
+                    L.call('gnx_conv3x3_bwd_f16_lb', dy, 32, w2b.data_ptr(), a.data_ptr(), 32, bs, dB.data_ptr(), L.ptr(new_like(w2)),
+                           M, s, L.ptr(s2[0]), L.ptr(layer.norm2.weight), L.ptr(layer.norm2.bias), L.ptr(dg2), L.ptr(db2), L.ptr(wsc3),
+                           lp, 0, fp, st)
+                    model._probe_mark('conv3x3_bwd_f16', t0, 4 * M * 9 * mid * g, 2 * M * (g + 2 * mid))
+                else:
+                    if want(w2):
+                        t0 = model._probe_begin()
+                        L.call('gnx_wgrad3x3_f16_lb', dy, 32, a.data_ptr(), 32, bs, L.ptr(new_like(w2)), L.ptr(ws3), M, s, lp, 0, fp, st)
+                        model._probe_mark('wgrad3x3_f16', t0, 2 * M * 9 * mid * g, 2 * M * (mid + g))
+                    t0 = model._probe_begin()
+                    L.call('gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb', dy, 32, w2b.data_ptr(), a.data_ptr(), 32, bs, dB.data_ptr(), M, s,
+                           L.ptr(s2[0]), L.ptr(layer.norm2.weight), L.ptr(layer.norm2.bias), L.ptr(dg2), L.ptr(db2), L.ptr(wsd3), lp, 0,
+                           fp, st)
+                    model._probe_mark('dgrad3x3_bn2_f16', t0, 2 * M * 9 * mid * g, 2 * M * (g + 2 * mid))
                 # conv1: data gradient + norm1 -> relu1's adjoint into the block gradient, and - from the same staged tiles - the
                 # weight gradient (ONE pass over dB, X and G)
                 w1 = layer.conv1.weight
@@ -301,7 +310,7 @@ class _DenseNetF16Fn(Function):
                                   2 * M * (mid + 3 * cin))
                 tape.layers[bi][li] = None
                 del a
-            del dB, ws3, wsd3
+            del dB, ws3, wsd3, wsc3
             if bi > 0:
                 # transition bi-1 -> bi: its output gradient is the first c_out / 32 channel blocks of this block's gradient;
                 # the two GEMMs that consume it read rows, so those blocks are copied out once as a row-major matrix

@@ -393,6 +393,14 @@ int gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb(const void* dY16, long lddy, const void*
                                         void* dB16, long M, int S, const float* scale2, const float* gamma2, const float* beta2,
                                         float* dgamma, float* dbeta, float* workspace, const float* ls, int accumulate, int* flag,
                                         gnx_stream_t stream);
+/* conv2's WHOLE backward in one pass over dY16 and A16 (round 5): dB16, dgamma2 / dbeta2 (= gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb)
+ * and dW2 [32][128][3][3] (= gnx_wgrad3x3_f16_lb) - a workgroup of eight waves stages each 128-pixel tile once, four waves take
+ * the data gradient, four the weight gradient: 576 instead of 896 bytes per pixel.  S in {4, 8, 16, 32, 64}, 128 | M; otherwise
+ * GNX_ERR_UNSUPPORTED (make the two calls).  workspace: gnx_conv3x3_bwd_f16_workspace(M) floats. */
+long gnx_conv3x3_bwd_f16_workspace(long M);
+int gnx_conv3x3_bwd_f16_lb(const void* dY16, long lddy, const void* W2b16, const void* A16, long lda, long bsa, void* dB16, float* dW,
+                           long M, int S, const float* scale2, const float* gamma2, const float* beta2, float* dgamma,
+                           float* dbeta, float* workspace, const float* ls, int accumulate, int* flag, gnx_stream_t stream);
 int gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16_lb(const void* dB16, const void* W1t16, const void* X16, long ldx, long bsx, void* G16,
                                               long ldg, long bsg, long M, int K, const float* scale, const float* shift,
                                               const float* mean, const float* invstd, float* dgamma, float* dbeta, float* dW,

@@ -353,6 +353,60 @@ def test_lb_entry_points_on_channel_blocked_buffers_equal_the_row_major_ones(L, 
         assert rel(b[k], a[k]) <= 1e-5, (k, rel(b[k], a[k]))
 
 
+@pytest.mark.parametrize("imgs,S,blk", [(8, 4, True), (64, 4, False), (6, 8, True), (2, 16, True), (3, 32, False), (1, 64, True),
+                                        (5, 64, True), (300, 16, True)])
+def test_conv3x3_bwd_one_pass_equals_the_two_kernels(L, imgs, S, blk):
+    """gnx_conv3x3_bwd_f16_lb - conv2's data gradient + norm2 adjoint AND weight gradient from ONE staging of each 128-pixel
+    tile (four waves per role) - against the two kernels it fuses on the same operands: dB bit for bit (the same arithmetic in the
+    same order), dW2 / dgamma2 / dbeta2 to 1e-5 (other slab boundaries: 256 workgroups instead of 512 slabs) and against fp64."""
+    g = torch.Generator().manual_seed(imgs * 10 + S)
+    M = imgs * S * S
+    if M % 128:
+        pytest.skip("whole 128-pixel tiles only")
+    ct = 96
+    G0 = (torch.randn(M, ct, generator=g) * 2).half().to(DEV)
+    A = torch.relu(torch.randn(M, 128, generator=g)).half().to(DEV)
+    W2 = (torch.randn(32, 128, 3, 3, generator=g) * 0.05).to(DEV)
+    w2b = W2.permute(2, 3, 1, 0).reshape(9, 128, 32).half().contiguous()
+    gam2, bet2 = (torch.rand(128, generator=g) + 0.5).to(DEV), (torch.randn(128, generator=g) * 0.1).to(DEV)
+    sc2 = (gam2 * 0.8).contiguous()
+    ls, st = ls_tensor(8.0), L.stream()
+    Gb = _blocked(G0) if blk else G0
+    Ab = _blocked(A) if blk else A
+    bs = M * 32
+    dy = Gb.data_ptr() + 2 * (2 * bs if blk else 64)
+    lddy, lda, bsa = (32, 32, bs) if blk else (ct, 128, 32)
+    out = {}
+    for mode in ('pair', 'one'):
+        flag = flag_tensor()
+        dW2 = torch.zeros(32, 128, 3, 3, device=DEV)
+        dB = torch.empty(M, 128, device=DEV, dtype=H)
+        dg2, db2 = torch.zeros(128, device=DEV), torch.zeros(128, device=DEV)
+        if mode == 'pair':
+            ws = f32(L.query('gnx_wgrad3x3_f16_workspace', M))
+            wsd = f32(L.query('gnx_conv3x3_dgrad_bnrelu_bwd_f16_workspace', M))
+            L.call('gnx_wgrad3x3_f16_lb', dy, lddy, Ab.data_ptr(), lda, bsa, L.ptr(dW2), L.ptr(ws), M, S, L.ptr(ls), 0, flag.data_ptr(), st)
+            L.call('gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb', dy, lddy, w2b.data_ptr(), Ab.data_ptr(), lda, bsa, dB.data_ptr(), M, S,
+                   L.ptr(sc2), L.ptr(gam2), L.ptr(bet2), L.ptr(dg2), L.ptr(db2), L.ptr(wsd), L.ptr(ls), 0, flag.data_ptr(), st)
+        else:
+            wsc = f32(L.query('gnx_conv3x3_bwd_f16_workspace', M))
+            L.call('gnx_conv3x3_bwd_f16_lb', dy, lddy, w2b.data_ptr(), Ab.data_ptr(), lda, bsa, dB.data_ptr(), L.ptr(dW2), M, S,
+                   L.ptr(sc2), L.ptr(gam2), L.ptr(bet2), L.ptr(dg2), L.ptr(db2), L.ptr(wsc), L.ptr(ls), 0, flag.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0
+        out[mode] = (dB, dW2, dg2, db2)
+    assert torch.equal(out['one'][0], out['pair'][0]), "dB differs"
+    for k in (1, 2, 3):
+        assert rel(out['one'][k], out['pair'][k]) <= 2e-5, (k, rel(out['one'][k], out['pair'][k]))
+    # ... and the weight gradient against fp64 on the same fp16 operands
+    dY = G0[:, 64:96].double().reshape(imgs, S, S, 32).permute(0, 3, 1, 2)
+    Ad = A.double().reshape(imgs, S, S, 128).permute(0, 3, 1, 2)
+    ref = torch.nn.grad.conv2d_weight(Ad, (32, 128, 3, 3), dY, padding=1) / 8.0
+    assert rel(out['one'][1], ref) <= 2e-4, rel(out['one'][1], ref)
+    assert L.query('gnx_conv3x3_bwd_f16_lb', dy, lddy, w2b.data_ptr(), Ab.data_ptr(), lda, bsa, dB.data_ptr(), L.ptr(dW2), M, 7,
+                   L.ptr(sc2), L.ptr(gam2), L.ptr(bet2), L.ptr(dg2), L.ptr(db2), L.ptr(wsc), L.ptr(ls), 0, None, st) in (-1, -3)
+
+
 def _rows(t):
     """A channel-blocked tape tensor [C / 32][rows][32] (densenet_train_f16: block buffers, activated bottlenecks) as the
     row-major [rows][C] matrix it stands for."""

@@ -24,6 +24,31 @@ def one_step_grads(m, xi, xc, y, idx, dev, scale):
         (loss * scale).backward()
 
 
+def two_steps(m, xi, xc, y, groups, dev, scale, reduce_fn):
+    """two optimizer steps (SGD as the worker's); returns per-array losses and the parameters after each step"""
+    import torch
+    from gridnext_amd import functional as GF
+    import dp_gpu_worker as wk
+    opt = torch.optim.SGD(m.corrector.parameters(), lr=0.05)
+    f_opt = torch.optim.SGD(list(m.image_classifier.parameters()) + list(m.count_classifier.parameters()), lr=0.01)
+    losses, snaps = [], []
+    m.train()
+    m.patch_classifier.eval()
+    for group in groups:
+        for i in group:
+            logits = m.forward_nhwc([xi[i:i + 1].to(dev), xc[i:i + 1].to(dev)])
+            loss, _, _ = GF.masked_cross_entropy(logits.reshape(-1, wk.C), y[i:i + 1].to(dev), 1)
+            (loss * scale).backward()
+            losses.append(float(loss.item()))
+        reduce_fn()
+        opt.step()
+        f_opt.step()
+        opt.zero_grad()
+        f_opt.zero_grad()
+        snaps.append({n: p.detach().cpu().clone() for n, p in m.named_parameters()})
+    return losses, snaps
+
+
 def worker(out_dir, fopt):
     import torch
     import dp_gpu_worker as wk
@@ -33,6 +58,12 @@ def worker(out_dir, fopt):
     m.to(dev)
     gdist.broadcast_module(m)
     params = [p for p in m.parameters() if p.requires_grad]
+    if os.environ.get('GNX_DIAG_STEPS') == '2':
+        losses, snaps = two_steps(m, xi, xc, y, [[rank], [2 + rank]], dev, 1.0, lambda: gdist.allreduce_gradients(params))
+        torch.save({'losses': losses, 'snaps': snaps}, os.path.join(out_dir, 'diag%d.pt' % rank))
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+        return
     one_step_grads(m, xi, xc, y, [rank], dev, 1.0)
     raw = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}
     early = set(gdist._EARLY)
@@ -68,6 +99,14 @@ def main():
     m, xi, xc, y = wk.make_problem(1000, fopt)
     dev = torch.device('cuda:0')
     m.to(dev)
+    if os.environ.get('GNX_DIAG_STEPS') == '2':
+        losses, snaps = two_steps(m, xi, xc, y, [[0, 1], [2, 3]], dev, 0.5, lambda: None)
+        print("overlap", os.environ.get('GNX_DP_OVERLAP', '1'), "losses reference", losses, "rank0", d0['losses'], "rank1", d1['losses'])
+        for k in range(2):
+            worst = sorted(((float((d0['snaps'][k][n].double() - snaps[k][n].double()).abs().max() /
+                                   snaps[k][n].double().abs().max().clamp_min(1e-30)), n) for n in snaps[k]), reverse=True)[:6]
+            print("after step %d: worst parameter differences (rel):" % (k + 1), ["%.2e %s" % w for w in worst])
+        return
     one_step_grads(m, xi, xc, y, [0, 1], dev, 0.5)
     ref = {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}
     print("early-reduced parameters on rank 0: %d of %d" % (len(d0['early']), len(ref)))

@@ -26,6 +26,7 @@ def _targs(n, kernel):
 GROUPS = [                                   # first match wins; names as bench.py's kernel kinds
     ('dgrad_wgrad1x1_bn1_f16', lambda n: 'dgrad1x1_bn_f16_kernel' in n and ('ILb1' in n or '<true>' in n)),
     ('dgrad1x1_bn1_f16', lambda n: 'dgrad1x1_bn_f16_kernel' in n),
+    ('conv3x3_bwd_f16', lambda n: 'conv3x3_bwd_f16_kernel' in n),
     ('dgrad3x3_bn2_f16', lambda n: 'dgrad3x3_bn_f16_kernel' in n),
     ('wgrad3x3_f16', lambda n: 'wgrad3x3_f16_kernel' in n or 'wgrad3x3_f16_p2_kernel' in n),
     ('wgrad1x1_f16', lambda n: 'wgrad1x1_f16_kernel' in n),
