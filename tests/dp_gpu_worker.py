@@ -22,15 +22,15 @@ from torch.utils.data import DataLoader                         # noqa: E402
 
 TINY = dict(growth_rate=4, block_config=(2, 2), num_init_features=8, bn_size=2, num_classes=5, small_inputs=False)
 WIDE = dict(growth_rate=32, block_config=(2, 2, 2, 2), num_init_features=64, bn_size=4, num_classes=5, small_inputs=False)
-G, H, W, P, C = 20, 6, 4, 32, 5
+G, C = 20, 5
 FOPT = os.environ.get('GNX_TEST_FOPT', '')
 
 
 def make_problem(seed_model, fopt=FOPT):
     import gridnext_amd as ga
     from gridnext_amd.synthetic import count_mlp
-    global H, W, P
     torch.manual_seed(seed_model)
+    H, W, P = 6, 4, 32                                          # (locals: the problem depends on `fopt` only, never on call order)
     if fopt == 'f16':
         H, W, P = 4, 2, 128                                     # 8 spots per array: one group of the fp16 kernels
         dn = ga.DenseNet(**WIDE)
