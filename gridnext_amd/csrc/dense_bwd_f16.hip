@@ -543,88 +543,102 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3_bn_f16_kernel(const _Float16*
 
 // ------------------------------------------------------------------------------------------------ conv2 backward in ONE pass (round 5)
 // The two kernels above read the same operands - the layer's dY strip and the activated bottleneck A - once each: 320 of the
-// 896 bytes per pixel the pair moves.  Here they run as ONE launch of PAIRED workgroups: workgroups b and b + 8 (block ids 8
-// apart share an XCD and are dispatched together) walk the SAME range of 128-pixel tiles in the same order,
-//   role 0  data gradient + norm2 -> relu2 adjoint (the body of dgrad3x3_bn_f16_kernel): D = [m][pixel], wave w = bottleneck
-//           channels 32 w .., W2's nine taps as 72 register fragments, dB written over the tile it read A from;
-//   role 1  weight gradient (the body of wgrad3x3_f16_p2_kernel on 128-pixel tiles): D = [n][k] per tap, wave w = channels
-//           k = 32 w .., nine accumulators (144 registers) for the workgroup's lifetime, operands by transposing reads,
-// so that whichever of the two asks for a tile second finds it in the XCD's L2: HBM sees 64 + 256 bytes per pixel in, 256 out.
-// No synchronisation between the two is needed for correctness - they only READ the same bytes and write disjoint outputs;
-// the pairing is for speed only (72 MFMAs per wave and tile either way keep them in step).  Arithmetic and summation order
-// of each role are those of the kernel it comes from.
-// (First form, measured: ONE workgroup of eight waves staging the tile once for both roles - 41.5 ms per 256-px array against
-// 27.1 + 18.0 for the two kernels: with 144 + 72 accumulator / weight registers per role only one such workgroup fits a CU, i.e.
-// ONE tile in flight per CU where the two kernels had two, and the pass is latency-bound per tile.)
+// 896 bytes per pixel the pair moves.  Here ONE workgroup of eight waves stages a 128-pixel tile once and splits the work by
+// ROLE (the waves of a role are the kernels above, unchanged in their arithmetic and summation order):
+//   waves 0-3  data gradient + norm2 -> relu2 adjoint (dgrad3x3_bn_f16_kernel): D = [m][pixel], wave w = bottleneck channels
+//              32 w .., W2's nine taps as 72 register fragments, dB written over the tile copy it reads A from;
+//   waves 4-7  weight gradient (wgrad3x3_f16_p2_kernel): D = [n][k] per tap, wave w = channels k = 32 w .., nine accumulators
+//              (144 registers) alive for the workgroup's lifetime, both operands by transposing reads.
+// 72 MFMAs per wave and tile either way.  The two roles want different LDS row strides (rows read by ds_read_b128 need
+// 4 x odd dwords, transposing reads 16 mod 64), so A and the zero-padded dY image are staged twice - LDS writes are cheap,
+// HBM reads are what the pass is bound by: 64 + 256 bytes per pixel in, 256 out.  Power-of-two maps, whole 128-pixel tiles.
 template <int SP>
-__global__ __launch_bounds__(256, 2) void conv3x3_bwd_pair_kernel(const _Float16* __restrict__ dY, long lddy,
-                                                                  const _Float16* __restrict__ W2b,
-                                                                  const _Float16* __restrict__ A, long lda, long bsa,
-                                                                  _Float16* __restrict__ dB, const float* __restrict__ scale2,
-                                                                  float* __restrict__ ws_bn, float* __restrict__ ws_w, long M,
-                                                                  long tiles_per_pair, int n_pairs) {
+__global__ __launch_bounds__(512, 1) void conv3x3_bwd_f16_kernel(const _Float16* __restrict__ dY, long lddy,
+                                                                 const _Float16* __restrict__ W2b,
+                                                                 const _Float16* __restrict__ A, long lda, long bsa,
+                                                                 _Float16* __restrict__ dB, const float* __restrict__ scale2,
+                                                                 float* __restrict__ ws_bn, float* __restrict__ ws_w, long M,
+                                                                 long tiles_per_wg) {
     constexpr int NIMG = SP >= 16 ? 1 : 128 / (SP * SP);            // images per tile
     constexpr int NR = SP >= 16 ? 128 / SP : SP;                    // image rows per tile and image
     constexpr int PW = SP + 2, PIMG = (NR + 2) * PW, NPOS = NIMG * PIMG;
     constexpr int LG = SP == 4 ? 2 : SP == 8 ? 3 : SP == 16 ? 4 : SP == 32 ? 5 : 6;
     constexpr int P_ITEMS = NIMG * (NR + 2) * SP * 4;               // (padded row, column, 16-B piece) to stage per tile
-    constexpr int NSV = (P_ITEMS + 255) / 256;
-    constexpr int LDS0 = 128 * R_RS + NPOS * Y_RS + 512, LDS1 = 128 * T_RS + NPOS * 64;
-    __shared__ __attribute__((aligned(16))) char smem[LDS0 > LDS1 ? LDS0 : LDS1];
+    constexpr int NSV = (P_ITEMS + 511) / 512;
+    __shared__ __attribute__((aligned(16))) char smem[128 * R_RS + 128 * T_RS + NPOS * (Y_RS + 64) + 512];
+    char* const AtR = smem;                                         // rows (the data-gradient role; rewritten with dB)
+    char* const AtT = smem + 128 * R_RS;                            // transposing reads (the weight-gradient role)
+    char* const stripR = AtT + 128 * T_RS;
+    char* const stripT = stripR + NPOS * Y_RS;
+    float* const sc2 = reinterpret_cast<float*>(stripT + NPOS * 64);
     const int t = threadIdx.x, lane = t & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int bx = blockIdx.x;
-    const int role = (bx >> 3) & 1;
-    const int pair = (bx >> 4) * 8 + (bx & 7);
-    if (pair >= n_pairs) return;                                    // (padding of the last group of 16; whole workgroup)
     const long ntiles = M / 128;
-    const long tile0 = (long)pair * tiles_per_pair;
-    const long tile1 = tile0 + tiles_per_pair < ntiles ? tile0 + tiles_per_pair : ntiles;
-    const int chunk = t & 15, row0 = t >> 4;                        // staging: 16-B column, rows row0 + 16 i
+    const long tile0 = blockIdx.x * tiles_per_wg;
+    const long tile1 = tile0 + tiles_per_wg < ntiles ? tile0 + tiles_per_wg : ntiles;
+    const int chunk = t & 15, row0 = t >> 4;                        // staging: 16-B column, rows row0 + 32 i
+    for (int i = t; i < NPOS * 5; i += 512) *reinterpret_cast<h8*>(stripR + i * 16) = zero8();   // incl. the pad columns, for good
+    for (int i = t; i < NPOS * 4; i += 512) *reinterpret_cast<h8*>(stripT + i * 16) = zero8();
+    if (t < 128) sc2[t] = scale2[t];
     const long acol = (long)(chunk >> 2) * bsa + (chunk & 3) * 8;
-    h8 av[8], sv[NSV];
+    h8 av[4], sv[NSV];
     auto fetch = [&](long tile) {
         const long P0 = tile * 128;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) av[i] = ldg8(A + (P0 + row0 + 16 * i) * lda + acol);
+        for (int i = 0; i < 4; ++i) av[i] = ldg8(A + (P0 + row0 + 32 * i) * lda + acol);
         const int y0 = SP >= 16 ? (int)((P0 & (SP * SP - 1)) >> LG) : 0;
         const long img0 = P0 - ((long)y0 << LG);
 #pragma unroll
         for (int i = 0; i < NSV; ++i) {
-            const int item = t + 256 * i, piece = item & 3, x = (item >> 2) & (SP - 1), pr = ((item >> 2) >> LG) % (NR + 2),
+            const int item = t + 512 * i, piece = item & 3, x = (item >> 2) & (SP - 1), pr = ((item >> 2) >> LG) % (NR + 2),
                       j = ((item >> 2) >> LG) / (NR + 2);
             const int y = y0 - 1 + pr;
             const long u = img0 + (long)j * SP * SP + ((long)y << LG) + x;
             sv[i] = (item < P_ITEMS && y >= 0 && y < SP && u < M) ? ldg8(dY + u * lddy + piece * 8) : zero8();
         }
     };
-    if (role == 0) {
-        // ------------------------------------------------ data gradient + adjoint (dgrad3x3_bn_f16_kernel<SP>)
-        char* const At = smem;
-        char* const strip = smem + 128 * R_RS;
-        float* const sc2 = reinterpret_cast<float*>(strip + NPOS * Y_RS);
-        for (int i = t; i < NPOS * 5; i += 256) *reinterpret_cast<h8*>(strip + i * 16) = zero8();   // incl. the pad columns, for good
-        if (t < 128) sc2[t] = scale2[t];
+    const int wq = wave & 3;
+    const int trow = 8 * h + ((lane & 15) >> 2);
+    const int tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    auto stage = [&]() {                                            // registers -> both copies of the tile and of the padded dY image
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<h8*>(AtR + (row0 + 32 * i) * R_RS + chunk * 16) = av[i];
+            *reinterpret_cast<h8*>(AtT + (row0 + 32 * i) * T_RS + chunk * 16) = av[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NSV; ++i) {
+            const int item = t + 512 * i, piece = item & 3, x = (item >> 2) & (SP - 1), pr = ((item >> 2) >> LG) % (NR + 2),
+                      j = ((item >> 2) >> LG) / (NR + 2);
+            if (item < P_ITEMS) {
+                *reinterpret_cast<h8*>(stripR + (j * PIMG + pr * PW + x + 1) * Y_RS + piece * 16) = sv[i];
+                *reinterpret_cast<h8*>(stripT + (j * PIMG + pr * PW + x + 1) * 64 + piece * 16) = sv[i];
+            }
+        }
+    };
+    auto store_out = [&](long P0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<h8*>(dB + (P0 + row0 + 32 * i) * 128 + chunk * 8) =
+                *reinterpret_cast<const h8*>(AtR + (row0 + 32 * i) * R_RS + chunk * 16);
+    };
+    if (tile0 < tile1) fetch(tile0);
+    // The two roles are two separate tile loops with the same three barriers per tile (a workgroup barrier counts waves, not
+    // code addresses): written as one loop with a role branch inside, the register state of BOTH roles - 72 + 32 and 144 -
+    // was live across it in every wave (560 spills).
+    if (wave < 4) {
+        // ------------------------------------------------ data gradient + adjoint (as dgrad3x3_bn_f16_kernel)
         h8 wf[9][2];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) wf[tap][q] = ldg8(W2b + ((tap * 128 + 32 * wave + r) * 32 + 16 * q + 8 * h));
+            for (int q = 0; q < 2; ++q) wf[tap][q] = ldg8(W2b + ((tap * 128 + 32 * wq + r) * 32 + 16 * q + 8 * h));
         float S0[16], S1[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) S0[i] = S1[i] = 0.f;
-        if (tile0 < tile1) fetch(tile0);
         for (long tile = tile0; tile < tile1; ++tile) {
-            const long P0 = tile * 128;
-            lds_barrier();                                          // the previous tile's store-out reads are done
-#pragma unroll
-            for (int i = 0; i < 8; ++i) *reinterpret_cast<h8*>(At + (row0 + 16 * i) * R_RS + chunk * 16) = av[i];
-#pragma unroll
-            for (int i = 0; i < NSV; ++i) {
-                const int item = t + 256 * i, piece = item & 3, x = (item >> 2) & (SP - 1), pr = ((item >> 2) >> LG) % (NR + 2),
-                          j = ((item >> 2) >> LG) / (NR + 2);
-                if (item < P_ITEMS) *reinterpret_cast<h8*>(strip + (j * PIMG + pr * PW + x + 1) * Y_RS + piece * 16) = sv[i];
-            }
+            lds_barrier();                                          // the previous tile's reads (and its store-out) are done
+            stage();
             lds_barrier();
             if (tile + 1 < tile1) fetch(tile + 1);                  // in flight while this tile multiplies
 #pragma unroll 1
@@ -633,7 +647,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bwd_pair_kernel(const _Float16
                 zero_acc(acc);
                 const int px = 32 * c + r;
                 const char* const centre =
-                    strip + ((SP >= 16 ? 0 : (px >> (2 * LG)) * PIMG) + (((px >> LG) & (NR - 1)) + 1) * PW + (px & (SP - 1)) + 1) * Y_RS;
+                    stripR + ((SP >= 16 ? 0 : (px >> (2 * LG)) * PIMG) + (((px >> LG) & (NR - 1)) + 1) * PW + (px & (SP - 1)) + 1) * Y_RS;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     h8 b[6];
@@ -650,8 +664,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bwd_pair_kernel(const _Float16
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int m0 = 32 * wave + 8 * g + 4 * h;
-                    h4* const cell = reinterpret_cast<h4*>(At + px * R_RS + m0 * 2);
+                    const int m0 = 32 * wq + 8 * g + 4 * h;
+                    h4* const cell = reinterpret_cast<h4*>(AtR + px * R_RS + m0 * 2);
                     const h4 a4 = *cell;
                     const f32x4 s4 = *reinterpret_cast<const f32x4*>(sc2 + m0);
                     h4 o;
@@ -667,10 +681,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bwd_pair_kernel(const _Float16
                 }
             }
             lds_barrier();
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                *reinterpret_cast<h8*>(dB + (P0 + row0 + 16 * i) * 128 + chunk * 8) =
-                    *reinterpret_cast<const h8*>(At + (row0 + 16 * i) * R_RS + chunk * 16);
+            store_out(tile * 128);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -681,46 +692,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bwd_pair_kernel(const _Float16
             }
         }
         if (r == 0) {
-            float* const out = ws_bn + (long)pair * 256;
+            float* const out = ws_bn + (long)blockIdx.x * 256;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int m = 32 * wave + 8 * (i >> 2) + 4 * h + (i & 3);
+                const int m = 32 * wq + 8 * (i >> 2) + 4 * h + (i & 3);
                 out[m] = S0[i];
                 out[128 + m] = S1[i];
             }
         }
     } else {
-        // ------------------------------------------------ weight gradient (wgrad3x3_f16_p2_kernel<SP> on 128-pixel tiles)
-        char* const At = smem;
-        char* const strip = smem + 128 * T_RS;
-        for (int i = t; i < NPOS * 4; i += 256) *reinterpret_cast<h8*>(strip + i * 16) = zero8();
-        const int trow = 8 * h + ((lane & 15) >> 2);
-        const int tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        // ------------------------------------------------ weight gradient (as wgrad3x3_f16_p2_kernel, 8 k-steps of 16 pixels)
         f32x16 wacc[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) zero_acc(wacc[k]);
-        if (tile0 < tile1) fetch(tile0);
         for (long tile = tile0; tile < tile1; ++tile) {
-            lds_barrier();                                          // the previous tile's reads are done
-#pragma unroll
-            for (int i = 0; i < 8; ++i) *reinterpret_cast<h8*>(At + (row0 + 16 * i) * T_RS + chunk * 16) = av[i];
-#pragma unroll
-            for (int i = 0; i < NSV; ++i) {
-                const int item = t + 256 * i, piece = item & 3, x = (item >> 2) & (SP - 1), pr = ((item >> 2) >> LG) % (NR + 2),
-                          j = ((item >> 2) >> LG) / (NR + 2);
-                if (item < P_ITEMS) *reinterpret_cast<h8*>(strip + (j * PIMG + pr * PW + x + 1) * 64 + piece * 16) = sv[i];
-            }
+            lds_barrier();
+            stage();
             lds_barrier();
             if (tile + 1 < tile1) fetch(tile + 1);
 #pragma unroll 1
             for (int ks = 0; ks < 8; ++ks) {
-                const char* pb = At + (16 * ks + trow) * T_RS + (32 * wave + tcol) * 2;
+                const char* pb = AtT + (16 * ks + trow) * T_RS + (32 * wq + tcol) * 2;
                 const h8 b = tr8(pb, pb + 4 * T_RS);
                 const int ilo = 16 * ks + trow, ihi = ilo + 4;
                 const int plo = (SP >= 16 ? 0 : (ilo >> (2 * LG)) * PIMG) + (((ilo >> LG) & (NR - 1)) + 1) * PW + (ilo & (SP - 1)) + 1;
                 const int phi = (SP >= 16 ? 0 : (ihi >> (2 * LG)) * PIMG) + (((ihi >> LG) & (NR - 1)) + 1) * PW + (ihi & (SP - 1)) + 1;
-                const char* lo = strip + plo * 64 + tcol * 2;
-                const char* hi = strip + phi * 64 + tcol * 2;
+                const char* lo = stripT + plo * 64 + tcol * 2;
+                const char* hi = stripT + phi * 64 + tcol * 2;
                 h8 a[9];
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
@@ -731,14 +729,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bwd_pair_kernel(const _Float16
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) wacc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[tap], b, wacc[tap], 0, 0, 0);
             }
+            lds_barrier();
+            store_out(tile * 128);
         }
-        float* const out = ws_w + (long)pair * (9L * 32 * 128);
+        float* const out = ws_w + (long)blockIdx.x * (9L * 32 * 128);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int n = (q & 3) + 8 * (q >> 2) + 4 * h;
-                out[(tap * 32 + n) * 128 + 32 * wave + (lane & 31)] = wacc[tap][q];
+                out[(tap * 32 + n) * 128 + 32 * wq + (lane & 31)] = wacc[tap][q];
             }
     }
 }
@@ -1278,14 +1278,14 @@ GNX_EXPORT int gnx_conv3x3_dgrad_bnrelu_bwd_f16(const void* dY16, long lddy, con
 }
 
 // conv2's whole backward in ONE pass over dY16 and A16 (round 5): dB16 (as gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb), dgamma2 / dbeta2
-// AND dW2 [32][128][3][3] (as gnx_wgrad3x3_f16_lb) - ONE launch of paired workgroups on one XCD that walk the same tiles, one
-// taking the data gradient, one the weight gradient, so that each tile leaves HBM once.  S in {4, 8, 16, 32, 64} and 128 | M; anything else: GNX_ERR_UNSUPPORTED
+// AND dW2 [32][128][3][3] (as gnx_wgrad3x3_f16_lb) - one workgroup of eight waves stages each 128-pixel tile once, four waves
+// take the data gradient, four the weight gradient.  S in {4, 8, 16, 32, 64} and 128 | M; anything else: GNX_ERR_UNSUPPORTED
 // (callers make the two calls).  workspace: gnx_conv3x3_bwd_f16_workspace(M) floats.
-static long conv3_bwd_pairs(long M) {
+static long conv3_bwd_grid(long M) {
     const long tiles = M / 128;
-    return tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256;            // one PAIR of workgroups per compute unit
+    return tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256;            // one 512-thread workgroup per compute unit
 }
-GNX_EXPORT long gnx_conv3x3_bwd_f16_workspace(long M) { return conv3_bwd_pairs(M) * (256L + 9L * 32 * 128); }
+GNX_EXPORT long gnx_conv3x3_bwd_f16_workspace(long M) { return conv3_bwd_grid(M) * (256L + 9L * 32 * 128); }
 GNX_EXPORT int gnx_conv3x3_bwd_f16_lb(const void* dY16, long lddy, const void* W2b16, const void* A16, long lda, long bsa, void* dB16,
                                       float* dW, long M, int S, const float* scale2, const float* gamma2, const float* beta2,
                                       float* dgamma, float* dbeta, float* workspace, const float* ls, int accumulate, int* flag,
@@ -1296,17 +1296,16 @@ GNX_EXPORT int gnx_conv3x3_bwd_f16_lb(const void* dY16, long lddy, const void* W
     if (lddy % 8 || lda % 8 || bsa % 8 || !al16b(dY16) || !al16b(A16) || !al16b(dB16) || !al16b(W2b16) || M % 128 != 0 ||
         (S != 4 && S != 8 && S != 16 && S != 32 && S != 64))
         return GNX_ERR_UNSUPPORTED;
-    const long cap = conv3_bwd_pairs(M);
-    const long tiles = M / 128, per = (tiles + cap - 1) / cap;
-    const long pairs = (tiles + per - 1) / per;                     // pairs that own at least one tile (slabs written)
+    const long grid = conv3_bwd_grid(M);
+    const long tiles = M / 128, per = (tiles + grid - 1) / grid;
+    const long used = (tiles + per - 1) / per;                      // workgroups that own at least one tile (slabs written)
     float* const ws_bn = workspace;
-    float* const ws_w = workspace + cap * 256;
+    float* const ws_w = workspace + grid * 256;
     const _Float16* dY = reinterpret_cast<const _Float16*>(dY16);
     const _Float16* Wb = reinterpret_cast<const _Float16*>(W2b16);
     const _Float16* A = reinterpret_cast<const _Float16*>(A16);
     _Float16* dB = reinterpret_cast<_Float16*>(dB16);
-    const int grid = (int)((pairs + 7) / 8 * 16);                   // block 16 q + 8 role + j = (pair 8 q + j, role)
-#define GNX_C3B(SS) conv3x3_bwd_pair_kernel<SS><<<grid, 256, 0, stream>>>(dY, lddy, Wb, A, lda, bsa, dB, scale2, ws_bn, ws_w, M, per, (int)pairs)
+#define GNX_C3B(SS) conv3x3_bwd_f16_kernel<SS><<<(int)used, 512, 0, stream>>>(dY, lddy, Wb, A, lda, bsa, dB, scale2, ws_bn, ws_w, M, per)
     switch (S) {
         case 4: GNX_C3B(4); break;
         case 8: GNX_C3B(8); break;
@@ -1316,9 +1315,9 @@ GNX_EXPORT int gnx_conv3x3_bwd_f16_lb(const void* dY16, long lddy, const void* W
     }
 #undef GNX_C3B
     if (dgamma || dbeta)
-        bn_reduce_kernel<<<8, 256, 0, stream>>>(ws_bn, pairs, 128, 128, dgamma, dbeta, gamma2, beta2, 1, ls, accumulate, flag);
+        bn_reduce_kernel<<<8, 256, 0, stream>>>(ws_bn, used, 128, 128, dgamma, dbeta, gamma2, beta2, 1, ls, accumulate, flag);
     const long n = 9L * 32 * 128;
-    reduce_slabs_kernel<<<(int)((n + 15) / 16), 256, 0, stream>>>(ws_w, pairs, n, dW, ls, accumulate, 1, flag);
+    reduce_slabs_kernel<<<(int)((n + 15) / 16), 256, 0, stream>>>(ws_w, used, n, dW, ls, accumulate, 1, flag);
     return gnx_launch_status();
 }
 
