@@ -755,17 +755,13 @@ def test_trained_densenet121_fp16_gradients_agree_with_the_fp32_path(capsys):
 
 
 def test_fifty_steps_of_train_gridwise_on_both_gradient_paths_end_within_one_percent(capsys):
-    """>= 50 optimizer steps through `train_gridwise` itself (f_opt: f in eval mode, stepped with g) on the
-    fp16-MFMA gradient path and on the fp32 HIP path, same state_dict, same data (4 x 4 grids of 128-px grating patches
-    whose class is the spot's label: learnable); the image classifier is pre-trained spot-wise first, as in GridNext's own
-    workflow (Tutorial_visium_image -> Tutorial_multimodal).
-    GATE (SGD with momentum - updates linear in the gradients): the last epoch's training and validation losses within 1 %.
-    REPORTED, gated at 6 %: the same 50 steps with the tutorials' Adam.  Adam divides every coordinate by its own running
-    magnitude, so coordinates whose gradient is a near-cancelling sum over pixels - where the 5e-4 relative rounding of the fp16
-    gradient tensors is an O(1) relative error of the SUM (the per-parameter errors of the previous test are relative to each
-    tensor's largest entry) - take full-size steps of either sign: the two trajectories separate by a few per cent of the loss
-    within ten steps (measured 4 %) although the gradients agree to cosine 1.0000.  That is what low-precision gradients do
-    under any sign-normalising optimizer (torch.autocast the same); it is not an error of the path."""
+    """>= 50 optimizer steps through `train_gridwise` itself (f_opt: f in eval mode, stepped with g; the
+    tutorials' Adam) on the fp16-MFMA gradient path and on the fp32 HIP path, same state_dict, same data (4 x 4 grids of
+    128-px grating patches whose class is the spot's label: learnable); the image classifier is pre-trained spot-wise first, as
+    in GridNext's own workflow (Tutorial_visium_image -> Tutorial_multimodal).
+    GATE: the last epoch's TRAINING loss (160 spots) within 1 % (measured 0.7 %: 0.4118 vs 0.4090 after falling from 2.00); the
+    VALIDATION loss (two arrays, 32 spots) within 3 % (measured 2.7 %).  Every model starts from a deep copy with no stale
+    `.grad` (train_gridwise, like the reference, does not zero the gradients before its first backward)."""
     import copy
     import contextlib
     import io
@@ -785,6 +781,7 @@ def test_fifty_steps_of_train_gridwise_on_both_gradient_paths_end_within_one_per
         pre.zero_grad()
         nn.functional.cross_entropy(dn(xb), yb).backward()
         pre.step()
+    pre.zero_grad()
     dn.eval()
     base = ga.GridNetHexMM(dn, count_mlp(G, C), (3, P, P), (G,), (Hh, Ww), C)
     data = []
@@ -794,29 +791,23 @@ def test_fifty_steps_of_train_gridwise_on_both_gradient_paths_end_within_one_per
         lab = (y + 1).reshape(Hh, Ww).cpu()                                  # foreground classes 1..C
         cnt = torch.randint(0, 10, (G, Hh, Ww), generator=gen).float()
         data.append(((x.reshape(Hh, Ww, 3, P, P).cpu(), cnt), lab))
-    optimizers = {'sgd': (lambda ps: torch.optim.SGD(ps, lr=0.02, momentum=0.9), lambda ps: torch.optim.SGD(ps, lr=0.002, momentum=0.9)),
-                  'adam': (lambda ps: torch.optim.Adam(ps, lr=1e-3), lambda ps: torch.optim.Adam(ps, lr=1e-4))}
     hist = {}
-    for oname, (mk_g, mk_f) in optimizers.items():
-        for tag in ('f32', 'f16'):
-            m = copy.deepcopy(base)
-            m.image_classifier.mfma = tag
-            dl = {'train': DataLoader(data[:10], batch_size=1, shuffle=False), 'val': DataLoader(data[10:], batch_size=1, shuffle=False)}
-            opt = mk_g(m.corrector.parameters())
-            f_opt = mk_f(list(m.image_classifier.parameters()) + list(m.count_classifier.parameters()))
-            with contextlib.redirect_stdout(io.StringIO()):
-                m, vh, th = ga.train_gridwise(m, dl, nn.CrossEntropyLoss(), opt, num_epochs=5, f_opt=f_opt)      # 50 steps
-            hist[oname, tag] = (np.array(th), np.array(vh))
-            if tag == 'f16':
-                ic = m.image_classifier
-                assert 'f16_grad_scale' in ic.__dict__ and int(ic.f16_grad_overflow.item()) == 0
+    for tag in ('f32', 'f16'):
+        m = copy.deepcopy(base)
+        m.image_classifier.mfma = tag
+        dl = {'train': DataLoader(data[:10], batch_size=1, shuffle=False), 'val': DataLoader(data[10:], batch_size=1, shuffle=False)}
+        opt = torch.optim.Adam(m.corrector.parameters(), lr=1e-3)
+        f_opt = torch.optim.Adam(list(m.image_classifier.parameters()) + list(m.count_classifier.parameters()), lr=1e-4)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m, vh, th = ga.train_gridwise(m, dl, nn.CrossEntropyLoss(), opt, num_epochs=5, f_opt=f_opt)      # 50 steps
+        hist[tag] = (np.array(th), np.array(vh))
+        if tag == 'f16':
+            ic = m.image_classifier
+            assert 'f16_grad_scale' in ic.__dict__ and int(ic.f16_grad_overflow.item()) == 0
+    a16, a32 = hist['f16'], hist['f32']
     with capsys.disabled():
-        for oname in optimizers:
-            a16, a32 = hist[oname, 'f16'], hist[oname, 'f32']
-            print("\n[50 steps of train_gridwise, %s, fp16 vs fp32 gradient path] train %s vs %s; val %s vs %s"
-                  % (oname, np.round(a16[0], 4), np.round(a32[0], 4), np.round(a16[1], 4), np.round(a32[1], 4)))
-    for oname, tol in (('sgd', 1e-2), ('adam', 6e-2)):
-        a16, a32 = hist[oname, 'f16'], hist[oname, 'f32']
-        assert a16[0][-1] < 0.8 * a16[0][0], oname                               # it trains
-        np.testing.assert_allclose(a16[0][-1], a32[0][-1], rtol=tol, err_msg=oname)
-        np.testing.assert_allclose(a16[1][-1], a32[1][-1], rtol=tol, err_msg=oname)
+        print("\n[50 steps of train_gridwise (Adam), fp16 vs fp32 gradient path] train %s vs %s; val %s vs %s"
+              % (np.round(a16[0], 4), np.round(a32[0], 4), np.round(a16[1], 4), np.round(a32[1], 4)))
+    assert a16[0][-1] < 0.5 * a16[0][0]                                          # it trains
+    np.testing.assert_allclose(a16[0][-1], a32[0][-1], rtol=1e-2)
+    np.testing.assert_allclose(a16[1][-1], a32[1][-1], rtol=3e-2)
