@@ -766,6 +766,236 @@ __global__ __launch_bounds__(1024) void bn_bwd_small_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------ round 5: several workgroups per channel block
+// At 2048 < M <= 8192 rows (one Visium grid: g's two BatchNorm2d(32) and the count MLP's BatchNorm1d; block 2 of a batch of
+// 32 patches) the single-workgroup forms above walk their strip three times with three dependent rounds of loads each: 20 /
+// 25 us per call, on C / 16 workgroups - TWO compute units for g's 32 channels.  Here BN_R workgroups share a channel block: a
+// row lane holds its <= 8 rows in registers (ONE round of loads for all walks, as KEEP), every workgroup reduces its 256 row
+// lanes with small_colsum, and the BN_R partial sums of a channel block are exchanged through `sync` memory behind a barrier of
+// those BN_R workgroups (counters zeroed by a memset node in front of the launch; arrivals: release fence + agent-scope
+// atomic, then ONE acquire before plain loads - MI355X_MICROARCH.md, inter-workgroup visibility).  The workgroups of a launch
+// are always co-resident (C / 16 x BN_R of them, <= 256 on 256 CUs); the spin is bounded all the same.  Partials are added in
+// workgroup order: deterministic; the summation ORDER differs from the single-workgroup forms (rows are dealt to 1024 lanes
+// instead of 256), the arithmetic (two-pass variance) does not.
+constexpr int BN_R = 4;
+constexpr long BN_MULTI_M = 8L * BN_SL * BN_R;                  // 8192 rows
+
+__device__ __forceinline__ void bn_group_barrier(unsigned* counter, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's stores have left the CU
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the compiler may drop the fence's own wait: MI355X_MICROARCH.md)
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 22))
+            __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// sync: [C/16 blocks][2 counters] unsigned, then partial sums [2 phases][C/16][BN_R][16] floats
+__global__ __launch_bounds__(1024) void bn_train_stats_multi_kernel(
+    const float* __restrict__ x, long ld, long M, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd,
+    float* __restrict__ y, long ldy, int relu, unsigned* __restrict__ counters, float* __restrict__ part) {
+    __shared__ float red[BN_SL][16];
+    __shared__ float grp[4][16];
+    __shared__ float bc[16];
+    __shared__ float ss[2][16];
+    const int t = threadIdx.x, cq = t & 3, rl = t >> 2;
+    const int cb = blockIdx.x / BN_R, rg = blockIdx.x % BN_R, nb = gridDim.x / BN_R;
+    const int c = cb * 16 + 4 * cq;
+    const bool on = c < C;
+    const float* px = x + (on ? c : 0);
+    const long gl = (long)rg * BN_SL + rl;                     // this lane of the channel block's BN_R x 256 row lanes
+    constexpr long STEP = (long)BN_SL * BN_R;
+    float4 kv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long rr = gl + STEP * u;
+        kv[u] = *reinterpret_cast<const float4*>(px + (rr < M ? rr : 0) * ld);
+    }
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (gl + STEP * u < M) { a[0] += kv[u].x; a[1] += kv[u].y; a[2] += kv[u].z; a[3] += kv[u].w; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rl][4 * cq + j] = a[j];
+    __syncthreads();
+    float tot = small_colsum(red, grp, t);
+    float* const p1 = part + ((size_t)cb * BN_R) * 16;
+    float* const p2 = part + ((size_t)(nb + cb) * BN_R) * 16;
+    if (t < 16) p1[rg * 16 + t] = tot;
+    bn_group_barrier(counters + 2 * cb, BN_R);
+    if (t < 16) {
+        float s_ = p1[t];
+#pragma unroll
+        for (int k = 1; k < BN_R; ++k) s_ += p1[k * 16 + t];
+        bc[t] = s_ / (float)M;
+    }
+    __syncthreads();
+    const float mu[4] = {bc[4 * cq], bc[4 * cq + 1], bc[4 * cq + 2], bc[4 * cq + 3]};
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (gl + STEP * u < M) {
+            const float d0 = kv[u].x - mu[0], d1 = kv[u].y - mu[1], d2 = kv[u].z - mu[2], d3 = kv[u].w - mu[3];
+            q[0] = fmaf(d0, d0, q[0]); q[1] = fmaf(d1, d1, q[1]); q[2] = fmaf(d2, d2, q[2]); q[3] = fmaf(d3, d3, q[3]);
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rl][4 * cq + j] = q[j];
+    __syncthreads();
+    tot = small_colsum(red, grp, t);
+    if (t < 16) p2[rg * 16 + t] = tot;
+    bn_group_barrier(counters + 2 * cb + 1, BN_R);
+    if (blockIdx.x == 0 && t == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (t < 16) {
+        float m2 = p2[t];
+#pragma unroll
+        for (int k = 1; k < BN_R; ++k) m2 += p2[k * 16 + t];
+        const int cc = cb * 16 + t;
+        if (cc < C) {
+            const float mean = bc[t];
+            const float var = m2 / (float)M;
+            const float invstd = 1.0f / sqrtf(var + eps);
+            const float g = gamma ? gamma[cc] : 1.f, bt = beta ? beta[cc] : 0.f;
+            ss[0][t] = g * invstd;
+            ss[1][t] = bt - mean * g * invstd;
+            if (rg == 0) {                                      // one of the BN_R writes the results
+                scale[cc] = g * invstd;
+                shift[cc] = bt - mean * g * invstd;
+                save_mean[cc] = mean;
+                save_invstd[cc] = invstd;
+                if (running_mean) running_mean[cc] = (1.f - momentum) * running_mean[cc] + momentum * mean;
+                if (running_var) {
+                    const float unbiased = M > 1 ? m2 / (float)(M - 1) : var;
+                    running_var[cc] = (1.f - momentum) * running_var[cc] + momentum * unbiased;
+                }
+            }
+        }
+    }
+    if (!y) return;
+    __syncthreads();
+    if (!on) return;
+    const float sc[4] = {ss[0][4 * cq], ss[0][4 * cq + 1], ss[0][4 * cq + 2], ss[0][4 * cq + 3]};
+    const float sh[4] = {ss[1][4 * cq], ss[1][4 * cq + 1], ss[1][4 * cq + 2], ss[1][4 * cq + 3]};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long r = gl + STEP * u;
+        if (r >= M) continue;
+        float o[4] = {fmaf(kv[u].x, sc[0], sh[0]), fmaf(kv[u].y, sc[1], sh[1]), fmaf(kv[u].z, sc[2], sh[2]), fmaf(kv[u].w, sc[3], sh[3])};
+        if (relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+        *reinterpret_cast<float4*>(y + r * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_multi_kernel(
+    const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, float* __restrict__ dx, long lddx, long M,
+    int C, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, float* dgamma, float* dbeta, int relu, int training, int accumulate,
+    int dx_accumulate, unsigned* __restrict__ counters, float* __restrict__ part) {
+    __shared__ float red[BN_SL][16];
+    __shared__ float grp[4][16];
+    __shared__ float bc[2][16];
+    const int t = threadIdx.x, cq = t & 3, rl = t >> 2;
+    const int cb = blockIdx.x / BN_R, rg = blockIdx.x % BN_R, nb = gridDim.x / BN_R;
+    const int c = cb * 16 + 4 * cq;
+    const bool on = c < C;
+    const int cc4 = on ? c : 0;
+    const float4 sc4 = *reinterpret_cast<const float4*>(scale + cc4), sh4 = *reinterpret_cast<const float4*>(shift + cc4);
+    const float4 mu4 = *reinterpret_cast<const float4*>(mean + cc4), is4 = *reinterpret_cast<const float4*>(invstd + cc4);
+    const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+    const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
+    const float* px = x + cc4;
+    const float* pd = dy + cc4;
+    const long gl = (long)rg * BN_SL + rl;
+    constexpr long STEP = (long)BN_SL * BN_R;
+    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 kx[8], kd[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long rr = gl + STEP * u < M ? gl + STEP * u : 0;
+        kx[u] = *reinterpret_cast<const float4*>(px + rr * ldx);
+        kd[u] = *reinterpret_cast<const float4*>(pd + rr * lddy);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (gl + STEP * u < M) {
+            const float xe[4] = {kx[u].x, kx[u].y, kx[u].z, kx[u].w}, de[4] = {kd[u].x, kd[u].y, kd[u].z, kd[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float dz = de[j];
+                if (relu && fmaf(xe[j], sc[j], sh[j]) <= 0.f) dz = 0.f;
+                a1[j] += dz;
+                a2[j] = fmaf(dz, (xe[j] - mu[j]) * is[j], a2[j]);
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rl][4 * cq + j] = a1[j];
+    __syncthreads();
+    const float t1 = small_colsum(red, grp, t);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rl][4 * cq + j] = a2[j];
+    __syncthreads();
+    const float t2 = small_colsum(red, grp, t);
+    float* const p1 = part + ((size_t)cb * BN_R) * 16;
+    float* const p2 = part + ((size_t)(nb + cb) * BN_R) * 16;
+    if (t < 16) {
+        p1[rg * 16 + t] = t1;
+        p2[rg * 16 + t] = t2;
+    }
+    bn_group_barrier(counters + 2 * cb, BN_R);
+    if (t < 16) {
+        float s1_ = p1[t], s2_ = p2[t];
+#pragma unroll
+        for (int k = 1; k < BN_R; ++k) { s1_ += p1[k * 16 + t]; s2_ += p2[k * 16 + t]; }
+        bc[0][t] = s1_;
+        bc[1][t] = s2_;
+        const int cc = cb * 16 + t;
+        if (cc < C && rg == 0) {
+            if (dbeta) dbeta[cc] = accumulate ? dbeta[cc] + s1_ : s1_;
+            if (dgamma) dgamma[cc] = accumulate ? dgamma[cc] + s2_ : s2_;
+        }
+    }
+    __syncthreads();
+    if (!dx || !on) return;
+    const float invM = 1.0f / (float)M;
+    float s1[4], s2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1[j] = bc[0][4 * cq + j]; s2[j] = bc[1][4 * cq + j]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long r = gl + STEP * u;
+        if (r >= M) continue;
+        const float xe[4] = {kx[u].x, kx[u].y, kx[u].z, kx[u].w}, de[4] = {kd[u].x, kd[u].y, kd[u].z, kd[u].w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float dz = de[j];
+            if (relu && fmaf(xe[j], sc[j], sh[j]) <= 0.f) dz = 0.f;
+            float g = dz;
+            if (training) {
+                const float xhat = (xe[j] - mu[j]) * is[j];
+                g = dz - s1[j] * invM - xhat * s2[j] * invM;
+            }
+            o[j] = sc[j] * g;
+        }
+        float4* dst = reinterpret_cast<float4*>(dx + r * lddx + c);
+        if (dx_accumulate) { const float4 ov = *dst; o[0] += ov.x; o[1] += ov.y; o[2] += ov.z; o[3] += ov.w; }
+        *dst = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// the sync area of the multi-workgroup forms inside a gnx_bn_workspace: counters (zeroed per launch), then partial sums
+inline long bn_sync_floats(int C) {
+    const long nb = (C + 15) / 16;
+    return 2 * nb /* counters */ + 2 * nb * BN_R * 16 + 16 /* alignment slack */;
+}
+
 inline int elementwise_grid(long total) {
     long b = (total + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -773,9 +1003,21 @@ inline int elementwise_grid(long total) {
 
 }  // namespace
 
+static bool bn_multi_ok(long M, int C) {
+    return M > 8 * BN_SL && M <= BN_MULTI_M && C % 4 == 0 && ((C + 15) / 16) * BN_R <= 256;
+}
+// counters + partial sums of the multi-workgroup forms: behind the slab area of the workspace; the counters are zeroed here
+static void bn_multi_sync(float* workspace, long M, int C, hipStream_t stream, unsigned** counters, float** part) {
+    const long nb = (C + 15) / 16;
+    float* base = workspace + 2L * slab_count(M) * C + 2L * C;
+    *counters = reinterpret_cast<unsigned*>(base);
+    *part = base + 2 * nb;
+    (void)hipMemsetAsync(base, 0, 2 * nb * sizeof(unsigned), stream);
+}
+
 // floats of workspace needed by gnx_bn_train_stats / gnx_bn_relu_bwd for an [M][C] matrix
 GNX_EXPORT long gnx_bn_workspace(long M, int C) {
-    return 2L * slab_count(M) * C + 2L * C;
+    return 2L * slab_count(M) * C + 2L * C + bn_sync_floats(C);
 }
 
 // Training-mode statistics of x[M][C]: fills scale/shift (folded affine), save_mean/save_invstd and
@@ -786,6 +1028,15 @@ GNX_EXPORT int gnx_bn_train_stats(const float* x, long ld, long M, int C, const 
                                   float* save_invstd, float* workspace, hipStream_t stream) {
     if (!x || !scale || !shift || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0 || ld < C)
         return GNX_ERR_BAD_ARG;
+    if (bn_multi_ok(M, C) && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        unsigned* counters;
+        float* part;
+        bn_multi_sync(workspace, M, C, stream, &counters, &part);
+        bn_train_stats_multi_kernel<<<gnx_cdiv(C, 16) * BN_R, 1024, 0, stream>>>(x, ld, M, C, gamma, beta, running_mean, running_var,
+                                                                                num_batches_tracked, momentum, eps, scale, shift,
+                                                                                save_mean, save_invstd, nullptr, 0, 0, counters, part);
+        return gnx_launch_status();
+    }
     if (M <= BN_SMALL_M && C % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         if (M <= 8 * BN_SL)
             bn_train_stats_small_kernel<true><<<gnx_cdiv(C, 16), 1024, 0, stream>>>(x, ld, M, C, gamma, beta, running_mean,
@@ -827,6 +1078,16 @@ GNX_EXPORT int gnx_bn_train_stats_apply(const float* x, long ld, long M, int C, 
                                         hipStream_t stream) {
     if (!x || !y || !scale || !shift || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0 || ld < C || ldy < C)
         return GNX_ERR_BAD_ARG;
+    if (bn_multi_ok(M, C) && ld % 4 == 0 && ldy % 4 == 0 &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
+        unsigned* counters;
+        float* part;
+        bn_multi_sync(workspace, M, C, stream, &counters, &part);
+        bn_train_stats_multi_kernel<<<gnx_cdiv(C, 16) * BN_R, 1024, 0, stream>>>(x, ld, M, C, gamma, beta, running_mean, running_var,
+                                                                                num_batches_tracked, momentum, eps, scale, shift,
+                                                                                save_mean, save_invstd, y, ldy, relu, counters, part);
+        return gnx_launch_status();
+    }
     if (M <= BN_SMALL_M && C % 4 == 0 && ld % 4 == 0 && ldy % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
         if (M <= 8 * BN_SL)
@@ -883,6 +1144,15 @@ GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long 
                              reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(save_mean) |
                              reinterpret_cast<uintptr_t>(save_invstd)) & 15) == 0;
         if (relu == 2 && (training || !v4all)) return GNX_ERR_UNSUPPORTED;     // activated-input form: eval statistics only
+        if (v4all && relu != 2 && bn_multi_ok(M, C)) {
+            unsigned* counters;
+            float* part;
+            bn_multi_sync(workspace, M, C, stream, &counters, &part);
+            bn_bwd_multi_kernel<<<gnx_cdiv(C, 16) * BN_R, 1024, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale, shift, save_mean,
+                                                                           save_invstd, dgamma, dbeta, relu, training, accumulate,
+                                                                           dx_accumulate, counters, part);
+            return gnx_launch_status();
+        }
         if (v4all && relu != 2 && M <= BN_SMALL_M) {
             if (M <= 8 * BN_SL)
                 bn_bwd_small_kernel<true><<<gnx_cdiv(C, 16), 1024, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale, shift,

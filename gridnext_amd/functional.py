@@ -22,35 +22,6 @@ def _rows(t):
 
 
 # ----------------------------------------------------------------------------- hexagonal convolution
-# ----------------------------------------------------------------------------- side-stream branches of a captured step
-# Under hipGraph capture (graphs.py) work that is OFF the critical path of a step - the weight gradients of the corrector's hex
-# convolutions: five launches + five slab reductions per array, ~100 us, none of which the data-gradient chain waits for - is
-# launched on a side stream: a parallel branch of the step graph.  The branch's operands are held here until the join (the
-# capture's memory pool would otherwise hand a freed operand to a later allocation of the main branch while the side branch
-# still reads it); graphs.GridStepGraph joins right after `loss.backward()`.  Eager steps never fork.
-_SIDE = {'stream': None, 'pending': []}
-
-
-def _side_stream(dev):
-    s = _SIDE['stream']
-    if s is None or s.device != dev:
-        s = _SIDE['stream'] = torch.cuda.Stream(device=dev)
-    return s
-
-
-def side_join():
-    """Make the current stream wait for every side-stream branch forked since the last join, then release their operands."""
-    if _SIDE['pending']:
-        cur = torch.cuda.current_stream()
-        for done, _keep in _SIDE['pending']:
-            cur.wait_event(done)
-        _SIDE['pending'].clear()
-
-
-def side_abort():
-    _SIDE['pending'].clear()
-
-
 class _HexConv(Function):
     @staticmethod
     def forward(ctx, x, kernel0, kernel1, bias, mode):
@@ -77,26 +48,11 @@ class _HexConv(Function):
             L.call('gnx_hexconv_bwd_data', L.ptr(dy), L.ptr(k0), L.ptr(k1), L.ptr(dx), B, H, W, I, O, ctx.mode,
                    L.stream())
         if any(ctx.needs_input_grad[1:4]):
-            def weight_gradient():
-                dk0, dk1 = torch.empty_like(k0), torch.empty_like(k1)
-                db = torch.empty(O, device=x.device, dtype=F32) if ctx.has_bias else None
-                ws = torch.empty(L.query('gnx_hexconv_bwd_weight_workspace', B, H, W, I, O), device=x.device, dtype=F32)
-                L.call('gnx_hexconv_bwd_weight', L.ptr(x), L.ptr(dy), L.ptr(dk0), L.ptr(dk1), L.ptr(db), L.ptr(ws),
-                       B, H, W, I, O, ctx.mode, 0, L.stream())
-                return dk0, dk1, db, ws
-            if torch.cuda.is_current_stream_capturing():
-                # a parallel branch of the step graph: nothing downstream in the backward needs these
-                cur, side = torch.cuda.current_stream(x.device), _side_stream(x.device)
-                fork = torch.cuda.Event()
-                fork.record(cur)
-                side.wait_event(fork)
-                with torch.cuda.stream(side):
-                    dk0, dk1, db, ws = weight_gradient()
-                    done = torch.cuda.Event()
-                    done.record(side)
-                _SIDE['pending'].append((done, (x, dy, ws, dk0, dk1, db)))
-            else:
-                dk0, dk1, db, _ = weight_gradient()
+            dk0, dk1 = torch.empty_like(k0), torch.empty_like(k1)
+            db = torch.empty(O, device=x.device, dtype=F32) if ctx.has_bias else None
+            ws = torch.empty(L.query('gnx_hexconv_bwd_weight_workspace', B, H, W, I, O), device=x.device, dtype=F32)
+            L.call('gnx_hexconv_bwd_weight', L.ptr(x), L.ptr(dy), L.ptr(dk0), L.ptr(dk1), L.ptr(db), L.ptr(ws),
+                   B, H, W, I, O, ctx.mode, 0, L.stream())
         return dx, dk0, dk1, db, None
 
 

@@ -120,15 +120,11 @@ class GridStepGraph:
                     loss, correct, n_fg = self.step_fn(self.s_inputs, self.s_labels)
                     if self.train:
                         loss.backward()
-                        from .functional import side_join
-                        side_join()                            # side-stream branches of the backward (functional._SIDE) end here
             self.outs = (loss.detach(), correct, n_fg)
             self.s_grads = [p.grad for p in self.params]       # graph-owned; None where a parameter got no gradient
             self.graph = graph                                 # only a COMPLETED capture makes this entry ready()
         except Exception:
             self.failed = True                                 # this (phase, shapes) stays eager for the rest of the call
-            from .functional import side_abort
-            side_abort()
             raise
         finally:
             for p, g in zip(self.params, keep):

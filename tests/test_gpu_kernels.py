@@ -83,7 +83,10 @@ def test_hexagdly_compatible_module(GF):
 
 # ----------------------------------------------------------------------------------------------- batch norm
 @pytest.mark.parametrize("M,C,relu,training", [(300, 32, True, True), (4992, 100, True, True), (77, 50, False, True),
-                                               (512, 32, True, False), (5, 3, True, True)])
+                                               (512, 32, True, False), (5, 3, True, True),
+                                               # round 5: the forms with several workgroups per channel block (2048 < M <= 8192)
+                                               (4992, 32, True, True), (8192, 512, True, True), (2049, 36, False, True),
+                                               (8192, 64, True, False), (5000, 1024, True, True), (4992, 50, True, True)])
 def test_bn_relu_fwd_bwd(GF, M, C, relu, training):
     g = torch.Generator().manual_seed(M + C)
     x = torch.randn(M, C, generator=g) * 3 + 5            # mean >> 0: exercises the two-pass variance
