@@ -796,12 +796,25 @@ __device__ __forceinline__ void bn_group_barrier(unsigned* counter, unsigned tar
     __syncthreads();
 }
 
-// sync: [C/16 blocks][2 counters] unsigned, then partial sums [2 phases][C/16][BN_R][16] floats
+// A PERSISTENT sync area (caller-owned, zeroed once: gnx_bn_sync_words) resets itself: a workgroup that has passed its last
+// barrier counts itself out, and the last of the BN_R to leave - when nobody polls any more - zeroes the block's three words.
+__device__ __forceinline__ void bn_group_leave(unsigned* words) {
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(words + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == BN_R - 1) {
+            __hip_atomic_store(words, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(words + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(words + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// counters: [C/16 blocks][arrivals 1, arrivals 2, leavers] unsigned; part: partial sums [2 phases][C/16][BN_R][16] floats
 __global__ __launch_bounds__(1024) void bn_train_stats_multi_kernel(
     const float* __restrict__ x, long ld, long M, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
     float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd,
-    float* __restrict__ y, long ldy, int relu, unsigned* __restrict__ counters, float* __restrict__ part) {
+    float* __restrict__ y, long ldy, int relu, unsigned* __restrict__ counters, float* __restrict__ part, int self_reset) {
     __shared__ float red[BN_SL][16];
     __shared__ float grp[4][16];
     __shared__ float bc[16];
@@ -830,7 +843,7 @@ __global__ __launch_bounds__(1024) void bn_train_stats_multi_kernel(
     float* const p1 = part + ((size_t)cb * BN_R) * 16;
     float* const p2 = part + ((size_t)(nb + cb) * BN_R) * 16;
     if (t < 16) p1[rg * 16 + t] = tot;
-    bn_group_barrier(counters + 2 * cb, BN_R);
+    bn_group_barrier(counters + 3 * cb, BN_R);
     if (t < 16) {
         float s_ = p1[t];
 #pragma unroll
@@ -851,7 +864,8 @@ __global__ __launch_bounds__(1024) void bn_train_stats_multi_kernel(
     __syncthreads();
     tot = small_colsum(red, grp, t);
     if (t < 16) p2[rg * 16 + t] = tot;
-    bn_group_barrier(counters + 2 * cb + 1, BN_R);
+    bn_group_barrier(counters + 3 * cb + 1, BN_R);
+    if (self_reset) bn_group_leave(counters + 3 * cb);
     if (blockIdx.x == 0 && t == 0 && num_batches_tracked) *num_batches_tracked += 1;
     if (t < 16) {
         float m2 = p2[t];
@@ -897,7 +911,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_multi_kernel(
     const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx, float* __restrict__ dx, long lddx, long M,
     int C, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, float* dgamma, float* dbeta, int relu, int training, int accumulate,
-    int dx_accumulate, unsigned* __restrict__ counters, float* __restrict__ part) {
+    int dx_accumulate, unsigned* __restrict__ counters, float* __restrict__ part, int self_reset) {
     __shared__ float red[BN_SL][16];
     __shared__ float grp[4][16];
     __shared__ float bc[2][16];
@@ -948,7 +962,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_multi_kernel(
         p1[rg * 16 + t] = t1;
         p2[rg * 16 + t] = t2;
     }
-    bn_group_barrier(counters + 2 * cb, BN_R);
+    bn_group_barrier(counters + 3 * cb, BN_R);
+    if (self_reset) bn_group_leave(counters + 3 * cb);
     if (t < 16) {
         float s1_ = p1[t], s2_ = p2[t];
 #pragma unroll
@@ -993,7 +1008,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_multi_kernel(
 // the sync area of the multi-workgroup forms inside a gnx_bn_workspace: counters (zeroed per launch), then partial sums
 inline long bn_sync_floats(int C) {
     const long nb = (C + 15) / 16;
-    return 2 * nb /* counters */ + 2 * nb * BN_R * 16 + 16 /* alignment slack */;
+    return 3 * nb /* counters */ + 2 * nb * BN_R * 16 + 16 /* alignment slack */;
 }
 
 inline int elementwise_grid(long total) {
@@ -1007,12 +1022,17 @@ static bool bn_multi_ok(long M, int C) {
     return M > 8 * BN_SL && M <= BN_MULTI_M && C % 4 == 0 && ((C + 15) / 16) * BN_R <= 256;
 }
 // counters + partial sums of the multi-workgroup forms: behind the slab area of the workspace; the counters are zeroed here
-static void bn_multi_sync(float* workspace, long M, int C, hipStream_t stream, unsigned** counters, float** part) {
+static void bn_multi_sync(float* workspace, long M, int C, hipStream_t stream, unsigned* persistent, unsigned** counters,
+                          float** part) {
     const long nb = (C + 15) / 16;
     float* base = workspace + 2L * slab_count(M) * C + 2L * C;
+    *part = base + 3 * nb;
+    if (persistent) {                                           // caller-owned, zeroed once, self-resetting: no memset node
+        *counters = persistent;
+        return;
+    }
     *counters = reinterpret_cast<unsigned*>(base);
-    *part = base + 2 * nb;
-    (void)hipMemsetAsync(base, 0, 2 * nb * sizeof(unsigned), stream);
+    (void)hipMemsetAsync(base, 0, 3 * nb * sizeof(unsigned), stream);
 }
 
 // floats of workspace needed by gnx_bn_train_stats / gnx_bn_relu_bwd for an [M][C] matrix
@@ -1031,10 +1051,10 @@ GNX_EXPORT int gnx_bn_train_stats(const float* x, long ld, long M, int C, const 
     if (bn_multi_ok(M, C) && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         unsigned* counters;
         float* part;
-        bn_multi_sync(workspace, M, C, stream, &counters, &part);
+        bn_multi_sync(workspace, M, C, stream, nullptr, &counters, &part);
         bn_train_stats_multi_kernel<<<gnx_cdiv(C, 16) * BN_R, 1024, 0, stream>>>(x, ld, M, C, gamma, beta, running_mean, running_var,
                                                                                 num_batches_tracked, momentum, eps, scale, shift,
-                                                                                save_mean, save_invstd, nullptr, 0, 0, counters, part);
+                                                                                save_mean, save_invstd, nullptr, 0, 0, counters, part, 0);
         return gnx_launch_status();
     }
     if (M <= BN_SMALL_M && C % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
@@ -1071,21 +1091,22 @@ GNX_EXPORT int gnx_scale_shift_relu(const float* x, long ldx, float* y, long ldy
 
 // gnx_bn_train_stats followed by gnx_scale_shift_relu (y = [relu](scale x + shift)) - in ONE launch where the matrix is small
 // enough for the single-launch statistics form (M <= 4992 rows, 4 | C, 16-B aligned rows of x and y), otherwise the two calls.
-GNX_EXPORT int gnx_bn_train_stats_apply(const float* x, long ld, long M, int C, const float* gamma, const float* beta,
-                                        float* running_mean, float* running_var, long long* num_batches_tracked,
-                                        float momentum, float eps, float* scale, float* shift, float* save_mean,
-                                        float* save_invstd, float* y, long ldy, int relu, float* workspace,
-                                        hipStream_t stream) {
+static int bn_train_stats_apply_impl(const float* x, long ld, long M, int C, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, long long* num_batches_tracked,
+                                     float momentum, float eps, float* scale, float* shift, float* save_mean,
+                                     float* save_invstd, float* y, long ldy, int relu, float* workspace, unsigned* sync,
+                                     hipStream_t stream) {
     if (!x || !y || !scale || !shift || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0 || ld < C || ldy < C)
         return GNX_ERR_BAD_ARG;
     if (bn_multi_ok(M, C) && ld % 4 == 0 && ldy % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0) {
         unsigned* counters;
         float* part;
-        bn_multi_sync(workspace, M, C, stream, &counters, &part);
+        bn_multi_sync(workspace, M, C, stream, sync, &counters, &part);
         bn_train_stats_multi_kernel<<<gnx_cdiv(C, 16) * BN_R, 1024, 0, stream>>>(x, ld, M, C, gamma, beta, running_mean, running_var,
                                                                                 num_batches_tracked, momentum, eps, scale, shift,
-                                                                                save_mean, save_invstd, y, ldy, relu, counters, part);
+                                                                                save_mean, save_invstd, y, ldy, relu, counters, part,
+                                                                                sync ? 1 : 0);
         return gnx_launch_status();
     }
     if (M <= BN_SMALL_M && C % 4 == 0 && ld % 4 == 0 && ldy % 4 == 0 &&
@@ -1104,6 +1125,24 @@ GNX_EXPORT int gnx_bn_train_stats_apply(const float* x, long ld, long M, int C, 
                                       scale, shift, save_mean, save_invstd, workspace, stream);
     if (rc != GNX_OK) return rc;
     return gnx_scale_shift_relu(x, ld, y, ldy, M, C, scale, shift, relu, stream);
+}
+GNX_EXPORT int gnx_bn_train_stats_apply(const float* x, long ld, long M, int C, const float* gamma, const float* beta,
+                                        float* running_mean, float* running_var, long long* num_batches_tracked,
+                                        float momentum, float eps, float* scale, float* shift, float* save_mean,
+                                        float* save_invstd, float* y, long ldy, int relu, float* workspace,
+                                        hipStream_t stream) {
+    return bn_train_stats_apply_impl(x, ld, M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
+                                     shift, save_mean, save_invstd, y, ldy, relu, workspace, nullptr, stream);
+}
+// 32-bit words of the persistent, self-resetting sync area of the `_sync` entry points (zero them once)
+GNX_EXPORT long gnx_bn_sync_words(int C) { return 3L * ((C + 15) / 16); }
+GNX_EXPORT int gnx_bn_train_stats_apply_sync(const float* x, long ld, long M, int C, const float* gamma, const float* beta,
+                                             float* running_mean, float* running_var, long long* num_batches_tracked,
+                                             float momentum, float eps, float* scale, float* shift, float* save_mean,
+                                             float* save_invstd, float* y, long ldy, int relu, float* workspace, void* sync,
+                                             hipStream_t stream) {
+    return bn_train_stats_apply_impl(x, ld, M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
+                                     shift, save_mean, save_invstd, y, ldy, relu, workspace, reinterpret_cast<unsigned*>(sync), stream);
 }
 
 // Eval-mode fold: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale
@@ -1127,10 +1166,10 @@ GNX_EXPORT int gnx_scale_shift_relu(const float* x, long ldx, float* y, long ldy
 // Backward of y = [relu](bn(x)).  dgamma/dbeta may be null; `training` selects batch-stat or running-stat form;
 // `accumulate` adds into dgamma/dbeta, `dx_accumulate` adds into dx (DenseNet: gradients of a block buffer's columns
 // arrive from every later layer of the block).
-GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long ldx, float* dx, long lddx, long M,
-                               int C, const float* scale, const float* shift, const float* save_mean,
-                               const float* save_invstd, float* dgamma, float* dbeta, int relu, int training,
-                               int accumulate, int dx_accumulate, float* workspace, hipStream_t stream) {
+static int bn_relu_bwd_impl(const float* dy, long lddy, const float* x, long ldx, float* dx, long lddx, long M,
+                            int C, const float* scale, const float* shift, const float* save_mean,
+                            const float* save_invstd, float* dgamma, float* dbeta, int relu, int training,
+                            int accumulate, int dx_accumulate, float* workspace, unsigned* sync, hipStream_t stream) {
     if (!dy || !x || !scale || !shift || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0)
         return GNX_ERR_BAD_ARG;
     const int nblk = slab_count(M);
@@ -1147,10 +1186,10 @@ GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long 
         if (v4all && relu != 2 && bn_multi_ok(M, C)) {
             unsigned* counters;
             float* part;
-            bn_multi_sync(workspace, M, C, stream, &counters, &part);
+            bn_multi_sync(workspace, M, C, stream, sync, &counters, &part);
             bn_bwd_multi_kernel<<<gnx_cdiv(C, 16) * BN_R, 1024, 0, stream>>>(dy, lddy, x, ldx, dx, lddx, M, C, scale, shift, save_mean,
                                                                            save_invstd, dgamma, dbeta, relu, training, accumulate,
-                                                                           dx_accumulate, counters, part);
+                                                                           dx_accumulate, counters, part, sync ? 1 : 0);
             return gnx_launch_status();
         }
         if (v4all && relu != 2 && M <= BN_SMALL_M) {
@@ -1198,6 +1237,24 @@ GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long 
                                                                           training, dx_accumulate);
     }
     return gnx_launch_status();
+}
+GNX_EXPORT int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long ldx, float* dx, long lddx, long M,
+                               int C, const float* scale, const float* shift, const float* save_mean,
+                               const float* save_invstd, float* dgamma, float* dbeta, int relu, int training,
+                               int accumulate, int dx_accumulate, float* workspace, hipStream_t stream) {
+    return bn_relu_bwd_impl(dy, lddy, x, ldx, dx, lddx, M, C, scale, shift, save_mean, save_invstd, dgamma, dbeta, relu, training,
+                            accumulate, dx_accumulate, workspace, nullptr, stream);
+}
+// The same with a PERSISTENT sync area for the several-workgroups-per-channel-block form (2049 ... 8192 rows): `sync` points at
+// gnx_bn_sync_words(C) 32-bit words the caller zeroed ONCE and keeps for this BatchNorm layer (never shared by two launches
+// that may run at the same time); the kernel leaves them zero again, so no memset node precedes the launch (4.7 us per call
+// under graph replay).  sync == NULL, or any other shape: exactly gnx_bn_relu_bwd.
+GNX_EXPORT int gnx_bn_relu_bwd_sync(const float* dy, long lddy, const float* x, long ldx, float* dx, long lddx, long M,
+                                    int C, const float* scale, const float* shift, const float* save_mean,
+                                    const float* save_invstd, float* dgamma, float* dbeta, int relu, int training,
+                                    int accumulate, int dx_accumulate, float* workspace, void* sync, hipStream_t stream) {
+    return bn_relu_bwd_impl(dy, lddy, x, ldx, dx, lddx, M, C, scale, shift, save_mean, save_invstd, dgamma, dbeta, relu, training,
+                            accumulate, dx_accumulate, workspace, reinterpret_cast<unsigned*>(sync), stream);
 }
 
 // out[c] = sum_r x[r][c]  (bias gradient of a Linear layer); workspace: gnx_bn_workspace(M, C) floats

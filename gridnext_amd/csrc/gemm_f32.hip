@@ -389,15 +389,14 @@ __global__ __launch_bounds__(256) void gemm_split_reduce_kernel(const float* __r
 
 // K splits of the wide form for this shape (1 = no workspace needed; 0 = the shape is not the wide form's)
 int gemm_wide_splits(long M, long N, long K) {
-    if (M < 2048 || N < 64 || K < 512) return 0;
+    // (round 5, measured: ONE column of tiles - the composed 2000 -> 100 count MLP over a 4 992-spot grid - split 8 ways took
+    //  60.7 + 5.3 us against 53 us on the 64 x 64 kernel's 156 workgroups: N >= 256 stays the rule)
+    if (M < 2048 || N < 256 || K < 512) return 0;
     const long tiles = gnx_cdiv(M, WM) * gnx_cdiv(N, WN), nkt = gnx_cdiv(K, TK);
-    // One column of tiles (64 <= N < 256; round 5: the frozen count MLP composed to 2000 -> 100 over a 4 992-spot grid ran the
-    // 64 x 64 kernel: 156 workgroups each walking all of K, 53 us = 19 TFLOP/s): the wide form only pays split - 8 slabs at
-    // most, their reduce is HBM traffic of its own (16 MB here) - so it is taken only with a workspace (see gemm_f32_impl).
-    const int target = N >= 256 ? 512 : 256;
+    const int target = 512;
     long s = target / tiles;
     if (s > nkt / 4) s = nkt / 4;                              // at least 4 K tiles per workgroup
-    if (s > (N >= 256 ? 16 : 8)) s = N >= 256 ? 16 : 8;
+    if (s > 16) s = 16;
     return (int)(s < 1 ? 1 : s);
 }
 
@@ -426,7 +425,6 @@ static int gemm_f32_impl(const float* A, long lda, int a_kmajor, const float* B,
                       (K + 2 * TK) * (lda > ldb ? lda : ldb) < (1L << 29);       // 32-bit byte offsets, one tile past the end
     int splits = t_ok ? gemm_wide_splits(M, N, K) : 0;
     if (splits > 1 && !workspace) splits = 1;
-    if (N < 256 && splits <= 1) splits = 0;                    // a single column of tiles unsplit: too few workgroups - the small-tile kernel
     if (splits >= 1) {
         const long units8 = (gnx_cdiv(M, WM) * splits + 7) / 8 * 8;
         const long nwg = units8 * gnx_cdiv(N, WN);

@@ -83,7 +83,7 @@ def bump_batchnorm_versions(modules):
 class _BNReLU(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps,
-                relu):
+                relu, sync=None):
         x, ld = _rows(x)
         M, C = x.shape
         dev = x.device
@@ -94,10 +94,10 @@ class _BNReLU(Function):
             # statistics and the apply pass in one call (one launch for a matrix of one Visium grid)
             ws = torch.empty(L.query('gnx_bn_workspace', M, C), device=dev, dtype=F32)
             y = torch.empty((M, C), device=dev, dtype=F32)
-            L.call('gnx_bn_train_stats_apply', L.ptr(x), ld, M, C, L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
+            L.call('gnx_bn_train_stats_apply_sync', L.ptr(x), ld, M, C, L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
                    L.ptr(running_var), L.ptr(num_batches_tracked, torch.int64), float(momentum), float(eps),
                    L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(y), C, 1 if relu else 0,
-                   L.ptr(ws), L.stream())
+                   L.ptr(ws), None if sync is None else sync.data_ptr(), L.stream())
             bump_versions(running_mean, running_var, num_batches_tracked)   # (the kernel wrote them through raw pointers)
         else:
             L.call('gnx_bn_fold_eval', C, L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var),
@@ -107,6 +107,7 @@ class _BNReLU(Function):
                    1 if relu else 0, L.stream())
         ctx.save_for_backward(x, stats)
         ctx.cfg = (ld, bool(training), bool(relu), gamma is not None)
+        ctx.sync = sync
         return y
 
     @staticmethod
@@ -121,10 +122,10 @@ class _BNReLU(Function):
         dgamma = torch.empty(C, device=dev, dtype=F32) if want_affine else None
         dbeta = torch.empty(C, device=dev, dtype=F32) if want_affine else None
         ws = torch.empty(L.query('gnx_bn_workspace', M, C), device=dev, dtype=F32)
-        L.call('gnx_bn_relu_bwd', L.ptr(dy), lddy, L.ptr(x), ld, L.ptr(dx), C, M, C, L.ptr(stats[0]),
+        L.call('gnx_bn_relu_bwd_sync', L.ptr(dy), lddy, L.ptr(x), ld, L.ptr(dx), C, M, C, L.ptr(stats[0]),
                L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(dgamma), L.ptr(dbeta), 1 if relu else 0,
-               1 if training else 0, 0, 0, L.ptr(ws), L.stream())
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+               1 if training else 0, 0, 0, L.ptr(ws), None if ctx.sync is None else ctx.sync.data_ptr(), L.stream())
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def batch_norm_relu(x2d, bn, relu):
@@ -137,7 +138,23 @@ def batch_norm_relu(x2d, bn, relu):
             x2 = x2d if x2d.dim() == 2 else x2d.reshape(-1, x2d.shape[-1])
             return gdist.sync_batch_norm_rows(x2, bn, relu)
     return _BNReLU.apply(x2d, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                         training, bn.momentum, bn.eps, relu)
+                         training, bn.momentum, bn.eps, relu, _bn_sync(bn, x2d.device))
+
+
+def _bn_sync(bn, device):
+    """The layer's persistent sync words for the several-workgroups-per-channel-block BatchNorm kernels (include/gridnext_hip.h:
+    gnx_bn_train_stats_apply_sync): zeroed once, left zero by every launch, owned by this module - two launches that could run at
+    the same time never share them.  Made outside graph capture only (a capture that meets a layer without them gets None: the
+    kernels then zero a scratch area with a memset node)."""
+    hit = bn.__dict__.get('_gnx_sync')
+    if hit is not None and hit.device == device:
+        return hit
+    if device.type != 'cuda' or torch.cuda.is_current_stream_capturing():
+        return None
+    with torch.no_grad():
+        hit = torch.zeros(int(L.query('gnx_bn_sync_words', bn.num_features)), device=device, dtype=torch.int32)
+    bn.__dict__['_gnx_sync'] = hit
+    return hit
 
 
 _UNIT = {}

@@ -67,6 +67,22 @@ int gnx_bn_relu_bwd(const float* dy, long lddy, const float* x, long ldx, float*
                     const float* scale, const float* shift, const float* save_mean, const float* save_invstd,
                     float* dgamma, float* dbeta, int relu, int training, int accumulate, int dx_accumulate,
                     float* workspace, gnx_stream_t stream);
+/* Round 5 - matrices of 2049 ... 8192 rows (one 78 x 64 Visium grid: the corrector's two BatchNorm2d(32), gridnet_models.py:131-140,
+ * and the count MLP's BatchNorm1d; dense block 2 of a batch of 32 patches) run gnx_bn_train_stats[_apply] / gnx_bn_relu_bwd with
+ * FOUR workgroups per 16-channel block: a row lane keeps its <= 8 rows in registers (one round of loads for all walks) and the
+ * four partial sums are exchanged behind a bounded barrier of those workgroups (added in workgroup order: deterministic; two-pass
+ * variance as before).  The barrier's counters live in the workspace and are zeroed by a memset node per call - or, with the
+ * `_sync` entry points, in gnx_bn_sync_words(C) 32-bit words the caller zeroed ONCE and keeps for this layer (never shared by
+ * launches that may overlap): the kernels leave them zero, no memset node is needed.  sync == NULL: the plain entry points. */
+long gnx_bn_sync_words(int C);
+int gnx_bn_train_stats_apply_sync(const float* x, long ld, long M, int C, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                                  float eps, float* scale, float* shift, float* save_mean, float* save_invstd, float* y, long ldy,
+                                  int relu, float* workspace, void* sync, gnx_stream_t stream);
+int gnx_bn_relu_bwd_sync(const float* dy, long lddy, const float* x, long ldx, float* dx, long lddx, long M, int C,
+                         const float* scale, const float* shift, const float* save_mean, const float* save_invstd, float* dgamma,
+                         float* dbeta, int relu, int training, int accumulate, int dx_accumulate, float* workspace, void* sync,
+                         gnx_stream_t stream);
 /* Transitions (norm -> relu -> conv 1x1 -> avgpool 2x2, densenet.py:47-54, run pool-first): gnx_bnrelu_avgpool2 = the pooled,
  * activated input [imgs*(S/2)^2][C] of the 1x1 conv (operand of its weight gradient); gnx_bn_relu_bwd_pooled = the adjoint
  * of norm -> relu given the gradient of the POOLED map (== gnx_avgpool2_bwd + gnx_bn_relu_bwd(relu = 1, training = 0)
