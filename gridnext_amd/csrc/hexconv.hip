@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void hexconv_bwd_weight2_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     float bsum = 0.f;
-#pragma unroll 4
+#pragma unroll                                                  // (all 16 position pairs' loads in flight: one round trip, not four)
     for (int pp = 0; pp < HW2_POS / 2; ++pp) {
         const int pos = base + 2 * pp + h;
         float a = 0.f, b0 = 0.f, b1 = 0.f;
