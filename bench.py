@@ -365,7 +365,7 @@ def _chunked_frozen_f(f, chunk):
     return ChunkedFrozenF()
 
 
-def full_grid_ce(model, patch, mfma, device, inputs=None, chunk=256):
+def full_grid_ce(model, patch, mfma, device, inputs=None, chunk=64):
     """BASELINE's "CE vs ref" at the benchmark's OWN size: ONE full 78 x 64 array (4992 spots of `patch`-px patches + 2000
     genes) through GridNetHexMM -> masked CE on the HIP path and through the CPU oracle (forward + CE only), same state_dict,
     same inputs, tutorial mode - g's train-mode BatchNorm statistics and n_fg are those of the timed step, not of a sub-grid
@@ -388,7 +388,10 @@ def cpu_leg(model, patch, mfma, device, timed_steps=2, sub_hw=None, u8=False, in
     from gridnext_amd.synthetic import count_mlp
     from oracle import densenet as odn, gridnet as ogn, masked_ce as oce
 
-    cores, cpu_model = _host_cpu()
+    host_cores, cpu_model = _host_cpu()
+    # the oracle's torch convolutions stop scaling beyond a few dozen threads (measured on the GPU box's EPYC 9575F,
+    # tools/diag/oracle_threads.py: 106 spots/s forward on 16 or 32 threads, 53 on 64, 19-22 on 128): 32 at most
+    cores = min(host_cores, 32)
     torch.set_num_threads(cores)
     SUB_H, SUB_W = sub_hw or (globals()['SUB_H'], globals()['SUB_W'])
     gen = torch.Generator().manual_seed(12345)
@@ -471,9 +474,10 @@ def cpu_leg(model, patch, mfma, device, timed_steps=2, sub_hw=None, u8=False, in
         ce["agreement_rate"] = agree / int(decided.sum())
     if timed_steps == 0:
         return None, ce
-    base = {"value": n / dt, "unit": "spots/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
+    base = {"value": n / dt, "unit": "spots/s", "cores": cores, "host_cores": host_cores, "cpu_model": cpu_model, "kind": "port",
             "sample": "1 warm-up (%.1f s) + %d timed training steps (%.1f s each) on a %dx%d sub-grid (%d spots of %d px, "
-                      "%d genes), torch CPU threads = physical cores" % (warm, timed_steps, dt, SUB_H, SUB_W, n, patch, GENES)}
+                      "%d genes), %d torch CPU threads (of %d physical cores: the oracle is 5x slower on 128 threads than on 32)"
+                      % (warm, timed_steps, dt, SUB_H, SUB_W, n, patch, GENES, cores, host_cores)}
     return base, ce
 
 

@@ -1392,7 +1392,7 @@ def test_full_78x64_array_ce_against_the_oracle(capsys):
     """BASELINE's "CE vs ref" at the benchmark's OWN size (missing 2): ONE whole 78 x 64 array - 4 992 spots of
     128-px patches + 2 000 genes, the bench's synthetic array - through GridNetHexMM (DenseNet-121 image f frozen / eval, count
     MLP in train mode by the reference's quirk, corrector g in train mode: batch statistics over all 4 992 positions) and the
-    foreground-masked CE, on the HIP path and through the CPU oracle (forward + CE only; its frozen image f in chunks of 256
+    foreground-masked CE, on the HIP path and through the CPU oracle (forward + CE only; its frozen image f in chunks of 64
     spots), same state_dict and inputs (/root/reference/gridnext/training.py:146-160, gridnet_models.py:226-235).
     Gates: |dCE| <= 1e-4; identical argmax on EVERY foreground spot whose top-2 margin exceeds 1e-3; near ties counted."""
     import bench
