@@ -1460,3 +1460,26 @@ def test_train_gridwise_skips_the_step_when_the_fp16_gradient_path_overflows():
     assert hit['steps'] == {2}, hit['steps']                                 # one of the three steps was skipped - by BOTH optimizers
     assert 'optimizer step skipped' in hit['printed'] and hit['target'] == 11.0
     assert hit['flag'] == 0 and hit['finite'] and np.isfinite(hit['vh']).all()
+
+
+def test_prefetcher_gathers_device_resident_tensor_datasets_in_the_loaders_own_order():
+    """Round 5: a DataLoader over a plain TensorDataset that already lives on the device (BASELINE configs 1-3 as the tutorials
+    build them) is fed by ONE index_select per tensor and batch instead of `batch_size` sample views stacked.  Same batches as
+    the plain loader for the same generator seed - order (shuffle), values, structure (a list), ragged last batch - and the
+    buffers are the loader's persistent ones."""
+    from gridnext_amd import prefetch
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(301, 7, generator=g).to(DEV)
+    y = torch.randint(0, 5, (301,), generator=g).to(DEV)
+    ds = TensorDataset(x, y)
+    plain = [[t.clone() for t in b] for b in DataLoader(ds, batch_size=32, shuffle=True, generator=torch.Generator().manual_seed(11))]
+    pf = prefetch.DevicePrefetcher(DataLoader(ds, batch_size=32, shuffle=True, generator=torch.Generator().manual_seed(11)), DEV)
+    got, ptrs = [], set()
+    for b in pf:
+        assert isinstance(b, list) and len(b) == 2 and getattr(b[0], '_gnx_stable', False)
+        ptrs.add(b[0].data_ptr())
+        got.append([t.clone() for t in b])
+    assert len(got) == len(plain) == 10 and got[-1][0].shape[0] == 301 - 9 * 32
+    for a, b in zip(got, plain):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert len(ptrs) == 2                                       # one persistent buffer per batch shape (full, ragged)
