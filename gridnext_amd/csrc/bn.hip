@@ -780,6 +780,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_small_kernel(
 constexpr int BN_R = 4;
 constexpr long BN_MULTI_M = 8L * BN_SL * BN_R;                  // 8192 rows
 
+// The exchanged partial sums are written and read with agent-scope (sc1: write-through / L2-bypassing) accesses: the BN_R
+// workgroups of a channel block sit on different XCDs, whose L2s are not coherent - with plain stores two producers' 64-B
+// halves of one 128-B line are two partially valid copies of that line in two L2s, and a consumer whose own L2 holds the line
+// (it wrote its half) read the other half STALE (round 5: wrong dx at C = 512 / 1024 while C <= 64 passed).
+__device__ __forceinline__ void part_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float part_load(const float* p) {
+    return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void bn_group_barrier(unsigned* counter, unsigned target) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's stores have left the CU
     __syncthreads();
@@ -842,12 +851,12 @@ __global__ __launch_bounds__(1024) void bn_train_stats_multi_kernel(
     float tot = small_colsum(red, grp, t);
     float* const p1 = part + ((size_t)cb * BN_R) * 16;
     float* const p2 = part + ((size_t)(nb + cb) * BN_R) * 16;
-    if (t < 16) p1[rg * 16 + t] = tot;
+    if (t < 16) part_store(p1 + rg * 16 + t, tot);
     bn_group_barrier(counters + 3 * cb, BN_R);
     if (t < 16) {
-        float s_ = p1[t];
+        float s_ = part_load(p1 + t);
 #pragma unroll
-        for (int k = 1; k < BN_R; ++k) s_ += p1[k * 16 + t];
+        for (int k = 1; k < BN_R; ++k) s_ += part_load(p1 + k * 16 + t);
         bc[t] = s_ / (float)M;
     }
     __syncthreads();
@@ -863,14 +872,14 @@ __global__ __launch_bounds__(1024) void bn_train_stats_multi_kernel(
     for (int j = 0; j < 4; ++j) red[rl][4 * cq + j] = q[j];
     __syncthreads();
     tot = small_colsum(red, grp, t);
-    if (t < 16) p2[rg * 16 + t] = tot;
+    if (t < 16) part_store(p2 + rg * 16 + t, tot);
     bn_group_barrier(counters + 3 * cb + 1, BN_R);
     if (self_reset) bn_group_leave(counters + 3 * cb);
     if (blockIdx.x == 0 && t == 0 && num_batches_tracked) *num_batches_tracked += 1;
     if (t < 16) {
-        float m2 = p2[t];
+        float m2 = part_load(p2 + t);
 #pragma unroll
-        for (int k = 1; k < BN_R; ++k) m2 += p2[k * 16 + t];
+        for (int k = 1; k < BN_R; ++k) m2 += part_load(p2 + k * 16 + t);
         const int cc = cb * 16 + t;
         if (cc < C) {
             const float mean = bc[t];
@@ -959,15 +968,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_multi_kernel(
     float* const p1 = part + ((size_t)cb * BN_R) * 16;
     float* const p2 = part + ((size_t)(nb + cb) * BN_R) * 16;
     if (t < 16) {
-        p1[rg * 16 + t] = t1;
-        p2[rg * 16 + t] = t2;
+        part_store(p1 + rg * 16 + t, t1);
+        part_store(p2 + rg * 16 + t, t2);
     }
     bn_group_barrier(counters + 3 * cb, BN_R);
     if (self_reset) bn_group_leave(counters + 3 * cb);
     if (t < 16) {
-        float s1_ = p1[t], s2_ = p2[t];
+        float s1_ = part_load(p1 + t), s2_ = part_load(p2 + t);
 #pragma unroll
-        for (int k = 1; k < BN_R; ++k) { s1_ += p1[k * 16 + t]; s2_ += p2[k * 16 + t]; }
+        for (int k = 1; k < BN_R; ++k) { s1_ += part_load(p1 + k * 16 + t); s2_ += part_load(p2 + k * 16 + t); }
         bc[0][t] = s1_;
         bc[1][t] = s2_;
         const int cc = cb * 16 + t;

@@ -1203,3 +1203,47 @@ def test_transition_pooled_activation_and_pooled_adjoint(L, n, S, C):
     # the column sums: same terms, but the two-call reference may take the single-launch small-M form (another fixed order)
     close(dg2, dg1, rtol=1e-5, atol=1e-5 * dg1.abs().max().item(), what='dgamma')
     close(db2, db1, rtol=1e-5, atol=1e-5 * db1.abs().max().item(), what='dbeta')
+
+
+@pytest.mark.parametrize("M,C", [(4992, 32), (8192, 512), (5000, 1024), (2049, 100)])
+def test_bn_multi_workgroup_forms_repeat_bit_for_bit(GF, M, C):
+    """Round 5: the BatchNorm forms with four workgroups per channel block exchange partial sums across XCDs (whose L2s are not
+    coherent) behind a barrier - a protocol error shows as an occasional stale read, not as a wrong formula.  Sixty
+    forward + backward calls on the same layer (persistent self-resetting sync words, workspaces recycled by the allocator, a
+    cache-disturbing copy in between): every call must give the first call's result bit for bit, and that result must be
+    torch's."""
+    g = torch.Generator().manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * 2 + 3).to(DEV)
+    dy = torch.randn(M, C, generator=g).to(DEV)
+    bn = nn.BatchNorm1d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g))
+    bn.train()
+    junk = torch.empty(64 * 1024 * 1024, device=DEV)
+    first = None
+    for it in range(60):
+        xd = x.clone().requires_grad_(True)
+        yd = GF.batch_norm_relu(xd, bn, True)
+        yd.backward(dy)
+        cur = (yd.detach().clone(), xd.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+        bn.zero_grad()
+        if first is None:
+            first = cur
+        else:
+            for a, b, what in zip(cur, first, ('y', 'dx', 'dgamma', 'dbeta')):
+                assert torch.equal(a, b), "%s differs in call %d" % (what, it)
+        if it % 3 == 0:
+            junk.fill_(float(it))                                   # 256 MB through every L2 between calls
+    assert getattr(bn, '_gnx_sync', None) is not None and int(bn._gnx_sync.abs().sum().item()) == 0     # left zero
+    ref = nn.BatchNorm1d(C)
+    with torch.no_grad():
+        ref.weight.copy_(bn.weight.cpu())
+        ref.bias.copy_(bn.bias.cpu())
+    ref.train()
+    xr = x.cpu().clone().requires_grad_(True)
+    yr = torch.relu(ref(xr))
+    yr.backward(dy.cpu())
+    close(first[0], yr, what='y')
+    close(first[1], xr.grad, rtol=3e-4, what='dx')
+    close(first[2], ref.weight.grad, rtol=3e-4, atol=1e-4, what='dgamma')
