@@ -779,6 +779,13 @@ __global__ __launch_bounds__(1024) void bn_bwd_small_kernel(
 // instead of 256), the arithmetic (two-pass variance) does not.
 constexpr int BN_R = 4;
 constexpr long BN_MULTI_M = 8L * BN_SL * BN_R;                  // 8192 rows
+// Floats per workgroup partial = ONE 128-B line (16 used).  A line must hold ONE producer's bytes and must not be fetched by
+// anybody before that producer has arrived: agent-scope loads are served by the reader's XCD L2, and a line that L2 fetched
+// earlier - because a NEIGHBOURING group's consumer read its own partials out of the same line - stays there with the bytes of
+// producers that had not written yet (round 5: with 64-B slots packed back to back, g's 32 channels passed and C = 512 / 1024
+// failed - but only behind other tests, whose freed memory made the not-yet-written bytes differ from the right values; a fresh
+// process, or the same call repeated, reads "stale" bytes that happen to be right).
+constexpr int BN_PS = 32;
 
 // The exchanged partial sums are written and read with agent-scope (sc1: write-through / L2-bypassing) accesses: the BN_R
 // workgroups of a channel block sit on different XCDs, whose L2s are not coherent - with plain stores two producers' 64-B
@@ -818,7 +825,7 @@ __device__ __forceinline__ void bn_group_leave(unsigned* words) {
     }
 }
 
-// counters: [C/16 blocks][arrivals 1, arrivals 2, leavers] unsigned; part: partial sums [2 phases][C/16][BN_R][16] floats
+// counters: [C/16 blocks][arrivals 1, arrivals 2, leavers] unsigned; part (128-B aligned): partial sums [2 phases][C/16][BN_R][BN_PS] floats
 __global__ __launch_bounds__(1024) void bn_train_stats_multi_kernel(
     const float* __restrict__ x, long ld, long M, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
@@ -849,14 +856,14 @@ __global__ __launch_bounds__(1024) void bn_train_stats_multi_kernel(
     for (int j = 0; j < 4; ++j) red[rl][4 * cq + j] = a[j];
     __syncthreads();
     float tot = small_colsum(red, grp, t);
-    float* const p1 = part + ((size_t)cb * BN_R) * 16;
-    float* const p2 = part + ((size_t)(nb + cb) * BN_R) * 16;
-    if (t < 16) part_store(p1 + rg * 16 + t, tot);
+    float* const p1 = part + ((size_t)cb * BN_R) * BN_PS;
+    float* const p2 = part + ((size_t)(nb + cb) * BN_R) * BN_PS;
+    if (t < 16) part_store(p1 + rg * BN_PS + t, tot);
     bn_group_barrier(counters + 3 * cb, BN_R);
     if (t < 16) {
         float s_ = part_load(p1 + t);
 #pragma unroll
-        for (int k = 1; k < BN_R; ++k) s_ += part_load(p1 + k * 16 + t);
+        for (int k = 1; k < BN_R; ++k) s_ += part_load(p1 + k * BN_PS + t);
         bc[t] = s_ / (float)M;
     }
     __syncthreads();
@@ -872,14 +879,14 @@ __global__ __launch_bounds__(1024) void bn_train_stats_multi_kernel(
     for (int j = 0; j < 4; ++j) red[rl][4 * cq + j] = q[j];
     __syncthreads();
     tot = small_colsum(red, grp, t);
-    if (t < 16) part_store(p2 + rg * 16 + t, tot);
+    if (t < 16) part_store(p2 + rg * BN_PS + t, tot);
     bn_group_barrier(counters + 3 * cb + 1, BN_R);
     if (self_reset) bn_group_leave(counters + 3 * cb);
     if (blockIdx.x == 0 && t == 0 && num_batches_tracked) *num_batches_tracked += 1;
     if (t < 16) {
         float m2 = part_load(p2 + t);
 #pragma unroll
-        for (int k = 1; k < BN_R; ++k) m2 += part_load(p2 + k * 16 + t);
+        for (int k = 1; k < BN_R; ++k) m2 += part_load(p2 + k * BN_PS + t);
         const int cc = cb * 16 + t;
         if (cc < C) {
             const float mean = bc[t];
@@ -965,18 +972,18 @@ __global__ __launch_bounds__(1024) void bn_bwd_multi_kernel(
     for (int j = 0; j < 4; ++j) red[rl][4 * cq + j] = a2[j];
     __syncthreads();
     const float t2 = small_colsum(red, grp, t);
-    float* const p1 = part + ((size_t)cb * BN_R) * 16;
-    float* const p2 = part + ((size_t)(nb + cb) * BN_R) * 16;
+    float* const p1 = part + ((size_t)cb * BN_R) * BN_PS;
+    float* const p2 = part + ((size_t)(nb + cb) * BN_R) * BN_PS;
     if (t < 16) {
-        part_store(p1 + rg * 16 + t, t1);
-        part_store(p2 + rg * 16 + t, t2);
+        part_store(p1 + rg * BN_PS + t, t1);
+        part_store(p2 + rg * BN_PS + t, t2);
     }
     bn_group_barrier(counters + 3 * cb, BN_R);
     if (self_reset) bn_group_leave(counters + 3 * cb);
     if (t < 16) {
         float s1_ = part_load(p1 + t), s2_ = part_load(p2 + t);
 #pragma unroll
-        for (int k = 1; k < BN_R; ++k) { s1_ += part_load(p1 + k * 16 + t); s2_ += part_load(p2 + k * 16 + t); }
+        for (int k = 1; k < BN_R; ++k) { s1_ += part_load(p1 + k * BN_PS + t); s2_ += part_load(p2 + k * BN_PS + t); }
         bc[0][t] = s1_;
         bc[1][t] = s2_;
         const int cc = cb * 16 + t;
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_multi_kernel(
 // the sync area of the multi-workgroup forms inside a gnx_bn_workspace: counters (zeroed per launch), then partial sums
 inline long bn_sync_floats(int C) {
     const long nb = (C + 15) / 16;
-    return 3 * nb /* counters */ + 2 * nb * BN_R * 16 + 16 /* alignment slack */;
+    return 3 * nb /* counters */ + 2 * nb * BN_R * BN_PS + 64 /* 128-B alignment of the partials */;
 }
 
 inline int elementwise_grid(long total) {
@@ -1035,7 +1042,7 @@ static void bn_multi_sync(float* workspace, long M, int C, hipStream_t stream, u
                           float** part) {
     const long nb = (C + 15) / 16;
     float* base = workspace + 2L * slab_count(M) * C + 2L * C;
-    *part = base + 3 * nb;
+    *part = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(base + 3 * nb) + 127) & ~(uintptr_t)127);
     if (persistent) {                                           // caller-owned, zeroed once, self-resetting: no memset node
         *counters = persistent;
         return;
