@@ -779,18 +779,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_small_kernel(
 // instead of 256), the arithmetic (two-pass variance) does not.
 constexpr int BN_R = 4;
 constexpr long BN_MULTI_M = 8L * BN_SL * BN_R;                  // 8192 rows
-// Floats per workgroup partial = ONE 128-B line (16 used).  A line must hold ONE producer's bytes and must not be fetched by
-// anybody before that producer has arrived: agent-scope loads are served by the reader's XCD L2, and a line that L2 fetched
-// earlier - because a NEIGHBOURING group's consumer read its own partials out of the same line - stays there with the bytes of
-// producers that had not written yet (round 5: with 64-B slots packed back to back, g's 32 channels passed and C = 512 / 1024
-// failed - but only behind other tests, whose freed memory made the not-yet-written bytes differ from the right values; a fresh
-// process, or the same call repeated, reads "stale" bytes that happen to be right).
+// Floats per workgroup partial = ONE 128-B line (16 used), 128-B aligned: a line holds ONE producer's bytes and is fetched
+// by nobody before that producer has arrived.  Agent-scope loads are served by the reader's XCD L2 (MI355X_MICROARCH.md); with
+// 64-B slots packed back to back a NEIGHBOURING group's consumer could pull a shared line into that L2 before its last producer
+// wrote.  (Defensive: the failures that prompted it - dx off by 0.2 at C = 512 / 1024, only when the whole suite ran - turned
+// out to be torch's single-threaded fp32 CPU BatchNorm backward, the tests' reference, which is that far from fp64 at those
+// sizes; the tests now compare with a float64 reference.)
 constexpr int BN_PS = 32;
 
-// The exchanged partial sums are written and read with agent-scope (sc1: write-through / L2-bypassing) accesses: the BN_R
-// workgroups of a channel block sit on different XCDs, whose L2s are not coherent - with plain stores two producers' 64-B
-// halves of one 128-B line are two partially valid copies of that line in two L2s, and a consumer whose own L2 holds the line
-// (it wrote its half) read the other half STALE (round 5: wrong dx at C = 512 / 1024 while C <= 64 passed).
+// The exchanged partial sums are written and read with agent-scope (sc1: write-through) accesses: the BN_R workgroups of a
+// channel block sit on different XCDs, whose L2s are not coherent - plain stores would leave a producer's bytes in ITS L2
+// until the release writes them back, and two producers' halves of one line as two partially valid copies of it.
 __device__ __forceinline__ void part_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float part_load(const float* p) {
     return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
