@@ -82,6 +82,24 @@ def test_hexagdly_compatible_module(GF):
 
 
 # ----------------------------------------------------------------------------------------------- batch norm
+def _away_from_relu_kink(x, weight, bias, eps, training, running_mean=None, running_var=None):
+    """Nudge the few entries of x whose BatchNorm output lies within 1e-4 of zero: there the fp32 kernel and a float64 reference
+    may take different sides of the ReLU, an O(dy) difference in dx at that element that says nothing about either."""
+    x = x.clone()
+    for _ in range(4):
+        xd = x.double()
+        if training:
+            mu, var = xd.mean(0), xd.var(0, unbiased=False)
+        else:
+            mu, var = running_mean.double(), running_var.double()
+        y = (xd - mu) / (var + eps).sqrt() * weight.double() + bias.double()
+        near = y.abs() < 1e-4
+        if not near.any():
+            break
+        x[near] += 0.05
+    return x
+
+
 @pytest.mark.parametrize("M,C,relu,training", [(300, 32, True, True), (4992, 100, True, True), (77, 50, False, True),
                                                (512, 32, True, False), (5, 3, True, True),
                                                # round 5: the forms with several workgroups per channel block (2048 < M <= 8192)
@@ -98,6 +116,9 @@ def test_bn_relu_fwd_bwd(GF, M, C, relu, training):
         bn_ref.running_mean.copy_(torch.randn(C, generator=g))
         bn_ref.running_var.copy_(torch.rand(C, generator=g) + 0.5)
     import copy
+    if relu:
+        x = _away_from_relu_kink(x, bn_ref.weight.detach(), bn_ref.bias.detach(), bn_ref.eps, training, bn_ref.running_mean,
+                                 bn_ref.running_var)
     bn_hip = copy.deepcopy(bn_ref).to(DEV)
     # the reference in float64: torch's fp32 CPU BatchNorm backward depends on the thread count and is FAR from fp64 at large
     # sizes on one or two threads (8192 x 512: dx off by 0.23 of its range on 1-2 threads, 2e-7 on 8) - and importing
@@ -1227,6 +1248,7 @@ def test_bn_multi_workgroup_forms_repeat_bit_for_bit(GF, M, C):
         bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
         bn.bias.copy_(torch.randn(C, generator=g))
     bn.train()
+    xs = [_away_from_relu_kink(x.cpu(), bn.weight.detach().cpu(), bn.bias.detach().cpu(), bn.eps, True).to(DEV) for x in xs]
     junk = torch.empty(64 * 1024 * 1024, device=DEV)
 
     def poison():
