@@ -893,6 +893,20 @@ GNX_EXPORT void gnx_dense_layer_f16_set_stamps(void* buf, int abl) {
 // blocks [0, K / 32), writes block K / 32.  bn_size * growth = 128 and growth = 32 are fixed; S in {4, 8, 16, 32, 64};
 // 32 | K, 64 <= K <= 1024; X16 16-B aligned; n_img * S * S a multiple of 128.  scale / shift: the folded running-statistics
 // BatchNorms (norm1: K, norm2: 128).
+// the k-split form for 64 x 64 and 32 x 32 maps (dense_layer_f16_ks.hip)
+int gnx_dense_layer_f16_ks_launch(void* X16, long rows_total, long n_img, int S, int K, const void* w1p, const void* w2p,
+                                  const float* scale1, const float* shift1, const float* scale2, const float* shift2, void* A16,
+                                  long a_rows_total, int cus, hipStream_t stream);
+// Which kernel runs 64 x 64 and 32 x 32 maps (K <= 512): 0 = the form that keeps W2 and the bottleneck tile in LDS (default:
+// faster or equal at every shape of config 5 but K = 64), 1 = the k-split form.  Process-wide.
+static int g_dense_layer_form = 0;
+GNX_EXPORT int gnx_dense_layer_f16_set_form(int form) {
+    if (form != 0 && form != 1) return GNX_ERR_BAD_ARG;
+    g_dense_layer_form = form;
+    return GNX_OK;
+}
+static bool dense_layer_ksplit() { return g_dense_layer_form == 1; }
+
 static int dense_layer_launch(void* X16, long rows_total, long n_img, int S, int K, const void* w1p, const void* w2p,
                               const float* scale1, const float* shift1, const float* scale2, const float* shift2, void* A16,
                               long a_rows_total, hipStream_t stream) {
@@ -913,6 +927,10 @@ static int dense_layer_launch(void* X16, long rows_total, long n_img, int S, int
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GNX_ERR_LAUNCH;
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    if ((S == 64 || S == 32) && K <= 512 && rows_total * 64 < (1L << 32) && (!A16 || a_rows_total * 64 < (1L << 32)) &&
+        dense_layer_ksplit())
+        return gnx_dense_layer_f16_ks_launch(X16, rows_total, n_img, S, K, w1p, w2p, scale1, shift1, scale2, shift2, A16,
+                                             a_rows_total, cus, stream);
     const int grid = (int)(units < cus ? units : cus);
     _Float16* X = reinterpret_cast<_Float16*>(X16);
     const _Float16* w1 = reinterpret_cast<const _Float16*>(w1p);

@@ -292,6 +292,13 @@ int gnx_dense_layer_f16(void* X16, long rows_total, long n_img, int S, int K, co
 int gnx_dense_layer_f16_tape(void* X16, long rows_total, long n_img, int S, int K, const void* w1p, const void* w2p,
                              const float* scale1, const float* shift1, const float* scale2, const float* shift2, void* A16,
                              long a_rows_total, gnx_stream_t stream);
+/* Which kernel gnx_dense_layer_f16 / _tape run on 64 x 64 and 32 x 32 maps with K <= 512 (densenet.py:35-44 either way; a
+ * process-wide tuning switch): 0 (default) keeps W2 and the bottleneck tile in LDS; 1 = the K-SPLIT form
+ * (csrc/dense_layer_f16_ks.hip): the four waves of a workgroup own 32 bottleneck channels each, conv1's accumulators become
+ * conv2's operand in registers, W2's slice lives in registers, dx taps are DPP lane shifts, the four partial sums are added
+ * through LDS in a fixed order.  Same rounding points; conv2's fp32 sum runs in another order (last-bit differences before the
+ * fp16 rounding of the output).  Any other value: GNX_ERR_BAD_ARG. */
+int gnx_dense_layer_f16_set_form(int form);
 int gnx_conv_stem_bnrelu_maxpool_f16mul_cb(const void* x, int x_is_u8, const float* w, void* out16, long rows_total, long imgs,
                                            int Cin, int H, int W, int O, int KH, int KW, int stride, int pad, const float* scale,
                                            const float* shift, const float* norm, gnx_stream_t stream);

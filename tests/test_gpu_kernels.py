@@ -757,13 +757,26 @@ def test_transition_f16_fused(L, S, n, K, N):
 @pytest.mark.parametrize("S,n,K,ct", [(64, 2, 64, 128), (64, 3, 96, 160), (64, 260, 64, 128), (64, 5, 224, 288),
                                       (64, 258, 160, 224), (64, 2, 480, 544), (32, 9, 992, 1056), (32, 4, 128, 192),
                                       (32, 300, 224, 288), (16, 8, 256, 320), (16, 520, 96, 160), (8, 16, 512, 576),
-                                      (8, 1040, 64, 128), (4, 64, 992, 1056), (4, 4160, 64, 128)])
-def test_dense_layer_f16_fused(L, S, n, K, ct):
-    """gnx_dense_layer_f16 (one kernel per dense layer, bottleneck in LDS only) against the layer evaluated in double on the
+                                      (8, 1040, 64, 128), (4, 64, 992, 1056), (4, 4160, 64, 128),
+                                      (64, 530, 96, 160), (32, 1100, 160, 224), (32, 515, 480, 544)])
+@pytest.mark.parametrize("form", [0, 1])
+def test_dense_layer_f16_fused(L, S, n, K, ct, form):
+    """(form 1: the k-split kernel of 64 x 64 / 32 x 32 maps with K <= 512, gnx_dense_layer_f16_set_form; other shapes run the
+    same kernel under both forms.)  gnx_dense_layer_f16 (one kernel per dense layer, bottleneck in LDS only) against the layer evaluated in double on the
     same fp16 values with the same rounding points.  Tolerance 3e-3 of the output range: the fp16 rounding of the output
     (2^-11 relative) plus bottleneck values that round the other way when conv1's fp32 sum runs in another order.  Also: the
     input columns and everything beyond the 32 new columns stay untouched.  Shapes: every map size the kernel takes, K from
     2 to 31 stages, single-step and swept images, fewer and more work units than compute units (260 ... 4160 images)."""
+    if form == 1 and not (S >= 32 and K <= 512):
+        pytest.skip("the k-split form takes 64 x 64 and 32 x 32 maps with K <= 512")
+    L.call('gnx_dense_layer_f16_set_form', form)
+    try:
+        _dense_layer_f16_fused_case(L, S, n, K, ct)
+    finally:
+        L.call('gnx_dense_layer_f16_set_form', 0)
+
+
+def _dense_layer_f16_fused_case(L, S, n, K, ct):
     g = torch.Generator().manual_seed(S * 1000 + K + n)
     x = torch.randn(n, S, S, ct, generator=g).half()
     x[:, :, :, K:] = 7.0

@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--const', action='store_true', help='constant operands (low bit toggling) instead of randn')
     ap.add_argument('--clamp', action='store_true', help='conv1x1 in its folded LDS-clamp form (gnx_conv1x1_clamped_act)')
     ap.add_argument('--wino', action='store_true', help='conv3x3 in its Winograd F(2,3) form (prologue-free operand)')
+    ap.add_argument('--form', type=int, default=0, help='fused dense layer: 0 = LDS form, 1 = k-split form (64/32-px maps)')
     ap.add_argument('--dense', action='store_true', help='operand rows exactly K wide (lda = K) instead of the block buffer stride')
     args = ap.parse_args()
     n = args.spots
@@ -113,6 +114,7 @@ def main():
         # 'fusedcmp' also times the two-kernel pair it replaces.  TB/s = algorithmic bytes of the fused layer (K columns in,
         # 32 out) over the time.
         H = torch.float16
+        L.call('gnx_dense_layer_f16_set_form', args.form)
         fshapes = [(64, 64, 256), (64, 128, 256), (64, 224, 256), (32, 128, 512), (32, 480, 512), (16, 256, 1024),
                    (16, 992, 1024), (8, 512, 1024), (8, 992, 1024)]
         for S, K, ct in fshapes:
