@@ -81,6 +81,7 @@ SIGNATURES = {
     'gnx_dense_layer_f16': (_I, [_P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     'gnx_dense_layer_f16_tape': (_I, [_P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     'gnx_dense_layer_f16_set_form': (_I, [_I]),
+    'gnx_dense_bwd_f16_pack': (_I, [_P, _P, _P, _P, _I, _P]),
     'gnx_wgrad3x3_f16_lb': (_I, [_P, _L, _P, _L, _L, _P, _P, _L, _I, _P, _I, _P, _P]),
     'gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb': (_I, [_P, _L, _P, _P, _L, _L, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'gnx_conv3x3_bwd_f16_workspace': (_L, [_L]),

@@ -1321,6 +1321,33 @@ GNX_EXPORT int gnx_conv3x3_bwd_f16_lb(const void* dY16, long lddy, const void* W
     return gnx_launch_status();
 }
 
+// The fp16 operands of one dense layer's backward from its fp32 weights, in ONE launch (the torch expressions they replace -
+// w1.reshape(128, K).t().half() and w2.permute(2, 3, 1, 0).reshape(9, 128, 32).half() - are two transposing copies of ~30 us
+// each per layer and step): W1t16 [K][128] = conv1.weight [128][K] transposed (the operand of the conv1 backward kernels),
+// W2b16 [tap 9][m 128][n 32] = conv2.weight [32][128][3][3] (the operand of the conv2 data-gradient kernels).  Rounded once.
+namespace {
+__global__ __launch_bounds__(256) void dense_bwd_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                             _Float16* __restrict__ w1t, _Float16* __restrict__ w2b, int K) {
+    const int n1 = 128 * K, total = n1 + 9 * 128 * 32;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        if (idx < n1) {
+            const int c = idx >> 7, m = idx & 127;                 // consecutive threads write consecutive halves of a row of W1t
+            w1t[idx] = (_Float16)w1[(long)m * K + c];
+        } else {
+            const int j = idx - n1, n = j & 31, m = (j >> 5) & 127, tap = j >> 12;
+            w2b[j] = (_Float16)w2[((long)n * 128 + m) * 9 + tap];
+        }
+    }
+}
+}  // namespace
+GNX_EXPORT int gnx_dense_bwd_f16_pack(const float* w1, const float* w2, void* W1t16, void* W2b16, int K, hipStream_t stream) {
+    if (!w1 || !w2 || !W1t16 || !W2b16 || K <= 0) return GNX_ERR_BAD_ARG;
+    const int total = 128 * K + 9 * 128 * 32;
+    dense_bwd_pack_kernel<<<gnx_cdiv(total, 1024), 256, 0, stream>>>(w1, w2, reinterpret_cast<_Float16*>(W1t16),
+                                                                      reinterpret_cast<_Float16*>(W2b16), K);
+    return gnx_launch_status();
+}
+
 // G16[:, :K] += scale1 * (dB16 . W1) * [bn1(X16) > 0]; dgamma1 / dbeta1 (fp32, (+)=).  W1t16: conv1.weight transposed to
 // [K][128] halves.  32 | K.
 GNX_EXPORT long gnx_conv1x1_dgrad_bnrelu_bwd_f16_workspace(long M, int K) {

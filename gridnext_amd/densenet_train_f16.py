@@ -275,7 +275,12 @@ class _DenseNetF16Fn(Function):
                 cin = c_in + li * g
                 dy = G.data_ptr() + 2 * (cin // 32) * bs     # the layer's 32 gradient columns: ONE contiguous [M][32] matrix
                 w2 = layer.conv2.weight
-                w2b = w2.detach().permute(2, 3, 1, 0).reshape(9, mid, g).to(H16).contiguous()      # [tap][m][n]
+                w1 = layer.conv1.weight
+                # both fp16 operands of the layer's backward in one launch: W2b [tap][m][n], W1t [cin][128]
+                w2b = torch.empty((9, mid, g), device=dev, dtype=H16)
+                w1t = torch.empty((cin, mid), device=dev, dtype=H16)
+                L.call('gnx_dense_bwd_f16_pack', L.ptr(w1.detach().contiguous()), L.ptr(w2.detach().contiguous()), w1t.data_ptr(),
+                       w2b.data_ptr(), cin, st)                   # (mid = 128, g = 32: `eligible`)
                 dg2, db2 = bn_out(layer.norm2)
                 if want(w2) and model.f16_fused_conv2_backward:
                     # conv2's whole backward - data gradient + norm2 adjoint AND weight gradient - in ONE pass over dY and A
@@ -296,8 +301,6 @@ class _DenseNetF16Fn(Function):
                     model._probe_mark('dgrad3x3_bn2_f16', t0, 2 * M * 9 * mid * g, 2 * M * (g + 2 * mid))
                 # conv1: data gradient + norm1 -> relu1's adjoint into the block gradient, and - from the same staged tiles - the
                 # weight gradient (ONE pass over dB, X and G)
-                w1 = layer.conv1.weight
-                w1t = w1.detach().reshape(mid, cin).t().to(H16).contiguous()                         # [cin][128]
                 dg1, db1 = bn_out(layer.norm1)
                 t0 = model._probe_begin()
                 wg = want(w1)

@@ -410,6 +410,10 @@ int gnx_h16_cols_to_f32(const void* G16, long ldg, float* out, long ldo, long M,
  * backward on the same buffers (a layer's dY = its own 32-channel block: pass that block's address with lddy = 32).
  * Same workspaces; gnx_conv1x1_dgrad_wgrad_bnrelu_bwd_f16_lb with dW == NULL is the pass without the weight gradient
  * (workspace gnx_conv1x1_dgrad_bnrelu_bwd_f16_workspace). */
+/* The fp16 operands of one dense layer's backward from its fp32 weights in one launch (densenet.py:35-44 backwards; bn_size *
+ * growth = 128, growth = 32): W1t16 [K][128] = conv1.weight [128][K] transposed, W2b16 [9][128][32] = conv2.weight
+ * [32][128][3][3] as [tap][m][n]; each value rounded once. */
+int gnx_dense_bwd_f16_pack(const float* w1, const float* w2, void* W1t16, void* W2b16, int K, gnx_stream_t stream);
 int gnx_wgrad3x3_f16_lb(const void* dY16, long lddy, const void* A16, long lda, long bsa, float* dW, float* workspace, long M, int S,
                         const float* ls, int accumulate, int* flag, gnx_stream_t stream);
 int gnx_conv3x3_dgrad_bnrelu_bwd_f16_lb(const void* dY16, long lddy, const void* W2b16, const void* A16, long lda, long bsa,

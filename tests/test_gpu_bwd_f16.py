@@ -267,6 +267,22 @@ def _blocked(t):
     return t.reshape(t.shape[0], -1, 32).permute(1, 0, 2).contiguous()
 
 
+@pytest.mark.parametrize("K", [64, 160, 992])
+def test_dense_bwd_pack_equals_the_torch_expressions(L, K):
+    """gnx_dense_bwd_f16_pack: W1t16 = conv1.weight.reshape(128, K).t().half(), W2b16 = conv2.weight.permute(2, 3, 1, 0)
+    .reshape(9, 128, 32).half(), bit for bit (one rounding each); nothing written past either operand."""
+    g = torch.Generator().manual_seed(K)
+    w1 = torch.randn(128, K, 1, 1, generator=g).to(DEV)
+    w2 = (torch.randn(32, 128, 3, 3, generator=g) * 0.1).to(DEV)
+    w1t = torch.full((K * 128 + 8,), 3.0, device=DEV, dtype=torch.float16)
+    w2b = torch.full((9 * 128 * 32 + 8,), 5.0, device=DEV, dtype=torch.float16)
+    L.call('gnx_dense_bwd_f16_pack', L.ptr(w1), L.ptr(w2), w1t.data_ptr(), w2b.data_ptr(), K, L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(w1t[:K * 128].view(K, 128), w1.reshape(128, K).t().half())
+    assert torch.equal(w2b[:9 * 128 * 32].view(9, 128, 32), w2.permute(2, 3, 1, 0).reshape(9, 128, 32).half())
+    assert float(w1t[K * 128:].float().min()) == 3.0 and float(w2b[9 * 128 * 32:].float().min()) == 5.0
+
+
 @pytest.mark.parametrize("imgs,S,cin,ct", [(8, 4, 96, 160), (2, 16, 224, 256), (1, 64, 64, 128), (24, 8, 992, 1024)])
 def test_lb_entry_points_on_channel_blocked_buffers_equal_the_row_major_ones(L, imgs, S, cin, ct):
     """Round 5: the backward kernels address block buffers, block gradients and the activated bottleneck through (ld, bs) -
