@@ -95,6 +95,7 @@ SIGNATURES = {
     'gnx_bnrelu_avgpool2_h16_cb': (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _P]),
     'gnx_transition_f16_pack': (_I, [_P, _P, _I, _I, _P]),
     'gnx_transition_f16': (_I, [_P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _L, _P]),
+    'gnx_transition_f16_tape': (_I, [_P, _L, _L, _I, _I, _I, _P, _P, _P, _P, _L, _P, _L, _P]),
     'gnx_bnrelu_avgpool_h16_cb': (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _P]),
     'gnx_conv3x3_bnrelu': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
     'gnx_winograd_conv3x3_weights': (_I, [_P, _P, _I, _I, _P]),

@@ -31,7 +31,7 @@ template <int NT>
 __global__ __launch_bounds__(512) void transition_f16_kernel(const _Float16* __restrict__ X, long xbs, long rows_in,
                                                              _Float16* __restrict__ Y, long ybs, int n_steps, int S, int K,
                                                              const _Float16* __restrict__ wp, const float* __restrict__ sc,
-                                                             const float* __restrict__ sh) {
+                                                             const float* __restrict__ sh, _Float16* __restrict__ Pout, long ldp) {
     __shared__ __attribute__((aligned(16))) char lds[TR_LDS];
     const int t = threadIdx.x, lane = t & 63, h = lane >> 5, i = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -122,6 +122,11 @@ __global__ __launch_bounds__(512) void transition_f16_kernel(const _Float16* __r
             return __builtin_bit_cast(u32x4, o);
         };
         int sa = 0, bdone = 0;                                 // in-step index of the stage applied next; pair barriers passed in its step
+        // the TAPE of the gradient path (gnx_transition_f16_tape): the pooled activated operand also goes to HBM as a row-major
+        // [pooled pixel][K] matrix - the operand of the 1x1 weight gradient - 16 B per lane and piece (the first output pass
+        // writes it; the stores only make the hand-counted load waits conservative)
+        const bool tape = Pout != nullptr && blockIdx.y == 0;
+        long prow = (long)bid * 128 + 32 * fw + (lane & 15);   // the lane's first pooled pixel of the step being applied
         auto gapply = [&](auto ph_c, int g) {
             constexpr int P = decltype(ph_c)::value;
             if (sa == 0 && g > 0) {                            // a new step: what is left of the previous one's barriers, then E
@@ -133,9 +138,17 @@ __global__ __launch_bounds__(512) void transition_f16_kernel(const _Float16* __r
             landed(rq[P]);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ks0), "+v"(ks1), "+v"(kb0), "+v"(kb1));
             char* d = lds + TR_AR + (sa & 3) * TR_SLOT + 2 * fw * 1024 + lane * 16;
-            *reinterpret_cast<u32x4*>(d) = pooled(rq[P][0], rq[P][1], rq[P][2], rq[P][3]);
-            *reinterpret_cast<u32x4*>(d + 1024) = pooled(rq[P][4], rq[P][5], rq[P][6], rq[P][7]);
+            const u32x4 p0 = pooled(rq[P][0], rq[P][1], rq[P][2], rq[P][3]);
+            const u32x4 p1 = pooled(rq[P][4], rq[P][5], rq[P][6], rq[P][7]);
+            *reinterpret_cast<u32x4*>(d) = p0;
+            *reinterpret_cast<u32x4*>(d + 1024) = p1;
+            if (tape) {
+                _Float16* q = Pout + prow * ldp + sa * 32 + col * 8;
+                *reinterpret_cast<u32x4*>(q) = p0;
+                *reinterpret_cast<u32x4*>(q + 16 * ldp) = p1;
+            }
             load_next(rq[P]);
+            if (sa + 1 == nst) prow += (long)G * 128;
             sa = sa + 1 == nst ? 0 : sa + 1;
             request_k(sa);
         };
@@ -292,11 +305,12 @@ GNX_EXPORT int gnx_transition_f16_pack(const float* w, void* wp, int N, int K, h
 // The transition on CHANNEL-BLOCKED fp16 buffers: X16 [K / 32][rows_in][32] (rows = n_img * S * S pixels, the first of rows_in)
 // -> Y16 [.. / 32][rows_out][32], channel blocks [0, N / 32) of it, rows n_img * (S / 2)^2.  S in {8, 16, 32, 64}; 32 | K,
 // 64 <= K <= 1024; 128 | N <= 512; 128 | n_img * (S / 2)^2; scale / shift: the folded running-statistics BatchNorm (K).
-GNX_EXPORT int gnx_transition_f16(const void* X16, long rows_in, long n_img, int S, int K, int N, const void* wp,
-                                  const float* scale, const float* shift, void* Y16, long rows_out, hipStream_t stream) {
+static int transition_launch(const void* X16, long rows_in, long n_img, int S, int K, int N, const void* wp, const float* scale,
+                             const float* shift, void* Y16, long rows_out, void* P16, long ldp, hipStream_t stream) {
     if (!X16 || !Y16 || !wp || !scale || !shift || n_img < 0 || K <= 0 || N <= 0 || S <= 0 || rows_in < n_img * (long)S * S ||
-        rows_out < n_img * (long)(S / 2) * (S / 2))
+        rows_out < n_img * (long)(S / 2) * (S / 2) || (P16 && ldp < K))
         return GNX_ERR_BAD_ARG;
+    if (P16 && (!al16(P16) || ldp % 8 != 0)) return GNX_ERR_UNSUPPORTED;
     const long mout = n_img * (long)(S / 2) * (S / 2);
     if ((S != 8 && S != 16 && S != 32 && S != 64) || K % 32 != 0 || K < 64 || K > 1024 || N % 128 != 0 || N > 512 ||
         mout % 128 != 0 || !al16(X16) || !al16(Y16) || !al16(wp) || rows_in * 64 >= (1L << 32) - (1L << 25) ||
@@ -314,14 +328,29 @@ GNX_EXPORT int gnx_transition_f16(const void* X16, long rows_in, long n_img, int
     const _Float16* X = reinterpret_cast<const _Float16*>(X16);
     _Float16* Y = reinterpret_cast<_Float16*>(Y16);
     const _Float16* w = reinterpret_cast<const _Float16*>(wp);
+    _Float16* Pt = reinterpret_cast<_Float16*>(P16);
     if (N % 256 == 0) {
         const int gx = (int)(steps < cus ? steps : cus);       // (N = 512: the two channel halves share a CU's time)
         transition_f16_kernel<2><<<dim3(gx, N / 256), 512, 0, stream>>>(X, rows_in * 32, rows_in, Y, rows_out * 32, (int)steps, S, K,
-                                                                         w, scale, shift);
+                                                                         w, scale, shift, Pt, ldp);
     } else {
         const int gx = (int)(steps < cus ? steps : cus);
         transition_f16_kernel<1><<<dim3(gx, N / 128), 512, 0, stream>>>(X, rows_in * 32, rows_in, Y, rows_out * 32, (int)steps, S, K, w,
-                                                                  scale, shift);
+                                                                  scale, shift, Pt, ldp);
     }
     return gnx_launch_status();
+}
+GNX_EXPORT int gnx_transition_f16(const void* X16, long rows_in, long n_img, int S, int K, int N, const void* wp,
+                                  const float* scale, const float* shift, void* Y16, long rows_out, hipStream_t stream) {
+    return transition_launch(X16, rows_in, n_img, S, K, N, wp, scale, shift, Y16, rows_out, nullptr, 0, stream);
+}
+// The same transition as the TAPED forward of the fp16 gradient path: additionally stores the pooled activated operand
+// avgpool2(relu(norm(x))) - the tile the feeders put into the LDS anyway, bit for bit gnx_bnrelu_avgpool2_h16's output - as a
+// row-major fp16 matrix P16 [n_img * (S / 2)^2][ldp] (columns [0, K)), the operand of the 1x1 weight gradient.  Everything else
+// is gnx_transition_f16 bit for bit.
+GNX_EXPORT int gnx_transition_f16_tape(const void* X16, long rows_in, long n_img, int S, int K, int N, const void* wp,
+                                       const float* scale, const float* shift, void* Y16, long rows_out, void* P16, long ldp,
+                                       hipStream_t stream) {
+    if (!P16) return GNX_ERR_BAD_ARG;
+    return transition_launch(X16, rows_in, n_img, S, K, N, wp, scale, shift, Y16, rows_out, P16, ldp, stream);
 }

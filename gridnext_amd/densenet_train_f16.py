@@ -143,10 +143,17 @@ class _DenseNetF16Fn(Function):
                 so = s // 2
                 stt = _bn(trans.norm, None, c_total, M, False, dev, st)
                 pooled = torch.empty((N * so * so, c_total), device=dev, dtype=H16)     # (row-major: the weight gradient's operand)
-                L.call('gnx_bnrelu_avgpool2_h16_cb', buf.data_ptr(), M, pooled.data_ptr(), c_total, N, c_total, s, L.ptr(stt[0]),
-                       L.ptr(stt[1]), st)
-                L.call('gnx_conv1x1_bnrelu_h16_cb', pooled.data_ptr(), c_total, wth[trans].data_ptr(), nxt.data_ptr(), nxt.shape[1],
-                       N * so * so, trans.conv.out_channels, c_total, None, None, None, None, st)
+                cout = trans.conv.out_channels
+                if (model.f16_fused_transitions and s in (8, 16, 32, 64) and 64 <= c_total <= 1024 and cout % 128 == 0 and
+                        cout <= 512 and (N * so * so) % 128 == 0 and M * 64 < 2 ** 32 - 2 ** 25):
+                    # ONE kernel (the eval forward's gnx_transition_f16), the pooled operand copied out of its LDS slots
+                    L.call('gnx_transition_f16_tape', buf.data_ptr(), M, N, s, c_total, cout, model._trans_f16_packed()[trans].data_ptr(),
+                           L.ptr(stt[0]), L.ptr(stt[1]), nxt.data_ptr(), nxt.shape[1], pooled.data_ptr(), c_total, st)
+                else:
+                    L.call('gnx_bnrelu_avgpool2_h16_cb', buf.data_ptr(), M, pooled.data_ptr(), c_total, N, c_total, s, L.ptr(stt[0]),
+                           L.ptr(stt[1]), st)
+                    L.call('gnx_conv1x1_bnrelu_h16_cb', pooled.data_ptr(), c_total, wth[trans].data_ptr(), nxt.data_ptr(), nxt.shape[1],
+                           N * so * so, cout, c_total, None, None, None, None, st)
                 tape.trans.append((stt, pooled))
             else:
                 tape.trans.append(None)

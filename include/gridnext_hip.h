@@ -273,6 +273,12 @@ int gnx_bnrelu_avgpool_h16(const void* in16, long ldi, float* out, long ldo, lon
 int gnx_transition_f16_pack(const float* w, void* wp, int N, int K, hipStream_t stream);
 int gnx_transition_f16(const void* X16, long rows_in, long n_img, int S, int K, int N, const void* wp, const float* scale,
                        const float* shift, void* Y16, long rows_out, hipStream_t stream);
+/* The same transition as the TAPED forward of the fp16 gradient path (training.py:164-171 stepping f_opt): additionally stores
+ * the pooled activated operand avgpool2(relu(norm(x))) - which the kernel holds in the LDS anyway; bit for bit
+ * gnx_bnrelu_avgpool2_h16_cb's output - as a row-major fp16 matrix P16 [n_img * (S / 2)^2][ldp] (columns [0, K); 8 | ldp), the
+ * operand of the transition's 1x1 weight gradient.  Everything else is gnx_transition_f16 bit for bit. */
+int gnx_transition_f16_tape(const void* X16, long rows_in, long n_img, int S, int K, int N, const void* wp, const float* scale,
+                            const float* shift, void* Y16, long rows_out, void* P16, long ldp, gnx_stream_t stream);
 /* One whole dense layer of config 5 in ONE kernel (gridnext/densenet.py:35-44: cat -> norm1 -> relu1 -> conv1 -> norm2 ->
  * relu2 -> conv2) on a CHANNEL-BLOCKED fp16 block buffer X16 [channels / 32][rows_total][32] - element (row, c) at
  * (c >> 5) * rows_total * 32 + row * 32 + (c & 31), so the 32 channels a K-loop stage needs of consecutive pixels are

@@ -752,6 +752,22 @@ def test_transition_f16_fused(L, S, n, K, N):
     err = (out - ref).abs().max().item()
     tol = 2e-3 * ref.abs().max().item()
     assert err <= tol, "S=%d n=%d K=%d N=%d: max abs err %.3e > %.3e" % (S, n, K, N, err, tol)
+    # the TAPED form (gnx_transition_f16_tape, the forward of the fp16 gradient path): the same output bit for bit, plus the
+    # pooled activated operand as a row-major [pooled pixel][ldp] matrix - bit for bit the pooling pass's output (the fp32
+    # arithmetic above in the same order, one rounding) - and nothing beyond its K columns or its rows
+    Yt = torch.full((cy // 32, rows_out, 32), 7.0, dtype=H, device=DEV)
+    ldp = K + 8
+    Pt = torch.full((rows_out + 3, ldp), 5.0, dtype=H, device=DEV)
+    L.call('gnx_transition_f16_tape', L.ptr(X, H), X.shape[1], n, S, K, N, L.ptr(wp, H), L.ptr(scd), L.ptr(shd), L.ptr(Yt, H), rows_out,
+           L.ptr(Pt, H), ldp, st)
+    torch.cuda.synchronize()
+    assert torch.equal(Yt, Y), "the taped form changed the transition's output"
+    assert torch.equal(Pt[:rows_out, :K].cpu().reshape(n, so, so, K), p), "taped pooled operand"
+    assert float(Pt[:rows_out, K:].float().min()) == 5.0 and float(Pt[rows_out:].float().min()) == 5.0
+    pool2 = torch.empty((rows_out, K), dtype=H, device=DEV)
+    L.call('gnx_bnrelu_avgpool2_h16_cb', L.ptr(X, H), X.shape[1], L.ptr(pool2, H), K, n, K, S, L.ptr(scd), L.ptr(shd), st)
+    torch.cuda.synchronize()
+    assert torch.equal(Pt[:rows_out, :K], pool2), "the tape differs from the pooling pass it replaces"
 
 
 @pytest.mark.parametrize("S,n,K,ct", [(64, 2, 64, 128), (64, 3, 96, 160), (64, 260, 64, 128), (64, 5, 224, 288),
