@@ -15,6 +15,7 @@
 // into registers while the current one is multiplied.  Bound: fp32 matrix peak 157.3 TFLOP/s
 // (2*M*N*K FLOP) for the 2000->500 layer, HBM for the count stream (K-major A is read once).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -89,19 +90,24 @@ template <bool A_KMAJOR, bool B_KMAJOR, bool A_VEC, bool B_VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long lda,
                                                        const float* __restrict__ B, long ldb,
                                                        const float* __restrict__ bias, float* __restrict__ C,
-                                                       long ldc, long M, long N, long K, int accumulate) {
+                                                       long ldc, long M, long N, long K, int accumulate,
+                                                       float* __restrict__ slabs) {
+    // gridDim.z > 1 (tall, narrow products: few 64 x 64 tiles, long K - the composed 2000 -> 100 layer of the count MLP over a
+    // 4 992-spot grid is 156 tiles for 256 CUs): workgroup z takes the z-th share of the K tiles and writes its partial tile
+    // into slabs [z][M][N], summed in index order (+ bias) by gemm_split_reduce_kernel: deterministic.
     __shared__ __attribute__((aligned(16))) float As[BK * LD];
     __shared__ __attribute__((aligned(16))) float Bs[BK * LD];
     const long m0 = (long)blockIdx.x * BM, n0 = (long)blockIdx.y * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, i = lane & 31;
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const long nkt = (K + BK - 1) / BK;
+    const long nkt_all = (K + BK - 1) / BK;
+    const long kt_first = nkt_all * blockIdx.z / gridDim.z, nkt = nkt_all * (blockIdx.z + 1) / gridDim.z;
     const __amdgpu_buffer_rsrc_t rA = A_VEC ? (A_KMAJOR ? operand_rsrc(A, K, lda, M) : operand_rsrc(A, M, lda, K)) : operand_rsrc(A, 1, 0, 4);
     const __amdgpu_buffer_rsrc_t rB = B_VEC ? (B_KMAJOR ? operand_rsrc(B, K, ldb, N) : operand_rsrc(B, N, ldb, K)) : operand_rsrc(B, 1, 0, 4);
-    TileRegs ra = load_tile<A_KMAJOR, A_VEC>(A, rA, lda, m0, M, 0, K);
-    TileRegs rb = load_tile<B_KMAJOR, B_VEC>(B, rB, ldb, n0, N, 0, K);
-    for (long kt = 0; kt < nkt; ++kt) {
+    TileRegs ra = load_tile<A_KMAJOR, A_VEC>(A, rA, lda, m0, M, kt_first * BK, K);
+    TileRegs rb = load_tile<B_KMAJOR, B_VEC>(B, rB, ldb, n0, N, kt_first * BK, K);
+    for (long kt = kt_first; kt < nkt; ++kt) {
         store_tile<A_KMAJOR>(As, ra);
         store_tile<B_KMAJOR>(Bs, rb);
         __syncthreads();
@@ -119,6 +125,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
     const long col = n0 + 32 * wn + i;
     if (col < N) {
+        if (gridDim.z > 1) {
+            float* const slab = slabs + (size_t)blockIdx.z * M * N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row < M) slab[row * N + col] = acc[r];
+            }
+            return;
+        }
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -400,14 +415,26 @@ int gemm_wide_splits(long M, long N, long K) {
     return (int)(s < 1 ? 1 : s);
 }
 
+// K splits of the 64 x 64 kernel (1 = none): tall, narrow products whose tiles do not fill the chip - about 480 workgroups,
+// at least 8 K tiles each.  Measured (tools/diag/gemm_tall_time.py, M = 4992, K = 2000, N = 100, reduce included): 50.6 us
+// unsplit, 45.8 / 36.0 / 37.7 / 37.4 / 38.7 us with 2 / 3 / 4 / 6 / 8 splits (the MFMA floor of the padded product is 16 us).
+int gemm_tall_splits(long M, long N, long K) {
+    if (M < 2048 || N > 128 || K < 1024) return 1;
+    const long tiles = gnx_cdiv(M, BM) * gnx_cdiv(N, BN), nkt = gnx_cdiv(K, BK);
+    long s = 480 / tiles;
+    if (s > nkt / 8) s = nkt / 8;
+    if (s > 8) s = 8;
+    return (int)(s < 1 ? 1 : s);
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
 // floats of workspace gnx_gemm_f32_ws wants for this shape (0: none)
 GNX_EXPORT long gnx_gemm_f32_workspace(long M, long N, long K) {
-    const int s = gemm_wide_splits(M, N, K);
-    return s > 1 ? (long)s * M * N : 0;
+    const int s = gemm_wide_splits(M, N, K), t = gemm_tall_splits(M, N, K);
+    return s > 1 ? (long)s * M * N : (s == 0 && t > 1 ? (long)t * M * N : 0);
 }
 
 static int gemm_f32_impl(const float* A, long lda, int a_kmajor, const float* B, long ldb, int b_kmajor,
@@ -460,7 +487,8 @@ static int gemm_f32_impl(const float* A, long lda, int a_kmajor, const float* B,
 #undef GNX_LAUNCHB
         return gnx_launch_status();
     }
-    dim3 grid(gnx_cdiv(M, BM), gnx_cdiv(N, BN));
+    const int tall = workspace ? gemm_tall_splits(M, N, K) : 1;
+    dim3 grid(gnx_cdiv(M, BM), gnx_cdiv(N, BN), tall);
     if (grid.y > 65535) return GNX_ERR_UNSUPPORTED;
     // buffer (vector) loads per operand: 16-B aligned rows of whole quads, 32-bit byte offsets up to one tile past the end
     const bool av = a_vec && (a_kmajor ? M % 4 == 0 : K % 4 == 0) && a_bytes < (1L << 31) && (K + 2 * BK) * lda < (1L << 29) &&
@@ -468,7 +496,7 @@ static int gemm_f32_impl(const float* A, long lda, int a_kmajor, const float* B,
     const bool bv = b_vec && (b_kmajor ? N % 4 == 0 : K % 4 == 0) && b_bytes < (1L << 31) && (K + 2 * BK) * ldb < (1L << 29) &&
                     (N + 2 * BN) * ldb < (1L << 29);
 #define GNX_LAUNCH2(AK, BKM, AV, BV) \
-    gemm_f32_kernel<AK, BKM, AV, BV><<<grid, 256, 0, stream>>>(A, lda, B, ldb, bias, C, ldc, M, N, K, accumulate)
+    gemm_f32_kernel<AK, BKM, AV, BV><<<grid, 256, 0, stream>>>(A, lda, B, ldb, bias, C, ldc, M, N, K, accumulate, workspace)
 #define GNX_LAUNCH(AK, BKM)                       \
     do {                                          \
         if (av && bv) GNX_LAUNCH2(AK, BKM, true, true);        \
@@ -482,6 +510,11 @@ static int gemm_f32_impl(const float* A, long lda, int a_kmajor, const float* B,
     else GNX_LAUNCH(true, true);
 #undef GNX_LAUNCH
 #undef GNX_LAUNCH2
+    if (tall > 1) {
+        long blocks = gnx_cdiv(M * N, 256);
+        if (blocks > 2048) blocks = 2048;
+        gemm_split_reduce_kernel<<<(unsigned)blocks, 256, 0, stream>>>(workspace, tall, M, N, bias, C, ldc, accumulate);
+    }
     return gnx_launch_status();
 }
 

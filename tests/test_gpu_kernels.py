@@ -246,10 +246,12 @@ def test_linear_count_grid_in_place(GF):
     close(wd.grad, wr.grad, rtol=2e-3)
 
 
-@pytest.mark.parametrize("kmajor,S,K,N", [(True, 4992, 2000, 500), (True, 2308, 516, 260), (False, 2500, 1000, 384)])
+@pytest.mark.parametrize("kmajor,S,K,N", [(True, 4992, 2000, 500), (True, 2308, 516, 260), (False, 2500, 1000, 384),
+                                          (True, 4992, 2000, 100), (False, 2100, 1030, 70), (True, 9984, 1024, 128)])
 def test_linear_whole_grid_split_k_form(GF, kmajor, S, K, N):
-    """The first Linear of the count MLP over a whole grid (gemm_f32.hip, 256 x 128 tiles, K split over workgroups,
-    slabs summed in a fixed order) against fp64: ragged tiles in every dimension, bias, twice the same bits."""
+    """The first Linear of the count MLP over a whole grid (gemm_f32.hip: 256 x 128 tiles for N >= 256, 64 x 64 tiles for the
+    tall, narrow composed 2000 -> 100 layer; K split over workgroups, slabs summed in a fixed order) against fp64: ragged
+    tiles in every dimension, bias, twice the same bits."""
     from gridnext_amd import _lib as L
     assert L.query('gnx_gemm_f32_workspace', S, N, K) > 0
     g = torch.Generator().manual_seed(S + K + N)
