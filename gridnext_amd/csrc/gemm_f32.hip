@@ -415,16 +415,18 @@ int gemm_wide_splits(long M, long N, long K) {
     return (int)(s < 1 ? 1 : s);
 }
 
-// K splits of the 64 x 64 kernel (1 = none): tall, narrow products whose tiles do not fill the chip - about 480 workgroups,
-// at least 8 K tiles each.  Measured (tools/diag/gemm_tall_time.py, M = 4992, K = 2000, N = 100, reduce included): 50.6 us
-// unsplit, 45.8 / 36.0 / 37.7 / 37.4 / 38.7 us with 2 / 3 / 4 / 6 / 8 splits (the MFMA floor of the padded product is 16 us).
+// K splits of the 64 x 64 kernel (1 = none) for narrow products with a long K, whose tiles do not fill the chip (the composed
+// 2000 -> 100 layer of the count MLP over a 4 992-spot grid: 156 tiles for 256 CUs).  A function of (N, K) ONLY - never of M -
+// so that a row's result does not depend on how many rows the call has (f evaluated on a subset of the spots equals the same
+// rows of the full evaluation bit for bit: tests/test_gpu_models.py); the slab workspace bounds it for absurd M.
+// Measured (tools/diag/gemm_tall_time.py, M = 4992, K = 2000, N = 100, reduce included): 50.6 us unsplit, 45.8 / 36.0 / 37.7 /
+// 37.4 / 38.7 us with 2 / 3 / 4 / 6 / 8 splits (the MFMA floor of the padded product is 16 us).
 int gemm_tall_splits(long M, long N, long K) {
-    if (M < 2048 || N > 128 || K < 1024) return 1;
-    const long tiles = gnx_cdiv(M, BM) * gnx_cdiv(N, BN), nkt = gnx_cdiv(K, BK);
-    long s = 480 / tiles;
-    if (s > nkt / 8) s = nkt / 8;
-    if (s > 8) s = 8;
-    return (int)(s < 1 ? 1 : s);
+    if (N > 128 || K < 1024) return 1;
+    long s = gnx_cdiv(K, BK) / 8;                              // at least 8 K tiles per workgroup
+    if (s > 3) s = 3;
+    if (s < 1 || s * M * N > (1L << 26)) return 1;
+    return (int)s;
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

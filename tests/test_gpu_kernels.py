@@ -247,7 +247,7 @@ def test_linear_count_grid_in_place(GF):
 
 
 @pytest.mark.parametrize("kmajor,S,K,N", [(True, 4992, 2000, 500), (True, 2308, 516, 260), (False, 2500, 1000, 384),
-                                          (True, 4992, 2000, 100), (False, 2100, 1030, 70), (True, 9984, 1024, 128)])
+                                          (True, 4992, 2000, 100), (False, 2100, 1030, 70), (True, 2496, 1024, 128)])
 def test_linear_whole_grid_split_k_form(GF, kmajor, S, K, N):
     """The first Linear of the count MLP over a whole grid (gemm_f32.hip: 256 x 128 tiles for N >= 256, 64 x 64 tiles for the
     tall, narrow composed 2000 -> 100 layer; K split over workgroups, slabs summed in a fixed order) against fp64: ragged
