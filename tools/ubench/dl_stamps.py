@@ -15,13 +15,14 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SRC = os.path.join(ROOT, 'gridnext_amd', 'csrc', 'dense_layer_f16.hip')
+SRC_KS = os.path.join(ROOT, 'gridnext_amd', 'csrc', 'dense_layer_f16_ks.hip')    # (the launcher dense_layer_f16.hip links to)
 OUT = os.path.join(HERE, 'build', 'libdl_stamp.so')
 
 
 def main():
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DGNX_DL_STAMP',
-                    '-I', os.path.dirname(SRC), SRC, '-o', OUT], check=True)
+                    '-I', os.path.dirname(SRC), SRC, SRC_KS, '-o', OUT], check=True)
     lib = ctypes.CDLL(OUT)
     P, I, Lg = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
     lib.gnx_dense_layer_f16_pack.argtypes = [P, P, P, P, I, P]

@@ -5,7 +5,7 @@ step instead of 3900) are loaded by name from tools/ubench/build/ and, per shape
 wave 0 and wave 4 spent in each stamped segment are printed.
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DGNX_DL_STAMP -DGNX_DL_NOABL -I gridnext_amd/csrc \
-          gridnext_amd/csrc/dense_layer_f16.hip -o tools/ubench/build/libdl_noabl.so
+          gridnext_amd/csrc/dense_layer_f16.hip gridnext_amd/csrc/dense_layer_f16_ks.hip -o tools/ubench/build/libdl_noabl.so
     python tools/ubench/dl_timers.py libdl_noabl.so
 """
 import ctypes, sys, os, torch
