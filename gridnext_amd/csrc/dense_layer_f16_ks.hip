@@ -14,12 +14,15 @@
 //    the 32-lane halves: two VALU moves per register, zero shifted in = the image border).  At S = 64 a row's even and odd
 //    pixels are separate tiles, so half of the shifted fragments are the other tile unshifted.
 //  * the four k-slices' partial sums of an output tile are added through LDS (fp32, fixed order wave 0..3: deterministic).
-// Two workgroups of four waves per CU (two independent chains per SIMD: one's VALU / LDS / barrier phases run under the
-// other's MFMAs).  Every wave stages its quarter of the input itself: global -> registers -> norm1 + relu1 -> LDS slot, one
-// pair of 32-channel stages per workgroup barrier; all loads are inline asm with hand-counted vmcnt (four loads per stage
-// and wave, always in the order x(pair p + 2), W1(pair p + 1): every wait is vmcnt(6)).
+// Two workgroups of four waves per CU.  Every wave stages its quarter of the input itself: global -> registers -> norm1 + relu1
+// -> LDS slot, one pair of 32-channel stages per workgroup barrier; conv1 runs as two passes of 64 pixels per 128-pixel step
+// (32 accumulator registers instead of 64: the register file is what bounds this form); all loads are inline asm with
+// hand-counted vmcnt, per pair and wave in the order W1(pair p + 1) x 4, x(pair p + 3) x 2 (see pair_iter).
 // Out rows complete one step late (they need the next image row): the fragments of the previous step's last two rows stay
 // in registers; an image's last row is finished during the next image's first step (or a final flush).
+// STATUS: correct (tests/test_gpu_kernels.py::test_dense_layer_f16_fused[form 1]) and NOT the default - equal or slower than
+// dense_layer_f16.hip on config 5's shapes (DESIGN.md Appendix A has the stamps and the reasons); selected by
+// gnx_dense_layer_f16_set_form(1).
 #include "fwd_common.h"
 
 namespace {
