@@ -895,8 +895,8 @@ def config5_trained_series(args, device, rank, world, steps=3, warmup=1, P=256, 
 # ------------------------------------------------------------------------------------------ configs 1-3
 def other_configs(device):
     """BASELINE configs 1-3 driven through train_spotwise / train_gridwise on synthetic, device-resident data
-    (tools/bench_configs.py): C1 count-MLP spot loop (batch 128), C2 DenseNet-121 @128 px spot loop (batch 32, train-mode
-    BatchNorm, forward + backward + Adam), C3 count f (frozen) + hex g grid loop (batch 1).  Loop output is swallowed."""
+    (tools/bench_configs.py): C1 count-MLP spot loop (batch 128), C2 DenseNet-121 @128 px spot loop (batch 32 as in the tutorial, and 256;
+    train-mode BatchNorm, forward + backward + Adam), C3 count f (frozen) + hex g grid loop (batch 1).  Loop output is swallowed."""
     import contextlib
     import io
     import torch
@@ -906,7 +906,10 @@ def other_configs(device):
     with contextlib.redirect_stdout(io.StringIO()):
         for key, fn in (("config1_count_mlp_spotwise_b128", lambda: bc.c1(3)),
                         ("config3_count_f_hex_g_gridwise_b1", lambda: bc.c3(40)),
-                        ("config2_densenet121_spotwise_b32", lambda: bc.c2(2048, 1))):
+                        ("config2_densenet121_spotwise_b32", lambda: bc.c2(2048, 1)),
+                        # (the tutorial's batch of 32 is launch-bound - ~1 040 kernels of 7-25 us per step; the same loop at
+                        #  batch 256 says what the kernels do when a step has work for the chip)
+                        ("config2_densenet121_spotwise_b256", lambda: bc.c2(4096, 1, 256))):
             r = fn()
             out[key] = {"value": r["spots_per_s"], "unit": "spots/s", "seconds": r["seconds"], "workload": r["config"]}
             torch.cuda.empty_cache()
