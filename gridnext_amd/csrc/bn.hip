@@ -1057,19 +1057,20 @@ GNX_EXPORT long gnx_bn_workspace(long M, int C) {
 
 // Training-mode statistics of x[M][C]: fills scale/shift (folded affine), save_mean/save_invstd and
 // applies torch's running-stat update (momentum; unbiased running_var; num_batches_tracked += 1).
-GNX_EXPORT int gnx_bn_train_stats(const float* x, long ld, long M, int C, const float* gamma, const float* beta,
-                                  float* running_mean, float* running_var, long long* num_batches_tracked,
-                                  float momentum, float eps, float* scale, float* shift, float* save_mean,
-                                  float* save_invstd, float* workspace, hipStream_t stream) {
+static int bn_train_stats_impl(const float* x, long ld, long M, int C, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, long long* num_batches_tracked,
+                               float momentum, float eps, float* scale, float* shift, float* save_mean,
+                               float* save_invstd, float* workspace, unsigned* sync, hipStream_t stream) {
     if (!x || !scale || !shift || !save_mean || !save_invstd || !workspace || M <= 0 || C <= 0 || ld < C)
         return GNX_ERR_BAD_ARG;
     if (bn_multi_ok(M, C) && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         unsigned* counters;
         float* part;
-        bn_multi_sync(workspace, M, C, stream, nullptr, &counters, &part);
+        bn_multi_sync(workspace, M, C, stream, sync, &counters, &part);
         bn_train_stats_multi_kernel<<<gnx_cdiv(C, 16) * BN_R, 1024, 0, stream>>>(x, ld, M, C, gamma, beta, running_mean, running_var,
                                                                                 num_batches_tracked, momentum, eps, scale, shift,
-                                                                                save_mean, save_invstd, nullptr, 0, 0, counters, part, 0);
+                                                                                save_mean, save_invstd, nullptr, 0, 0, counters, part,
+                                                                                sync ? 1 : 0);
         return gnx_launch_status();
     }
     if (M <= BN_SMALL_M && C % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
@@ -1099,6 +1100,23 @@ GNX_EXPORT int gnx_bn_train_stats(const float* x, long ld, long M, int C, const 
                                                                  momentum, eps, scale, shift, save_mean,
                                                                  save_invstd);
     return gnx_launch_status();
+}
+
+GNX_EXPORT int gnx_bn_train_stats(const float* x, long ld, long M, int C, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, long long* num_batches_tracked,
+                                  float momentum, float eps, float* scale, float* shift, float* save_mean,
+                                  float* save_invstd, float* workspace, hipStream_t stream) {
+    return bn_train_stats_impl(x, ld, M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift,
+                               save_mean, save_invstd, workspace, nullptr, stream);
+}
+// The same with the layer's PERSISTENT sync words (see gnx_bn_train_stats_apply_sync): no memset node in front of the
+// several-workgroups-per-channel-block form.  sync == NULL, or any other shape: exactly gnx_bn_train_stats.
+GNX_EXPORT int gnx_bn_train_stats_sync(const float* x, long ld, long M, int C, const float* gamma, const float* beta,
+                                       float* running_mean, float* running_var, long long* num_batches_tracked,
+                                       float momentum, float eps, float* scale, float* shift, float* save_mean,
+                                       float* save_invstd, float* workspace, void* sync, hipStream_t stream) {
+    return bn_train_stats_impl(x, ld, M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift,
+                               save_mean, save_invstd, workspace, reinterpret_cast<unsigned*>(sync), stream);
 }
 
 GNX_EXPORT int gnx_scale_shift_relu(const float* x, long ldx, float* y, long ldy, long M, int C, const float* scale,

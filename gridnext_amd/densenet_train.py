@@ -20,6 +20,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as L
+from .functional import _bn_sync
 
 F32 = torch.float32
 
@@ -40,10 +41,12 @@ def _bn(model_bn, X_ptr, ld, M, training, dev, st):
     stats = torch.empty((4, cp), device=dev, dtype=F32)
     if training:
         ws = torch.empty(L.query('gnx_bn_workspace', M, C), device=dev, dtype=F32)
-        L.call('gnx_bn_train_stats', X_ptr, ld, M, C, L.ptr(model_bn.weight), L.ptr(model_bn.bias),
+        sync = _bn_sync(model_bn, torch.device(dev))           # (the layer's persistent sync words: no memset node per call)
+        L.call('gnx_bn_train_stats_sync', X_ptr, ld, M, C, L.ptr(model_bn.weight), L.ptr(model_bn.bias),
                L.ptr(model_bn.running_mean), L.ptr(model_bn.running_var),
                L.ptr(model_bn.num_batches_tracked, torch.int64), float(model_bn.momentum), float(model_bn.eps),
-               L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(ws), st)
+               L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(ws),
+               sync.data_ptr() if sync is not None else None, st)
     else:
         L.call('gnx_bn_fold_eval', C, L.ptr(model_bn.weight), L.ptr(model_bn.bias), L.ptr(model_bn.running_mean),
                L.ptr(model_bn.running_var), float(model_bn.eps), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]),
@@ -287,9 +290,10 @@ class _DenseNetFn(Function):
             dg = new_like(bn.weight) if want(bn.weight) else None
             db = new_like(bn.bias) if want(bn.bias) else None
             ws = torch.empty(L.query('gnx_bn_workspace', M, C), device=dev, dtype=F32)
-            L.call('gnx_bn_relu_bwd', dy_ptr, lddy, x_ptr, ldx, dx_ptr, lddx, M, C, L.ptr(stats[0]), L.ptr(stats[1]),
+            sync = _bn_sync(bn, torch.device(dev))
+            L.call('gnx_bn_relu_bwd_sync', dy_ptr, lddy, x_ptr, ldx, dx_ptr, lddx, M, C, L.ptr(stats[0]), L.ptr(stats[1]),
                    L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(dg), L.ptr(db), relu, 1 if training else 0, 0, dx_acc,
-                   L.ptr(ws), st)
+                   L.ptr(ws), sync.data_ptr() if sync is not None else None, st)
 
         def wgrad(w, dy_ptr, lddy, x_ptr, ldx, stats, M, Nn, K, S, taps, pool):
             if not want(w):

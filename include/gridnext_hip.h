@@ -50,6 +50,12 @@ int gnx_bn_train_stats(const float* x, long ld, long M, int C, const float* gamm
                        float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
                        float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
                        float* workspace, gnx_stream_t stream);
+/* The same with the layer's persistent sync words (gnx_bn_sync_words; see gnx_bn_train_stats_apply_sync): the form that puts
+ * several workgroups on a channel block then needs no memset node in front of it.  sync == NULL: exactly gnx_bn_train_stats. */
+int gnx_bn_train_stats_sync(const float* x, long ld, long M, int C, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                       float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
+                       float* workspace, void* sync, gnx_stream_t stream);
 /* gnx_bn_train_stats + gnx_scale_shift_relu in one call (one launch for matrices of up to 4992 rows: g's BatchNorm2d(32)
  * over one Visium grid, gridnet_models.py:134-146; the count MLP's BatchNorm1d). */
 int gnx_bn_train_stats_apply(const float* x, long ld, long M, int C, const float* gamma, const float* beta,
