@@ -108,6 +108,7 @@ SIGNATURES = {
     'gnx_bnrelu_avgpool': (_I, [_P, _L, _P, _L, _L, _I, _I, _P, _P, _P]),
     'gnx_wgrad_workspace': (_L, [_L, _I, _I, _I]),
     'gnx_wgrad_bnrelu': (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
+    'gnx_wgrad_bnrelu_batch': (_I, [_P, _I, _I, _P]),
     'gnx_transpose_weight': (_I, [_P, _P, _I, _I, _P]),
     'gnx_relayout_weights_batch': (_I, [_P, _I, _I, _P]),
     'gnx_repack_conv3x3_bwd': (_I, [_P, _P, _I, _I, _P]),

@@ -393,18 +393,19 @@ __device__ __forceinline__ float4 bufld4(__amdgpu_buffer_rsrc_t r, int voff, int
 // of one position range (one per 256-wide k block) get block ids with equal residue mod 8 and consecutive quotients: same
 // XCD, launched together, so the dY tile they all read comes from HBM once.  grid (splits * k blocks, N / 128), 256 threads.
 constexpr int W1_TILE = 32, W1_P = W1_TILE + WT_PAD;          // 36 = 4 * 9
-__global__ __launch_bounds__(256, 2) void wgrad1_t_kernel(const float* __restrict__ dY, long lddy,
-                                                          const float* __restrict__ X, long ldx,
-                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                          float* __restrict__ slabs, long M, int N, int K, int nsplit,
-                                                          int kblocks, long tiles_per_split) {
+// (bx, by): the block's coordinates in the grid of ONE layer's launch - blockIdx of wgrad1_t_kernel, or derived from the flat
+// block id of wgrad1_t_batch_kernel, which runs several layers' grids as one launch.
+__device__ __forceinline__ void wgrad1_t_body(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx,
+                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                              float* __restrict__ slabs, long M, int N, int K, int nsplit, int kblocks,
+                                              long tiles_per_split, int bx, int by) {
     __shared__ __attribute__((aligned(16))) float Yt[128 * W1_P];       // [n][position]
     __shared__ __attribute__((aligned(16))) float Xt[256 * W1_P];       // [k][position]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
     // block id -> (split, k block): id = 8 * slot + xcd, slot = group * kblocks + kb, split = 8 * group + xcd  (8 | nsplit)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = bx & 7, slot = bx >> 3;
     const int split = 8 * (slot / kblocks) + xcd, kb = slot % kblocks;
-    const int n0 = blockIdx.y * 128, kbase = kb * 256;
+    const int n0 = by * 128, kbase = kb * 256;
     const int wn = wave >> 1, wk = wave & 1;
     const bool has_act = scale != nullptr;
     const long ntiles = (M + W1_TILE - 1) / W1_TILE;
@@ -522,24 +523,54 @@ __global__ __launch_bounds__(256, 2) void wgrad1_t_kernel(const float* __restric
             }
     }
 }
+__global__ __launch_bounds__(256, 2) void wgrad1_t_kernel(const float* __restrict__ dY, long lddy,
+                                                          const float* __restrict__ X, long ldx,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ slabs, long M, int N, int K, int nsplit,
+                                                          int kblocks, long tiles_per_split) {
+    wgrad1_t_body(dY, lddy, X, ldx, scale, shift, slabs, M, N, K, nsplit, kblocks, tiles_per_split, blockIdx.x, blockIdx.y);
+}
+
+// ---- several layers' weight gradients as ONE launch (gnx_wgrad_bnrelu_batch).  At a batch of 32 patches a dense layer's
+// weight-gradient kernel is 16-64 workgroups of a few tiles each and costs its launch (14-18 us) whatever it computes; the
+// layers of a dense block are independent (each has its own dY / bottleneck, all read the same block buffer), so their grids
+// are laid end to end: entry e owns flat block ids [first_block, first_block + blocks).  The kernel body, the slab layout and
+// the fixed-order reduce are those of the single launches: the results are bit-identical.
+struct WgBatchEntry {
+    const float* dY; const float* X; const float* scale; const float* shift; float* slabs; float* dW;
+    long lddy, ldx, M, tps;
+    int N, K, ns, kblocks, first_block, accumulate;
+};
+constexpr int WG_BATCH = 24;                                   // entries per launch (2.5 KB of kernel arguments)
+struct WgBatch { WgBatchEntry e[WG_BATCH]; int n; };
+__device__ __forceinline__ int wg_batch_find(const WgBatch& b, int bid) {
+    int k = 0;
+    while (k + 1 < b.n && bid >= b.e[k + 1].first_block) ++k;  // (uniform: a scalar loop over at most 24 entries)
+    return k;
+}
+__global__ __launch_bounds__(256, 2) void wgrad1_t_batch_kernel(const WgBatch b) {
+    const int k = wg_batch_find(b, blockIdx.x);
+    const WgBatchEntry& e = b.e[k];
+    const int local = blockIdx.x - e.first_block, gx = e.ns * e.kblocks;
+    wgrad1_t_body(e.dY, e.lddy, e.X, e.ldx, e.scale, e.shift, e.slabs, e.M, e.N, e.K, e.ns, e.kblocks, e.tps, local % gx, local / gx);
+}
 
 // ---- 3x3: dW[tap][n][k], N == 32, 128 | K, maps of S x S with S in {4, 8, 16, 32};  grid (split, 1, K / 128), 256 threads
 constexpr int W9_TILE = 32, W9_PX = W9_TILE + WT_PAD;         // 36 = 4 * 9
 template <int S>
-__global__ __launch_bounds__(256, 2) void wgrad9_t_kernel(const float* __restrict__ dY, long lddy,
-                                                          const float* __restrict__ X, long ldx,
-                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                          float* __restrict__ slabs, long M, int K, long tiles_per_split) {
+__device__ __forceinline__ void wgrad9_t_body(const float* __restrict__ dY, long lddy, const float* __restrict__ X, long ldx,
+                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                              float* __restrict__ slabs, long M, int K, long tiles_per_split, int bx, int bz) {
     constexpr int NPOS = W9_TILE + 2 * S;         // dY strip: positions m0 - S .. m0 + 32 + S - 1
     constexpr int P2 = NPOS + 8 + WT_PAD;         // + 8 zero columns; 108 / 76 / 60 = 4 * odd
     constexpr int NB = NPOS / 4;                  // position blocks of the strip: 24 / 16 / 12
     __shared__ __attribute__((aligned(16))) float Xt[128 * W9_PX];       // [k][position]
     __shared__ __attribute__((aligned(16))) float Yc[3 * 32 * P2];       // [dx + 1][n][strip position]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, i = lane & 31;
-    const int kbase = blockIdx.z * 128;
+    const int kbase = bz * 128;
     const bool has_act = scale != nullptr;
     const long ntiles = M / W9_TILE;
-    const long tile0 = (long)blockIdx.x * tiles_per_split;
+    const long tile0 = (long)bx * tiles_per_split;
     const long tile1 = min(tile0 + tiles_per_split, ntiles);
 
     f32x16 acc[9];
@@ -653,13 +684,28 @@ __global__ __launch_bounds__(256, 2) void wgrad9_t_kernel(const float* __restric
     const int k = kbase + 32 * wave + i;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        float* dst = slabs + ((long)blockIdx.x * 9 + tap) * 32 * K;
+        float* dst = slabs + ((long)bx * 9 + tap) * 32 * K;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = (r & 3) + 8 * (r >> 2) + 4 * h;
             dst[(long)n * K + k] = acc[tap][r];
         }
     }
+}
+template <int S>
+__global__ __launch_bounds__(256, 2) void wgrad9_t_kernel(const float* __restrict__ dY, long lddy,
+                                                          const float* __restrict__ X, long ldx,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ slabs, long M, int K, long tiles_per_split) {
+    wgrad9_t_body<S>(dY, lddy, X, ldx, scale, shift, slabs, M, K, tiles_per_split, blockIdx.x, blockIdx.z);
+}
+// (entry e: ns splits x kblocks = K / 128 channel blocks, laid out split-fastest)
+template <int S>
+__global__ __launch_bounds__(256, 2) void wgrad9_t_batch_kernel(const WgBatch b) {
+    const int k = wg_batch_find(b, blockIdx.x);
+    const WgBatchEntry& e = b.e[k];
+    const int local = blockIdx.x - e.first_block;
+    wgrad9_t_body<S>(e.dY, e.lddy, e.X, e.ldx, e.scale, e.shift, e.slabs, e.M, e.K, e.tps, local % e.ns, local / e.ns);
 }
 
 // dW (torch layout [N][K][T]) = fixed-order sum over splits of slab[split][tap][n][k]
@@ -689,6 +735,36 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit,
     const float s = (s0 + s1) + (s2 + s3);
     float* dst = dW + ((long)n * K + k) * T + tap;
     *dst = accumulate ? *dst + s : s;
+}
+
+// the same reduction for the entries of a batch: blockIdx.y = entry, grid-stride over its T * N * K elements
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const WgBatch b, int T) {
+    const WgBatchEntry& e = b.e[blockIdx.y];
+    const long total = (long)T * e.N * e.K;
+    const int nsplit = e.ns, K = e.K, N = e.N;
+    const float* __restrict__ slabs = e.slabs;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int k = (int)(idx % K), n = (int)((idx / K) % N), tap = (int)(idx / ((long)K * N));
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;         // (the chains and their order: wgrad_reduce_kernel's)
+        int sp = 0;
+        for (; sp + 15 < nsplit; sp += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = slabs[(long)(sp + u) * total + idx];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+        }
+        for (; sp + 3 < nsplit; sp += 4) {
+            s0 += slabs[(long)sp * total + idx];
+            s1 += slabs[(long)(sp + 1) * total + idx];
+            s2 += slabs[(long)(sp + 2) * total + idx];
+            s3 += slabs[(long)(sp + 3) * total + idx];
+        }
+        for (; sp < nsplit; ++sp) s0 += slabs[(long)sp * total + idx];
+        const float s = (s0 + s1) + (s2 + s3);
+        float* dst = e.dW + ((long)n * K + k) * T + tap;
+        *dst = e.accumulate ? *dst + s : s;
+    }
 }
 
 __global__ void transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int K) {
@@ -1198,6 +1274,79 @@ GNX_EXPORT int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long
 #undef GNX_WG
     const long total = (long)taps * N * K;
     wgrad_reduce_kernel<<<gnx_cdiv(total, 256), 256, 0, stream>>>(workspace, nsplit, taps, N, K, dW, accumulate);
+    return gnx_launch_status();
+}
+
+// n independent weight gradients of ONE kind (taps = 1: plain 1x1; taps = 9: 3x3 on S x S maps, the same S for all) as one
+// launch per 24 of them plus one batched reduce - exactly gnx_wgrad_bnrelu(item, taps, pool = 0) for every item, bit for
+// bit, for the shapes its transposed-image kernels take (the dense layers' own); anything else: GNX_ERR_UNSUPPORTED and
+// nothing is launched (make the single calls).  `items`: host array of GnxWgradItem (include/gridnext_hip.h).
+struct GnxWgradItem {
+    const float* dY; long lddy; const float* X; long ldx; const float* scale; const float* shift; float* dW; float* workspace;
+    long M; int N, K, S, accumulate;
+};
+GNX_EXPORT int gnx_wgrad_bnrelu_batch(const void* items_v, int n, int taps, hipStream_t stream) {
+    const GnxWgradItem* it = static_cast<const GnxWgradItem*>(items_v);
+    if (!it || n < 0 || (taps != 1 && taps != 9)) return GNX_ERR_BAD_ARG;
+    if (n == 0) return GNX_OK;
+    // every item must be one the transposed-image kernels take, exactly as gnx_wgrad_bnrelu decides
+    for (int q = 0; q < n; ++q) {
+        const GnxWgradItem& a = it[q];
+        if (!a.dY || !a.X || !a.dW || !a.workspace || a.M <= 0 || a.N <= 0 || a.K <= 0 || a.lddy < a.N || a.ldx < a.K ||
+            (!a.scale) != (!a.shift))
+            return GNX_ERR_BAD_ARG;
+        const bool aligned = al16b(a.X) && al16b(a.dY) && a.ldx % 4 == 0 && a.lddy % 4 == 0 &&
+                             (!a.scale || (al16b(a.scale) && al16b(a.shift)));
+        if (!aligned) return GNX_ERR_UNSUPPORTED;
+        if (taps == 1) {
+            if (wgrad1_t_splits(a.M, a.N, a.K) <= 0 || 64L * (a.lddy > a.ldx ? a.lddy : a.ldx) >= (1L << 28)) return GNX_ERR_UNSUPPORTED;
+        } else {
+            if (a.S != it[0].S || a.N != 32 || a.K % 128 != 0 || !(a.S == 4 || a.S == 8 || a.S == 16 || a.S == 32) ||
+                a.M % W9_TILE != 0 || a.M % ((long)a.S * a.S) != 0)
+                return GNX_ERR_UNSUPPORTED;
+        }
+    }
+    for (int q0 = 0; q0 < n; q0 += WG_BATCH) {
+        WgBatch b;
+        b.n = n - q0 < WG_BATCH ? n - q0 : WG_BATCH;
+        int blocks = 0;
+        long max_total = 0;
+        for (int q = 0; q < b.n; ++q) {
+            const GnxWgradItem& a = it[q0 + q];
+            WgBatchEntry& e = b.e[q];
+            e.dY = a.dY; e.X = a.X; e.scale = a.scale; e.shift = a.shift; e.slabs = a.workspace; e.dW = a.dW;
+            e.lddy = a.lddy; e.ldx = a.ldx; e.M = a.M; e.N = a.N; e.K = a.K; e.accumulate = a.accumulate;
+            e.first_block = blocks;
+            if (taps == 1) {
+                e.ns = wgrad1_t_splits(a.M, a.N, a.K);
+                e.kblocks = gnx_cdiv(a.K, 256);
+                const long nt1 = (a.M + W1_TILE - 1) / W1_TILE;
+                e.tps = (nt1 + e.ns - 1) / e.ns;
+                blocks += e.ns * e.kblocks * (a.N / 128);
+            } else {
+                e.ns = wgrad_splits(a.M, a.N, a.K);
+                e.kblocks = a.K / 128;
+                const long nt9 = a.M / W9_TILE;
+                e.tps = (nt9 + e.ns - 1) / e.ns;
+                blocks += e.ns * e.kblocks;
+            }
+            const long total = (long)taps * a.N * a.K;
+            if (total > max_total) max_total = total;
+        }
+        if (taps == 1) {
+            wgrad1_t_batch_kernel<<<blocks, 256, 0, stream>>>(b);
+        } else {
+            switch (it[0].S) {
+                case 32: wgrad9_t_batch_kernel<32><<<blocks, 256, 0, stream>>>(b); break;
+                case 16: wgrad9_t_batch_kernel<16><<<blocks, 256, 0, stream>>>(b); break;
+                case 8: wgrad9_t_batch_kernel<8><<<blocks, 256, 0, stream>>>(b); break;
+                default: wgrad9_t_batch_kernel<4><<<blocks, 256, 0, stream>>>(b); break;
+            }
+        }
+        int gx = gnx_cdiv(max_total, 256);
+        if (gx > 64) gx = 64;
+        wgrad_reduce_batch_kernel<<<dim3(gx, b.n), 256, 0, stream>>>(b, taps);
+    }
     return gnx_launch_status();
 }
 

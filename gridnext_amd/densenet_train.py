@@ -13,6 +13,7 @@ activated under running statistics); every other BN+ReLU is re-evaluated inside 
 and backward.  One autograd node covers the whole network; gradients are returned for every parameter that requires one.
 `DenseNet.mfma = 'f16'` under running statistics takes the fp16 tape and the fp16-MFMA backward of densenet_train_f16.
 """
+import ctypes
 import os
 import struct
 
@@ -21,6 +22,13 @@ from torch.autograd import Function
 
 from . import _lib as L
 from .functional import _bn_sync
+
+
+class _WgradItem(ctypes.Structure):
+    """gnx_wgrad_item of include/gridnext_hip.h: one weight gradient of a batch (gnx_wgrad_bnrelu_batch)."""
+    _fields_ = [('dY', ctypes.c_void_p), ('lddy', ctypes.c_long), ('X', ctypes.c_void_p), ('ldx', ctypes.c_long),
+                ('scale', ctypes.c_void_p), ('shift', ctypes.c_void_p), ('dW', ctypes.c_void_p), ('workspace', ctypes.c_void_p),
+                ('M', ctypes.c_long), ('N', ctypes.c_int), ('K', ctypes.c_int), ('S', ctypes.c_int), ('accumulate', ctypes.c_int)]
 
 F32 = torch.float32
 
@@ -321,6 +329,40 @@ class _DenseNetFn(Function):
         cur = torch.cuda.current_stream(dev)
         deferred, held, side_done = [], [], []
 
+        def wgrad_batch(calls):
+            """The deferred weight gradients of one dense block.  Calls that are plain (w, dy_ptr, ...) argument tuples of one kind
+            go out as ONE launch per 24 layers plus one batched reduce (gnx_wgrad_bnrelu_batch: the same kernel bodies, slab
+            layout and reduce order - bit-identical to the single calls); whatever that entry point does not take, and the
+            callables, are made one by one."""
+            for taps in (9, 1):
+                items = [c for c in calls if isinstance(c, tuple) and c[10] == taps and c[11] == 0 and want(c[0])]
+                if taps == 1:                                       # (K <= 128 runs another kernel: those go out singly)
+                    items = [c for c in items if c[8] > 128 and c[8] % 4 == 0 and c[7] % 128 == 0]
+                if len(items) < 2:
+                    continue
+                arr = (_WgradItem * len(items))()
+                keep = []
+                for a, (w, dy_ptr, lddy, x_ptr, ldx, stats, M_, Nn, K_, S_, _t, _p) in zip(arr, items):
+                    dw = torch.empty_like(w, memory_format=torch.contiguous_format)
+                    ws = torch.empty(L.query('gnx_wgrad_workspace', M_, Nn, K_, taps), device=dev, dtype=F32)
+                    keep.append((dw, ws))
+                    a.dY, a.lddy, a.X, a.ldx = dy_ptr, lddy, x_ptr, ldx
+                    a.scale, a.shift = (L.ptr(stats[0]), L.ptr(stats[1])) if stats is not None else (None, None)
+                    a.dW, a.workspace, a.M, a.N, a.K, a.S, a.accumulate = L.ptr(dw), L.ptr(ws), M_, Nn, K_, S_, 0
+                rc = L.query('gnx_wgrad_bnrelu_batch', ctypes.addressof(arr), len(items), taps, L.stream())
+                if rc == 0:
+                    for (w, *_), (dw, _ws) in zip(items, keep):
+                        grads[w] = dw
+                    done_ids = {id(c) for c in items}
+                    calls = [c for c in calls if id(c) not in done_ids]
+                elif rc != L.ERR_UNSUPPORTED:
+                    raise RuntimeError("gnx_wgrad_bnrelu_batch failed (%d)" % rc)
+            for c in calls:
+                if isinstance(c, tuple):
+                    wgrad(*c)
+                else:
+                    c()
+
         def flush_deferred():
             if not deferred:
                 return
@@ -328,8 +370,7 @@ class _DenseNetFn(Function):
             ev.record(cur)
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                for fn in deferred:
-                    fn()
+                wgrad_batch(list(deferred))
             deferred.clear()
             done = torch.cuda.Event()
             done.record(side)
@@ -405,12 +446,11 @@ class _DenseNetFn(Function):
                     held.append((bott, s1, s2, tB, buf, dbuf))
                 # conv2: weight gradient (no prologue when the bottleneck was stored activated), then data gradient
                 # (adjoint conv with flipped taps)
-                w2_call = (lambda layer=layer, dy2=dy2, bott=bott, s2=s2, activated=activated, cin=cin:
-                           wgrad(layer.conv2.weight, dy2, c_total, L.ptr(bott), mid, None if activated else s2, M, g, mid, s, 9, 0))
+                w2_args = (layer.conv2.weight, dy2, c_total, L.ptr(bott), mid, None if activated else s2, M, g, mid, s, 9, 0)
                 if side is not None:
-                    deferred.append(w2_call)
+                    deferred.append(w2_args)
                 else:
-                    w2_call()
+                    wgrad(*w2_args)
                 wb = w2b[layer.conv2.weight]
                 # conv2's data gradient and norm2 -> relu2's adjoint: ONE kernel where the bottleneck was stored activated
                 # (eval statistics) and the shape is the LDS-DMA kernel's; otherwise the product, then the adjoint pass
@@ -437,8 +477,7 @@ class _DenseNetFn(Function):
                            relu=2 if activated else 1)
                     model._probe_mark('bn2_bwd', t0, 0, 4 * M * 3 * mid)
                 # conv1
-                w1_call = (lambda layer=layer, tB=tB, s1=s1, cin=cin:
-                           wgrad(layer.conv1.weight, L.ptr(tB), mid, L.ptr(buf), c_total, s1, M, mid, cin, s, 1, 0))
+                w1_args = (layer.conv1.weight, L.ptr(tB), mid, L.ptr(buf), c_total, s1, M, mid, cin, s, 1, 0)
                 w1t = w1ts[layer.conv1.weight]
                 # Optional (`model.fused_conv1_backward = True`): data gradient + norm1/relu1 adjoint into the block gradient AND
                 # the weight gradient from the same staged tiles, ONE pass over dB, X and G (gnx_conv1x1_dgrad_wgrad_bnrelu_bwd).
@@ -465,9 +504,9 @@ class _DenseNetFn(Function):
                         model._probe_mark('dgrad_wgrad1x1_bn1', t0, 4 * M * cin * mid, 4 * M * (mid + 3 * cin))
                 if not done_w1:
                     if side is not None:
-                        deferred.append(w1_call)
+                        deferred.append(w1_args)
                     else:
-                        w1_call()
+                        wgrad(*w1_args)
                 # conv1's data gradient + norm1/relu1 backward, accumulated into the block-buffer gradient: one kernel where
                 # the statistics are the running ones and the tiles are whole (3 passes over [M][cin] instead of 5)
                 if not done_w1 and not training:

@@ -332,6 +332,16 @@ long gnx_wgrad_workspace(long M, int N, int K, int taps); /* floats */
 int gnx_wgrad_bnrelu(const float* dY, long lddy, const float* X, long ldx, const float* scale, const float* shift,
                      float* dW, float* workspace, long M, int N, int K, int S, int taps, int pool, int accumulate,
                      gnx_stream_t stream);
+/* n independent weight gradients of ONE kind as one launch per 24 items plus one batched reduce: exactly
+ * gnx_wgrad_bnrelu(item..., taps, pool = 0) for every item, bit for bit (same kernel bodies, slab layout and fixed-order
+ * reduce) - the dense layers of a block at a batch of 32 patches are 16-64 workgroups each and cost their launch whatever they
+ * compute (densenet.py:35-44 backwards, training.py:45-71).  taps = 9: the same S for all items.  Shapes the transposed-image
+ * kernels do not take: GNX_ERR_UNSUPPORTED, nothing launched (make the single calls).  `items`: HOST array. */
+typedef struct {
+    const float* dY; long lddy; const float* X; long ldx; const float* scale; const float* shift; float* dW; float* workspace;
+    long M; int N, K, S, accumulate;
+} gnx_wgrad_item;
+int gnx_wgrad_bnrelu_batch(const void* items, int n, int taps, gnx_stream_t stream);
 int gnx_transpose_weight(const float* w, float* wt, int N, int K, gnx_stream_t stream);
 /* Every weight re-layout of one kind for a whole network in one launch (a training step re-lays all conv weights out after
  * each optimizer step: 3 x 58 launches for DenseNet-121).  `table`: n entries {const float* src; float* dst; int N; int K;}
