@@ -19,6 +19,7 @@ SIGNATURES = {
     'gnx_hexconv_bwd_data': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'gnx_hexconv_bwd_weight_workspace': (_L, [_I, _I, _I, _I, _I]),
     'gnx_hexconv_bwd_weight': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'gnx_hexconv_bwd_weight_batch': (_I, [_P, _I, _P]),
     'gnx_bn_workspace': (_L, [_L, _I]),
     'gnx_bn_train_stats': (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
     'gnx_bn_train_stats_sync': (_I, [_P, _L, _L, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),

@@ -224,12 +224,13 @@ __global__ __launch_bounds__(256) void hexconv_mfma_kernel(
 // x[neighbour_t(position)][ch = c], both 128-B coalesced rows.  (The first form staged 64 x 7 neighbour rows element by
 // element, a division and a neighbour computation per float: 35 us per launch.)
 constexpr int HW2_POS = 32;
-__global__ __launch_bounds__(256) void hexconv_bwd_weight2_kernel(
+// (bx: the block's index in ONE layer's grid - blockIdx.x, or derived from the flat block id of the batched launch)
+__device__ __forceinline__ void hexconv_bwd_weight2_body(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
-    HexGeom g, int I, int O, int IF, int OF, int i0, int o0) {
+    const HexGeom& g, int I, int O, int IF, int OF, int i0, int o0, int bx) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, h = lane >> 5, c = lane & 31;
     const int npos = g.B * g.H * g.W;
-    const int base = blockIdx.x * HW2_POS;
+    const int base = bx * HW2_POS;
     const int ta = wave, tb = wave + 4;                         // tb == 7: this wave has one tap only
     f32x16 acc0, acc1;
 #pragma unroll
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void hexconv_bwd_weight2_kernel(
         if (tb < 7) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
     }
     const int nout = 7 * O * I + O;
-    float* dst = partial + (size_t)blockIdx.x * nout;
+    float* dst = partial + (size_t)bx * nout;
     if (c < I) {                                               // D[row = o][col = ch = c]
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -272,13 +273,36 @@ __global__ __launch_bounds__(256) void hexconv_bwd_weight2_kernel(
         if (h == 0 && c < O) dst[7 * O * I + c] = bsum;
     }
 }
+__global__ __launch_bounds__(256) void hexconv_bwd_weight2_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+    HexGeom g, int I, int O, int IF, int OF, int i0, int o0) {
+    hexconv_bwd_weight2_body(x, dy, partial, g, I, O, IF, OF, i0, o0, blockIdx.x);
+}
+
+// ---- the weight gradients of SEVERAL hex layers as one launch (gnx_hexconv_bwd_weight_batch): the five layers of the
+// corrector g are independent once their output gradients exist, 156 workgroups of 32 positions each, and cost a launch
+// (12 us + 8 us of reduce) apiece - a quarter of a count-only training step.  Their grids are laid end to end (entry e owns
+// flat block ids [first_block, first_block + nblk)); kernel body, slabs and the fixed-order reduce are the single launches'.
+struct HexWEntry {
+    const float* x; const float* dy; float* partial; float* dk0; float* dk1; float* dbias;
+    HexGeom g;
+    int I, O, nblk, first_block, accumulate;
+};
+constexpr int HEXW_BATCH = 8;
+struct HexWBatch { HexWEntry e[HEXW_BATCH]; int n; };
+__global__ __launch_bounds__(256) void hexconv_bwd_weight2_batch_kernel(const HexWBatch b) {
+    int k = 0;
+    while (k + 1 < b.n && (int)blockIdx.x >= b.e[k + 1].first_block) ++k;      // (uniform: at most 8 entries)
+    const HexWEntry& e = b.e[k];
+    hexconv_bwd_weight2_body(e.x, e.dy, e.partial, e.g, e.I, e.O, e.I, e.O, 0, 0, blockIdx.x - e.first_block);
+}
 
 // fixed-order sum of the partial slabs, scattered into hexagdly's parameter layouts (accumulating or not)
-__global__ void hexconv_reduce_weight_kernel(const float* __restrict__ partial, int nblk, int I, int O,
-                                             float* __restrict__ dk0, float* __restrict__ dk1,
-                                             float* __restrict__ dbias, int accumulate, int IF, int i0, int o0) {
+__device__ __forceinline__ void hexconv_reduce_weight_body(const float* __restrict__ partial, int nblk, int I, int O,
+                                                           float* __restrict__ dk0, float* __restrict__ dk1,
+                                                           float* __restrict__ dbias, int accumulate, int IF, int i0, int o0,
+                                                           int out) {
     const int nout = 7 * O * I + O;
-    const int out = blockIdx.x * blockDim.x + threadIdx.x;
     if (out >= nout) return;
     // slabs added in index order, their loads issued 16 at a time (a plain loop over ~1000 slabs is one memory round trip
     // per term: 74 us for 29 MB)
@@ -302,6 +326,16 @@ __global__ void hexconv_reduce_weight_kernel(const float* __restrict__ partial, 
         dst = dbias + o0 + (out - 7 * O * I);
     }
     *dst = accumulate ? *dst + s : s;
+}
+__global__ void hexconv_reduce_weight_kernel(const float* __restrict__ partial, int nblk, int I, int O,
+                                             float* __restrict__ dk0, float* __restrict__ dk1,
+                                             float* __restrict__ dbias, int accumulate, int IF, int i0, int o0) {
+    hexconv_reduce_weight_body(partial, nblk, I, O, dk0, dk1, dbias, accumulate, IF, i0, o0, blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void hexconv_reduce_weight_batch_kernel(const HexWBatch b) {        // grid (blocks of 64 outputs, entries)
+    const HexWEntry& e = b.e[blockIdx.y];
+    hexconv_reduce_weight_body(e.partial, e.nblk, e.I, e.O, e.dk0, e.dk1, e.dbias, e.accumulate, e.I, 0, 0,
+                               blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 int pow2_at_least(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -390,5 +424,41 @@ GNX_EXPORT int gnx_hexconv_bwd_weight(const float* x, const float* dy, float* dk
             hexconv_reduce_weight_kernel<<<gnx_cdiv(nout, 64), 64, 0, stream>>>(workspace, nblk, ic, oc, dkernel0,
                                                                                 dkernel1, dbias, accumulate, I, i0, o0);
         }
+    return gnx_launch_status();
+}
+
+// n hex layers' weight gradients as ONE launch plus one batched reduce: exactly gnx_hexconv_bwd_weight for every item, bit for
+// bit (same kernel body, slab layout and reduce order).  Layers wider than 32 channels on either side (which the single entry
+// point cuts into chunk pairs) or more than 8 items: GNX_ERR_UNSUPPORTED, nothing launched.  `items`: HOST array of
+// gnx_hexconv_wgrad_item (include/gridnext_hip.h); each item's workspace: gnx_hexconv_bwd_weight_workspace floats.
+struct GnxHexWgradItem {
+    const float* x; const float* dy; float* dkernel0; float* dkernel1; float* dbias; float* workspace;
+    int B, H, W, I, O, mode, accumulate, pad;
+};
+GNX_EXPORT int gnx_hexconv_bwd_weight_batch(const void* items_v, int n, hipStream_t stream) {
+    const GnxHexWgradItem* it = static_cast<const GnxHexWgradItem*>(items_v);
+    if (!it || n < 0) return GNX_ERR_BAD_ARG;
+    if (n == 0) return GNX_OK;
+    if (n > HEXW_BATCH) return GNX_ERR_UNSUPPORTED;
+    HexWBatch b;
+    b.n = n;
+    int blocks = 0, max_nout = 0;
+    for (int q = 0; q < n; ++q) {
+        const GnxHexWgradItem& a = it[q];
+        if (!a.x || !a.dy || !a.dkernel0 || !a.dkernel1 || !a.workspace || a.I <= 0 || a.O <= 0 || a.H <= 0 || a.W <= 0 || a.B < 0)
+            return GNX_ERR_BAD_ARG;
+        if (a.I > HEX_WCHUNK || a.O > HEX_WCHUNK) return GNX_ERR_UNSUPPORTED;
+        const long npos = (long)a.B * a.H * a.W;
+        if (npos <= 0 || npos >= (1L << 30)) return GNX_ERR_UNSUPPORTED;
+        HexWEntry& e = b.e[q];
+        e.x = a.x; e.dy = a.dy; e.partial = a.workspace; e.dk0 = a.dkernel0; e.dk1 = a.dkernel1; e.dbias = a.dbias;
+        e.g = HexGeom{a.B, a.H, a.W, a.mode};
+        e.I = a.I; e.O = a.O; e.nblk = gnx_cdiv(npos, HW2_POS); e.first_block = blocks; e.accumulate = a.accumulate;
+        blocks += e.nblk;
+        const int nout = 7 * a.O * a.I + a.O;
+        if (nout > max_nout) max_nout = nout;
+    }
+    hexconv_bwd_weight2_batch_kernel<<<blocks, 256, 0, stream>>>(b);
+    hexconv_reduce_weight_batch_kernel<<<dim3(gnx_cdiv(max_nout, 64), n), 64, 0, stream>>>(b);
     return gnx_launch_status();
 }

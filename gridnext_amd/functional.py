@@ -4,6 +4,8 @@ torch is plumbing here: it owns device memory (caching allocator), streams and t
 every arithmetic step below is a hand-written gfx950 kernel.  All matrices are channels-last:
 a spot (grid position) is a row, its features are contiguous.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -34,6 +36,7 @@ class _HexConv(Function):
                L.stream())
         ctx.save_for_backward(x, k0, k1)
         ctx.mode, ctx.has_bias = mode, bias is not None
+        ctx.leaves = (kernel0, kernel1, bias)                  # (the parameters themselves: see _hex_flush)
         return y
 
     @staticmethod
@@ -50,10 +53,77 @@ class _HexConv(Function):
         if any(ctx.needs_input_grad[1:4]):
             dk0, dk1 = torch.empty_like(k0), torch.empty_like(k1)
             db = torch.empty(O, device=x.device, dtype=F32) if ctx.has_bias else None
-            ws = torch.empty(L.query('gnx_hexconv_bwd_weight_workspace', B, H, W, I, O), device=x.device, dtype=F32)
-            L.call('gnx_hexconv_bwd_weight', L.ptr(x), L.ptr(dy), L.ptr(dk0), L.ptr(dk1), L.ptr(db), L.ptr(ws),
-                   B, H, W, I, O, ctx.mode, 0, L.stream())
+            item = (x, dy, dk0, dk1, db, B, H, W, I, O, ctx.mode, ctx.leaves)
+            # Inside a step capture (graphs.py: every parameter's .grad is None there, so autograd only STORES what is returned
+            # here - as the tensor itself or as a copy of it, no arithmetic) the weight gradients of the backward's hex layers
+            # are filled by ONE batched launch at the end of the backward instead of a launch + reduce per layer.  Only for
+            # leaf parameters met once in the backward (a weight used twice would have its two tensors ADDED right away).
+            leaves = [t for t in ctx.leaves if t is not None]
+            if torch.cuda.is_current_stream_capturing() and I <= 32 and O <= 32 and len(_HEX_DEFERRED) < 8 and \
+                    all(t.is_leaf and t.grad is None for t in leaves) and \
+                    all(t is not u for it in _HEX_DEFERRED for u in it[-1] for t in leaves):
+                torch.autograd.Variable._execution_engine.queue_callback(_hex_flush)   # (the first one flushes, the rest find nothing)
+                # (the list keeps NO reference to the returned tensors: autograd then keeps them as .grad instead of copying them)
+                _HEX_DEFERRED.append((x, dy, None, None, None, B, H, W, I, O, ctx.mode, ctx.leaves))
+            else:
+                _hex_wgrad_now(item)
         return dx, dk0, dk1, db, None
+
+
+class _HexWgradItem(ctypes.Structure):
+    """gnx_hexconv_wgrad_item of include/gridnext_hip.h."""
+    _fields_ = [('x', ctypes.c_void_p), ('dy', ctypes.c_void_p), ('dkernel0', ctypes.c_void_p), ('dkernel1', ctypes.c_void_p),
+                ('dbias', ctypes.c_void_p), ('workspace', ctypes.c_void_p), ('B', ctypes.c_int), ('H', ctypes.c_int),
+                ('W', ctypes.c_int), ('I', ctypes.c_int), ('O', ctypes.c_int), ('mode', ctypes.c_int),
+                ('accumulate', ctypes.c_int), ('pad', ctypes.c_int)]
+
+
+_HEX_DEFERRED = []          # hex weight gradients of the running (captured) backward, filled by _hex_flush at its end
+
+
+def _hex_wgrad_now(item):
+    x, dy, dk0, dk1, db, B, H, W, I, O, mode, _leaves = item
+    ws = torch.empty(L.query('gnx_hexconv_bwd_weight_workspace', B, H, W, I, O), device=x.device, dtype=F32)
+    L.call('gnx_hexconv_bwd_weight', L.ptr(x), L.ptr(dy), L.ptr(dk0), L.ptr(dk1), L.ptr(db), L.ptr(ws), B, H, W, I, O, mode, 0,
+           L.stream())
+
+
+def _hex_flush():
+    """End of a backward pass: the deferred hex weight gradients as one launch + one batched reduce
+    (gnx_hexconv_bwd_weight_batch: bit-identical to the single calls); singly where that entry point declines."""
+    items = list(_HEX_DEFERRED)
+    _HEX_DEFERRED.clear()
+    if not items:
+        return
+    # The destinations are the parameters' .grad tensors as autograd left them: it either kept the (still unfilled) tensor the
+    # backward returned or stored a COPY of it (AccumulateGrad clones a gradient someone else still references - this list
+    # does), so the tensors in the items may no longer be the ones anybody reads.
+    fixed = []
+    for (x, dy, dk0, dk1, db, B, H, W, I, O, mode, leaves) in items:
+        dst = []
+        for leaf in leaves:
+            g = None if leaf is None else leaf.grad
+            if leaf is not None and (g is None or not g.is_contiguous() or g.shape != leaf.shape or g.dtype != F32):
+                raise RuntimeError("gridnext_amd: a deferred hex-conv weight gradient has no destination (.grad missing or of "
+                                   "another layout after the backward pass)")
+            dst.append(g)
+        fixed.append((x, dy, dst[0], dst[1], dst[2], B, H, W, I, O, mode, leaves))
+    items = fixed
+    if len(items) > 1:
+        arr = (_HexWgradItem * len(items))()
+        keep = []
+        for a, (x, dy, dk0, dk1, db, B, H, W, I, O, mode, _leaves) in zip(arr, items):
+            ws = torch.empty(L.query('gnx_hexconv_bwd_weight_workspace', B, H, W, I, O), device=x.device, dtype=F32)
+            keep.append(ws)
+            a.x, a.dy, a.dkernel0, a.dkernel1, a.dbias, a.workspace = L.ptr(x), L.ptr(dy), L.ptr(dk0), L.ptr(dk1), L.ptr(db), L.ptr(ws)
+            a.B, a.H, a.W, a.I, a.O, a.mode, a.accumulate, a.pad = B, H, W, I, O, mode, 0, 0
+        rc = L.query('gnx_hexconv_bwd_weight_batch', ctypes.addressof(arr), len(items), L.stream())
+        if rc == 0:
+            return
+        if rc != L.ERR_UNSUPPORTED:
+            raise RuntimeError("gnx_hexconv_bwd_weight_batch failed (%d)" % rc)
+    for item in items:
+        _hex_wgrad_now(item)
 
 
 def hexconv(x_nhwc, kernel0, kernel1, bias, oddr):

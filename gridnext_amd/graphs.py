@@ -181,6 +181,8 @@ class GridStepGraphs:
         self.table = {}
 
     def _drop_after_failed_capture(self):
+        from . import functional as GF
+        GF._HEX_DEFERRED.clear()                               # (weight gradients an aborted backward left unflushed)
         if self.drop_derived is not None:
             self.drop_derived()
         from .densenet import DenseNet

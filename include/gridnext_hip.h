@@ -40,6 +40,16 @@ long gnx_hexconv_bwd_weight_workspace(int B, int H, int W, int I, int O); /* flo
 int gnx_hexconv_bwd_weight(const float* x, const float* dy, float* dkernel0, float* dkernel1, float* dbias,
                            float* workspace, int B, int H, int W, int I, int O, int mode, int accumulate,
                            gnx_stream_t stream);
+/* n hex layers' weight gradients as ONE launch plus one batched reduce - exactly gnx_hexconv_bwd_weight for every item, bit
+ * for bit (same kernel body, slab layout, fixed-order reduce): the five hexagdly.Conv2d layers of the corrector
+ * (gridnet_models.py:128-148) are independent once their output gradients exist and cost a launch apiece.  Layers wider than
+ * 32 channels on either side, or more than 8 items: GNX_ERR_UNSUPPORTED, nothing launched (make the single calls).  `items`:
+ * HOST array; each item's workspace: gnx_hexconv_bwd_weight_workspace(B, H, W, I, O) floats. */
+typedef struct {
+    const float* x; const float* dy; float* dkernel0; float* dkernel1; float* dbias; float* workspace;
+    int B, H, W, I, O, mode, accumulate, pad;
+} gnx_hexconv_wgrad_item;
+int gnx_hexconv_bwd_weight_batch(const void* items, int n, gnx_stream_t stream);
 
 /* ---- batch normalisation (+ReLU) over matrix rows -----------------------------------------------------------
  * nn.BatchNorm2d(32) of the corrector (gridnet_models.py:134-146) and nn.BatchNorm1d of the count MLP
