@@ -906,6 +906,9 @@ def other_configs(device):
     with contextlib.redirect_stdout(io.StringIO()):
         for key, fn in (("config1_count_mlp_spotwise_b128", lambda: bc.c1(3)),
                         ("config3_count_f_hex_g_gridwise_b1", lambda: bc.c3(40)),
+                        # (the same loop with the user's optimizer built as torch.optim.Adam(fused=True): the plain one's host
+                        #  side, ~170 us per step, bounds a count-only step whose device work is ~250 us)
+                        ("config3_count_f_hex_g_gridwise_b1_fused_adam", lambda: bc.c3(40, fused_adam=True)),
                         ("config2_densenet121_spotwise_b32", lambda: bc.c2(2048, 1)),
                         # (the tutorial's batch of 32 is launch-bound - ~1 040 kernels of 7-25 us per step; the same loop at
                         #  batch 256 says what the kernels do when a step has work for the chip)

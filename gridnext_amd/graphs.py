@@ -99,6 +99,7 @@ class GridStepGraph:
         self.params = [p for p in params if p.requires_grad] if train else []
         self.graph = None
         self.out_grads = None
+        self.bn_buffers = None
         self.seen = 0
         self.failed = False
 
@@ -139,8 +140,16 @@ class GridStepGraph:
         if self.train:
             self._deliver_gradients()
             if self.models:
-                from .functional import bump_batchnorm_versions
-                bump_batchnorm_versions(self.models)             # (train-mode BatchNorm kernels ran inside the graph)
+                # train-mode BatchNorm kernels ran inside the graph: their buffers changed without any Python running.  The
+                # buffers are the ones that were in train mode at CAPTURE time - found once, not by walking the module tree after
+                # every replay (35 us of a ~250-us count-only step)
+                from .functional import bump_versions
+                if self.bn_buffers is None:
+                    import torch.nn as nn
+                    self.bn_buffers = [t for mod in self.models for m in mod.modules()
+                                       if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.running_mean is not None and m.training
+                                       for t in (m.running_mean, m.running_var, m.num_batches_tracked)]
+                bump_versions(*self.bn_buffers)
         return self.outs
 
     def _deliver_gradients(self):

@@ -63,7 +63,7 @@ def c2(n_train, epochs, batch=32):
             "spots_per_s": epochs * (n_train + 64) / dt, "seconds": dt}
 
 
-def c3(epochs):
+def c3(epochs, fused_adam=False):
     xs, ys = [], []
     for a in range(10):
         _, xc, y = visium_array(a, image=False, device=DEV)
@@ -75,11 +75,13 @@ def c3(epochs):
     m = ga.GridNetHexOddr(count_mlp(2000, 8), (2000,), (78, 64), 8)
     for p in m.patch_classifier.parameters():
         p.requires_grad = False
-    opt = torch.optim.Adam(m.corrector.parameters(), lr=1e-3)
+    # (the tutorials build a plain torch.optim.Adam: its host side - ~170 us per step for g's 14 tensors - is then most of a
+    #  count-only step, whose device work is ~250 us; fused_adam = the same optimizer with torch's own fused=True)
+    opt = torch.optim.Adam(m.corrector.parameters(), lr=1e-3, **({'fused': True} if fused_adam else {}))
     ga.train_gridwise(m, dl, nn.CrossEntropyLoss(), opt, num_epochs=1)
     dt = timed(lambda: ga.train_gridwise(m, dl, nn.CrossEntropyLoss(), opt, num_epochs=epochs))
-    return {"config": "C3 count f (frozen) + hex g, train_gridwise, 78x64, batch 1", "spots_per_s": epochs * 10 * 4992 / dt,
-            "arrays_per_s": epochs * 10 / dt, "seconds": dt}
+    return {"config": "C3 count f (frozen) + hex g, train_gridwise, 78x64, batch 1" + (", torch.optim.Adam(fused=True)" if fused_adam else ""),
+            "spots_per_s": epochs * 10 * 4992 / dt, "arrays_per_s": epochs * 10 / dt, "seconds": dt}
 
 
 if __name__ == '__main__':
@@ -91,6 +93,7 @@ if __name__ == '__main__':
         out.append(c1(3))
     if args.only in ('', 'c3'):
         out.append(c3(40))        # the tutorials train g for 50-100 epochs; 10 would make a fifth of the call warm-up + graph capture
+        out.append(c3(40, fused_adam=True))
     if args.only in ('', 'c2'):
         out.append(c2(2048, 1))
     if args.only == 'c2batch':                                # beyond the tutorial's batch of 32: what the kernels do when fed
