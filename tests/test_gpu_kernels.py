@@ -246,6 +246,43 @@ def test_linear_count_grid_in_place(GF):
     close(wd.grad, wr.grad, rtol=2e-3)
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 8, 6), (1, 78, 64), (2, 9, 7)])
+def test_hexconv_weight_gradients_batched_equal_the_single_calls(L, B, H, W):
+    """gnx_hexconv_bwd_weight_batch (the corrector's five layers as one launch + one batched reduce, what a captured step runs)
+    == gnx_hexconv_bwd_weight per layer, bit for bit: dkernel0, dkernel1 and the bias gradient; a layer wider than 32 channels
+    is declined (UNSUPPORTED, nothing written)."""
+    import ctypes
+    from gridnext_amd import functional as GF
+    layers = [(5, 32), (32, 32), (32, 32), (32, 32), (32, 5)]
+    g = torch.Generator().manual_seed(H * 7 + W)
+    single, batched, ops = [], [], []
+    for (I, O) in layers:
+        x = torch.randn(B, H, W, I, generator=g).to(DEV)
+        dy = torch.randn(B, H, W, O, generator=g).to(DEV)
+        outs = [(torch.full((O, I, 3, 1), 7.0, device=DEV), torch.full((O, I, 2, 2), 7.0, device=DEV), torch.full((O,), 7.0, device=DEV))
+                for _ in range(2)]
+        ws = torch.empty(L.query('gnx_hexconv_bwd_weight_workspace', B, H, W, I, O), device=DEV)
+        L.call('gnx_hexconv_bwd_weight', L.ptr(x), L.ptr(dy), L.ptr(outs[0][0]), L.ptr(outs[0][1]), L.ptr(outs[0][2]), L.ptr(ws),
+               B, H, W, I, O, 1, 0, L.stream())
+        single.append(outs[0])
+        batched.append(outs[1])
+        ops.append((x, dy, I, O))
+    arr = (GF._HexWgradItem * len(layers))()
+    keep = []
+    for a, (x, dy, I, O), (dk0, dk1, db) in zip(arr, ops, batched):
+        ws = torch.empty(L.query('gnx_hexconv_bwd_weight_workspace', B, H, W, I, O), device=DEV)
+        keep.append(ws)
+        a.x, a.dy, a.dkernel0, a.dkernel1, a.dbias, a.workspace = L.ptr(x), L.ptr(dy), L.ptr(dk0), L.ptr(dk1), L.ptr(db), L.ptr(ws)
+        a.B, a.H, a.W, a.I, a.O, a.mode, a.accumulate, a.pad = B, H, W, I, O, 1, 0, 0
+    L.call('gnx_hexconv_bwd_weight_batch', ctypes.addressof(arr), len(layers), L.stream())
+    torch.cuda.synchronize()
+    for s_, b_ in zip(single, batched):
+        for ts, tb in zip(s_, b_):
+            assert torch.equal(ts, tb)
+    arr[0].I = 40
+    assert L.query('gnx_hexconv_bwd_weight_batch', ctypes.addressof(arr), len(layers), L.stream()) == L.ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("kmajor,S,K,N", [(True, 4992, 2000, 500), (True, 2308, 516, 260), (False, 2500, 1000, 384),
                                           (True, 4992, 2000, 100), (False, 2100, 1030, 70), (True, 2496, 1024, 128)])
 def test_linear_whole_grid_split_k_form(GF, kmajor, S, K, N):
