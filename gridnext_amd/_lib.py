@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GNX_LIB') or os.path.join(_HERE, 'libgridnext_hip.so')   # GNX_LIB: debug builds only
 
-_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+_P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 
 # name -> (restype, argtypes)   [stream is always the last pointer]
 SIGNATURES = {
@@ -36,6 +36,7 @@ SIGNATURES = {
     'gnx_masked_ce_workspace': (_L, [_L]),
     'gnx_masked_ce_fwd': (_I, [_P, _L, _P, _L, _I, _I, _F, _P, _P, _P, _P, _P]),
     'gnx_masked_ce_bwd': (_I, [_P, _L, _P, _L, _I, _I, _P, _P, _F, _P, _L, _P]),
+    'gnx_meter_add': (_I, [_P, _P, _D, _P, _P, _D, _P]),
     'gnx_conv1x1_bnrelu': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _I, _I, _P]),
     'gnx_conv1x1_workspace': (_L, [_L, _I, _I]),
     'gnx_conv1x1_bnrelu_ws': (_I, [_P, _L, _P, _P, _L, _L, _I, _I, _P, _P, _P, _P]),

@@ -53,9 +53,23 @@ class _PhaseMeter:
         self.correct = 0
         self.counted = 0
         self.items = 0             # dataset items this rank actually saw (wrap-around duplicates of a sharded sampler included)
+        self.acc = None            # [loss, correct, counted] sums on the device (the HIP loops' path: gnx_meter_add)
 
     def add(self, loss, batch_size, correct, counted):
         self.items += batch_size
+        if (torch.is_tensor(loss) and loss.is_cuda and loss.dtype == torch.float32 and loss.numel() == 1 and
+                torch.is_tensor(correct) and correct.is_cuda and correct.dtype == torch.int64 and correct.numel() == 1 and
+                (isinstance(counted, int) or (torch.is_tensor(counted) and counted.is_cuda and counted.dtype == torch.int64 and
+                                              counted.numel() == 1))):
+            # the HIP loops' case: ONE launch on three device-resident double sums (the same arithmetic: the fp32 loss widened,
+            # times the batch size, added in double; counts are exact in double) instead of five elementwise launches
+            if self.acc is None:
+                self.acc = torch.zeros(3, device=loss.device, dtype=torch.float64)
+            from . import _lib as L
+            L.call('gnx_meter_add', self.acc.data_ptr(), loss.data_ptr(), float(batch_size), correct.data_ptr(),
+                   None if isinstance(counted, int) else counted.data_ptr(), float(counted) if isinstance(counted, int) else 0.0,
+                   L.stream())
+            return
         if torch.is_tensor(loss):
             loss = loss.detach().double()
         self.loss = self.loss + loss * batch_size
@@ -64,6 +78,9 @@ class _PhaseMeter:
 
     def totals(self):
         vals = [float(v) for v in (self.loss, self.correct, self.counted, self.items)]   # the only host sync of a phase
+        if self.acc is not None:
+            a = self.acc.tolist()
+            vals = [vals[0] + a[0], vals[1] + a[1], vals[2] + a[2], vals[3]]
         return gdist.allreduce_sums(vals, self.device)
 
     def n_items(self, dataset_len, items_seen):

@@ -122,6 +122,12 @@ int gnx_masked_ce_fwd(const float* logits, long ld, const long long* labels, lon
 int gnx_masked_ce_bwd(const float* logits, long ld, const long long* labels, long M, int C, int label_base,
                       const long long* stats, const float* dloss, float accum_iters, float* dlogits, long lddz,
                       gnx_stream_t stream);
+/* The loops' per-batch bookkeeping (training.py:73-75, :176-178: running_loss += loss.item() * batch_size; running_corrects +=
+ * correct) on device-resident sums, one launch: acc[0] += (double)*loss * weight, acc[1] += *correct, acc[2] += counted ?
+ * *counted : counted_const (acc: 3 doubles on the device; loss / correct / counted: device scalars as gnx_masked_ce_fwd
+ * leaves them). */
+int gnx_meter_add(double* acc, const float* loss, double weight, const long long* correct, const long long* counted,
+                  double counted_const, gnx_stream_t stream);
 
 /* Row softmax + first-argmax of channels-last logits: torch.argmax / F.softmax of gridnext/utils.py:43-47. */
 int gnx_softmax_rows(const float* logits, long ld, long M, int C, float* probs, long ldp, long long* preds,
