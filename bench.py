@@ -581,6 +581,84 @@ def from_host_series(args, model, optimizer, criterion, device, rank, world):
 
 
 # ------------------------------------------------------------------------------------------ config 5 (fp16, 256 px)
+def split_conv1_series(args, device, rank, world, steps=4, warmup=2, P=128):
+    """The headline's step (config 4: f frozen, fp32 tensors) with conv1 of every dense layer on SPLIT bf16 operands
+    (`DenseNet.split_conv1 = True`: every fp32 operand = hi + lo in bf16, three 16-bit matrix instructions per product, fp32
+    accumulation; csrc/conv1x1_split.hip) - opt-in, NOT the headline.  Reported with the loss and the f logits of the same
+    array on the fp32-instruction path, so that what the split costs in accuracy stands next to what it buys."""
+    import torch
+    import torch.nn as nn
+    from gridnext_amd import distributed as gdist
+    from gridnext_amd import training as gtrain
+    model = build_model(device, P)
+    gdist.broadcast_module(model)
+    for p in model.patch_classifier.parameters():
+        p.requires_grad = False
+    opt = torch.optim.Adam(model.corrector.parameters(), lr=1e-3)
+    crit = nn.CrossEntropyLoss()
+    gen = torch.Generator(device=device).manual_seed(700 + rank)
+    y = torch.randint(0, CLASSES + 1, (1, H, W), device=device, generator=gen)
+    x = torch.rand((1, H, W, 3, P, P), device=device, generator=gen)
+    xc = torch.randint(0, 10, (1, GENES, H, W), device=device, generator=gen).float()
+    f_img = model.image_classifier
+    model.train()
+    model.patch_classifier.eval()
+    stepped = gdist.optimizer_params(opt)
+    cmp = {}
+    with torch.no_grad():
+        for name, flag in (("fp32", False), ("split", True)):
+            f_img.split_conv1 = flag
+            cmp[name] = (float(gtrain._grid_loss(model, [x, xc], y, crit, 1, True)[0].item()),
+                         f_img(x.reshape(-1, 3, P, P)).double())
+    d = (cmp["split"][1] - cmp["fp32"][1]).abs().max().item()
+    rng = cmp["fp32"][1].abs().max().item()
+    same = int((cmp["split"][1].argmax(1) == cmp["fp32"][1].argmax(1)).sum().item())
+    f_img.split_conv1 = True
+
+    def step():
+        loss, _, _ = gtrain._grid_loss(model, [x, xc], y, crit, 1, True)
+        loss.backward()
+        gdist.allreduce_gradients(stepped)
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    for _ in range(warmup):
+        step()
+    f_img._probe = []
+    if gdist.is_active():
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    if gdist.is_active():
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if gdist.is_active():
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    probe, f_img._probe = f_img._probe, None
+    kt = kernel_table(probe, P, steps)
+    k1 = kt.get('conv1x1')
+    if k1:
+        k1["kernel"] = "conv1x1_split_kernel (bf16 hi/lo operands, 3 x v_mfma_f32_32x32x16_bf16 per product)"
+        k1["bound"], k1["peak"], k1["unit"] = "hbm", PEAK_HBM_GBS, "GB/s"
+        k1["achieved"] = k1["algorithmic_gbs"]
+        k1["frac"] = k1["achieved"] / PEAK_HBM_GBS
+        k1["executed_matrix_tflops"] = 3 * k1["flops_per_launch_avg"] * k1["launches"] / (k1["ms_per_step"] * steps * 1e-3) / 1e12
+    return {"value": H * W * world * steps / elapsed, "unit": "spots/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+            "warmup": warmup, "dtype": "f32 tensors and accumulation; conv1 products as three bf16 matrix instructions (hi/lo split)",
+            "final_loss": float(last.item()), "patch": P,
+            "vs_fp32_instruction_path": {"ce_fp32": cmp["fp32"][0], "ce_split": cmp["split"][0],
+                                         "abs_diff_ce": abs(cmp["split"][0] - cmp["fp32"][0]),
+                                         "f_logits_max_abs_diff": d, "f_logits_range": rng, "argmax_equal": same, "spots": H * W},
+            "kernels": {k: kt[k] for k in ('conv1x1', 'conv3x3') if k in kt},
+            "workload": "the headline's step (config 4, 128-px fp32 patches resident, f frozen, g trained) with DenseNet.split_conv1"}
+
+
 def config5_series(args, device, rank, world, steps=4, warmup=2, P=256):
     """BASELINE config 5's step on this GPU: the same multimodal f + g step with 256-px patches and the fp16 MFMA conv path
     (`DenseNet.mfma = 'f16'`: fp16 matrix operands incl. the stem, fp16 block buffers, fp32 accumulate), uint8 patches
@@ -1141,6 +1219,7 @@ def worker_main(args):
         # the headline's own geometry (128-px patches, f frozen) on the fp16 MFMA conv path: what that path buys where the
         # fp32 number is quoted; its CE is reported against the fp32 oracle, not gated at 1e-4 (dtype f16)
         optional("headline_geometry_f16_128px", lambda: config5_series(args, device, rank, world, P=128))
+        optional("headline_split_conv1_128px", lambda: split_conv1_series(args, device, rank, world))
 
     # ---- the reference's own patch size (224 px)
     if more and not args.train_f and args.mfma == 'f32' and args.patch == 128:

@@ -65,6 +65,8 @@ class DenseNet(nn.Module):
                                               # it the batch is cut into recomputed chunks (a 256-px array: 3 chunks)
         self.atonce = None          # spots per chunk in eval mode (None = auto)
         self.mfma = 'f32'           # 'f16': fp16 matrix-core operands in the eval forward (BASELINE config 5)
+        self.split_conv1 = False    # eval forward, fp32 path: conv1 on SPLIT bf16 operands (three 16-bit matrix instructions per
+                                    # product, fp32 tensors and accumulation: csrc/conv1x1_split.hip; opt-in, fp32-grade results)
         self.winograd = True        # eval forward: conv2 as Winograd F(2,3) along x where the shape allows (fp32 path;
                                     # same arithmetic type, 1.5x fewer matrix operations, rounding-level differences)
         self.f16_buffers = True     # mfma = 'f16' only: the block buffers themselves in fp16 where the shapes allow
@@ -286,6 +288,25 @@ class DenseNet(nn.Module):
         self._cache['w2u'] = (key, table)
         return table
 
+    def _split_conv1(self):
+        """{layer: conv1 weight split into bf16 hi / lo planes by 64-wide K chunks (gnx_conv1x1_split_pack)} refreshed with the
+        weights."""
+        layers = [l for _, ls, _, _ in self._blocks for l in ls]
+        key = self._key([l.conv1.weight for l in layers])
+        hit = self._cache.get('w1s')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        table = {}
+        st = L.stream()
+        for l in layers:
+            w = l.conv1.weight
+            k = w.shape[1]
+            wp = torch.empty(L.query('gnx_conv1x1_split_pack_halves', k), device=w.device, dtype=torch.bfloat16)
+            L.call('gnx_conv1x1_split_pack', L.ptr(w.detach().contiguous()), wp.data_ptr(), k, st)
+            table[l] = wp
+        self._cache['w1s'] = (key, table)
+        return table
+
     def _norm_vector(self, dev):
         """Device floats {mean[3], std[3], 1/std[3]} for the uint8 entry points, or None (ToTensor only)."""
         if self.input_norm is None:
@@ -483,6 +504,7 @@ class DenseNet(nn.Module):
         w2 = self._repacked_conv2()
         w2u = self._winograd_conv2() if (self.winograd and self.mfma == 'f32') else None
         w2h = self._repacked_conv2_f16() if self.mfma == 'f16' else None
+        w1s = self._split_conv1() if (self.split_conv1 and self.mfma == 'f32' and self.bn_size * self.growth_rate == 128) else None
         if self.mfma not in ('f32', 'f16'):
             raise ValueError("DenseNet.mfma must be 'f32' or 'f16'")
         sfx = '_f16' if self.mfma == 'f16' else ''
@@ -597,8 +619,16 @@ class DenseNet(nn.Module):
                         else:
                             # norm2 + relu2 ride on conv1's store: conv2 then takes its operand as it lies in HBM
                             # (global -> LDS DMA, no prologue)
-                            L.call('gnx_conv1x1_bnrelu_act', L.ptr(rows), c_total, L.ptr(layer.conv1.weight),
-                                   L.ptr(bott), mid, M, mid, cin, L.ptr(sc1), L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), st)
+                            rc = L.ERR_UNSUPPORTED
+                            if w1s is not None:
+                                # (opt-in) the same product on split bf16 operands; shapes it declines keep the fp32 instruction
+                                rc = L.query('gnx_conv1x1_bnrelu_act_split', L.ptr(rows), c_total, w1s[layer].data_ptr(), L.ptr(bott),
+                                             mid, M, cin, L.ptr(sc1), L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), st)
+                                if rc not in (0, L.ERR_UNSUPPORTED):
+                                    raise RuntimeError("gnx_conv1x1_bnrelu_act_split failed (%d)" % rc)
+                            if rc == L.ERR_UNSUPPORTED:
+                                L.call('gnx_conv1x1_bnrelu_act', L.ptr(rows), c_total, L.ptr(layer.conv1.weight),
+                                       L.ptr(bott), mid, M, mid, cin, L.ptr(sc1), L.ptr(sh1), L.ptr(sc2), L.ptr(sh2), st)
                             t1 = self._probe_mark('conv1x1', t0, *work1)
                             # conv2 on the ready operand: Winograd F(2,3) along x (1.5x fewer matrix operations, rounding-
                             # level differences) for maps of 8 x 8 and up (4 x 4 measured faster direct).  The choice

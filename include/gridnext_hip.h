@@ -164,6 +164,17 @@ int gnx_conv1x1_bnrelu_ws(const float* A, long lda, const float* W, float* out, 
 int gnx_conv1x1_bnrelu_act(const float* A, long lda, const float* W, float* out, long ldc, long M, int N, int K,
                            const float* scale, const float* shift, const float* out_scale, const float* out_shift,
                            gnx_stream_t stream);
+/* Opt-in form of conv1x1_bnrelu_act / conv1x1_bnrelu (pool = 0) for N = 128 on SPLIT bf16 operands (csrc/conv1x1_split.hip): every
+ * fp32 operand = hi + lo in bf16, a product = three v_mfma_f32_32x32x16_bf16 with fp32 accumulation (a_lo b_hi + a_hi b_lo +
+ * a_hi b_hi); tensors stay fp32 in HBM.  A whole DenseNet-121 in this arithmetic: logits 7e-6 of their range, CE 1e-6 from float64
+ * (tools/diag/split_operand_feasibility.py).  Wp = gnx_conv1x1_split_pack of conv1.weight [128][K]
+ * (gnx_conv1x1_split_pack_halves(K) 16-bit elements).  out_scale = NULL: no activation on the store.  4 | K, 4 | lda, 16-B aligned
+ * A / scale / shift, else GNX_ERR_UNSUPPORTED. */
+long gnx_conv1x1_split_pack_halves(int K);
+int gnx_conv1x1_split_pack(const float* W, void* Wp, int K, gnx_stream_t stream);
+int gnx_conv1x1_bnrelu_act_split(const float* A, long lda, const void* Wp, float* out, long ldc, long M, int K,
+                                 const float* scale, const float* shift, const float* out_scale, const float* out_shift,
+                                 gnx_stream_t stream);
 /* Training backward of norm1 -> relu1 -> conv1 (:35-37) w.r.t. the layer input, eval statistics: conv1's data gradient
  * dY . Wt^T (Wt = gnx_transpose_weight of conv1.weight) fused with the BN + ReLU backward and accumulated into the block
  * gradient dX[:, :N]; dbeta / dgamma from per-tile column sums (fixed order).  Same result as gnx_conv1x1_bnrelu followed by

@@ -401,6 +401,41 @@ def test_conv1x1_bnrelu_act(L, M, K, N):
                                           None, None, L.stream()) != 0       # both output vectors are required
 
 
+@pytest.mark.parametrize("M,K,lda,act", [(128, 64, 64, True), (1000, 96, 128, True), (333, 224, 256, False), (4096, 480, 512, True),
+                                          (2050, 992, 1024, True), (77, 36, 40, True)])
+def test_conv1x1_split_bf16_operands(L, M, K, lda, act):
+    """Late round 5: conv1 (+ norm2 / relu2 on the store) with every fp32 operand split into two bf16 numbers and three matrix
+    instructions per product (csrc/conv1x1_split.hip).  Against float64 on ragged M, K not a multiple of the 64-wide chunk, a wider
+    operand row (block buffer): error of fp32 grade - gated at 3e-5 of the output range, where bf16 operands alone sit at 4e-3 and
+    the fp32 instruction at 1e-6 - tail columns untouched, and the error reported beside the fp32 kernel's."""
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, lda, generator=g)
+    W = torch.randn(128, K, generator=g) * (1.0 / K ** 0.5)
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+    osc, osh = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.5
+    y = torch.relu(A[:, :K].double() * sc.double() + sh.double()) @ W.double().t()
+    ref = torch.relu(y * osc.double() + osh.double()) if act else y
+    Ad, Wd, scd, shd, oscd, oshd = (v.to(DEV) for v in (A, W, sc, sh, osc, osh))
+    Wp = torch.empty(L.query('gnx_conv1x1_split_pack_halves', K), device=DEV, dtype=torch.bfloat16)
+    L.call('gnx_conv1x1_split_pack', L.ptr(Wd), Wp.data_ptr(), K, L.stream())
+    out = torch.full((M, 131), 7.0, device=DEV)
+    L.call('gnx_conv1x1_bnrelu_act_split', L.ptr(Ad), lda, Wp.data_ptr(), L.ptr(out), 131, M, K, L.ptr(scd), L.ptr(shd),
+           L.ptr(oscd) if act else None, L.ptr(oshd) if act else None, L.stream())
+    rng = ref.abs().max().item()
+    err = (out[:, :128].double().cpu() - ref).abs().max().item()
+    assert err <= 3e-5 * rng, (err, rng)
+    assert float(out[:, 128:].min()) == 7.0 and float(out[:, 128:].max()) == 7.0
+    if act:
+        o32 = torch.empty(M, 128, device=DEV)
+        L.call('gnx_conv1x1_bnrelu_act', L.ptr(Ad), lda, L.ptr(Wd), L.ptr(o32), 128, M, 128, K, L.ptr(scd), L.ptr(shd), L.ptr(oscd),
+               L.ptr(oshd), L.stream())
+        e32 = (o32.double().cpu() - ref).abs().max().item()
+        print("\n[conv1x1 split bf16, M=%d K=%d] max error / range: split %.2e, fp32 instruction %.2e" % (M, K, err / rng, e32 / rng))
+    # unsupported operand layouts are declined, not computed differently
+    assert L.lib().gnx_conv1x1_bnrelu_act_split(L.ptr(Ad), lda + 1, Wp.data_ptr(), L.ptr(out), 131, M, K, L.ptr(scd), L.ptr(shd), None,
+                                                None, L.stream()) == -3
+
+
 def test_frozen_count_mlp_composed_into_affine_stages(GF):
     """A frozen count MLP in eval mode (train_gridwise's tutorial recipe, training.py:126) evaluates as three affine stages -
     Linear -> Linear -> BatchNorm1d composed into one map each (there is no activation between the paired Linears,

@@ -106,6 +106,38 @@ def test_densenet121_many_spots_vs_oracle():
     assert torch.equal(out.argmax(1)[decided], ref.argmax(1)[decided])
 
 
+def test_densenet121_split_conv1_is_of_fp32_grade():
+    """Late round 5: `DenseNet.split_conv1` - conv1 of every dense layer on split bf16 operands (three 16-bit matrix instructions
+    per product, fp32 tensors and accumulation).  DenseNet-121 on 130 spots, closed-form weights, against the fp32 CPU oracle: the
+    same gate as the fp32-instruction path passes (rtol 1e-3, argmax on every decided spot); against the fp32-instruction path on
+    the device the logits differ by at most 3e-5 of their range (plain 16-bit operands: 1e-3..1e-2); chunked == unchunked bit for
+    bit; and the switch does select another kernel."""
+    import gridnext_amd as ga
+    from oracle import densenet as odn
+    cfg = odn.DenseNetCfg(num_classes=8, **odn.DENSENET121)
+    sd = odn.closed_form_state(cfg)
+    m = ga.DenseNet(num_classes=8, **odn.DENSENET121)
+    m.load_state_dict(sd)
+    m.to(DEV).eval()
+    x = torch.rand(130, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        base = m(x.to(DEV)).cpu()
+        m.split_conv1 = True
+        out = m(x.to(DEV)).cpu()
+        m.atonce = 48
+        chunked = m(x.to(DEV)).cpu()
+        ref = odn.forward(sd, x, cfg)
+    close(out, ref, rtol=1e-3, what='130 spots, split conv1')
+    margin = ref.topk(2, dim=1).values
+    decided = (margin[:, 0] - margin[:, 1]) > 1e-3
+    assert torch.equal(out.argmax(1)[decided], ref.argmax(1)[decided])
+    d, rng = (out - base).abs().max().item(), base.abs().max().item()
+    print("\n[DenseNet-121 split conv1 vs the fp32-instruction path] max |dlogit| %.2e of the range; vs the fp32 CPU oracle: split "
+          "%.2e, fp32 instruction %.2e" % (d / rng, (out - ref).abs().max().item() / rng, (base - ref).abs().max().item() / rng))
+    assert 0 < d <= 3e-5 * rng
+    assert torch.equal(out, chunked)
+
+
 def _loaders(x, y, n_train, batch):
     return {'train': DataLoader(TensorDataset(x[:n_train], y[:n_train]), batch_size=batch, shuffle=False),
             'val': DataLoader(TensorDataset(x[n_train:], y[n_train:]), batch_size=batch, shuffle=False)}

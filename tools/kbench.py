@@ -72,6 +72,26 @@ def main():
             byts = 4.0 * M * (K + 128)
             print("conv1x1 S=%2d K=%4d M=%8d  %8.3f ms  %6.1f TFLOP/s  %5.2f TB/s" % (S, K, M, ms, fl / ms / 1e9, byts / ms / 1e9))
             del A, out
+    if args.only == 'conv1x1split':
+        # conv1 + norm2 / relu2 on the store: the fp32 instruction (gnx_conv1x1_bnrelu_act) beside the split-bf16 form
+        for S, K, ct in shapes:
+            M = n * S * S
+            A = torch.randn(M, ct, device=DEV)
+            W = torch.randn(128, K, device=DEV) * 0.05
+            out = torch.empty(M, 128, device=DEV)
+            sc, sh = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
+            osc, osh = torch.rand(128, device=DEV) + 0.5, torch.randn(128, device=DEV) * 0.1
+            Wp = torch.empty(L.query('gnx_conv1x1_split_pack_halves', K), device=DEV, dtype=torch.bfloat16)
+            L.call('gnx_conv1x1_split_pack', L.ptr(W), Wp.data_ptr(), K, st)
+            ms0 = timeit(lambda: L.call('gnx_conv1x1_bnrelu_act', L.ptr(A), ct, L.ptr(W), L.ptr(out), 128, M, 128, K, L.ptr(sc),
+                                        L.ptr(sh), L.ptr(osc), L.ptr(osh), st), args.reps)
+            ms1 = timeit(lambda: L.call('gnx_conv1x1_bnrelu_act_split', L.ptr(A), ct, Wp.data_ptr(), L.ptr(out), 128, M, K, L.ptr(sc),
+                                        L.ptr(sh), L.ptr(osc), L.ptr(osh), st), args.reps)
+            fl = 2.0 * M * K * 128
+            byts = 4.0 * M * (K + 128)
+            print("conv1x1 S=%2d K=%4d M=%8d  fp32 mfma %8.3f ms %6.1f TFLOP/s %5.2f TB/s | split bf16 %8.3f ms %6.1f TFLOP/s %5.2f TB/s  (x%.2f)" %
+                  (S, K, M, ms0, fl / ms0 / 1e9, byts / ms0 / 1e9, ms1, fl / ms1 / 1e9, byts / ms1 / 1e9, ms0 / ms1), flush=True)
+            del A, out
     if args.only in ('', 'conv3x3'):
         for S in (32, 16, 8, 4):
             M = n * S * S
