@@ -67,6 +67,7 @@ class DenseNet(nn.Module):
         self.mfma = 'f32'           # 'f16': fp16 matrix-core operands in the eval forward (BASELINE config 5)
         self.split_conv1 = False    # eval forward, fp32 path: conv1 on SPLIT bf16 operands (three 16-bit matrix instructions per
                                     # product, fp32 tensors and accumulation: csrc/conv1x1_split.hip; opt-in, fp32-grade results)
+        self.split_conv2 = False    # ... and conv2 as nine shifted products of split bf16 operands (csrc/conv3x3_split.hip)
         self.winograd = True        # eval forward: conv2 as Winograd F(2,3) along x where the shape allows (fp32 path;
                                     # same arithmetic type, 1.5x fewer matrix operations, rounding-level differences)
         self.f16_buffers = True     # mfma = 'f16' only: the block buffers themselves in fp16 where the shapes allow
@@ -307,6 +308,23 @@ class DenseNet(nn.Module):
         self._cache['w1s'] = (key, table)
         return table
 
+    def _split_conv2(self):
+        """{layer: conv2 weight split into bf16 hi / lo planes by 32-channel chunks and taps (gnx_conv3x3_split_pack)}."""
+        layers = [l for _, ls, _, _ in self._blocks for l in ls]
+        key = self._key([l.conv2.weight for l in layers])
+        hit = self._cache.get('w2s')
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        table = {}
+        st = L.stream()
+        for l in layers:
+            w = l.conv2.weight
+            wp = torch.empty(L.query('gnx_conv3x3_split_pack_halves'), device=w.device, dtype=torch.bfloat16)
+            L.call('gnx_conv3x3_split_pack', L.ptr(w.detach().contiguous()), wp.data_ptr(), st)
+            table[l] = wp
+        self._cache['w2s'] = (key, table)
+        return table
+
     def _norm_vector(self, dev):
         """Device floats {mean[3], std[3], 1/std[3]} for the uint8 entry points, or None (ToTensor only)."""
         if self.input_norm is None:
@@ -505,6 +523,8 @@ class DenseNet(nn.Module):
         w2u = self._winograd_conv2() if (self.winograd and self.mfma == 'f32') else None
         w2h = self._repacked_conv2_f16() if self.mfma == 'f16' else None
         w1s = self._split_conv1() if (self.split_conv1 and self.mfma == 'f32' and self.bn_size * self.growth_rate == 128) else None
+        w2s = self._split_conv2() if (self.split_conv2 and self.mfma == 'f32' and self.bn_size * self.growth_rate == 128 and
+                                      self.growth_rate == 32) else None
         if self.mfma not in ('f32', 'f16'):
             raise ValueError("DenseNet.mfma must be 'f32' or 'f16'")
         sfx = '_f16' if self.mfma == 'f16' else ''
@@ -635,7 +655,13 @@ class DenseNet(nn.Module):
                             # depends on the map size only - never on how many spots a call or a chunk holds - so chunked
                             # and unchunked evaluation stay bit-identical.
                             rc = L.ERR_UNSUPPORTED
-                            if w2u is not None and s >= 8:
+                            if w2s is not None:
+                                # (opt-in) nine shifted products of split bf16 operands; declined shapes fall through
+                                rc = L.query('gnx_conv3x3_split', L.ptr(bott), mid, w2s[layer].data_ptr(), rows.data_ptr() + 4 * cin,
+                                             c_total, M, s, st)
+                                if rc not in (0, L.ERR_UNSUPPORTED):
+                                    raise RuntimeError("gnx_conv3x3_split failed (%d)" % rc)
+                            if rc == L.ERR_UNSUPPORTED and w2u is not None and s >= 8:
                                 rc = L.query('gnx_conv3x3_winograd', L.ptr(bott), mid, L.ptr(w2u[layer]),
                                              rows.data_ptr() + 4 * cin, c_total, M, self.growth_rate, mid, s, st)
                                 if rc not in (0, L.ERR_UNSUPPORTED):

@@ -175,6 +175,14 @@ int gnx_conv1x1_split_pack(const float* W, void* Wp, int K, gnx_stream_t stream)
 int gnx_conv1x1_bnrelu_act_split(const float* A, long lda, const void* Wp, float* out, long ldc, long M, int K,
                                  const float* scale, const float* shift, const float* out_scale, const float* out_shift,
                                  gnx_stream_t stream);
+/* The 3x3 companion (csrc/conv3x3_split.hip): conv2 (:41; N = 32, K = 128, padding 1) on an fp32 bottleneck that conv1 stored
+ * activated, as nine shifted products of split bf16 operands - gnx_conv3x3_bnrelu with scale = shift = NULL in fp32-grade
+ * arithmetic, bound by the bottleneck's bytes instead of the fp32 matrix instruction.  Wp = gnx_conv3x3_split_pack of
+ * conv2.weight [32][128][3][3] (gnx_conv3x3_split_pack_halves() 16-bit elements).  S in {4, 8, 16, 32, 64}, S * S | M, 4 | lda,
+ * 16-B aligned A, else GNX_ERR_UNSUPPORTED. */
+long gnx_conv3x3_split_pack_halves(void);
+int gnx_conv3x3_split_pack(const float* W, void* Wp, gnx_stream_t stream);
+int gnx_conv3x3_split(const float* A, long lda, const void* Wp, float* out, long ldc, long M, int S, gnx_stream_t stream);
 /* Training backward of norm1 -> relu1 -> conv1 (:35-37) w.r.t. the layer input, eval statistics: conv1's data gradient
  * dY . Wt^T (Wt = gnx_transpose_weight of conv1.weight) fused with the BN + ReLU backward and accumulated into the block
  * gradient dX[:, :N]; dbeta / dgamma from per-tile column sums (fixed order).  Same result as gnx_conv1x1_bnrelu followed by

@@ -436,6 +436,32 @@ def test_conv1x1_split_bf16_operands(L, M, K, lda, act):
                                                 None, L.stream()) == -3
 
 
+@pytest.mark.parametrize("n,S,ldc", [(3, 4, 40), (5, 8, 32), (3, 16, 96), (2, 32, 64), (1, 64, 32), (37, 4, 32), (9, 8, 48)])
+def test_conv3x3_split_bf16_operands(L, n, S, ldc):
+    """Late round 5: conv2 (3x3, 128 -> 32, zero padding) as nine shifted products of split bf16 operands
+    (csrc/conv3x3_split.hip).  Against float64 conv2d on whole maps of every size, tiles that start and end inside maps (n S S not
+    a multiple of 256), an output that is a column range of a wider buffer: error of fp32 grade (gate 3e-5 of the range), the
+    buffer's other columns untouched."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(100 * n + S)
+    M = n * S * S
+    A = torch.relu(torch.randn(M, 128, generator=g))                      # (an activated bottleneck)
+    W = torch.randn(32, 128, 3, 3, generator=g) * (1.0 / 1152 ** 0.5)
+    ref = F.conv2d(A.double().reshape(n, S, S, 128).permute(0, 3, 1, 2), W.double(), padding=1).permute(0, 2, 3, 1).reshape(M, 32)
+    Ad, Wd = A.to(DEV), W.to(DEV)
+    Wp = torch.empty(L.query('gnx_conv3x3_split_pack_halves'), device=DEV, dtype=torch.bfloat16)
+    L.call('gnx_conv3x3_split_pack', L.ptr(Wd), Wp.data_ptr(), L.stream())
+    out = torch.full((M, ldc + 5), 7.0, device=DEV)
+    L.call('gnx_conv3x3_split', L.ptr(Ad), 128, Wp.data_ptr(), out.data_ptr() + 4 * 4, ldc + 5, M, S, L.stream())
+    got = out[:, 4:36].double().cpu()
+    rng = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    assert err <= 3e-5 * rng, (err, rng)
+    assert float(out[:, :4].min()) == 7.0 and float(out[:, 36:].min()) == 7.0 and float(out[:, 36:].max()) == 7.0
+    print("\n[conv3x3 split bf16, n=%d S=%d] max error / range %.2e" % (n, S, err / rng))
+    assert L.lib().gnx_conv3x3_split(L.ptr(Ad), 128, Wp.data_ptr(), L.ptr(out), ldc + 5, M - 1, S, L.stream()) == -3
+
+
 def test_frozen_count_mlp_composed_into_affine_stages(GF):
     """A frozen count MLP in eval mode (train_gridwise's tutorial recipe, training.py:126) evaluates as three affine stages -
     Linear -> Linear -> BatchNorm1d composed into one map each (there is no activation between the paired Linears,

@@ -106,9 +106,9 @@ def test_densenet121_many_spots_vs_oracle():
     assert torch.equal(out.argmax(1)[decided], ref.argmax(1)[decided])
 
 
-def test_densenet121_split_conv1_is_of_fp32_grade():
-    """Late round 5: `DenseNet.split_conv1` - conv1 of every dense layer on split bf16 operands (three 16-bit matrix instructions
-    per product, fp32 tensors and accumulation).  DenseNet-121 on 130 spots, closed-form weights, against the fp32 CPU oracle: the
+def test_densenet121_split_operands_are_of_fp32_grade():
+    """Late round 5: `DenseNet.split_conv1` / `split_conv2` - conv1 and conv2 of every dense layer on split bf16 operands (three
+    16-bit matrix instructions per product, fp32 tensors and accumulation).  DenseNet-121 on 130 spots, closed-form weights, against the fp32 CPU oracle: the
     same gate as the fp32-instruction path passes (rtol 1e-3, argmax on every decided spot); against the fp32-instruction path on
     the device the logits differ by at most 3e-5 of their range (plain 16-bit operands: 1e-3..1e-2); chunked == unchunked bit for
     bit; and the switch does select another kernel."""
@@ -123,6 +123,8 @@ def test_densenet121_split_conv1_is_of_fp32_grade():
     with torch.no_grad():
         base = m(x.to(DEV)).cpu()
         m.split_conv1 = True
+        only1 = m(x.to(DEV)).cpu()
+        m.split_conv2 = True
         out = m(x.to(DEV)).cpu()
         m.atonce = 48
         chunked = m(x.to(DEV)).cpu()
@@ -132,9 +134,9 @@ def test_densenet121_split_conv1_is_of_fp32_grade():
     decided = (margin[:, 0] - margin[:, 1]) > 1e-3
     assert torch.equal(out.argmax(1)[decided], ref.argmax(1)[decided])
     d, rng = (out - base).abs().max().item(), base.abs().max().item()
-    print("\n[DenseNet-121 split conv1 vs the fp32-instruction path] max |dlogit| %.2e of the range; vs the fp32 CPU oracle: split "
+    print("\n[DenseNet-121 split conv1 + conv2 vs the fp32-instruction path] max |dlogit| %.2e of the range; vs the fp32 CPU oracle: split "
           "%.2e, fp32 instruction %.2e" % (d / rng, (out - ref).abs().max().item() / rng, (base - ref).abs().max().item() / rng))
-    assert 0 < d <= 3e-5 * rng
+    assert 0 < d <= 3e-5 * rng and 0 < (only1 - base).abs().max().item() <= 3e-5 * rng and not torch.equal(only1, out)
     assert torch.equal(out, chunked)
 
 

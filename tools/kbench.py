@@ -92,6 +92,31 @@ def main():
             print("conv1x1 S=%2d K=%4d M=%8d  fp32 mfma %8.3f ms %6.1f TFLOP/s %5.2f TB/s | split bf16 %8.3f ms %6.1f TFLOP/s %5.2f TB/s  (x%.2f)" %
                   (S, K, M, ms0, fl / ms0 / 1e9, byts / ms0 / 1e9, ms1, fl / ms1 / 1e9, byts / ms1 / 1e9, ms0 / ms1), flush=True)
             del A, out
+    if args.only == 'conv3x3split':
+        # conv2 on the ready (activated) bottleneck: Winograd F(2,3) on the fp32 instruction beside the split-bf16 direct form
+        for S in (32, 16, 8, 4):
+            M = n * S * S
+            A = torch.relu(torch.randn(M, 128, device=DEV))
+            ct = 256
+            out = torch.empty(M, ct, device=DEV)
+            Wt = torch.randn(32, 128, 3, 3, device=DEV) * 0.05
+            Wu = torch.empty(12, 32, 128, device=DEV)
+            L.call('gnx_winograd_conv3x3_weights', L.ptr(Wt), L.ptr(Wu), 32, 128, st)
+            Wr = torch.randn(9, 32, 128, device=DEV) * 0.05
+            Wp = torch.empty(L.query('gnx_conv3x3_split_pack_halves'), device=DEV, dtype=torch.bfloat16)
+            L.call('gnx_conv3x3_split_pack', L.ptr(Wt), Wp.data_ptr(), st)
+            if S >= 8:
+                ms0 = timeit(lambda: L.call('gnx_conv3x3_winograd', L.ptr(A), 128, L.ptr(Wu), out.data_ptr() + 4 * 64, ct, M, 32, 128, S,
+                                            st), args.reps)
+            else:
+                ms0 = timeit(lambda: L.call('gnx_conv3x3_bnrelu', L.ptr(A), 128, L.ptr(Wr), out.data_ptr() + 4 * 64, ct, M, 32, 128, S,
+                                            None, None, st), args.reps)
+            ms1 = timeit(lambda: L.call('gnx_conv3x3_split', L.ptr(A), 128, Wp.data_ptr(), out.data_ptr() + 4 * 64, ct, M, S, st), args.reps)
+            fl = 2.0 * M * 1152 * 32
+            byts = 4.0 * M * (128 + 32)
+            print("conv3x3 S=%2d M=%8d  fp32 mfma %8.3f ms %6.1f TFLOP/s (direct-conv FLOPs) %5.2f TB/s | split bf16 %8.3f ms %6.1f TFLOP/s %5.2f TB/s  (x%.2f)" %
+                  (S, M, ms0, fl / ms0 / 1e9, byts / ms0 / 1e9, ms1, fl / ms1 / 1e9, byts / ms1 / 1e9, ms0 / ms1), flush=True)
+            del A, out
     if args.only in ('', 'conv3x3'):
         for S in (32, 16, 8, 4):
             M = n * S * S
