@@ -423,6 +423,21 @@ def cpu_leg(model, patch, mfma, device, timed_steps=2, sub_hw=None, u8=False, in
         loss_hip, stats, preds = GF.masked_cross_entropy(logits.reshape(-1, CLASSES), y.to(device), 1)
     torch.cuda.synchronize()
     loss_hip, preds_hip = float(loss_hip.item()), preds.cpu()
+    # the same forward with the image f's conv1 / conv2 on split bf16 operands (opt-in form of the fp32 path): held to the same
+    # oracle result below, at no extra CPU cost
+    split_hip = None
+    f_hip = model.image_classifier
+    if mfma == 'f32' and hasattr(f_hip, 'split_conv1') and getattr(f_hip, 'mfma', None) == 'f32':
+        keep = (f_hip.split_conv1, f_hip.split_conv2)
+        f_hip.split_conv1 = f_hip.split_conv2 = True
+        try:
+            with torch.no_grad():
+                logits2 = sub.forward_nhwc([x_hip.to(device), x_cnt.to(device)])
+                loss2, _, preds2 = GF.masked_cross_entropy(logits2.reshape(-1, CLASSES), y.to(device), 1)
+            torch.cuda.synchronize()
+            split_hip = (float(loss2.item()), preds2.cpu())
+        finally:
+            f_hip.split_conv1, f_hip.split_conv2 = keep
     del sub
 
     # ---- oracle with the same weights
@@ -473,6 +488,12 @@ def cpu_leg(model, patch, mfma, device, timed_steps=2, sub_hw=None, u8=False, in
           "dtype": mfma, "gate": "abs_diff <= 1e-4 (f32)" if mfma == 'f32' else "reported only (fp16 operands)"}
     if decided.any():
         ce["agreement_rate"] = agree / int(decided.sum())
+    if split_hip is not None:
+        ce["split_operands"] = {"hip": split_hip[0], "abs_diff": abs(split_hip[0] - loss_ref),
+                                "abs_diff_vs_fp32_instruction_path": abs(split_hip[0] - loss_hip),
+                                "argmax_agree": int((split_hip[1][decided] == rows.argmax(1)[decided]).sum()),
+                                "argmax_equal_to_fp32_instruction_path": int((split_hip[1] == preds_hip).sum()),
+                                "what": "DenseNet.split_conv1 / split_conv2 on the same inputs and weights, against the same oracle result"}
     if timed_steps == 0:
         return None, ce
     base = {"value": n / dt, "unit": "spots/s", "cores": cores, "host_cores": host_cores, "cpu_model": cpu_model, "kind": "port",

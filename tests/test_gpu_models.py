@@ -1442,6 +1442,15 @@ def test_full_78x64_array_ce_against_the_oracle(capsys):
     assert ce['foreground_spots'] > 4000 and ce['argmax_compared'] > 0
     assert ce['abs_diff'] <= 1e-4, ce
     assert ce['argmax_agree'] == ce['argmax_compared'], ce
+    # late round 5: the same array with the image f's conv1 / conv2 on split bf16 operands (DenseNet.split_conv1 / split_conv2),
+    # held to the SAME gates against the same oracle result
+    sp = ce['split_operands']
+    with capsys.disabled():
+        print("   split bf16 operands: CE hip %.7f |d vs oracle| %.2e |d vs fp32-instruction path| %.2e; argmax %d / %d decided spots, "
+              "%d / %d spots equal to the fp32-instruction path's" % (sp['hip'], sp['abs_diff'], sp['abs_diff_vs_fp32_instruction_path'],
+                                                                   sp['argmax_agree'], ce['argmax_compared'],
+                                                                   sp['argmax_equal_to_fp32_instruction_path'], 78 * 64))
+    assert sp['abs_diff'] <= 1e-4 and sp['argmax_agree'] == ce['argmax_compared'], sp
 
 
 def test_train_gridwise_skips_the_step_when_the_fp16_gradient_path_overflows():
