@@ -179,6 +179,9 @@ class _DenseNetFn(Function):
         tape.layers = []          # per block: list of (bott, stats1, stats2, bottleneck stored activated?)
         act_ok = (not training) and gammas_nonzero(model)
         w2u = model._winograd_conv2() if (act_ok and model.winograd and model.mfma == 'f32') else None
+        split_ok = act_ok and model.mfma == 'f32' and mid == 128
+        w1s = model._split_conv1() if (split_ok and model.split_conv1) else None
+        w2s = model._split_conv2() if (split_ok and model.split_conv2 and g == 32) else None
         tape.trans = []           # per block: stats of the transition BN (or None)
         n_drop = 0
         for bi, ((c_in, layers, trans, c_total), s) in enumerate(zip(model._blocks, sizes)):
@@ -197,8 +200,17 @@ class _DenseNetFn(Function):
                 if activated:
                     s2 = _bn(layer.norm2, None, mid, M, False, dev, st)
                     t0 = model._probe_begin()
-                    L.call('gnx_conv1x1_bnrelu_act', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid, M,
-                           mid, cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s2[0]), L.ptr(s2[1]), st)
+                    rc = L.ERR_UNSUPPORTED
+                    if w1s is not None:
+                        # (opt-in, `model.split_conv1`) the same product on split bf16 operands: fp32-grade values, HBM-bound;
+                        # the backward differentiates the same function on the fp32 instruction
+                        rc = L.query('gnx_conv1x1_bnrelu_act_split', L.ptr(buf), c_total, w1s[layer].data_ptr(), L.ptr(bott), mid, M, cin,
+                                     L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s2[0]), L.ptr(s2[1]), st)
+                        if rc not in (0, L.ERR_UNSUPPORTED):
+                            raise RuntimeError("gnx_conv1x1_bnrelu_act_split failed (%d)" % rc)
+                    if rc == L.ERR_UNSUPPORTED:
+                        L.call('gnx_conv1x1_bnrelu_act', L.ptr(buf), c_total, L.ptr(layer.conv1.weight), L.ptr(bott), mid, M,
+                               mid, cin, L.ptr(s1[0]), L.ptr(s1[1]), L.ptr(s2[0]), L.ptr(s2[1]), st)
                     model._probe_mark('conv1x1', t0, 2 * M * cin * mid, 4 * M * (cin + mid))
                     # conv2 on the ready operand as in the eval forward: Winograd F(2,3) along x for maps of 8 x 8 and up
                     # (`model.winograd`), the direct form otherwise.  The backward is the adjoint of whichever ran (masks
@@ -207,7 +219,11 @@ class _DenseNetFn(Function):
                     # integer weights) can flip a ReLU mask of the next layer - such tests set `model.winograd = False`.
                     rc = L.ERR_UNSUPPORTED
                     t0 = model._probe_begin()
-                    if w2u is not None and s >= 8:
+                    if w2s is not None:
+                        rc = L.query('gnx_conv3x3_split', L.ptr(bott), mid, w2s[layer].data_ptr(), _cols(buf, cin), c_total, M, s, st)
+                        if rc not in (0, L.ERR_UNSUPPORTED):
+                            raise RuntimeError("gnx_conv3x3_split failed (%d)" % rc)
+                    if rc == L.ERR_UNSUPPORTED and w2u is not None and s >= 8:
                         rc = L.query('gnx_conv3x3_winograd', L.ptr(bott), mid, L.ptr(w2u[layer]), _cols(buf, cin), c_total, M,
                                      g, mid, s, st)
                         if rc not in (0, L.ERR_UNSUPPORTED):

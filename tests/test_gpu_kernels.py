@@ -462,6 +462,31 @@ def test_conv3x3_split_bf16_operands(L, n, S, ldc):
     assert L.lib().gnx_conv3x3_split(L.ptr(Ad), 128, Wp.data_ptr(), L.ptr(out), ldc + 5, M - 1, S, L.stream()) == -3
 
 
+@pytest.mark.parametrize("S", [32, 8])
+def test_conv3x3_split_wide_and_narrow_tiles_agree_bit_for_bit(L, S):
+    """gnx_conv3x3_split gives a wave 64 pixels (weight fragments shared between its two blocks) once the matrix holds 1 024 tiles of
+    512 pixels, 32 pixels below that.  A pixel's sums are formed in the same order either way: the large matrix in one call equals
+    its two halves in two calls bit for bit (so a model's chunk size never changes a result), and its first map equals float64."""
+    import torch.nn.functional as F
+    n = 512 * 1024 // (S * S)
+    M = n * S * S
+    g = torch.Generator(device=DEV).manual_seed(S)
+    A = torch.relu(torch.randn(M, 128, device=DEV, generator=g))
+    W = torch.randn(32, 128, 3, 3, device=DEV, generator=g) * (1.0 / 1152 ** 0.5)
+    Wp = torch.empty(L.query('gnx_conv3x3_split_pack_halves'), device=DEV, dtype=torch.bfloat16)
+    L.call('gnx_conv3x3_split_pack', L.ptr(W), Wp.data_ptr(), L.stream())
+    whole = torch.empty(M, 32, device=DEV)
+    L.call('gnx_conv3x3_split', L.ptr(A), 128, Wp.data_ptr(), L.ptr(whole), 32, M, S, L.stream())
+    halves = torch.empty(M, 32, device=DEV)
+    for k in range(2):
+        L.call('gnx_conv3x3_split', A.data_ptr() + k * (M // 2) * 128 * 4, 128, Wp.data_ptr(), halves.data_ptr() + k * (M // 2) * 32 * 4, 32,
+               M // 2, S, L.stream())
+    assert torch.equal(whole, halves)
+    ref = F.conv2d(A[:S * S].double().cpu().reshape(1, S, S, 128).permute(0, 3, 1, 2), W.double().cpu(), padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(S * S, 32)
+    assert (whole[:S * S].double().cpu() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+
+
 def test_frozen_count_mlp_composed_into_affine_stages(GF):
     """A frozen count MLP in eval mode (train_gridwise's tutorial recipe, training.py:126) evaluates as three affine stages -
     Linear -> Linear -> BatchNorm1d composed into one map each (there is no activation between the paired Linears,

@@ -140,6 +140,36 @@ def test_densenet121_split_operands_are_of_fp32_grade():
     assert torch.equal(out, chunked)
 
 
+def test_split_forward_on_the_gradient_path_changes_gradients_at_rounding_level_only():
+    """`split_conv1` / `split_conv2` also select the taped forward's conv kernels when f is trained under running statistics
+    (train_gridwise with f_opt): the backward differentiates the same function on the fp32 instruction, from activations that
+    differ at the 1e-6 level - loss and every parameter gradient agree with the default path to 1e-4 of their scale."""
+    import gridnext_amd as ga
+    torch.manual_seed(5)
+    m = ga.DenseNet(num_classes=5, growth_rate=32, block_config=(2, 3), num_init_features=64, bn_size=4, small_inputs=False).to(DEV)
+    for mod in m.modules():
+        if isinstance(mod, nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.2)
+            mod.running_var.uniform_(0.6, 1.5)
+            mod.weight.data.uniform_(0.6, 1.4)
+            mod.bias.data.normal_(0, 0.2)
+    m.eval()
+    x = torch.rand(8, 3, 64, 64, device=DEV)
+    y = torch.randint(0, 5, (8,), device=DEV)
+    res = []
+    for flag in (False, True):
+        m.split_conv1 = m.split_conv2 = flag
+        m.zero_grad(set_to_none=True)
+        loss = nn.functional.cross_entropy(m(x), y)
+        loss.backward()
+        res.append((loss.item(), [p.grad.detach().double().clone() for p in m.parameters()]))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * max(1.0, abs(res[0][0]))
+    worst = 0.0
+    for a, b in zip(res[0][1], res[1][1]):
+        worst = max(worst, (a - b).abs().max().item() / max(a.abs().max().item(), 1e-12))
+    assert 0 < worst <= 1e-4, worst
+
+
 def _loaders(x, y, n_train, batch):
     return {'train': DataLoader(TensorDataset(x[:n_train], y[:n_train]), batch_size=batch, shuffle=False),
             'val': DataLoader(TensorDataset(x[n_train:], y[n_train:]), batch_size=batch, shuffle=False)}
