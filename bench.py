@@ -208,6 +208,8 @@ KIND_SOURCES = {
     'conv3x3_bwd_f16': ('dense_bwd_f16.hip', 'common.h'),
     'wgrad1x1_f16': ('dense_bwd_f16.hip', 'common.h'),
     'stem_bwd_f16': ('stem_bwd_f16.hip', 'common.h'),
+    'conv1x1_split': ('conv1x1_split.hip', 'fwd_common.h', 'common.h'),
+    'conv3x3_split': ('conv3x3_split.hip', 'fwd_common.h', 'common.h'),
 }
 
 
@@ -679,6 +681,9 @@ def split_series(args, device, rank, world, steps=4, warmup=2, P=128):
         k3["achieved"] = k3["algorithmic_gbs"]
         k3["frac"] = k3["achieved"] / PEAK_HBM_GBS
         k3["executed_matrix_tflops"] = 3 * k3["flops_per_launch_avg"] * k3["launches"] / (k3["ms_per_step"] * steps * 1e-3) / 1e12
+    # PMC traffic of the two kernels (tools/profile_round.sh <tag> split), attached while their sources are the profiled ones
+    named = {('conv1x1_split' if k == 'conv1x1' else 'conv3x3_split'): kt[k] for k in ('conv1x1', 'conv3x3') if k in kt}
+    attach_traffic(named, '_split')
     return {"value": H * W * world * steps / elapsed, "unit": "spots/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
             "warmup": warmup, "dtype": "f32 tensors and accumulation; conv1 / conv2 products as three bf16 matrix instructions (hi/lo split)",
             "final_loss": float(last.item()), "patch": P,

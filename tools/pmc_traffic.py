@@ -36,6 +36,9 @@ GROUPS = [                                   # first match wins; names as bench.
     ('dgrad3x3_bn2', lambda n: len(_targs(n, 'conv3x3_dma_kernel')) >= 7 and _targs(n, 'conv3x3_dma_kernel')[6] == 'true'),
     ('wgrad1x1', lambda n: 'wgrad1_t_kernel' in n),
     ('wgrad3x3', lambda n: 'wgrad9_t_kernel' in n),
+    ('conv1x1_split', lambda n: 'conv1x1_split_kernel' in n),
+    ('conv3x3_split', lambda n: 'conv3x3_split_kernel' in n),
+    ('split_pack', lambda n: 'split_pack_kernel' in n),
     ('conv1x1', lambda n: 'conv1x1_ws_kernel<true, false' in n or 'conv1x1_ws_kernel<false, false' in n
         or 'conv1x1_kernel<false' in n or 'conv1x1_h16' in n),
     ('transition', lambda n: 'conv1x1_ws_kernel<true, true' in n or 'conv1x1_kernel<true' in n or 'transition_f16_kernel' in n),

@@ -4,7 +4,7 @@
 # rocprofv3 rules of this pool: program directly after `--`, PMC passes separate from each other and with
 # --kernel-trace only.
 tag=${1:-rXX}
-only=${2:-all}        # "c5trained": only the four passes of the config-5 everything-trained step (a change to the fp16 backward kernels)
+only=${2:-all}        # "split": the four passes of the split-operand step; "c5trained": only the four passes of the config-5 everything-trained step (a change to the fp16 backward kernels)
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 if [ "$only" = "c5trained" ]; then
@@ -18,6 +18,21 @@ if [ "$only" = "c5trained" ]; then
   python3 tools/pmc_mfma_util.py gpurun_out/${tag}_g_mfma > gpurun_out/${tag}_pmc_mfma_util_c5trained.json
   find gpurun_out/${tag}_g_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_bench_c5trained_kernel_stats.csv \;
   for d in g_stats g_fetch g_write g_mfma; do rm -rf gpurun_out/${tag}_$d; done
+  echo done
+  exit 0
+fi
+if [ "$only" = "split" ]; then
+  # the headline's step on the opt-in split-operand convs (bench.py's series headline_split_128px alone)
+  P="python3 $R/tools/bench_split.py"
+  rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_s_stats -o r --output-format csv -- $P > $R/gpurun_out/${tag}_s_stats.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_s_fetch -o r --output-format csv -- $P > $R/gpurun_out/${tag}_s_fetch.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_s_write -o r --output-format csv -- $P > $R/gpurun_out/${tag}_s_write.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA -d $R/gpurun_out/${tag}_s_mfma -o r --output-format csv -- $P > $R/gpurun_out/${tag}_s_mfma.log 2>&1 || exit 1
+  cd $R
+  python3 tools/pmc_traffic.py gpurun_out/${tag}_s_fetch gpurun_out/${tag}_s_write > gpurun_out/${tag}_pmc_traffic_split.json
+  python3 tools/pmc_mfma_util.py gpurun_out/${tag}_s_mfma > gpurun_out/${tag}_pmc_mfma_util_split.json
+  find gpurun_out/${tag}_s_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/${tag}_bench_split_kernel_stats.csv \;
+  for d in s_stats s_fetch s_write s_mfma; do rm -rf gpurun_out/${tag}_$d; done
   echo done
   exit 0
 fi
