@@ -319,7 +319,7 @@ def build_model(device, patch=128):
     torch.manual_seed(0)
     f_img = ga.DenseNet(num_classes=CLASSES, **DENSENET121)
     if os.environ.get('GNX_BENCH_SPLIT') == '1':               # (diagnosis only: every series of the run on the opt-in split-operand convs)
-        f_img.split_conv1 = f_img.split_conv2 = True
+        f_img.split_conv1 = f_img.split_conv2 = f_img.split_wgrad = True
     f_cnt = count_mlp(GENES, CLASSES)
     return ga.GridNetHexMM(f_img, f_cnt, (3, patch, patch), (GENES,), (H, W), CLASSES).to(device)
 

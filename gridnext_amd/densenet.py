@@ -68,6 +68,7 @@ class DenseNet(nn.Module):
         self.split_conv1 = False    # eval forward, fp32 path: conv1 on SPLIT bf16 operands (three 16-bit matrix instructions per
                                     # product, fp32 tensors and accumulation: csrc/conv1x1_split.hip; opt-in, fp32-grade results)
         self.split_conv2 = False    # ... and conv2 as nine shifted products of split bf16 operands (csrc/conv3x3_split.hip)
+        self.split_wgrad = False    # fp32 gradient path: conv1's weight gradient on split bf16 operands (csrc/wgrad_split.hip)
         self.winograd = True        # eval forward: conv2 as Winograd F(2,3) along x where the shape allows (fp32 path;
                                     # same arithmetic type, 1.5x fewer matrix operations, rounding-level differences)
         self.f16_buffers = True     # mfma = 'f16' only: the block buffers themselves in fp16 where the shapes allow

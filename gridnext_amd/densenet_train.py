@@ -323,8 +323,18 @@ class _DenseNetFn(Function):
             if not want(w):
                 return
             dw = new_like(w)
-            ws = torch.empty(L.query('gnx_wgrad_workspace', M, Nn, K, taps), device=dev, dtype=F32)
             sc, sh = (L.ptr(stats[0]), L.ptr(stats[1])) if stats is not None else (None, None)
+            if model.split_wgrad and taps == 1 and not pool and Nn % 4 == 0 and K % 4 == 0:
+                # (opt-in) the same contraction on split bf16 operands: HBM-bound instead of bound by the fp32 matrix instruction
+                t0 = model._probe_begin()
+                ws = torch.empty(L.query('gnx_wgrad1x1_split_workspace', M, Nn, K), device=dev, dtype=F32)
+                rc = L.query('gnx_wgrad1x1_split', dy_ptr, lddy, x_ptr, ldx, sc, sh, L.ptr(dw), L.ptr(ws), M, Nn, K, 0, L.stream())
+                if rc == 0:
+                    model._probe_mark('wgrad1x1', t0, 2 * M * Nn * K, 4 * M * (Nn + K))
+                    return
+                if rc != L.ERR_UNSUPPORTED:
+                    raise RuntimeError("gnx_wgrad1x1_split failed (%d)" % rc)
+            ws = torch.empty(L.query('gnx_wgrad_workspace', M, Nn, K, taps), device=dev, dtype=F32)
             t0 = model._probe_begin()
             L.call('gnx_wgrad_bnrelu', dy_ptr, lddy, x_ptr, ldx, sc, sh, L.ptr(dw), L.ptr(ws), M, Nn, K, S, taps, pool, 0,
                    L.stream())

@@ -183,6 +183,13 @@ int gnx_conv1x1_bnrelu_act_split(const float* A, long lda, const void* Wp, float
 long gnx_conv3x3_split_pack_halves(void);
 int gnx_conv3x3_split_pack(const float* W, void* Wp, gnx_stream_t stream);
 int gnx_conv3x3_split(const float* A, long lda, const void* Wp, float* out, long ldc, long M, int S, gnx_stream_t stream);
+/* conv1's weight gradient on split bf16 operands (csrc/wgrad_split.hip; opt-in): gnx_wgrad_bnrelu with taps = 1, pool = 0 -
+ * dW [N][K] (+)= dY^T relu(scale . X + shift) as torch.autograd derives it for densenet.py:35-37 - with fp32 operands in HBM, three
+ * 16-bit matrix instructions per product and fp32 accumulation; slabs over pixels summed in a fixed order.  scale = shift = NULL: no
+ * activation.  4 | N, K, lddy, ldx and 16-B aligned operands, else GNX_ERR_UNSUPPORTED. */
+long gnx_wgrad1x1_split_workspace(long M, int N, int K);
+int gnx_wgrad1x1_split(const float* dY, long lddy, const float* X, long ldx, const float* scale, const float* shift, float* dW,
+                       float* workspace, long M, int N, int K, int accumulate, gnx_stream_t stream);
 /* Training backward of norm1 -> relu1 -> conv1 (:35-37) w.r.t. the layer input, eval statistics: conv1's data gradient
  * dY . Wt^T (Wt = gnx_transpose_weight of conv1.weight) fused with the BN + ReLU backward and accumulated into the block
  * gradient dX[:, :N]; dbeta / dgamma from per-tile column sums (fixed order).  Same result as gnx_conv1x1_bnrelu followed by

@@ -487,6 +487,38 @@ def test_conv3x3_split_wide_and_narrow_tiles_agree_bit_for_bit(L, S):
     assert (whole[:S * S].double().cpu() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,K,ldx,act,accumulate", [(1000, 128, 96, 128, True, 0), (4096, 128, 480, 512, True, 1),
+                                                         (777, 128, 992, 1024, True, 0), (300, 128, 64, 64, False, 0),
+                                                         (70000, 128, 160, 256, True, 0)])
+def test_wgrad1x1_split_bf16_operands(L, M, N, K, ldx, act, accumulate):
+    """Late round 5: conv1's weight gradient dW = dY^T relu(scale X + shift) on split bf16 operands (csrc/wgrad_split.hip: fp32
+    operands in HBM, transposing LDS reads, three matrix instructions per product, slabs summed in a fixed order) against float64:
+    ragged M (rows beyond it contribute nothing), K not a multiple of the 128-wide block, a wider X row, accumulation into an
+    existing gradient, no activation.  Error of fp32 grade: gate 3e-5 of the result's range."""
+    g = torch.Generator().manual_seed(M + K)
+    dY = torch.randn(M, N, generator=g)
+    X = torch.randn(M, ldx, generator=g)
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+    ax = torch.relu(X[:, :K].double() * sc.double() + sh.double()) if act else X[:, :K].double()
+    ref = dY.double().t() @ ax
+    prior = torch.randn(N, K, generator=g)
+    if accumulate:
+        ref = ref + prior.double()
+    dYd, Xd, scd, shd = (v.to(DEV) for v in (dY, X, sc, sh))
+    dW = prior.to(DEV).clone()
+    ws = torch.empty(L.query('gnx_wgrad1x1_split_workspace', M, N, K), device=DEV)
+    L.call('gnx_wgrad1x1_split', L.ptr(dYd), N, L.ptr(Xd), ldx, L.ptr(scd) if act else None, L.ptr(shd) if act else None, L.ptr(dW),
+           L.ptr(ws), M, N, K, accumulate, L.stream())
+    rng = ref.abs().max().item()
+    err = (dW.double().cpu() - ref).abs().max().item()
+    print("\n[wgrad1x1 split bf16, M=%d K=%d] max error / range %.2e" % (M, K, err / rng))
+    assert err <= 3e-5 * rng, (err, rng)
+    dW2 = prior.to(DEV).clone()
+    L.call('gnx_wgrad1x1_split', L.ptr(dYd), N, L.ptr(Xd), ldx, L.ptr(scd) if act else None, L.ptr(shd) if act else None, L.ptr(dW2),
+           L.ptr(ws), M, N, K, accumulate, L.stream())
+    assert torch.equal(dW, dW2)                                           # fixed summation order: the same bits every time
+
+
 def test_frozen_count_mlp_composed_into_affine_stages(GF):
     """A frozen count MLP in eval mode (train_gridwise's tutorial recipe, training.py:126) evaluates as three affine stages -
     Linear -> Linear -> BatchNorm1d composed into one map each (there is no activation between the paired Linears,

@@ -142,8 +142,9 @@ def test_densenet121_split_operands_are_of_fp32_grade():
 
 def test_split_forward_on_the_gradient_path_changes_gradients_at_rounding_level_only():
     """`split_conv1` / `split_conv2` also select the taped forward's conv kernels when f is trained under running statistics
-    (train_gridwise with f_opt): the backward differentiates the same function on the fp32 instruction, from activations that
-    differ at the 1e-6 level - loss and every parameter gradient agree with the default path to 1e-4 of their scale."""
+    (train_gridwise with f_opt), `split_wgrad` conv1's weight gradient: the backward differentiates the same function, from
+    activations that differ at the 1e-6 level - loss and every parameter gradient agree with the default path to 1e-4 of
+    their scale."""
     import gridnext_amd as ga
     torch.manual_seed(5)
     m = ga.DenseNet(num_classes=5, growth_rate=32, block_config=(2, 3), num_init_features=64, bn_size=4, small_inputs=False).to(DEV)
@@ -158,7 +159,7 @@ def test_split_forward_on_the_gradient_path_changes_gradients_at_rounding_level_
     y = torch.randint(0, 5, (8,), device=DEV)
     res = []
     for flag in (False, True):
-        m.split_conv1 = m.split_conv2 = flag
+        m.split_conv1 = m.split_conv2 = m.split_wgrad = flag
         m.zero_grad(set_to_none=True)
         loss = nn.functional.cross_entropy(m(x), y)
         loss.backward()

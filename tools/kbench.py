@@ -92,6 +92,25 @@ def main():
             print("conv1x1 S=%2d K=%4d M=%8d  fp32 mfma %8.3f ms %6.1f TFLOP/s %5.2f TB/s | split bf16 %8.3f ms %6.1f TFLOP/s %5.2f TB/s  (x%.2f)" %
                   (S, K, M, ms0, fl / ms0 / 1e9, byts / ms0 / 1e9, ms1, fl / ms1 / 1e9, byts / ms1 / 1e9, ms0 / ms1), flush=True)
             del A, out
+    if args.only == 'wgrad1split':
+        # conv1's weight gradient: the fp32-instruction kernel (gnx_wgrad_bnrelu) beside the split-bf16 form
+        for S, K, ct in shapes:
+            M = n * S * S
+            X = torch.randn(M, ct, device=DEV)
+            dY = torch.randn(M, 128, device=DEV)
+            sc, sh = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
+            dW = torch.empty(128, K, device=DEV)
+            ws0 = torch.empty(L.query('gnx_wgrad_workspace', M, 128, K, 1), device=DEV)
+            ws1 = torch.empty(L.query('gnx_wgrad1x1_split_workspace', M, 128, K), device=DEV)
+            ms0 = timeit(lambda: L.call('gnx_wgrad_bnrelu', L.ptr(dY), 128, L.ptr(X), ct, L.ptr(sc), L.ptr(sh), L.ptr(dW), L.ptr(ws0), M, 128,
+                                        K, S, 1, 0, 0, st), args.reps)
+            ms1 = timeit(lambda: L.call('gnx_wgrad1x1_split', L.ptr(dY), 128, L.ptr(X), ct, L.ptr(sc), L.ptr(sh), L.ptr(dW), L.ptr(ws1), M,
+                                        128, K, 0, st), args.reps)
+            fl = 2.0 * M * K * 128
+            byts = 4.0 * M * (K + 128)
+            print("wgrad1x1 S=%2d K=%4d M=%8d  fp32 mfma %8.3f ms %6.1f TFLOP/s %5.2f TB/s | split bf16 %8.3f ms %6.1f TFLOP/s %5.2f TB/s  (x%.2f)" %
+                  (S, K, M, ms0, fl / ms0 / 1e9, byts / ms0 / 1e9, ms1, fl / ms1 / 1e9, byts / ms1 / 1e9, ms0 / ms1), flush=True)
+            del X, dY
     if args.only == 'conv3x3split':
         # conv2 on the ready (activated) bottleneck: Winograd F(2,3) on the fp32 instruction beside the split-bf16 direct form
         for S in (32, 16, 8, 4):
