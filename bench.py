@@ -1292,6 +1292,21 @@ def worker_main(args):
                 return ser
             optional("train_f", train_f_series)
 
+            def train_f_split_series():
+                # the same f-trained step with the opt-in split-operand kernels: taped forward convs and conv1's weight gradient
+                keep = (f_img.split_conv1, f_img.split_conv2, f_img.split_wgrad)
+                f_img.split_conv1 = f_img.split_conv2 = f_img.split_wgrad = True
+                try:
+                    el, loss_tf, _ = run_series(True, args.series_steps, 1, False)
+                finally:
+                    f_img.split_conv1, f_img.split_conv2, f_img.split_wgrad = keep
+                return {"value": H * W * world * args.series_steps / el, "unit": "spots/s",
+                        "ms_per_step": 1e3 * el / args.series_steps, "steps": args.series_steps, "warmup": 1,
+                        "dtype": "f32 tensors and accumulation; forward conv1 / conv2 and conv1's weight gradient as three bf16 matrix "
+                                 "instructions per product (hi/lo split); data gradients and conv2's weight gradient on the fp32 instruction",
+                        "workload": "series train_f with DenseNet.split_conv1 / split_conv2 / split_wgrad", "final_loss": loss_tf}
+            optional("train_f_split", train_f_split_series)
+
     # ---- the other BASELINE configs through the product's own loops (tools/bench_configs.py), single process only
     if world == 1 and not args.no_series and not args.train_f and args.mfma == 'f32' and args.patch == 128:
         optional("other_configs", lambda: other_configs(device))
