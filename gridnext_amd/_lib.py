@@ -49,6 +49,8 @@ SIGNATURES = {
     'gnx_conv3x3_split': (_I, [_P, _L, _P, _P, _L, _L, _I, _P]),
     'gnx_wgrad1x1_split_workspace': (_L, [_L, _I, _I]),
     'gnx_wgrad1x1_split': (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    'gnx_wgrad3x3_split_workspace': (_L, [_L]),
+    'gnx_wgrad3x3_split': (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _P]),
     'gnx_conv1x1_dgrad_bn_workspace': (_L, [_L, _I]),
     'gnx_conv1x1_dgrad_bnrelu_bwd': (_I, [_P, _L, _P, _P, _L, _P, _L, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'gnx_conv1x1_dgrad_wgrad_workspace': (_L, [_L, _I]),

@@ -150,6 +150,167 @@ __global__ __launch_bounds__(256) void wgrad_split_reduce_kernel(const float* __
     out[i] = accumulate ? out[i] + s : s;
 }
 
+// ------------------------------------------------------------------------------------------------ conv2's weight gradient
+// ws[slab][tap][n][k] = sum over the slab's pixels p of dY[p - (dy, dx)][n] A[p][k], tap = 3 (dy + 1) + (dx + 1), where the output
+// pixel p - (dy, dx) lies in p's map (torch.autograd through densenet.py:41; A = the activated bottleneck, dY = the layer's 32
+// gradient columns).  64-pixel tiles of A; the dY strip of the tile [P0 - S - 1, P0 + 64 + S + 1) is staged once and read at nine
+// row offsets; rows a tap may not read are redirected - by the lane that supplies that row's address - to a row of zeros.  Wave w
+// owns channels k = 32 w .. 32 w + 31 for all nine taps.  One workgroup per CU: nine accumulators and two operand planes each
+// need the register file of a whole SIMD.
+template <int S>
+__global__ __launch_bounds__(256, 1) void wgrad3x3_split_kernel(const float* __restrict__ dY, long lddy, const float* __restrict__ A,
+                                                                long lda, float* __restrict__ ws, long M, long tiles_per_slab) {
+    constexpr int NROWS = 66 + 2 * S;
+    constexpr int SPLANE = (NROWS + 1) * 64;                             // a strip plane: [row][32 ch] bf16 + the row of zeros
+    constexpr int NI = (NROWS * 8 + 255) / 256;                          // 16-B pieces of the strip per thread
+    __shared__ __attribute__((aligned(16))) char smem[2 * WS_PLANE + 2 * SPLANE];
+    char* const strip = smem + 2 * WS_PLANE;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long slab = blockIdx.x;
+    const long ntiles = (M + 63) / 64;
+    const long tile0 = slab * tiles_per_slab;
+    const long tile1 = tile0 + tiles_per_slab < ntiles ? tile0 + tiles_per_slab : ntiles;
+    const int chunk = t & 31, row0 = t >> 5;
+    const int trow = 8 * (lane >> 5) + ((lane & 15) >> 2);
+    const int tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    if (t < 32) reinterpret_cast<unsigned*>(strip + (t < 16 ? 0 : SPLANE) + NROWS * 64)[t & 15] = 0u;
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[k][q] = 0.f;
+    constexpr int S2 = S * S;
+    f32x4 av[8], sv[NI];
+    for (long tile = tile0; tile <= tile1; ++tile) {
+        const long Pp = (tile - 1) * 64;                                 // the tile in the staging registers
+        if (tile > tile0) {
+            lds_barrier();                                               // the previous tile's reads are done
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool ok = Pp + row0 + 8 * i < M;
+                bf4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = ok ? av[i][e] : 0.f;
+                    hi[e] = (__bf16)v;
+                    lo[e] = (__bf16)(v - (float)hi[e]);
+                }
+                char* const d = smem + (row0 + 8 * i) * WS_RS + chunk * 8;
+                *reinterpret_cast<bf4*>(d) = hi;
+                *reinterpret_cast<bf4*>(d + WS_PLANE) = lo;
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int item = t + 256 * i;                            // (strip row, 16-B piece of its 32 channels)
+                const long u = Pp - S - 1 + (item >> 3);
+                if ((item >> 3) < NROWS) {
+                    const bool ok = u >= 0 && u < M;
+                    bf4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = ok ? sv[i][e] : 0.f;
+                        hi[e] = (__bf16)v;
+                        lo[e] = (__bf16)(v - (float)hi[e]);
+                    }
+                    char* const d = strip + (item >> 3) * 64 + (item & 7) * 8;
+                    *reinterpret_cast<bf4*>(d) = hi;
+                    *reinterpret_cast<bf4*>(d + SPLANE) = lo;
+                }
+            }
+            lds_barrier();
+        }
+        if (tile < tile1) {                                              // in flight while the previous tile multiplies
+            const long P0 = tile * 64;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                long row = P0 + row0 + 8 * i;
+                row = row < M ? row : M - 1;
+                av[i] = *reinterpret_cast<const f32x4*>(A + row * lda + chunk * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int item = t + 256 * i;
+                long u = P0 - S - 1 + (item >> 3);
+                u = u < 0 ? 0 : (u < M ? u : M - 1);
+                sv[i] = *reinterpret_cast<const f32x4*>(dY + u * lddy + (item & 7) * 4);
+            }
+        }
+        if (tile > tile0) {
+            const int rem0 = (int)(Pp & (S2 - 1));                       // position of the tile's first pixel inside its map
+#pragma unroll 1
+            for (int ks = 0; ks < 4; ++ks) {
+                const char* pb = smem + (16 * ks + trow) * WS_RS + (32 * wave + tcol) * 2;
+                const bf8 b_hi = tr8(pb, pb + 4 * WS_RS);
+                const bf8 b_lo = tr8(pb + WS_PLANE, pb + WS_PLANE + 4 * WS_RS);
+                // which taps may read the rows this lane supplies (pixel p of A; its partner is the output pixel p - (dy, dx))
+                unsigned vlo = 0, vhi = 0;
+                {
+                    const int rem_lo = (rem0 + 16 * ks + trow) & (S2 - 1), rem_hi = (rem0 + 16 * ks + trow + 4) & (S2 - 1);
+                    const int ylo = rem_lo / S, xlo = rem_lo & (S - 1), yhi = rem_hi / S, xhi = rem_hi & (S - 1);
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                        if (ylo - dy >= 0 && ylo - dy < S && xlo - dx >= 0 && xlo - dx < S) vlo |= 1u << tap;
+                        if (yhi - dy >= 0 && yhi - dy < S && xhi - dx >= 0 && xhi - dx < S) vhi |= 1u << tap;
+                    }
+                }
+#pragma unroll
+                for (int g3 = 0; g3 < 3; ++g3) {                         // three taps at a time: their six fragments, then nine products
+                    bf8 a_hi[3], a_lo[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int tap = 3 * g3 + j;
+                        const int off = (tap / 3 - 1) * S + (tap % 3 - 1);
+                        const char* lo = strip + (((vlo >> tap) & 1) ? (16 * ks + trow - off + S + 1) : NROWS) * 64 + tcol * 2;
+                        const char* hi = strip + (((vhi >> tap) & 1) ? (16 * ks + trow + 4 - off + S + 1) : NROWS) * 64 + tcol * 2;
+                        a_hi[j] = tr8(lo, hi);
+                        a_lo[j] = tr8(lo + SPLANE, hi + SPLANE);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int tap = 3 * g3 + j;
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[j], b_hi, acc[tap], 0, 0, 0);
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[j], b_lo, acc[tap], 0, 0, 0);
+                        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[j], b_hi, acc[tap], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    float* const out = ws + slab * (9L * 32 * 128);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            out[(tap * 32 + n) * 128 + 32 * wave + (lane & 31)] = acc[tap][r];
+        }
+}
+
+// dW [n][k][tap] (conv2.weight's layout) (+)= sum over slabs of ws[slab][tap][n][k], fixed order
+__global__ __launch_bounds__(256) void wgrad3x3_split_reduce_kernel(const float* __restrict__ ws, long nslab, float* __restrict__ out,
+                                                                   int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;                        // index into [n][k][tap]
+    if (i >= 32 * 128 * 9) return;
+    const int tap = i % 9, k = i / 9 % 128, n = i / (9 * 128);
+    const long src = ((long)tap * 32 + n) * 128 + k;
+    float s = 0.f;
+    for (long j = 0; j < nslab; ++j) s += ws[j * (9L * 32 * 128) + src];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+struct W3Plan {
+    long slabs, per;
+};
+W3Plan w3_plan(long M) {
+    W3Plan p;
+    const long tiles = (M + 63) / 64;
+    long want = 256 < tiles ? 256 : tiles;                               // one workgroup per CU
+    p.per = (tiles + want - 1) / want;
+    p.slabs = (tiles + p.per - 1) / p.per;
+    return p;
+}
+
 struct WsPlan {
     long tiles, slabs, per;
     int n_kb, n_nb;
@@ -191,5 +352,28 @@ GNX_EXPORT int gnx_wgrad1x1_split(const float* dY, long lddy, const float* X, lo
                                                         p.slabs);
     const long n = (long)N * K;
     wgrad_split_reduce_kernel<<<(int)((n + 255) / 256), 256, 0, stream>>>(workspace, p.slabs, n, dW, accumulate);
+    return gnx_launch_status();
+}
+
+GNX_EXPORT long gnx_wgrad3x3_split_workspace(long M) { return M < 1 ? 0 : w3_plan(M).slabs * (9L * 32 * 128); }
+// dW [32][128][3][3] (+)= the weight gradient of conv2 (gnx_wgrad_bnrelu with taps = 9, N = 32, K = 128, no prologue: A is the
+// ACTIVATED bottleneck) on split bf16 operands.  Maps of S x S pixels, S in {4, 8, 16, 32, 64}, S * S | M; fp32 operands, 16-B
+// aligned, 4 | lddy, lda; else GNX_ERR_UNSUPPORTED.  workspace: gnx_wgrad3x3_split_workspace(M) floats.
+GNX_EXPORT int gnx_wgrad3x3_split(const float* dY, long lddy, const float* A, long lda, float* dW, float* workspace, long M, int S,
+                                  int accumulate, hipStream_t stream) {
+    if (!dY || !A || !dW || !workspace || M < 1 || lddy < 32 || lda < 128 || S < 1) return GNX_ERR_BAD_ARG;
+    if ((lddy & 3) || (lda & 3) || (reinterpret_cast<uintptr_t>(dY) & 15) || (reinterpret_cast<uintptr_t>(A) & 15) || M % ((long)S * S))
+        return GNX_ERR_UNSUPPORTED;
+    const W3Plan p = w3_plan(M);
+    const int grid = (int)p.slabs;
+    switch (S) {
+        case 4: wgrad3x3_split_kernel<4><<<grid, 256, 0, stream>>>(dY, lddy, A, lda, workspace, M, p.per); break;
+        case 8: wgrad3x3_split_kernel<8><<<grid, 256, 0, stream>>>(dY, lddy, A, lda, workspace, M, p.per); break;
+        case 16: wgrad3x3_split_kernel<16><<<grid, 256, 0, stream>>>(dY, lddy, A, lda, workspace, M, p.per); break;
+        case 32: wgrad3x3_split_kernel<32><<<grid, 256, 0, stream>>>(dY, lddy, A, lda, workspace, M, p.per); break;
+        case 64: wgrad3x3_split_kernel<64><<<grid, 256, 0, stream>>>(dY, lddy, A, lda, workspace, M, p.per); break;
+        default: return GNX_ERR_UNSUPPORTED;
+    }
+    wgrad3x3_split_reduce_kernel<<<(32 * 128 * 9 + 255) / 256, 256, 0, stream>>>(workspace, p.slabs, dW, accumulate);
     return gnx_launch_status();
 }

@@ -334,6 +334,16 @@ class _DenseNetFn(Function):
                     return
                 if rc != L.ERR_UNSUPPORTED:
                     raise RuntimeError("gnx_wgrad1x1_split failed (%d)" % rc)
+            if model.split_wgrad and taps == 9 and stats is None and Nn == 32 and K == 128 and S >= 8:
+                # (opt-in) conv2's weight gradient from the activated bottleneck, same arithmetic (4 x 4 maps: the fp32 kernel is faster)
+                t0 = model._probe_begin()
+                ws = torch.empty(L.query('gnx_wgrad3x3_split_workspace', M), device=dev, dtype=F32)
+                rc = L.query('gnx_wgrad3x3_split', dy_ptr, lddy, x_ptr, ldx, L.ptr(dw), L.ptr(ws), M, S, 0, L.stream())
+                if rc == 0:
+                    model._probe_mark('wgrad3x3', t0, 2 * M * 9 * Nn * K, 4 * M * (Nn + K))
+                    return
+                if rc != L.ERR_UNSUPPORTED:
+                    raise RuntimeError("gnx_wgrad3x3_split failed (%d)" % rc)
             ws = torch.empty(L.query('gnx_wgrad_workspace', M, Nn, K, taps), device=dev, dtype=F32)
             t0 = model._probe_begin()
             L.call('gnx_wgrad_bnrelu', dy_ptr, lddy, x_ptr, ldx, sc, sh, L.ptr(dw), L.ptr(ws), M, Nn, K, S, taps, pool, 0,

@@ -190,6 +190,11 @@ int gnx_conv3x3_split(const float* A, long lda, const void* Wp, float* out, long
 long gnx_wgrad1x1_split_workspace(long M, int N, int K);
 int gnx_wgrad1x1_split(const float* dY, long lddy, const float* X, long ldx, const float* scale, const float* shift, float* dW,
                        float* workspace, long M, int N, int K, int accumulate, gnx_stream_t stream);
+/* ... and conv2's (taps = 9, N = 32, K = 128, no prologue: A is the activated bottleneck, dY the layer's 32 gradient columns; dW in
+ * conv2.weight's layout [32][128][3][3]).  S in {4, 8, 16, 32, 64}, S * S | M, 4 | lddy, lda, 16-B aligned operands. */
+long gnx_wgrad3x3_split_workspace(long M);
+int gnx_wgrad3x3_split(const float* dY, long lddy, const float* A, long lda, float* dW, float* workspace, long M, int S,
+                       int accumulate, gnx_stream_t stream);
 /* Training backward of norm1 -> relu1 -> conv1 (:35-37) w.r.t. the layer input, eval statistics: conv1's data gradient
  * dY . Wt^T (Wt = gnx_transpose_weight of conv1.weight) fused with the BN + ReLU backward and accumulated into the block
  * gradient dX[:, :N]; dbeta / dgamma from per-tile column sums (fixed order).  Same result as gnx_conv1x1_bnrelu followed by

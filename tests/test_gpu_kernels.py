@@ -519,6 +519,37 @@ def test_wgrad1x1_split_bf16_operands(L, M, N, K, ldx, act, accumulate):
     assert torch.equal(dW, dW2)                                           # fixed summation order: the same bits every time
 
 
+@pytest.mark.parametrize("n,S,lddy,accumulate", [(5, 4, 32, 0), (3, 8, 64, 1), (3, 16, 96, 0), (2, 32, 32, 0), (1, 64, 160, 0), (40, 8, 32, 0)])
+def test_wgrad3x3_split_bf16_operands(L, n, S, lddy, accumulate):
+    """Late round 5: conv2's weight gradient on split bf16 operands (csrc/wgrad_split.hip: the dY strip of a 64-pixel tile staged
+    once and read at nine row offsets by transposing reads, out-of-map partners redirected to a row of zeros) against float64
+    autograd: every map size, tiles that straddle maps, dY as a column range of a wider buffer, accumulation.  Gate 3e-5 of the
+    range; the same bits on a second call."""
+    g = torch.Generator().manual_seed(31 * n + S)
+    M = n * S * S
+    A = torch.relu(torch.randn(M, 128, generator=g))
+    dYw = torch.randn(M, lddy, generator=g)
+    c0 = lddy - 32
+    x = A.double().reshape(n, S, S, 128).permute(0, 3, 1, 2).contiguous()
+    gy = dYw[:, c0:].double().reshape(n, S, S, 32).permute(0, 3, 1, 2).contiguous()
+    ref = torch.nn.grad.conv2d_weight(x, (32, 128, 3, 3), gy, padding=1)
+    prior = torch.randn(32, 128, 3, 3, generator=g)
+    if accumulate:
+        ref = ref + prior.double()
+    Ad, dYd = A.to(DEV), dYw.to(DEV)
+    dW = prior.to(DEV).clone()
+    ws = torch.empty(L.query('gnx_wgrad3x3_split_workspace', M), device=DEV)
+    args = (dYd.data_ptr() + 4 * c0, lddy, L.ptr(Ad), 128, L.ptr(dW), L.ptr(ws), M, S, accumulate, L.stream())
+    L.call('gnx_wgrad3x3_split', *args)
+    rng = ref.abs().max().item()
+    err = (dW.double().cpu() - ref).abs().max().item()
+    print("\n[wgrad3x3 split bf16, n=%d S=%d] max error / range %.2e" % (n, S, err / rng))
+    assert err <= 3e-5 * rng, (err, rng)
+    dW2 = prior.to(DEV).clone()
+    L.call('gnx_wgrad3x3_split', dYd.data_ptr() + 4 * c0, lddy, L.ptr(Ad), 128, L.ptr(dW2), L.ptr(ws), M, S, accumulate, L.stream())
+    assert torch.equal(dW, dW2)
+
+
 def test_frozen_count_mlp_composed_into_affine_stages(GF):
     """A frozen count MLP in eval mode (train_gridwise's tutorial recipe, training.py:126) evaluates as three affine stages -
     Linear -> Linear -> BatchNorm1d composed into one map each (there is no activation between the paired Linears,

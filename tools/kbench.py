@@ -111,6 +111,24 @@ def main():
             print("wgrad1x1 S=%2d K=%4d M=%8d  fp32 mfma %8.3f ms %6.1f TFLOP/s %5.2f TB/s | split bf16 %8.3f ms %6.1f TFLOP/s %5.2f TB/s  (x%.2f)" %
                   (S, K, M, ms0, fl / ms0 / 1e9, byts / ms0 / 1e9, ms1, fl / ms1 / 1e9, byts / ms1 / 1e9, ms0 / ms1), flush=True)
             del X, dY
+    if args.only == 'wgrad9split':
+        # conv2's weight gradient: the fp32-instruction kernel (gnx_wgrad_bnrelu, taps = 9) beside the split-bf16 form
+        for S in (32, 16, 8, 4):
+            M = n * S * S
+            A = torch.relu(torch.randn(M, 128, device=DEV))
+            dY = torch.randn(M, 256, device=DEV)
+            dW = torch.empty(32, 128, 3, 3, device=DEV)
+            ws0 = torch.empty(L.query('gnx_wgrad_workspace', M, 32, 128, 9), device=DEV)
+            ws1 = torch.empty(L.query('gnx_wgrad3x3_split_workspace', M), device=DEV)
+            ms0 = timeit(lambda: L.call('gnx_wgrad_bnrelu', dY.data_ptr() + 4 * 64, 256, L.ptr(A), 128, None, None, L.ptr(dW), L.ptr(ws0), M, 32,
+                                        128, S, 9, 0, 0, st), args.reps)
+            ms1 = timeit(lambda: L.call('gnx_wgrad3x3_split', dY.data_ptr() + 4 * 64, 256, L.ptr(A), 128, L.ptr(dW), L.ptr(ws1), M, S, 0, st),
+                         args.reps)
+            fl = 2.0 * M * 1152 * 32
+            byts = 4.0 * M * (128 + 32)
+            print("wgrad3x3 S=%2d M=%8d  fp32 mfma %8.3f ms %6.1f TFLOP/s %5.2f TB/s | split bf16 %8.3f ms %6.1f TFLOP/s %5.2f TB/s  (x%.2f)" %
+                  (S, M, ms0, fl / ms0 / 1e9, byts / ms0 / 1e9, ms1, fl / ms1 / 1e9, byts / ms1 / 1e9, ms0 / ms1), flush=True)
+            del A, dY
     if args.only == 'conv3x3split':
         # conv2 on the ready (activated) bottleneck: Winograd F(2,3) on the fp32 instruction beside the split-bf16 direct form
         for S in (32, 16, 8, 4):
