@@ -489,12 +489,14 @@ def test_conv3x3_split_wide_and_narrow_tiles_agree_bit_for_bit(L, S):
 
 @pytest.mark.parametrize("M,N,K,ldx,act,accumulate", [(1000, 128, 96, 128, True, 0), (4096, 128, 480, 512, True, 1),
                                                          (777, 128, 992, 1024, True, 0), (300, 128, 64, 64, False, 0),
-                                                         (70000, 128, 160, 256, True, 0)])
+                                                         (70000, 128, 160, 256, True, 0), (2000, 256, 512, 512, False, 0),
+                                                         (1111, 512, 1024, 1024, False, 1), (900, 64, 128, 128, False, 0)])
 def test_wgrad1x1_split_bf16_operands(L, M, N, K, ldx, act, accumulate):
     """Late round 5: conv1's weight gradient dW = dY^T relu(scale X + shift) on split bf16 operands (csrc/wgrad_split.hip: fp32
     operands in HBM, transposing LDS reads, three matrix instructions per product, slabs summed in a fixed order) against float64:
     ragged M (rows beyond it contribute nothing), K not a multiple of the 128-wide block, a wider X row, accumulation into an
-    existing gradient, no activation.  Error of fp32 grade: gate 3e-5 of the result's range."""
+    existing gradient, no activation, the transitions' shapes (N = 64 .. 512 output channels: several 128-wide blocks of n).  Error of
+    fp32 grade: gate 3e-5 of the result's range."""
     g = torch.Generator().manual_seed(M + K)
     dY = torch.randn(M, N, generator=g)
     X = torch.randn(M, ldx, generator=g)
